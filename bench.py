@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py -- point-clouds/sec, forward+backward(+SGD step), PointNet++ SSG cls, B=32 per GPU, N=1024.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job clouds/s with inputs resident in
+HBM, `roofline` for the dominant own kernel (HIP events on the launch stream inside the timed region) and
+`cpu_baseline` (the CPU restatement of the reference semantics timed on the host cores; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_PEAK_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
+
+# which roofline bounds each C-ABI entry point
+BOUND = {"pcl_fps_f32": "hbm", "pcl_ball_query_f32": "hbm", "pcl_group_f32": "hbm", "pcl_group_bwd_f32": "hbm",
+         "pcl_group_all_f32": "hbm", "pcl_knn_f32": "hbm"}
+
+
+def make_batches(B, N, n_batches, rank, dev):
+    from pointcloudlib_amd import synth
+    out = []
+    for i in range(n_batches):
+        seed = 20242 + 1000 * rank + i
+        out.append((torch.from_numpy(synth.gauss_ball(B, N, seed)).to(dev),
+                    torch.from_numpy(synth.unit_normals(B, N, seed + 500)).to(dev),
+                    torch.from_numpy(synth.labels(B, 40, seed + 900)).to(dev)))
+    return out
+
+
+def cpu_baseline(state, B, N, budget_s=12.0, max_steps=3):
+    """The CPU restatement (oracle index ops, OpenMP over clouds + PyTorch-CPU fp32 dense ops) timed on the
+    host cores on a bounded sample of the same workload."""
+    import oracle
+    from oracle.cpu_model import PointNet2ClsCPU
+    from pointcloudlib_amd import synth
+    from pointcloudlib_amd.train_utils import soft_cross_entropy_loss
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = PointNet2ClsCPU(state, tie_stride=oracle.optimal_block(B)).train()
+    net.use_dropout = True
+    opt = torch.optim.SGD(net.parameters(), lr=0.02, momentum=0.9)
+    x = torch.from_numpy(synth.gauss_ball(B, N, 20242))
+    f = torch.from_numpy(synth.unit_normals(B, N, 20742))
+    y = torch.from_numpy(synth.labels(B, 40, 21142))
+
+    def step():
+        opt.zero_grad()
+        loss = soft_cross_entropy_loss(net(x, f), y)
+        loss.backward()
+        opt.step()
+
+    step()                                   # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < max_steps and (n == 0 or time.perf_counter() - t0 < budget_s):
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {"value": round(B * n / dt, 3), "unit": "point-clouds/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fwd+bwd+SGD steps of PointNet++ SSG B={B} N={N} after 1 warm-up "
+                      f"(oracle FPS/ball-query with {oracle.num_threads()} OpenMP threads + PyTorch-CPU fp32, {model})",
+            "label": "CPU restatement of reference semantics (Jittor not runnable)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="clouds per GPU (BASELINE config 2: 32)")
+    ap.add_argument("--npoints", type=int, default=1024, help="points per cloud (1024; 4096 is the north-star extra)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-kernel", default="auto")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)       # nccl == RCCL on ROCm
+
+    from pointcloudlib_amd import _lib
+    from pointcloudlib_amd.dp import FlatBucketDP
+    from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
+    from pointcloudlib_amd.train_utils import make_sgd, soft_cross_entropy_loss
+    _lib.lib()                                                # fail loudly when the extension is missing
+
+    B, N = args.batch, args.npoints
+    torch.manual_seed(0)
+    net = PointNet2_cls().to(dev).train()
+    state0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    dp = FlatBucketDP(net)
+    opt = make_sgd(net.parameters(), lr=0.02, momentum=0.9)   # train_cls.py:374-377,404
+    batches = make_batches(B, N, 4, rank, dev)
+
+    def step(i):
+        x, f, y = batches[i % len(batches)]
+        dp.zero_grad()
+        loss = soft_cross_entropy_loss(net(x, f), y)
+        loss.backward()
+        dp.all_reduce()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    # pick the dominant own kernel (untimed 2-step pre-pass with every entry point bracketed by events)
+    target = args.roofline_kernel
+    if target == "auto":
+        _lib.PROFILER = _lib.KernelTimer()
+        step(0); step(1)
+        torch.cuda.synchronize()
+        summ = _lib.PROFILER.summary()
+        _lib.PROFILER = None
+        target = max(summ.items(), key=lambda kv: kv[1]["total_ms"])[0] if summ else None
+    elif target != "none":
+        target = (target, None)
+    timer = None
+    if target:
+        timer = _lib.KernelTimer([target[0]])
+        _lib.PROFILER = timer
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    _lib.PROFILER = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        roofline = None
+        if timer is not None:
+            summ = timer.summary()
+            key = target if target[1] is not None and target in summ else max(summ, key=lambda k: summ[k]["total_ms"])
+            r = summ[key]
+            bound = BOUND.get(key[0], "hbm")
+            if bound == "hbm":
+                ach = r["algo_bytes"] / (r["avg_ms"] * 1e-3) / 1e9
+                peak, unit = HBM_PEAK_GBS, "GB/s"
+            else:
+                ach = r["algo_flops"] / (r["avg_ms"] * 1e-3) / 1e12
+                peak, unit = FP32_PEAK_TFLOPS, "TFLOP/s"
+            roofline = {"kernel": key[0], "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
+                        "frac": round(ach / peak, 5), "traffic": None, "avg_launch_ms": round(r["avg_ms"], 5),
+                        "launches": r["launches"], "algo_bytes_per_launch": r["algo_bytes"],
+                        "algo_flops_per_launch": r["algo_flops"]}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(state0, B, N)
+        value = world * B * args.steps / dt
+        line = {
+            "metric": "point-clouds/sec fwd+bwd, PointNet++ SSG B=32 N=1024", "value": round(value, 2),
+            "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"PointNet++ SSG cls train step (fwd+bwd+SGD), B={B}/GPU, N={N} xyz+normal, "
+                                   "gauss_ball clouds (BASELINE configs[1])",
+                       "global_batch": world * B, "n_points": N, "parallelism": f"dp{world}",
+                       "grad_bucket_bytes": dp.nbytes},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

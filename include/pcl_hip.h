@@ -1,0 +1,115 @@
+/*
+ * pcl_hip.h -- C ABI of libpcl_hip.so: the MI355X (gfx950) implementation of the
+ * point-cloud hot path of Jittor/PointCloudLib.
+ *
+ * Boundary replaced: the reference reaches its three native kernels through Jittor's inline-op
+ * FFI  jt.code(out_shapes, out_dtypes, inputs, cuda_src=...)  (misc/ops.py:278, :376-381,
+ * :656-662), which hands the CUDA text raw device pointers (in0_p, out0_p, ...) and shapes
+ * (in0_shape0, ...).  The entry points below are what a `jt.code`-style binding (or any FFI:
+ * ctypes, cgo, JNI) would call instead: plain device pointers + sizes + a HIP stream, no
+ * framework types.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless said otherwise; fp32 data, int32 indices,
+ *    row-major, channel-last ([B,N,3], [B,N,C]) exactly as the reference's modules pass them;
+ *  - the caller owns all buffers; the library never allocates, frees or synchronises; work is
+ *    enqueued on `stream` (a hipStream_t passed as void*, NULL = default stream);
+ *  - every output element is defined on return (the reference leaves some rows uninitialised);
+ *  - return value: PCL_OK (0) or a negative PCL_E* code; pcl_last_error() gives a thread-local
+ *    message for the last failure.
+ */
+#ifndef PCL_HIP_H
+#define PCL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCL_OK 0
+#define PCL_EINVAL (-1)   /* bad argument (null pointer, size out of range, ...) */
+#define PCL_EHIP (-2)     /* HIP runtime / launch error                           */
+#define PCL_ENOSUP (-3)   /* valid request this build cannot serve (size limits)  */
+#define PCL_EWS (-4)      /* workspace too small                                  */
+
+int pcl_version(void);
+const char* pcl_last_error(void);
+
+/* misc/ops.py:110-111  optimal_block(): 2 ** int(ln(batch_size)).  The reference launches FPS and
+ * ball query with this many threads per block; for FPS it decides how exact distance ties are
+ * broken, so callers that want reference-identical sampling pass it as `tie_stride`. */
+int pcl_optimal_block(int batch_size);
+
+/* ---- farthest point sampling -----------------------------------------------------------------
+ * Replaces FurthestPointSampler's jt.code kernel, misc/ops.py:124-234 (launch :236-251), and the
+ * gather of :280-284.
+ *   xyz [B,N,3] -> idx_out [B,m] int32, new_xyz_out [B,m,3] (nullable).
+ *   tie_stride     power of two in [1,512]: exact ties go to the smallest
+ *                  (bitreverse_{log2 S}(k mod S), k) -- the order the reference's S-thread block
+ *                  reduction produces (S = pcl_optimal_block(B)); 1 = lowest index wins.
+ *   skip_sqnorm_le points with (double)(x*x+y*y+z*z) <= this are never sampled and never updated
+ *                  (misc/ops.py:162-163 uses 1e-3, a double literal); negative disables the rule
+ *                  (misc/pointconv_utils.py:74-116 has none).
+ *   start_idx      [B] first sample per cloud, nullable = 0 (misc/ops.py:143; pointconv draws it
+ *                  at random, pointconv_utils.py:88).
+ * Requires 1 <= m <= N. */
+int pcl_fps_f32(const float* xyz, int B, int N, int m, int tie_stride, double skip_sqnorm_le,
+                const int32_t* start_idx, int32_t* idx_out, float* new_xyz_out, void* stream);
+
+/* ---- ball query -------------------------------------------------------------------------------
+ * Replaces query_ball_point_kernel, misc/ops.py:291-330 (launch :332-337).
+ *   new_xyz [B,m,3], xyz [B,N,3] -> idx_out [B,m,nsample], cnt_out [B,m] (nullable).
+ * First `nsample` indices k (ascending) with d2 < fl(radius*radius), padded with the first hit;
+ * rows without any hit are zero-filled with cnt 0 (undefined in the reference). */
+int pcl_ball_query_f32(const float* new_xyz, const float* xyz, int B, int m, int N, float radius,
+                       int nsample, int32_t* idx_out, int32_t* cnt_out, void* stream);
+
+/* ---- grouping ---------------------------------------------------------------------------------
+ * Replaces the three Var.reindex gathers + subtract + concat of BallQueryGrouper.execute,
+ * misc/ops.py:383-407.   out [B,m,ns,D], D = (use_xyz?3:0)+C, channel order [xyz-new_xyz, feat].
+ * feat nullable when C == 0.  pcl_group_bwd_f32 is the gradient w.r.t. feat (scatter-add, the
+ * gradient of reindex); it zero-fills gfeat [B,N,C] itself. */
+int pcl_group_f32(const float* xyz, const float* new_xyz, const float* feat, const int32_t* idx,
+                  int B, int N, int m, int ns, int C, int use_xyz, float* out, void* stream);
+int pcl_group_bwd_f32(const float* gout, const int32_t* idx, int B, int N, int m, int ns, int C,
+                      int use_xyz, float* gfeat, void* stream);
+/* GroupAll.execute, misc/ops.py:415-419: out [B,1,N,D] = concat(xyz, feat), xyz not re-centred. */
+int pcl_group_all_f32(const float* xyz, const float* feat, int B, int N, int C, int use_xyz,
+                      float* out, void* stream);
+int pcl_group_all_bwd_f32(const float* gout, int B, int N, int C, int use_xyz, float* gfeat,
+                          void* stream);
+/* Plain row gather out[b,i,:] = src[b,idx[b,i],:]  (index_points, misc/ops.py:12-27) and its
+ * scatter-add gradient (zero-fills gsrc). */
+int pcl_gather_rows_f32(const float* src, const int32_t* idx, int B, int N, int M, int C, float* out,
+                        void* stream);
+int pcl_gather_rows_bwd_f32(const float* gout, const int32_t* idx, int B, int N, int M, int C,
+                            float* gsrc, void* stream);
+
+/* ---- brute-force k-NN -------------------------------------------------------------------------
+ * Replaces knn_cuda_global (compute_distances + modified_insertion_sort), misc/ops.py:429-638.
+ *   ref [B,C,Nr] (the reference's in0 = x_r), qry [B,C,Nq] (in1 = x_q), channel-major
+ *   -> idx_out [B,k,Nq] int32: the k nearest refs of each query, ascending by
+ *   (sum_c (ref-qry)^2 accumulated in ascending c, index).
+ * The reference takes an uninitialised [B,Nr,Nq] scratch as a third input (misc/ops.py:655); here
+ * the caller provides `workspace` of at least pcl_knn_workspace_bytes(...) bytes. */
+size_t pcl_knn_workspace_bytes(int B, int C, int Nr, int Nq, int k);
+int pcl_knn_f32(const float* ref, const float* qry, int B, int C, int Nr, int Nq, int k,
+                int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- 3-NN inverse-distance interpolation (PointNetFeaturePropagation, misc/ops.py:83-93) -----
+ *   xyz1 [B,N,3] (targets), xyz2 [B,S,3] (sources) -> idx3 [B,N,3], w3 [B,N,3]
+ *   (3 nearest by (direct-form d2, index); w = 1/(d2+1e-8) normalised; S==1 -> idx 0, w (1,0,0)).
+ *   interp fwd: out[b,n,:] = sum_j w3[b,n,j] * points2[b,idx3[b,n,j],:];  bwd zero-fills gpoints2. */
+int pcl_three_nn_f32(const float* xyz1, const float* xyz2, int B, int N, int S, int32_t* idx3,
+                     float* w3, void* stream);
+int pcl_three_interp_f32(const float* points2, const int32_t* idx3, const float* w3, int B, int N,
+                         int S, int D, float* out, void* stream);
+int pcl_three_interp_bwd_f32(const float* gout, const int32_t* idx3, const float* w3, int B, int N,
+                             int S, int D, float* gpoints2, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCL_HIP_H */

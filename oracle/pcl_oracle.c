@@ -1,0 +1,342 @@
+/*
+ * pcl_oracle.c -- CPU restatement of the reference's point-cloud hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under pointcloudlib_amd/ may import, link
+ * or call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and there only as the checker / the CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (Jittor/PointCloudLib) ships no golden
+ * vectors, no tests and no CPU path for these ops (they exist only as CUDA
+ * strings handed to jt.code, misc/ops.py:278,376,656) and Jittor is not
+ * installable here.  This file restates the *source-level* semantics of that
+ * CUDA text in plain C, one function per kernel, single-rounded IEEE fp32
+ * operations in the order the source writes them (compile with
+ * -ffp-contract=off; what nvcc's default -fmad=true did to the original is
+ * not knowable here).  It is cross-checked against an independent NumPy
+ * restatement (oracle/np_oracle.py) and hand-derived known answers
+ * (tests/test_oracle_kat.py).
+ *
+ * All citations are into /root/reference/.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PCLO_OK 0
+#define PCLO_EINVAL -1
+#define PCLO_ENOMEM -2
+
+int pclo_version(void) { return 1; }
+
+int pclo_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* misc/ops.py:110-111  optimal_block(batch_size) = 2 ** int(math.log(batch_size))
+ * (natural log -- reproduced as written).  */
+int pclo_optimal_block(int batch_size) {
+    if (batch_size < 1) return 1;
+    int e = (int)log((double)batch_size);
+    return 1 << e;
+}
+
+/* ------------------------------------------------------------------------- *
+ * FPS: thread-level emulation of furthest_point_sampling_kernel,
+ * misc/ops.py:124-234 (+ __update :116-122), one "block" per cloud, with
+ * `block_size` emulated threads executed in tid order between barriers.
+ *
+ *  skip_enabled  : 1 -> the `mag <= 1e-3` skip of :162-163 (double compare,
+ *                  the literal is a double in the source)
+ *                  0 -> no skip (misc/pointconv_utils.py:74-116 variant)
+ *  start_idx     : per-cloud first index (NULL -> 0 as in :143-144);
+ *                  pointconv_utils.py:88 draws it at random.
+ * Outputs idx[B,m] and, when new_xyz != NULL, the gathered coordinates
+ * (the reindex at misc/ops.py:280-284).
+ * ------------------------------------------------------------------------- */
+int pclo_fps_f32(const float* xyz, int B, int N, int m, int block_size, int skip_enabled,
+                 const int32_t* start_idx, int32_t* idx, float* new_xyz) {
+    if (!xyz || !idx || B < 0 || N < 1 || m < 0 || m > N) return PCLO_EINVAL;
+    if (block_size < 1 || block_size > 512 || (block_size & (block_size - 1))) return PCLO_EINVAL;
+    int rc = PCLO_OK;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b) {
+        const float* dataset = xyz + (size_t)b * N * 3;
+        int32_t* idxs = idx + (size_t)b * m;
+        if (m <= 0) continue;                                   /* :130 */
+        float* temp = (float*)malloc(sizeof(float) * (size_t)N);
+        float* dists = (float*)malloc(sizeof(float) * (size_t)block_size);
+        int* dists_i = (int*)malloc(sizeof(int) * (size_t)block_size);
+        if (!temp || !dists || !dists_i) { rc = PCLO_ENOMEM; free(temp); free(dists); free(dists_i); continue; }
+        const int stride = block_size;                          /* :141 */
+        int old = start_idx ? start_idx[b] : 0;                 /* :143 */
+        idxs[0] = old;                                          /* :144 */
+        for (int k = 0; k < N; ++k) temp[k] = 1e10f;            /* :147-148 */
+        for (int j = 1; j < m; ++j) {                           /* :151 */
+            const float x1 = dataset[old * 3 + 0];
+            const float y1 = dataset[old * 3 + 1];
+            const float z1 = dataset[old * 3 + 2];
+            for (int tid = 0; tid < block_size; ++tid) {
+                int besti = 0;                                  /* :152 */
+                float best = -1.0f;                             /* :153 */
+                for (int k = tid; k < N; k += stride) {         /* :157 */
+                    const float x2 = dataset[k * 3 + 0];
+                    const float y2 = dataset[k * 3 + 1];
+                    const float z2 = dataset[k * 3 + 2];
+                    if (skip_enabled) {
+                        const float mag = (x2 * x2) + (y2 * y2) + (z2 * z2);   /* :162 */
+                        if ((double)mag <= 1e-3) continue;                     /* :163 */
+                    }
+                    const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) +
+                                    (z2 - z1) * (z2 - z1);                     /* :165 */
+                    const float d2 = fminf(d, temp[k]);                        /* :167 */
+                    temp[k] = d2;
+                    besti = d2 > best ? k : besti;                             /* :169 */
+                    best = d2 > best ? d2 : best;                              /* :170 */
+                }
+                dists[tid] = best;                              /* :172 */
+                dists_i[tid] = besti;                           /* :173 */
+            }
+            /* tree :176-229: for s = 256,128,...,1 (those < block_size):
+             *   if (tid < s) __update(tid, tid+s)                            */
+            for (int s = block_size >> 1; s >= 1; s >>= 1) {
+                for (int tid = 0; tid < s; ++tid) {
+                    const float v1 = dists[tid], v2 = dists[tid + s];          /* :118 */
+                    const int i1 = dists_i[tid], i2 = dists_i[tid + s];
+                    dists[tid] = fmaxf(v1, v2);                                /* :120 */
+                    dists_i[tid] = v2 > v1 ? i2 : i1;                          /* :121 */
+                }
+            }
+            old = dists_i[0];                                   /* :231 */
+            idxs[j] = old;                                      /* :232 */
+        }
+        free(temp); free(dists); free(dists_i);
+        if (new_xyz) {                                          /* :280-284 */
+            float* o = new_xyz + (size_t)b * m * 3;
+            for (int j = 0; j < m; ++j)
+                for (int c = 0; c < 3; ++c) o[j * 3 + c] = dataset[idxs[j] * 3 + c];
+        }
+    }
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- *
+ * Ball query: query_ball_point_kernel, misc/ops.py:291-330.
+ * `radius` arrives as float (the text splice `#radius` at :370 becomes a
+ * double literal converted to the kernel's `float radius` parameter);
+ * radius2 = radius*radius in fp32 (:306); strict `<` (:320).
+ * A query with no hit leaves its row unwritten in the reference; here (and
+ * in the HIP library) such rows are defined as all-zero, cnt = 0.
+ * ------------------------------------------------------------------------- */
+int pclo_ball_query_f32(const float* new_xyz, const float* xyz, int B, int m, int N, float radius,
+                        int nsample, int32_t* idx, int32_t* cnt_out) {
+    if (!new_xyz || !xyz || !idx || B < 0 || m < 0 || N < 1 || nsample < 1) return PCLO_EINVAL;
+    const float radius2 = radius * radius;                                    /* :306 */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b) {
+        const float* P = xyz + (size_t)b * N * 3;
+        const float* Q = new_xyz + (size_t)b * m * 3;
+        int32_t* I = idx + (size_t)b * m * nsample;
+        for (int j = 0; j < m; ++j) {                                         /* :307 */
+            const float new_x = Q[j * 3 + 0], new_y = Q[j * 3 + 1], new_z = Q[j * 3 + 2];
+            int cnt = 0;                                                      /* :311 */
+            for (int l = 0; l < nsample; ++l) I[j * nsample + l] = 0;         /* defined fill */
+            for (int k = 0; k < N && cnt < nsample; ++k) {                    /* :313 */
+                const float x = P[k * 3 + 0], y = P[k * 3 + 1], z = P[k * 3 + 2];
+                const float d2 = (new_x - x) * (new_x - x) + (new_y - y) * (new_y - y) +
+                                 (new_z - z) * (new_z - z);                   /* :317-318 */
+                if (d2 < radius2) {                                           /* :320 */
+                    if (cnt == 0)
+                        for (int l = 0; l < nsample; ++l) I[j * nsample + l] = k;   /* :321-324 */
+                    I[j * nsample + cnt] = k;                                 /* :325 */
+                    ++cnt;
+                }
+            }
+            if (cnt_out) cnt_out[(size_t)b * m + j] = cnt;
+        }
+    }
+    return PCLO_OK;
+}
+
+/* ------------------------------------------------------------------------- *
+ * Grouping: BallQueryGrouper.execute, misc/ops.py:383-407.
+ *  out[b,j,s,:] = concat(xyz[b,idx]-new_xyz[b,j]  (if use_xyz),  feat[b,idx,:])
+ * channel order [local_xyz(3), feature(C)] (:403).  feat may be NULL (C=0).
+ * ------------------------------------------------------------------------- */
+int pclo_group_f32(const float* xyz, const float* new_xyz, const float* feat, const int32_t* idx,
+                   int B, int N, int m, int ns, int C, int use_xyz, float* out) {
+    if (!idx || !out || (use_xyz && (!xyz || !new_xyz)) || (C > 0 && !feat)) return PCLO_EINVAL;
+    const int D = (use_xyz ? 3 : 0) + C;
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        for (int j = 0; j < m; ++j)
+            for (int s = 0; s < ns; ++s) {
+                const int k = idx[((size_t)b * m + j) * ns + s];
+                float* o = out + (((size_t)b * m + j) * ns + s) * D;
+                int off = 0;
+                if (use_xyz) {
+                    for (int c = 0; c < 3; ++c)
+                        o[c] = xyz[((size_t)b * N + k) * 3 + c] - new_xyz[((size_t)b * m + j) * 3 + c]; /* :401 */
+                    off = 3;
+                }
+                for (int c = 0; c < C; ++c) o[off + c] = feat[((size_t)b * N + k) * C + c];   /* :392-396 */
+            }
+    }
+    return PCLO_OK;
+}
+
+/* Gradient of pclo_group_f32 w.r.t. feat: scatter-add (Var.reindex's grad). Sequential order
+ * (b, j, s ascending) -- an fp32 sum; the HIP path uses atomics so parity is to tolerance. */
+int pclo_group_bwd_f32(const float* gout, const int32_t* idx, int B, int N, int m, int ns, int C,
+                       int use_xyz, float* gfeat) {
+    if (!gout || !idx || !gfeat || C < 1) return PCLO_EINVAL;
+    const int D = (use_xyz ? 3 : 0) + C, off = use_xyz ? 3 : 0;
+    memset(gfeat, 0, sizeof(float) * (size_t)B * N * C);
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < m; ++j)
+            for (int s = 0; s < ns; ++s) {
+                const int k = idx[((size_t)b * m + j) * ns + s];
+                const float* g = gout + (((size_t)b * m + j) * ns + s) * D + off;
+                float* d = gfeat + ((size_t)b * N + k) * C;
+                for (int c = 0; c < C; ++c) d[c] += g[c];
+            }
+    return PCLO_OK;
+}
+
+/* GroupAll.execute, misc/ops.py:415-419: concat([pointset, feature], -1).unsqueeze(1),
+ * xyz NOT re-centred. */
+int pclo_group_all_f32(const float* xyz, const float* feat, int B, int N, int C, int use_xyz,
+                       float* out) {
+    if (!out || (use_xyz && !xyz) || (C > 0 && !feat)) return PCLO_EINVAL;
+    const int D = (use_xyz ? 3 : 0) + C, off = use_xyz ? 3 : 0;
+    for (size_t p = 0; p < (size_t)B * N; ++p) {
+        if (use_xyz) for (int c = 0; c < 3; ++c) out[p * D + c] = xyz[p * 3 + c];
+        for (int c = 0; c < C; ++c) out[p * D + off + c] = feat[p * C + c];
+    }
+    return PCLO_OK;
+}
+
+/* ------------------------------------------------------------------------- *
+ * KNN: knn_cuda_global, misc/ops.py:562-638
+ *   compute_distances (:429-502): dist[b,r,q] = sum_c (ref[b,c,r]-qry[b,c,q])^2,
+ *     `ssd += tmp*tmp` in ascending c (:488-491); the zero-padded tail of the
+ *     last 16-wide tile adds exact zeros.
+ *   modified_insertion_sort (:504-552), literally, per (b,q) column.
+ * ref  = x_r [B,C,Nr]  (in0),  qry = x_q [B,C,Nq] (in1)  (:642-649, :651-663)
+ * out idx[B,k,Nq]; `dist_scratch` [B,Nr,Nq] as in the reference (sorted
+ * distances end up in its first k rows), allocated here when NULL.
+ * ------------------------------------------------------------------------- */
+int pclo_knn_f32(const float* ref, const float* qry, int B, int C, int Nr, int Nq, int k,
+                 int32_t* idx, float* dist_scratch) {
+    if (!ref || !qry || !idx || B < 0 || C < 1 || Nr < 1 || Nq < 1 || k < 1 || k > Nr) return PCLO_EINVAL;
+    float* dist = dist_scratch;
+    if (!dist) {
+        dist = (float*)malloc(sizeof(float) * (size_t)B * Nr * Nq);
+        if (!dist) return PCLO_ENOMEM;
+    }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b) {
+        const float* R = ref + (size_t)b * C * Nr;
+        const float* Q = qry + (size_t)b * C * Nq;
+        float* D = dist + (size_t)b * Nr * Nq;
+        for (int r = 0; r < Nr; ++r)
+            for (int q = 0; q < Nq; ++q) {
+                float ssd = 0.f;                                              /* :456 */
+                for (int c = 0; c < C; ++c) {
+                    const float tmp = R[(size_t)c * Nr + r] - Q[(size_t)c * Nq + q];   /* :489 */
+                    ssd += tmp * tmp;                                         /* :490 */
+                }
+                D[(size_t)r * Nq + q] = ssd;                                  /* :500 */
+            }
+        const int index_pitch = Nq, height = Nr;
+        for (int x = 0; x < Nq; ++x) {                                        /* :514-518 */
+            float* p_dist = D + x;                                            /* :521 */
+            int32_t* p_index = idx + x + (size_t)b * index_pitch * k;         /* :522 */
+            p_index[0] = 0;                                                   /* :525 */
+            for (int i = 1; i < height; ++i) {                                /* :528 */
+                const float curr_dist = p_dist[(size_t)i * index_pitch];
+                const int curr_index = i;
+                if (i >= k && curr_dist >= p_dist[(size_t)(k - 1) * index_pitch]) continue;   /* :535 */
+                int j = i < k - 1 ? i : k - 1;                                /* :540 */
+                while (j > 0 && p_dist[(size_t)(j - 1) * index_pitch] > curr_dist) {          /* :541 */
+                    p_dist[(size_t)j * index_pitch] = p_dist[(size_t)(j - 1) * index_pitch];
+                    p_index[(size_t)j * index_pitch] = p_index[(size_t)(j - 1) * index_pitch];
+                    --j;
+                }
+                p_dist[(size_t)j * index_pitch] = curr_dist;                  /* :548 */
+                p_index[(size_t)j * index_pitch] = curr_index;                /* :549 */
+            }
+        }
+    }
+    if (!dist_scratch) free(dist);
+    return PCLO_OK;
+}
+
+/* ------------------------------------------------------------------------- *
+ * 3-NN inverse-distance interpolation: PointNetFeaturePropagation.execute,
+ * misc/ops.py:66-107 (interpolation part :83-93).
+ * The reference computes distances in matmul form (:48-50) and takes the
+ * first 3 of a full jt.argsort (:87-88): parity unpinned (Jittor's argsort
+ * tie order and matmul rounding are not reproducible).  DEFINED here, and in
+ * the HIP library, as: direct-form d = (x1-x2)^2+(y1-y2)^2+(z1-z2)^2 in source
+ * order, 3 smallest by (d, index) ascending; weights 1/(d+1e-8) normalised
+ * (:90-92).  S == 1 -> broadcast (:83-84): idx = 0, w = (1,0,0).
+ * Requires S >= 3 or S == 1 (S == 2: third neighbour repeats the second).
+ * ------------------------------------------------------------------------- */
+int pclo_three_nn_f32(const float* xyz1, const float* xyz2, int B, int N, int S, int32_t* idx3,
+                      float* w3) {
+    if (!xyz1 || !xyz2 || !idx3 || !w3 || S < 1) return PCLO_EINVAL;
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n) {
+            const float* p = xyz1 + ((size_t)b * N + n) * 3;
+            int32_t* oi = idx3 + ((size_t)b * N + n) * 3;
+            float* ow = w3 + ((size_t)b * N + n) * 3;
+            if (S == 1) { oi[0] = oi[1] = oi[2] = 0; ow[0] = 1.f; ow[1] = ow[2] = 0.f; continue; }
+            float bd[3] = {INFINITY, INFINITY, INFINITY};
+            int bi[3] = {0, 0, 0};
+            for (int s = 0; s < S; ++s) {
+                const float* q = xyz2 + ((size_t)b * S + s) * 3;
+                const float d = (p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) +
+                                (p[2] - q[2]) * (p[2] - q[2]);
+                if (d < bd[0]) { bd[2] = bd[1]; bi[2] = bi[1]; bd[1] = bd[0]; bi[1] = bi[0]; bd[0] = d; bi[0] = s; }
+                else if (d < bd[1]) { bd[2] = bd[1]; bi[2] = bi[1]; bd[1] = d; bi[1] = s; }
+                else if (d < bd[2]) { bd[2] = d; bi[2] = s; }
+            }
+            if (S == 2) { bd[2] = bd[1]; bi[2] = bi[1]; }
+            const float r0 = 1.0f / (bd[0] + 1e-8f), r1 = 1.0f / (bd[1] + 1e-8f), r2 = 1.0f / (bd[2] + 1e-8f); /* :90 */
+            const float norm = (r0 + r1) + r2;                                                              /* :91 */
+            oi[0] = bi[0]; oi[1] = bi[1]; oi[2] = bi[2];
+            ow[0] = r0 / norm; ow[1] = r1 / norm; ow[2] = r2 / norm;                                        /* :92 */
+        }
+    return PCLO_OK;
+}
+
+/* interpolated[b,n,:] = sum_j points2[b,idx3[b,n,j],:] * w3[b,n,j]  (:93), j ascending. */
+int pclo_three_interp_f32(const float* points2, const int32_t* idx3, const float* w3, int B, int N,
+                          int S, int D, float* out) {
+    if (!points2 || !idx3 || !w3 || !out) return PCLO_EINVAL;
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n) {
+            const int32_t* ii = idx3 + ((size_t)b * N + n) * 3;
+            const float* ww = w3 + ((size_t)b * N + n) * 3;
+            float* o = out + ((size_t)b * N + n) * D;
+            for (int c = 0; c < D; ++c) {
+                float acc = points2[((size_t)b * S + ii[0]) * D + c] * ww[0];
+                acc = acc + points2[((size_t)b * S + ii[1]) * D + c] * ww[1];
+                acc = acc + points2[((size_t)b * S + ii[2]) * D + c] * ww[2];
+                o[c] = acc;
+            }
+        }
+    return PCLO_OK;
+}

@@ -1,0 +1,134 @@
+"""ctypes loader of ``libpcl_hip.so`` (the C ABI declared in ``include/pcl_hip.h``).
+
+There is NO fallback: if the HIP library is missing or a call fails, we raise.  The CPU oracle under
+``oracle/`` is test infrastructure and is never imported from here.
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_PKG, "libpcl_hip.so")
+_HEADER = os.path.join(os.path.dirname(_PKG), "include", "pcl_hip.h")
+_lib = None
+
+c_void_p, c_int, c_float, c_double, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
+                                                ctypes.c_double, ctypes.c_size_t)
+
+
+class PclError(RuntimeError):
+    pass
+
+
+def so_path():
+    return _SO
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into ``pointcloudlib_amd/libpcl_hip.so`` (in-tree)."""
+    cmd = ["make", "-C", os.path.join(_PKG, "csrc"), "-j8"]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return _SO
+
+
+def declared_symbols():
+    """Every function name ``include/pcl_hip.h`` declares (used by the symbol-export test)."""
+    txt = open(_HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pcl_[a-z0-9_]+)\s*\(", txt)))
+
+
+_P = c_void_p
+_SIGS = {
+    "pcl_version": (c_int, []),
+    "pcl_last_error": (ctypes.c_char_p, []),
+    "pcl_optimal_block": (c_int, [c_int]),
+    "pcl_fps_f32": (c_int, [_P, c_int, c_int, c_int, c_int, c_double, _P, _P, _P, _P]),
+    "pcl_ball_query_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),
+    "pcl_group_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcl_group_bwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcl_group_all_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcl_group_all_bwd_f32": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcl_gather_rows_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcl_gather_rows_bwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcl_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "pcl_knn_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
+    "pcl_three_nn_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "pcl_three_interp_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcl_three_interp_bwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+}
+
+
+def lib():
+    """The loaded library; raises PclError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise PclError(f"{_SO} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = ctypes.CDLL(_SO)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().pcl_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise PclError(f"{what}: rc={rc}: {msg}")
+
+
+# ---------------------------------------------------------------- per-kernel event timing (bench.py)
+PROFILER = None   # set to a KernelTimer by bench.py; None in normal operation (zero overhead)
+
+
+class KernelTimer:
+    """Brackets selected C-ABI calls with HIP events on the stream they are launched on (torch's current
+    stream) and accumulates per-entry-point time plus the algorithmic bytes/flops the caller states."""
+
+    def __init__(self, names=None):
+        self.names = None if names is None else set(names)
+        self.records = {}
+
+    def want(self, name):
+        return self.names is None or name in self.names
+
+    def begin(self):
+        import torch
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, name, tag, start, algo_bytes, algo_flops):
+        import torch
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.records.setdefault((name, tag), []).append((start, ev, algo_bytes, algo_flops))
+
+    def summary(self):
+        """{(name, tag): dict(launches, avg_ms, algo_bytes, algo_flops)} -- call after a device sync."""
+        out = {}
+        for key, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _, _ in recs]
+            out[key] = {"launches": len(recs), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms),
+                        "algo_bytes": recs[0][2], "algo_flops": recs[0][3]}
+        return out
+
+
+def call(name, *args, algo_bytes=0, algo_flops=0, tag=""):
+    """Invoke one C-ABI entry point; raises on a non-zero return code."""
+    fn = getattr(lib(), name)
+    prof = PROFILER
+    if prof is not None and prof.want(name):
+        start = prof.begin()
+        rc = fn(*args)
+        prof.end(name, tag or f"{algo_bytes}", start, algo_bytes, algo_flops)
+    else:
+        rc = fn(*args)
+    check(rc, name)

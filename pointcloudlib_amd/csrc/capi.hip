@@ -1,0 +1,23 @@
+// capi.hip -- library-level entry points of libpcl_hip.so (version, error string, launch helper).
+#include "common.h"
+#include <math.h>
+#include <string.h>
+
+namespace pcl {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+}  // namespace pcl
+
+extern "C" int pcl_version(void) { return 100; }   // 0.1.0
+extern "C" const char* pcl_last_error(void) { return pcl::g_err; }
+
+// misc/ops.py:110-111: 2 ** int(math.log(batch_size)) -- natural log, as written.
+extern "C" int pcl_optimal_block(int batch_size) {
+    if (batch_size < 1) return 1;
+    return 1 << (int)log((double)batch_size);
+}

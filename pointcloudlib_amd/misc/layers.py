@@ -1,0 +1,109 @@
+"""Per-group pointwise MLP blocks -- host-side mirror of the 1x1-conv + BatchNorm + activation stacks
+of the reference (``build_mlps`` networks/cls/pointnet2.py:18-31; ``Dense_Conv1d/2d``, ``Conv``
+misc/layers.py:173-270; DGCNN conv1-4 networks/cls/dgcnn.py:72-83).
+
+The reference transposes to NCHW and calls ``nn.Conv(kernel_size=1)``; a 1x1 conv is a row-wise linear
+map, so here activations stay channel-last ``[..., C]`` and each layer is ``Y = X W^T (+b)`` over
+P = prod(leading dims) rows, followed by training-mode BatchNorm over all P rows and ReLU/LeakyReLU.
+
+BatchNorm semantics (Jittor's ``nn.BatchNorm``): batch mean and *biased*
+variance ``max(E[x^2]-E[x]^2, 0)``, eps 1e-5, running stats ``r += (batch - r) * momentum`` with
+momentum 0.1 and the biased variance; affine gamma=1, beta=0 at init.
+
+Two backends with identical parameters:
+  * ``hip``   -- fused gfx950 kernels of libpcl_hip.so (default whenever the input is on the GPU);
+  * ``torch`` -- plain PyTorch fp32 ops; the numerics reference for the tests, never a fallback.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+__all__ = ["PointwiseMLP", "batch_norm_train", "max_over_group"]
+
+
+def batch_norm_train(x2d, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5):
+    """BatchNorm over the rows of ``x2d`` [P,C] with Jittor's running-stat rule (biased variance)."""
+    if not training:
+        return F.batch_norm(x2d, running_mean, running_var, gamma, beta, False, 0.0, eps)
+    with torch.no_grad():
+        var, mean = torch.var_mean(x2d, dim=0, unbiased=False)
+        running_mean += (mean - running_mean) * momentum
+        running_var += (var - running_var) * momentum
+    return F.batch_norm(x2d, None, None, gamma, beta, True, 0.0, eps)
+
+
+def max_over_group(x, dim):
+    """``Var.argmax(dim)[1]`` (networks/cls/pointnet2.py:57) / ``x.max(dim=-1)`` (dgcnn.py:102): max VALUE."""
+    return x.max(dim=dim)[0]
+
+
+class PointwiseMLP(nn.Module):
+    """Stack of [Linear(Cin->Cout, bias) -> BatchNorm(train) -> (Leaky)ReLU] on channel-last rows.
+
+    ``spec`` = [C0, C1, ..., CL].  ``bias=False`` mirrors ``nn.Conv(..., bias=not bn)``
+    (networks/cls/pointnet2.py:26); ``slope`` 0 = ReLU, 0.2 = DGCNN's LeakyReLU."""
+
+    def __init__(self, spec, bias=False, bn=True, slope=0.0, momentum=0.1, eps=1e-5, backend="auto",
+                 last_act=True):
+        super().__init__()
+        self.spec = list(spec)
+        self.bn = bn
+        self.slope = float(slope)
+        self.momentum = momentum
+        self.eps = eps
+        self.backend = backend
+        self.last_act = last_act
+        self.weights = nn.ParameterList()
+        self.biases = nn.ParameterList() if bias else None
+        self.gammas = nn.ParameterList()
+        self.betas = nn.ParameterList()
+        for i in range(1, len(spec)):
+            cin, cout = spec[i - 1], spec[i]
+            w = torch.empty(cout, cin)
+            nn.init.kaiming_uniform_(w, a=math.sqrt(5))          # torch's Conv/Linear default
+            self.weights.append(nn.Parameter(w))
+            if bias:
+                bound = 1.0 / math.sqrt(cin)
+                self.biases.append(nn.Parameter(torch.empty(cout).uniform_(-bound, bound)))
+            if bn:
+                self.gammas.append(nn.Parameter(torch.ones(cout)))
+                self.betas.append(nn.Parameter(torch.zeros(cout)))
+                self.register_buffer(f"running_mean_{i - 1}", torch.zeros(cout))
+                self.register_buffer(f"running_var_{i - 1}", torch.ones(cout))
+
+    @property
+    def n_layers(self):
+        return len(self.weights)
+
+    def _act(self, y):
+        return F.relu(y) if self.slope == 0.0 else F.leaky_relu(y, self.slope)
+
+    def forward_torch(self, x):
+        lead = x.shape[:-1]
+        y = x.reshape(-1, x.shape[-1])
+        for i in range(self.n_layers):
+            y = F.linear(y, self.weights[i], None if self.biases is None else self.biases[i])
+            if self.bn:
+                y = batch_norm_train(y, self.gammas[i], self.betas[i], getattr(self, f"running_mean_{i}"),
+                                     getattr(self, f"running_var_{i}"), self.training, self.momentum, self.eps)
+            if i < self.n_layers - 1 or self.last_act:
+                y = self._act(y)
+        return y.reshape(*lead, y.shape[-1])
+
+    def forward(self, x, group_max=None):
+        """x [..., C0] -> [..., CL]; with ``group_max=ns`` the rows are groups of ns consecutive rows and
+        the result is max-reduced over each group ([B,m,ns,C] -> [B,m,C])."""
+        backend = self.backend
+        if backend == "auto":
+            backend = "hip" if x.is_cuda else "torch"
+        if backend == "hip":
+            from . import mlp_hip
+            if mlp_hip.available():
+                return mlp_hip.pointwise_mlp(self, x, group_max)
+        y = self.forward_torch(x)
+        if group_max is not None:
+            assert x.shape[-2] == group_max
+            y = max_over_group(y, dim=-2)
+        return y

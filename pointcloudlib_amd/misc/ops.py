@@ -1,0 +1,322 @@
+"""Point-cloud operators -- host-side mirror of the reference's ``misc/ops.py``.
+
+Same class names, constructor arguments, call arguments, shapes, dtypes and channel-last layouts as
+/root/reference/misc/ops.py (FurthestPointSampler :114, BallQueryGrouper :289, GroupAll :410,
+KNN :422, PointNetFeaturePropagation :54, index_points :12), written as ``torch.nn.Module``s with an
+``execute`` alias for Jittor's method name.  All arithmetic runs in ``libpcl_hip.so`` (hand-written
+gfx950 kernels) through the C ABI of ``include/pcl_hip.h``; PyTorch only owns the device buffers, the
+stream and autograd bookkeeping.  CPU tensors are rejected: there is no fallback path.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import _lib
+
+__all__ = [
+    "optimal_block", "furthest_point_sample", "ball_query", "group_points", "group_all", "index_points",
+    "knn_indices", "three_nn", "three_interpolate", "FurthestPointSampler", "BallQueryGrouper", "GroupAll",
+    "KNN", "PointNetFeaturePropagation",
+]
+
+
+# ----------------------------------------------------------------------------- plumbing
+def _dev(t, name, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the GPU (libpcl_hip has no CPU path), got {t.device}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def optimal_block(batch_size):
+    """misc/ops.py:110-111 -- ``2 ** int(math.log(batch_size))`` (natural log, as written)."""
+    return 2 ** int(math.log(batch_size)) if batch_size >= 1 else 1
+
+
+# ----------------------------------------------------------------------------- index producers
+def furthest_point_sample(xyz, n_samples, tie_stride=None, skip_sqnorm_le=1e-3, start_idx=None):
+    """xyz [B,N,3] f32 -> (idx [B,n] int32, new_xyz [B,n,3]).  misc/ops.py:124-234, :280-284.
+
+    ``tie_stride`` defaults to the reference's launch block size ``optimal_block(B)``, which fixes how
+    exact distance ties are broken; ``skip_sqnorm_le=None`` disables the near-origin skip
+    (misc/pointconv_utils.py:74-116 has none)."""
+    xyz = _dev(xyz, "xyz")
+    if xyz.dim() != 3 or xyz.shape[2] != 3:
+        raise ValueError(f"xyz must be [B,N,3], got {tuple(xyz.shape)}")
+    B, N, _ = xyz.shape
+    if not (1 <= n_samples <= N):
+        raise ValueError(f"n_samples={n_samples} must be in [1, N={N}]")  # assert at misc/ops.py:269
+    if tie_stride is None:
+        tie_stride = optimal_block(B)
+    start_idx = _dev(start_idx, "start_idx", torch.int32)
+    idx = torch.empty((B, n_samples), dtype=torch.int32, device=xyz.device)
+    new_xyz = torch.empty((B, n_samples, 3), dtype=torch.float32, device=xyz.device)
+    thr = -1.0 if skip_sqnorm_le is None else float(skip_sqnorm_le)
+    _lib.call("pcl_fps_f32", _p(xyz), B, N, n_samples, int(tie_stride), thr, _p(start_idx), _p(idx),
+                                      _p(new_xyz), _stream(), algo_bytes=B * (12 * N + 16 * n_samples))
+    return idx, new_xyz
+
+
+def ball_query(new_xyz, xyz, radius, n_samples, return_cnt=False):
+    """new_xyz [B,m,3], xyz [B,N,3] -> idx [B,m,ns] int32.  misc/ops.py:291-330."""
+    new_xyz = _dev(new_xyz, "new_xyz")
+    xyz = _dev(xyz, "xyz")
+    if new_xyz.dim() != 3 or new_xyz.shape[2] != 3 or xyz.dim() != 3 or xyz.shape[2] != 3:
+        raise ValueError("new_xyz / xyz must be [B,*,3]")
+    if new_xyz.shape[0] != xyz.shape[0]:
+        raise ValueError("batch size mismatch")   # assert at misc/ops.py:361
+    B, m, _ = new_xyz.shape
+    N = xyz.shape[1]
+    idx = torch.empty((B, m, n_samples), dtype=torch.int32, device=xyz.device)
+    cnt = torch.empty((B, m), dtype=torch.int32, device=xyz.device) if return_cnt else None
+    _lib.call("pcl_ball_query_f32", _p(new_xyz), _p(xyz), B, m, N, float(radius), int(n_samples), _p(idx),
+                                             _p(cnt), _stream(), algo_bytes=B * (12 * (N + m) + 4 * m * n_samples))
+    return (idx, cnt) if return_cnt else idx
+
+
+def knn_indices(x_q, x_r, k):
+    """KNN(k).execute(x_q [B,C,Nq], x_r [B,C,Nr]) -> int32 [B,k,Nq].  misc/ops.py:651-663."""
+    x_q = _dev(x_q, "x_q")
+    x_r = _dev(x_r, "x_r")
+    if x_q.dim() != 3 or x_r.dim() != 3 or x_q.shape[:2] != x_r.shape[:2]:
+        raise ValueError(f"x_q/x_r must be [B,C,N*] with equal B and C, got {tuple(x_q.shape)} {tuple(x_r.shape)}")
+    B, C, Nq = x_q.shape
+    Nr = x_r.shape[2]
+    idx = torch.empty((B, k, Nq), dtype=torch.int32, device=x_q.device)
+    nbytes = _lib.lib().pcl_knn_workspace_bytes(B, C, Nr, Nq, k)
+    ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=x_q.device)   # the reference's tmp_dist
+    _lib.call("pcl_knn_f32", _p(x_r), _p(x_q), B, C, Nr, Nq, int(k), _p(idx), _p(ws), nbytes, _stream(),
+              algo_bytes=4 * B * C * (Nr + Nq) + 4 * B * k * Nq, algo_flops=3 * B * Nr * Nq * C)
+    return idx
+
+
+def three_nn(xyz1, xyz2):
+    """xyz1 [B,N,3] targets, xyz2 [B,S,3] sources -> (idx [B,N,3] int32, weight [B,N,3])."""
+    xyz1 = _dev(xyz1, "xyz1")
+    xyz2 = _dev(xyz2, "xyz2")
+    B, N, _ = xyz1.shape
+    S = xyz2.shape[1]
+    idx = torch.empty((B, N, 3), dtype=torch.int32, device=xyz1.device)
+    w = torch.empty((B, N, 3), dtype=torch.float32, device=xyz1.device)
+    _lib.call("pcl_three_nn_f32", _p(xyz1), _p(xyz2), B, N, S, _p(idx), _p(w), _stream())
+    return idx, w
+
+
+# ----------------------------------------------------------------------------- differentiable gathers
+class _GroupPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feat, idx, use_xyz):
+        idx = _dev(idx, "idx", torch.int32)
+        B, m, ns = idx.shape
+        xyz = _dev(xyz, "xyz")
+        new_xyz = _dev(new_xyz, "new_xyz")
+        feat = _dev(feat, "feature")
+        N = xyz.shape[1]
+        C = 0 if feat is None else feat.shape[2]
+        D = (3 if use_xyz else 0) + C
+        out = torch.empty((B, m, ns, D), dtype=torch.float32, device=idx.device)
+        _lib.call("pcl_group_f32", _p(xyz), _p(new_xyz), _p(feat), _p(idx), B, N, m, ns, C, int(use_xyz),
+                                            _p(out), _stream(),
+                  algo_bytes=B * (4 * m * ns + 12 * m + 4 * N * (3 + C) + 4 * m * ns * D))
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, m, ns, C, int(use_xyz))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (idx,) = ctx.saved_tensors
+        B, N, m, ns, C, use_xyz = ctx.dims
+        gfeat = None
+        if C > 0 and ctx.needs_input_grad[2]:
+            gout = _dev(gout, "grad")
+            gfeat = torch.empty((B, N, C), dtype=torch.float32, device=gout.device)
+            _lib.call("pcl_group_bwd_f32", _p(gout), _p(idx), B, N, m, ns, C, use_xyz, _p(gfeat), _stream(),
+                      algo_bytes=B * (4 * m * ns * C + 4 * m * ns + 4 * N * C))
+        return None, None, gfeat, None, None
+
+
+def group_points(xyz, new_xyz, feature, idx, use_xyz=True):
+    """[B,m,ns,(3)+C] = concat(xyz[idx]-new_xyz, feature[idx]).  misc/ops.py:383-407."""
+    if not use_xyz and feature is None:
+        raise ValueError("use_xyz=False needs features")
+    return _GroupPoints.apply(xyz, new_xyz, feature, idx, bool(use_xyz))
+
+
+class _GroupAll(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, feat, use_xyz):
+        xyz = _dev(xyz, "xyz")
+        feat = _dev(feat, "feature")
+        B, N, _ = xyz.shape
+        C = 0 if feat is None else feat.shape[2]
+        D = (3 if use_xyz else 0) + C
+        out = torch.empty((B, 1, N, D), dtype=torch.float32, device=xyz.device)
+        _lib.call("pcl_group_all_f32", _p(xyz), _p(feat), B, N, C, int(use_xyz), _p(out), _stream())
+        ctx.dims = (B, N, C, int(use_xyz))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        B, N, C, use_xyz = ctx.dims
+        gfeat = None
+        if C > 0 and ctx.needs_input_grad[1]:
+            gout = _dev(gout, "grad")
+            gfeat = torch.empty((B, N, C), dtype=torch.float32, device=gout.device)
+            _lib.call("pcl_group_all_bwd_f32", _p(gout), B, N, C, use_xyz, _p(gfeat), _stream())
+        return None, gfeat, None
+
+
+def group_all(xyz, feature, use_xyz=True):
+    """[B,1,N,3+C] = concat(xyz, feature) (xyz not re-centred).  misc/ops.py:415-419."""
+    return _GroupAll.apply(xyz, feature, bool(use_xyz))
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, idx):
+        src = _dev(src, "points")
+        idx = _dev(idx, "idx", torch.int32)
+        B, N, C = src.shape
+        M = idx.numel() // B
+        out = torch.empty(tuple(idx.shape) + (C,), dtype=torch.float32, device=src.device)
+        _lib.call("pcl_gather_rows_f32", _p(src), _p(idx), B, N, M, C, _p(out), _stream())
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, M, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (idx,) = ctx.saved_tensors
+        B, N, M, C = ctx.dims
+        gout = _dev(gout, "grad")
+        gsrc = torch.empty((B, N, C), dtype=torch.float32, device=gout.device)
+        _lib.call("pcl_gather_rows_bwd_f32", _p(gout), _p(idx), B, N, M, C, _p(gsrc), _stream())
+        return gsrc, None
+
+
+def index_points(points, idx):
+    """points [B,N,C], idx [B,S] or [B,S,K] (int32) -> [B,S,(K,)C].  misc/ops.py:12-27."""
+    return _GatherRows.apply(points, idx.to(torch.int32))
+
+
+class _ThreeInterpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points2, idx3, w3):
+        points2 = _dev(points2, "points2")
+        idx3 = _dev(idx3, "idx3", torch.int32)
+        w3 = _dev(w3, "w3")
+        B, S, D = points2.shape
+        N = idx3.shape[1]
+        out = torch.empty((B, N, D), dtype=torch.float32, device=points2.device)
+        _lib.call("pcl_three_interp_f32", _p(points2), _p(idx3), _p(w3), B, N, S, D, _p(out), _stream())
+        ctx.save_for_backward(idx3, w3)
+        ctx.dims = (B, N, S, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        idx3, w3 = ctx.saved_tensors
+        B, N, S, D = ctx.dims
+        gout = _dev(gout, "grad")
+        g = torch.empty((B, S, D), dtype=torch.float32, device=gout.device)
+        _lib.call("pcl_three_interp_bwd_f32", _p(gout), _p(idx3), _p(w3), B, N, S, D, _p(g), _stream())
+        return g, None, None
+
+
+def three_interpolate(points2, idx3, w3):
+    """sum_j w3[b,n,j] * points2[b, idx3[b,n,j], :]  ->  [B,N,D].  misc/ops.py:93."""
+    return _ThreeInterpolate.apply(points2, idx3, w3)
+
+
+# ----------------------------------------------------------------------------- modules (reference names)
+class _Module(nn.Module):
+    def execute(self, *a, **k):   # Jittor's name for forward
+        return self(*a, **k)
+
+
+class FurthestPointSampler(_Module):
+    """misc/ops.py:114-286: ``FurthestPointSampler(n_samples)(x[B,N,3]) -> [B,n_samples,3]``."""
+
+    def __init__(self, n_samples, tie_stride=None):
+        super().__init__()
+        self.n_samples = n_samples
+        self.tie_stride = tie_stride
+
+    def forward(self, x, return_idx=False):
+        idx, y = furthest_point_sample(x, self.n_samples, self.tie_stride)
+        return (y, idx) if return_idx else y
+
+
+class BallQueryGrouper(_Module):
+    """misc/ops.py:289-407: ``(new_xyz[B,m,3], pointset[B,N,3], feature[B,N,C]|None) -> [B,m,ns,3+C]``."""
+
+    def __init__(self, radius, n_samples, use_xyz):
+        super().__init__()
+        self.radius = radius
+        self.n_samples = n_samples
+        self.use_xyz = use_xyz
+
+    def forward(self, new_xyz, pointset, feature, return_idx=False):
+        idx = ball_query(new_xyz, pointset, self.radius, self.n_samples)
+        if self.use_xyz or feature is not None:
+            out = group_points(pointset, new_xyz, feature, idx, self.use_xyz)
+        else:
+            out = None   # misc/ops.py:405: use_xyz=False and feature=None returns None
+        return (out, idx) if return_idx else out
+
+
+class GroupAll(_Module):
+    """misc/ops.py:410-419 (``use_xyz=False`` is a latent NameError upstream; here it returns features only)."""
+
+    def __init__(self, use_xyz):
+        super().__init__()
+        self.use_xyz = use_xyz
+
+    def forward(self, new_xyz, pointset, feature):
+        return group_all(pointset, feature, self.use_xyz)
+
+
+class KNN(_Module):
+    """misc/ops.py:422-663: ``KNN(k)(x_q[B,C,Nq], x_r[B,C,Nr]) -> int32 [B,k,Nq]``."""
+
+    def __init__(self, k):
+        super().__init__()
+        self.k = k
+
+    def forward(self, x_q, x_r):
+        return knn_indices(x_q, x_r, self.k)
+
+
+class PointNetFeaturePropagation(_Module):
+    """misc/ops.py:54-107.  ``(xyz1[B,N,3], xyz2[B,S,3], points1[B,N,D1]|None, points2[B,S,D2]) -> [B,N,mlp[-1]]``.
+
+    3-NN inverse-distance interpolation (HIP three_nn + three_interpolate instead of the reference's
+    dense matrix + full argsort), concat, then Conv1d(k=1, bias)+BatchNorm1d+ReLU per ``mlp`` entry."""
+
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        from .layers import PointwiseMLP
+        self.mlp = PointwiseMLP([in_channel] + list(mlp), bias=True)
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        B, N, _ = xyz1.shape
+        S = xyz2.shape[1]
+        if S == 1:
+            interpolated = points2.expand(B, N, points2.shape[2])          # :83-84
+        else:
+            idx, w = three_nn(xyz1, xyz2)
+            interpolated = three_interpolate(points2, idx, w)              # :86-93
+        new_points = torch.cat([points1, interpolated], dim=-1) if points1 is not None else interpolated
+        return self.mlp(new_points.contiguous())

@@ -1,0 +1,119 @@
+"""PointNet++ classification (SSG / MSG) -- counterpart of /root/reference/networks/cls/pointnet2.py.
+
+Same module structure and constructor arguments as the reference (PointNetModuleBase :11-62,
+PointnetModule :65-80, PointnetModuleMSG :83-97, PointNet2_cls :100-158, PointNetMSG :161-196), on
+channel-last tensors end to end: the reference's two NCHW transposes around ``nn.Conv(k=1)``
+(:53, :56) disappear because a 1x1 conv is a row-wise linear map (misc/layers.py: PointwiseMLP).
+
+Deliberate deviations from upstream bugs: ``PointnetModuleMSG`` iterates the
+``mlps`` list directly (upstream :96 calls ``.layers.items()`` on a Python list and cannot be built).
+"""
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from ...misc.layers import PointwiseMLP
+from ...misc.ops import BallQueryGrouper, FurthestPointSampler, GroupAll
+
+
+class PointNetModuleBase(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.n_points = None
+        self.sampler = None
+        self.groupers = None
+        self.mlps = None
+
+    def build_mlps(self, mlp_spec: List[int], use_xyz: bool = True, bn: bool = True) -> PointwiseMLP:
+        spec = list(mlp_spec)           # upstream mutates the caller's list in place (:22-23); we copy
+        if use_xyz:
+            spec[0] += 3
+        return PointwiseMLP(spec, bias=not bn, bn=bn, slope=0.0)
+
+    def forward(self, xyz: torch.Tensor, feature: Optional[torch.Tensor]):
+        """xyz [B,N,3], feature [B,N,C] -> (new_xyz [B,n_points,3] | None, new_feature [B,n_points,C'])."""
+        new_xyz = self.sampler(xyz) if self.n_points is not None else None      # :45
+        new_feature_list = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            grouped = grouper(new_xyz, xyz, feature)                            # [B, m, ns, C]      :51
+            ns = grouped.shape[2]
+            new_feature_list.append(mlp(grouped, group_max=ns))                 # conv/bn/relu x3 + max  :54-57
+        new_feature = new_feature_list[0] if len(new_feature_list) == 1 else torch.cat(new_feature_list, dim=-1)
+        return new_xyz, new_feature
+
+    def execute(self, *a, **k):
+        return self(*a, **k)
+
+
+class PointnetModule(PointNetModuleBase):
+    def __init__(self, mlp: List[int], n_points=None, radius=None, n_samples=None, bn=True, use_xyz=True):
+        super().__init__()
+        self.n_points = n_points
+        self.groupers = nn.ModuleList()
+        if self.n_points is not None:
+            self.sampler = FurthestPointSampler(n_points)
+            self.groupers.append(BallQueryGrouper(radius, n_samples, use_xyz))
+        else:
+            self.groupers.append(GroupAll(use_xyz))
+        self.mlps = nn.ModuleList()
+        self.mlps.append(self.build_mlps(mlp, use_xyz, bn))
+
+
+class PointnetModuleMSG(PointNetModuleBase):
+    def __init__(self, n_points: int, radius: List[float], n_samples: List[int], mlps: List[List[int]], bn=True,
+                 use_xyz=True):
+        super().__init__()
+        self.n_points = n_points
+        self.sampler = FurthestPointSampler(n_points)
+        self.groupers = nn.ModuleList()
+        for r, s in zip(radius, n_samples):
+            self.groupers.append(BallQueryGrouper(r, s, use_xyz))
+        self.mlps = nn.ModuleList()
+        for mlp in mlps:
+            self.mlps.append(self.build_mlps(mlp, use_xyz, bn))
+
+
+class PointNet2_cls(nn.Module):
+    def __init__(self, n_classes=40, use_xyz=True):
+        super().__init__()
+        self.n_classes = n_classes
+        self.use_xyz = use_xyz
+        self.build_model()
+
+    def build_model(self):
+        self.pointnet_modules = nn.ModuleList()
+        self.pointnet_modules.append(PointnetModule(n_points=512, radius=0.2, n_samples=64, mlp=[3, 64, 64, 128],
+                                                    use_xyz=self.use_xyz))                       # :111-119
+        self.pointnet_modules.append(PointnetModule(n_points=128, radius=0.4, n_samples=64, mlp=[128, 128, 128, 256],
+                                                    use_xyz=self.use_xyz))                       # :121-129
+        self.pointnet_modules.append(PointnetModule(mlp=[256, 256, 512, 1024], use_xyz=self.use_xyz))   # :131-136
+        self.fc_layer = nn.Sequential(                                                           # :138-147
+            nn.Linear(1024, 512, bias=False), nn.BatchNorm1d(512), nn.ReLU(),
+            nn.Linear(512, 256, bias=False), nn.BatchNorm1d(256), nn.ReLU(),
+            nn.Dropout(0.5), nn.Linear(256, self.n_classes),
+        )
+
+    def forward(self, xyz, feature):
+        for module in self.pointnet_modules:
+            xyz, feature = module(xyz, feature)
+        feature = feature.squeeze(dim=1)                                                         # :157
+        return self.fc_layer(feature)
+
+    def execute(self, *a, **k):
+        return self(*a, **k)
+
+
+class PointNetMSG(PointNet2_cls):
+    def build_model(self):
+        super().build_model()
+        self.pointnet_modules = nn.ModuleList()
+        self.pointnet_modules.append(PointnetModuleMSG(
+            n_points=512, radius=[0.1, 0.2, 0.4], n_samples=[16, 32, 128],
+            mlps=[[3, 32, 32, 64], [3, 64, 64, 128], [3, 64, 96, 128]], use_xyz=self.use_xyz))  # :165-173
+        input_channels = 64 + 128 + 128
+        self.pointnet_modules.append(PointnetModuleMSG(
+            n_points=128, radius=[0.2, 0.4, 0.8], n_samples=[32, 64, 128],
+            mlps=[[input_channels, 64, 64, 128], [input_channels, 128, 128, 256], [input_channels, 128, 128, 256]],
+            use_xyz=self.use_xyz))                                                               # :175-187
+        self.pointnet_modules.append(PointnetModule(mlp=[128 + 256 + 256, 256, 512, 1024], use_xyz=self.use_xyz))

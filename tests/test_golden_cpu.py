@@ -1,0 +1,89 @@
+"""CPU: the oracle reproduces the committed fixtures; the C-ABI library loads and exports every symbol the
+header declares (no compute calls without a GPU)."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_small_cases_match_oracle(oracle):
+    g = np.load(os.path.join(GOLD, "small_cases.npz"))
+    names = sorted({k.split(".")[0] for k in g.files if k.endswith(".xyz")})
+    assert names
+    for name in names:
+        pts = g[f"{name}.xyz"]
+        N = pts.shape[1]
+        m = max(2, N // 3)
+        for S in (1, 2, 4, 8, 16):
+            assert np.array_equal(oracle.fps(pts, m, block_size=S), g[f"{name}.fps_S{S}"]), (name, S)
+        _, new_xyz = oracle.fps(pts, m, block_size=1, return_xyz=True)
+        for key in [k for k in g.files if k.startswith(f"{name}.bq_r")]:
+            r, ns = re.match(r".*bq_r([0-9.]+)_ns(\d+)", key).groups()
+            assert np.array_equal(oracle.ball_query(new_xyz, pts, float(r), int(ns)), g[key]), key
+    for k in (1, 7, 33):
+        assert np.array_equal(oracle.knn(g["knn.q"], g["knn.r"], k), g[f"knn.k{k}"])
+
+
+def test_full_size_digests_match_oracle(oracle):
+    from pointcloudlib_amd import synth
+    big = json.load(open(os.path.join(GOLD, "full_size_digests.json")))
+    c = big["cfg2_N1024"]
+    pts = synth.gauss_ball(c["B"], c["N"], c["seed"])
+    assert sha(pts) == c["xyz_sha"], "synthetic generator changed"
+    i1, x1 = oracle.fps(pts, 512, block_size=c["tie_stride"], return_xyz=True)
+    assert sha(i1) == c["fps1_sha"]
+    assert sha(oracle.ball_query(x1, pts, 0.2, 64)) == c["bq1_sha"]
+
+
+def test_capi_exports_every_declared_symbol():
+    from pointcloudlib_amd import _lib
+    so = _lib.so_path()
+    assert os.path.exists(so), "libpcl_hip.so not built (run __graft_entry__.build())"
+    L = ctypes.CDLL(so)
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/pcl_hip.h but not exported"
+    assert set(declared) == set(_lib._SIGS), "ctypes signature table out of sync with the header"
+    lib = _lib.lib()
+    assert lib.pcl_version() >= 100
+    assert [lib.pcl_optimal_block(b) for b in (1, 2, 3, 8, 16, 32, 55)] == [1, 1, 2, 4, 4, 8, 16]
+
+
+def test_capi_argument_validation_needs_no_gpu():
+    """Argument errors are detected on the host before any launch: negative code + message."""
+    from pointcloudlib_amd import _lib
+    lib = _lib.lib()
+    assert lib.pcl_fps_f32(None, 1, 8, 4, 1, 1e-3, None, None, None, None) == -1
+    assert b"null" in lib.pcl_last_error()
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.pcl_fps_f32(p, 1, 8, 9, 1, 1e-3, None, p, None, None) == -1         # m > N
+    assert lib.pcl_fps_f32(p, 1, 8, 4, 3, 1e-3, None, p, None, None) == -1         # tie_stride not a power of two
+    assert lib.pcl_knn_f32(p, p, 1, 3, 8, 8, 9, p, None, 0, None) == -1            # k > Nr
+    assert lib.pcl_knn_f32(p, p, 1, 3, 8, 8, 2, p, None, 0, None) == -4            # workspace too small
+    assert lib.pcl_knn_workspace_bytes(2, 3, 8, 16, 2) == 2 * 8 * 16 * 4
+
+
+def test_ops_reject_cpu_tensors():
+    import torch
+    from pointcloudlib_amd.misc import ops
+    x = torch.zeros(1, 8, 3)
+    for fn in (lambda: ops.furthest_point_sample(x, 4), lambda: ops.ball_query(x, x, 0.1, 2),
+               lambda: ops.knn_indices(x.transpose(1, 2), x.transpose(1, 2), 2)):
+        try:
+            fn()
+        except RuntimeError as e:
+            assert "GPU" in str(e)
+        else:
+            raise AssertionError("CPU tensor accepted: the HIP path must fail loudly")

@@ -1,0 +1,250 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI, against the CPU oracle on the same
+seeded inputs -- bit-exact for indices, and for pure copies/subtractions; tolerance stated where fp32 sums
+are reordered (atomics).  Plus the committed fixtures and full-size digests."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from pointcloudlib_amd import synth
+from pointcloudlib_amd.misc import ops
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ------------------------------------------------------------------------------------ FPS
+@pytest.mark.parametrize("B,N,m", [(1, 64, 64), (2, 100, 37), (3, 512, 128), (16, 1024, 512), (32, 1024, 512),
+                                   (4, 2048, 512), (2, 4096, 1024), (1, 5000, 300), (1, 12000, 64), (1, 20000, 16)])
+def test_fps_matches_oracle(oracle, dev, B, N, m):
+    pts = synth.gauss_ball(B, N, 100 + N + B)
+    for S in (1, oracle.optimal_block(B)):
+        want, want_xyz = oracle.fps(pts, m, block_size=S, return_xyz=True)
+        idx, new_xyz = ops.furthest_point_sample(T(pts, dev), m, tie_stride=S)
+        assert np.array_equal(idx.cpu().numpy(), want), (B, N, m, S)
+        assert np.array_equal(new_xyz.cpu().numpy(), want_xyz)
+
+
+@pytest.mark.parametrize("threads", [64, 128, 256, 512, 1024])
+def test_fps_every_launch_shape(oracle, dev, threads, monkeypatch):
+    """The winner must not depend on the workgroup shape (tie rule is an explicit parameter)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import os, sys, numpy as np, torch
+        sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+        import oracle
+        from pointcloudlib_amd import synth
+        from pointcloudlib_amd.misc import ops
+        for name, pts in synth.adversarial_clouds(0).items():
+            B, N, _ = pts.shape
+            for S in (1, 2, 4, 8):
+                want = oracle.fps(pts, N // 2, block_size=S)
+                got, _ = ops.furthest_point_sample(torch.from_numpy(pts).cuda(), N // 2, tie_stride=S)
+                assert np.array_equal(got.cpu().numpy(), want), (name, S)
+        pts = synth.gauss_ball(4, 1024, 5)
+        want = oracle.fps(pts, 256, block_size=4)
+        got, _ = ops.furthest_point_sample(torch.from_numpy(pts).cuda(), 256, tie_stride=4)
+        assert np.array_equal(got.cpu().numpy(), want)
+        print("OK")
+    """)
+    env = dict(os.environ, PCL_FPS_THREADS=str(threads))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_fps_adversarial_ties_and_skips(oracle, dev):
+    g = np.load(os.path.join(GOLD, "small_cases.npz"))
+    for name, pts in synth.adversarial_clouds(0).items():
+        N = pts.shape[1]
+        m = max(2, N // 3)
+        for S in (1, 2, 4, 8, 16):
+            idx, _ = ops.furthest_point_sample(T(pts, dev), m, tie_stride=S)
+            assert np.array_equal(idx.cpu().numpy(), g[f"{name}.fps_S{S}"]), (name, S)
+            assert np.array_equal(idx.cpu().numpy(), oracle.fps(pts, m, block_size=S))
+
+
+def test_fps_no_skip_start_idx(oracle, dev):
+    pts = synth.gauss_ball(5, 300, 9) * 0.02             # everything near the origin
+    start = np.array([0, 7, 299, 150, 3], np.int32)
+    want = oracle.fps(pts, 64, block_size=1, skip=False, start_idx=start)
+    idx, _ = ops.furthest_point_sample(T(pts, dev), 64, tie_stride=1, skip_sqnorm_le=None, start_idx=T(start, dev))
+    assert np.array_equal(idx.cpu().numpy(), want)
+    # with the skip enabled the whole cloud is dead: all zeros (misc/ops.py:152-153)
+    idx, _ = ops.furthest_point_sample(T(pts, dev), 8, tie_stride=1)
+    assert np.array_equal(idx.cpu().numpy(), oracle.fps(pts, 8, block_size=1))
+
+
+def test_fps_properties_full_size(dev):
+    """Size-independent properties at BASELINE size: distinct indices, farthest-first radii non-increasing."""
+    pts = synth.gauss_ball(32, 4096, 77)
+    idx, new_xyz = ops.furthest_point_sample(T(pts, dev), 1024)
+    idx = idx.cpu().numpy()
+    live = (pts.astype(np.float32) ** 2).sum(-1) > 1e-3
+    for b in range(32):
+        assert len(set(idx[b].tolist())) == 1024
+        assert live[b, idx[b, 1:]].all()
+    x = new_xyz.cpu().numpy()[0].astype(np.float64)
+    d = np.full(1024, np.inf)
+    radii = []
+    mask = live[0]
+    P = pts[0].astype(np.float64)
+    run = np.full(4096, np.inf)
+    for j in range(1, 200):
+        run = np.minimum(run, ((P - x[j - 1]) ** 2).sum(-1))
+        radii.append(run[mask].max())
+    assert all(radii[i] >= radii[i + 1] - 1e-12 for i in range(len(radii) - 1))
+
+
+# ------------------------------------------------------------------------------------ ball query
+@pytest.mark.parametrize("B,N,m,r,ns", [(2, 64, 10, 0.3, 8), (3, 1000, 77, 0.2, 64), (32, 1024, 512, 0.2, 64),
+                                        (32, 512, 128, 0.4, 64), (2, 4096, 512, 0.1, 16), (2, 2048, 512, 0.4, 128),
+                                        (1, 14000, 33, 0.15, 32)])
+def test_ball_query_matches_oracle(oracle, dev, B, N, m, r, ns):
+    pts = synth.gauss_ball(B, N, 11 + N)
+    q = oracle.fps(pts, m, block_size=1, return_xyz=True)[1]
+    want, wcnt = oracle.ball_query(q, pts, r, ns, return_cnt=True)
+    idx, cnt = ops.ball_query(T(q, dev), T(pts, dev), r, ns, return_cnt=True)
+    assert np.array_equal(idx.cpu().numpy(), want)
+    assert np.array_equal(cnt.cpu().numpy(), wcnt)
+
+
+def test_ball_query_edges(oracle, dev):
+    g = np.load(os.path.join(GOLD, "small_cases.npz"))
+    for name, pts in synth.adversarial_clouds(0).items():
+        m = max(2, pts.shape[1] // 3)
+        q = oracle.fps(pts, m, block_size=1, return_xyz=True)[1]
+        for r, ns in ((0.1, 4), (0.3, 8), (1.0, 16)):
+            idx, cnt = ops.ball_query(T(q, dev), T(pts, dev), r, ns, return_cnt=True)
+            assert np.array_equal(idx.cpu().numpy(), g[f"{name}.bq_r{r}_ns{ns}"]), (name, r, ns)
+            assert np.array_equal(cnt.cpu().numpy(), g[f"{name}.bqcnt_r{r}_ns{ns}"])
+    # queries that are not cloud points: rows with no hit are zero-filled, cnt 0
+    pts = synth.sphere_shell(2, 256, 3)
+    q = np.zeros((2, 4, 3), np.float32) + 5.0
+    idx, cnt = ops.ball_query(T(q, dev), T(pts, dev), 0.5, 8, return_cnt=True)
+    assert (idx.cpu().numpy() == 0).all() and (cnt.cpu().numpy() == 0).all()
+    # shell clouds never saturate: every query is a full scan with padding
+    q = oracle.fps(pts, 64, block_size=1, return_xyz=True)[1]
+    assert np.array_equal(ops.ball_query(T(q, dev), T(pts, dev), 0.2, 64).cpu().numpy(), oracle.ball_query(q, pts, 0.2, 64))
+
+
+# ------------------------------------------------------------------------------------ grouping
+@pytest.mark.parametrize("C,use_xyz", [(3, True), (128, True), (0, True), (5, False)])
+def test_group_fwd_bwd(oracle, dev, C, use_xyz):
+    B, N, m, ns = 4, 300, 50, 16
+    rng = np.random.default_rng(C)
+    pts = synth.gauss_ball(B, N, 21)
+    feat = rng.standard_normal((B, N, C)).astype(np.float32) if C else None
+    q = oracle.fps(pts, m, block_size=1, return_xyz=True)[1]
+    idx = oracle.ball_query(q, pts, 0.3, ns)
+    want = oracle.group(pts, q, feat, idx, use_xyz)
+    f = T(feat, dev).requires_grad_(True) if C else None
+    out = ops.group_points(T(pts, dev), T(q, dev), f, T(idx, dev), use_xyz)
+    assert np.array_equal(out.detach().cpu().numpy(), want)          # copies and one subtraction: bit-exact
+    if C:
+        gout = rng.standard_normal(want.shape).astype(np.float32)
+        out.backward(T(gout, dev))
+        wantg = oracle.group_bwd(gout, idx, N, C, use_xyz)
+        # scatter-add via fp32 atomics: order differs from the sequential oracle -> tolerance, not bits
+        np.testing.assert_allclose(f.grad.cpu().numpy(), wantg, rtol=1e-5, atol=1e-5)
+
+
+def test_group_all_and_modules(oracle, dev):
+    B, N, C = 3, 128, 7
+    rng = np.random.default_rng(0)
+    pts = synth.gauss_ball(B, N, 5)
+    feat = rng.standard_normal((B, N, C)).astype(np.float32)
+    f = T(feat, dev).requires_grad_(True)
+    out = ops.GroupAll(True)(None, T(pts, dev), f)
+    assert np.array_equal(out.detach().cpu().numpy(), oracle.group_all(pts, feat))
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(T(g, dev))
+    assert np.array_equal(f.grad.cpu().numpy(), g[:, 0, :, 3:])
+    # module signatures of the reference
+    y, idx = ops.FurthestPointSampler(32)(T(pts, dev), return_idx=True)
+    assert y.shape == (B, 32, 3) and idx.dtype == torch.int32
+    grouped = ops.BallQueryGrouper(0.3, 8, True).execute(y, T(pts, dev), T(feat, dev))
+    assert grouped.shape == (B, 32, 8, 3 + C)
+    want = oracle.group(pts, y.cpu().numpy(), feat, oracle.ball_query(y.cpu().numpy(), pts, 0.3, 8))
+    assert np.array_equal(grouped.cpu().numpy(), want)
+    assert ops.BallQueryGrouper(0.3, 8, True)(y, T(pts, dev), None).shape == (B, 32, 8, 3)
+    gi = ops.index_points(T(feat, dev), idx)
+    assert np.array_equal(gi.cpu().numpy(), feat[np.arange(B)[:, None], idx.cpu().numpy()])
+
+
+# ------------------------------------------------------------------------------------ KNN
+@pytest.mark.parametrize("B,C,Nr,Nq,k", [(2, 3, 64, 64, 5), (2, 5, 33, 20, 33), (4, 3, 1024, 1024, 20),
+                                         (2, 64, 1024, 1024, 20), (2, 128, 256, 1024, 200), (1, 7, 2048, 100, 40),
+                                         (1, 3, 5000, 70, 9)])
+def test_knn_matches_oracle(oracle, dev, B, C, Nr, Nq, k):
+    rng = np.random.default_rng(Nr + C)
+    r = rng.standard_normal((B, C, Nr)).astype(np.float32)
+    q = r[:, :, :Nq].copy() if Nq <= Nr else rng.standard_normal((B, C, Nq)).astype(np.float32)
+    want = oracle.knn(q, r, k)
+    got = ops.KNN(k)(T(q, dev), T(r, dev))
+    assert got.shape == (B, k, Nq) and got.dtype == torch.int32
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_knn_ties_by_index(oracle, dev):
+    g = np.load(os.path.join(GOLD, "small_cases.npz"))
+    for k in (1, 7, 33):
+        got = ops.knn_indices(T(g["knn.q"], dev), T(g["knn.r"], dev), k)
+        assert np.array_equal(got.cpu().numpy(), g[f"knn.k{k}"])
+    z = np.zeros((1, 4, 100), np.float32)
+    assert np.array_equal(ops.knn_indices(T(z[:, :, :3], dev), T(z, dev), 100).cpu().numpy()[0, :, 0], np.arange(100))
+
+
+# ------------------------------------------------------------------------------------ 3-NN interpolation
+@pytest.mark.parametrize("N,S", [(200, 40), (2048, 512), (512, 128), (128, 1), (64, 2), (300, 5000)])
+def test_three_nn_interp(oracle, dev, N, S):
+    B, D = 3, 19
+    rng = np.random.default_rng(N + S)
+    a = synth.gauss_ball(B, N, 1)
+    b = synth.gauss_ball(B, S, 2)
+    p2 = rng.standard_normal((B, S, D)).astype(np.float32)
+    wi, ww = oracle.three_nn(a, b)
+    idx, w = ops.three_nn(T(a, dev), T(b, dev))
+    assert np.array_equal(idx.cpu().numpy(), wi)
+    assert np.array_equal(w.cpu().numpy(), ww)
+    p = T(p2, dev).requires_grad_(True)
+    out = ops.three_interpolate(p, idx, w)
+    assert np.array_equal(out.detach().cpu().numpy(), oracle.three_interp(p2, wi, ww))
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(T(g, dev))
+    ref = torch.zeros(B, S, D, dtype=torch.float64)
+    for j in range(3):
+        ref.scatter_add_(1, torch.from_numpy(wi[..., j].astype(np.int64))[..., None].expand(B, N, D),
+                         torch.from_numpy(g).double() * torch.from_numpy(ww[..., j:j + 1]).double())
+    np.testing.assert_allclose(p.grad.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------ fixtures at full size
+def test_full_size_digests(dev):
+    big = json.load(open(os.path.join(GOLD, "full_size_digests.json")))
+    for cfg in ("cfg2_N1024", "cfg2_N4096", "cfg4_N2048"):
+        c = big[cfg]
+        pts = synth.gauss_ball(c["B"], c["N"], c["seed"])
+        assert sha(pts) == c["xyz_sha"]
+        i1, x1 = ops.furthest_point_sample(T(pts, dev), 512, tie_stride=c["tie_stride"])
+        i2, x2 = ops.furthest_point_sample(x1, 128, tie_stride=c["tie_stride"])
+        b1 = ops.ball_query(x1, T(pts, dev), 0.2, 64)
+        b2 = ops.ball_query(x2, x1, 0.4, 64)
+        assert sha(i1.cpu().numpy()) == c["fps1_sha"], cfg
+        assert sha(i2.cpu().numpy()) == c["fps2_sha"], cfg
+        assert sha(b1.cpu().numpy()) == c["bq1_sha"], cfg
+        assert sha(b2.cpu().numpy()) == c["bq2_sha"], cfg
+    c = big["cfg3_knn_xyz"]
+    pts = synth.gauss_ball(c["B"], c["N"], c["seed"])
+    x = T(np.ascontiguousarray(pts.transpose(0, 2, 1)), dev)
+    assert sha(ops.knn_indices(x, x, c["k"]).cpu().numpy()) == c["knn_sha"]
