@@ -109,6 +109,58 @@ int pcl_three_interp_f32(const float* points2, const int32_t* idx3, const float*
 int pcl_three_interp_bwd_f32(const float* gout, const int32_t* idx3, const float* w3, int B, int N,
                              int S, int D, float* gpoints2, void* stream);
 
+/* ---- per-group pointwise MLP: 1x1 conv + BatchNorm(train) + (Leaky)ReLU [+ max over the group] ---------
+ * Replaces the nn.Conv(k=1)+nn.BatchNorm+nn.ReLU stacks of build_mlps (networks/cls/pointnet2.py:18-31;
+ * DGCNN conv1-4 networks/cls/dgcnn.py:72-83; FP stacks misc/ops.py:54-64) and the max over the group
+ * (pointnet2.py:57, dgcnn.py:102), forward and backward, on channel-last rows [P,C] (P = B*m*ns).
+ * fp32-input MFMA kernels; BatchNorm+activation of the layer below is folded into the operand staging, the
+ * batch statistics come out of the GEMM epilogues.  Notation per layer l: y = z_prev W^T (+bias) (stored),
+ * u = scale*y + shift (BatchNorm, scale = gamma*invstd, shift = beta - scale*mean), z = lrelu(u).
+ *
+ * Statistics workspaces `stats_ws` are [rows][2][C] doubles with rows <= 256; the producer uses
+ * pcl_mlp_stat_rows(P) rows for GEMM epilogues, or reports the count through *stat_rows_out. */
+int pcl_mlp_stat_rows(int P);
+/* Y[P,Cout] = act_in(X[P,Cin]) W[Cout,Cin]^T (+bias);  act_in = identity (in_scale NULL) or
+ * lrelu(in_scale*x+in_shift, in_slope).  stats_ws rows: (sum Y, sum Y^2) per channel. */
+int pcl_linear_fwd_f32(const float* X, const float* W, const float* bias, const float* in_scale,
+                       const float* in_shift, float in_slope, int P, int Cin, int Cout, float* Y,
+                       double* stats_ws, void* stream);
+/* mean/var (biased, max(E[y^2]-E[y]^2,0)) from the partials -> scale, shift, mean, invstd; running stats
+ * r += (batch - r)*momentum with the biased variance (nullable). */
+int pcl_bn_finalize_f32(const double* stats_ws, int stat_rows, const float* gamma, const float* beta, int P,
+                        int C, float eps, float momentum, float* scale, float* shift, float* mean_out,
+                        float* invstd_out, float* running_mean, float* running_var, void* stream);
+/* out[g,c] = max_s lrelu(scale*Y[g*ns+s,c]+shift); arg = first s attaining it; ymax = Y there (nullable). */
+int pcl_bn_act_max_f32(const float* Y, const float* scale, const float* shift, float slope, int G, int ns,
+                       int C, float* out, int32_t* arg, float* ymax, void* stream);
+/* out = lrelu(scale*Y+shift) on [P,C];  bwd: du = gz*act'(u) plus partial (sum du, sum du*y). */
+int pcl_bn_act_f32(const float* Y, const float* scale, const float* shift, float slope, int P, int C,
+                   float* out, void* stream);
+int pcl_bn_act_bwd_f32(const float* gz, const float* Y, const float* scale, const float* shift, float slope,
+                       int P, int C, float* du, double* stats_ws, int* stat_rows_out, void* stream);
+/* backward of the max: gz[g,c] = gout*act'(out) plus partial (sum gz, sum gz*ymax). */
+int pcl_maxgrad_prep_f32(const float* gout, const float* out, const float* ymax, float slope, int G, int C,
+                         float* gz, double* stats_ws, int* stat_rows_out, void* stream);
+/* BatchNorm backward constants from (sum du, sum du*y): dgamma, dbeta (nullable) and a, k1, k2 with
+ * dy = a*du - k1 - k2*y. */
+int pcl_bn_bwd_consts_f32(const double* stats_ws, int stat_rows, const float* gamma, const float* mean,
+                          const float* invstd, int P, int C, float* dgamma, float* dbeta, float* a_out,
+                          float* k1, float* k2, void* stream);
+/* dUprev[P,Cin] = act'_prev(.) * (dy[P,Cout] Wt[Cin,Cout]^T), dy = a*du - k1 - k2*Y formed on the fly from
+ * dU (dense) or from (arg, gz, ns) (sparse max gradient; pass dU = NULL).  With Yprev: masked by the layer
+ * below's activation and stats_ws gets (sum dUprev, sum dUprev*Yprev); Yprev NULL: plain store (input grad).
+ * Wt is W transposed, [Cin,Cout] row-major. */
+int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2,
+                          const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
+                          int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
+                          float prev_slope, float* dUprev, double* stats_ws, void* stream);
+/* dW[Cout,Cin] = dy^T act_prev(Xprev);  workspace of pcl_linear_bwd_dw_workspace_bytes() bytes. */
+size_t pcl_linear_bwd_dw_workspace_bytes(int P, int Cout, int Cin);
+int pcl_linear_bwd_dw_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2,
+                          const int32_t* arg, const float* gz, int ns, const float* Xprev,
+                          const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
+                          int Cin, float* dW, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

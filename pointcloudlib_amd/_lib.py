@@ -57,6 +57,19 @@ _SIGS = {
     "pcl_three_nn_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "pcl_three_interp_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_three_interp_bwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcl_mlp_stat_rows": (c_int, [c_int]),
+    "pcl_linear_fwd_f32": (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P]),
+    "pcl_bn_finalize_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "pcl_bn_act_max_f32": (c_int, [_P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "pcl_bn_act_f32": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P]),
+    "pcl_bn_act_bwd_f32": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, ctypes.POINTER(c_int), _P]),
+    "pcl_maxgrad_prep_f32": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P, ctypes.POINTER(c_int), _P]),
+    "pcl_bn_bwd_consts_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "pcl_linear_bwd_dx_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_float,
+                                      _P, _P, _P]),
+    "pcl_linear_bwd_dw_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "pcl_linear_bwd_dw_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_float, c_int, c_int, c_int, _P,
+                                      _P, c_size_t, _P]),
 }
 
 

@@ -31,7 +31,12 @@ inline int check_launch(const char* what) {
 #define PCL_REQUIRE(cond, ...) \
     do { if (!(cond)) return ::pcl::fail(PCL_EINVAL, __VA_ARGS__); } while (0)
 
-static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+// Every entry point converts its `void* stream` exactly once, before launching: we use that moment to drop a
+// stale sticky error left by somebody else's HIP call in this thread, so check_launch() reports only ours.
+static inline hipStream_t as_stream(void* s) {
+    (void)hipGetLastError();
+    return reinterpret_cast<hipStream_t>(s);
+}
 
 // ---------------------------------------------------------------- device helpers
 #define PCL_WAVE 64

@@ -1,0 +1,661 @@
+// mlp.hip -- per-group pointwise MLP (1x1 conv + BatchNorm(train) + (Leaky)ReLU [+ max over the group])
+// for gfx950, forward and backward, on fp32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32, 157 TF peak).
+//
+// Reference arithmetic: build_mlps / PointNetModuleBase.execute, /root/reference/networks/cls/pointnet2.py:18-62
+// (nn.Conv(k=1,bias=not bn) + nn.BatchNorm + nn.ReLU, then argmax(dim=2)[1] = max VALUE over the group),
+// DGCNN conv1-4 networks/cls/dgcnn.py:72-83, FP stacks misc/ops.py:54-64.  A 1x1 conv over [B,C,m,ns] is a
+// row-wise linear map over P = B*m*ns channel-last rows, so everything here is a thin-K GEMM on [P,C] rows.
+//
+// What is fused (the activations are 0.25-0.5 GB each; HBM traffic, not FLOPs, bounds the big layers):
+//   * the previous layer's folded BatchNorm + activation is applied while STAGING the A operand
+//     (never materialised);
+//   * BatchNorm batch statistics (sum, sum of squares per channel) are produced by the GEMM epilogue as
+//     per-workgroup fp64 partials (no atomics; summed by the tiny finalize kernel);
+//   * backward: dy = a*du - k1 - k2*y (BatchNorm backward, affine per channel once the two channel sums are
+//     known) is formed while staging, for the dense case and for the sparse max-pool gradient; the ReLU mask
+//     of the layer below and ITS two channel sums are produced by the dX GEMM's epilogue.
+//
+// Tiling (wave64): workgroup = 4 waves, block tile 128x128, K step 32; each wave owns a 64x64 tile = 2x2
+// MFMA 32x32 accumulators (64 VGPRs).  LDS rows are padded to 36 dwords so the per-lane ds_read_b128
+// fragment reads (4 consecutive k per lane; lanes 0-31 take k..k+3, lanes 32-63 take k+4..k+7 of each
+// 8-wide k block, identically for A and B) are bank-conflict-free.  Grids are persistent over row tiles so
+// statistics are reduced in registers across tiles.
+#include "common.h"
+
+namespace pcl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = BK + 4;
+constexpr int MLP_T = 256;
+constexpr int STAT_ROWS = 256;   // max workgroups along the row axis == rows of the stats workspace
+
+enum AMode { A_PLAIN = 0, A_BNACT = 1, A_DY = 2, A_DY_SPARSE = 3 };
+enum EMode { E_STORE_STATS = 0, E_MASK_STORE_STATS = 1, E_STORE = 2 };
+
+struct LinArgs {
+    const float* A;      // [M,K] primary rows (X / Y_prev / dU)
+    const float* A2;     // [M,K] pre-BN output y of THIS layer (A_DY, A_DY_SPARSE)
+    const float* B;      // [N,K] weights (forward: W[Cout,Cin]; dX: W^T[Cin,Cout])
+    const float* bias;   // [N] or null
+    const float* sc;     // [K] A_BNACT: scale; A_DY*: a = gamma*invstd
+    const float* sh;     // [K] A_BNACT: shift; A_DY*: k1
+    const float* k2;     // [K] A_DY*
+    const int32_t* arg;  // [M/ns, K] A_DY_SPARSE: row-in-group of the max
+    const float* gz;     // [M/ns, K] A_DY_SPARSE: gradient at the max (already masked by the activation)
+    float* C;            // [M,N]
+    double* stats;       // [STAT_ROWS][2][N] partials (E_STORE_STATS, E_MASK_STORE_STATS)
+    const float* Yprev;  // [M,N] E_MASK_STORE_STATS: pre-BN output of the layer below
+    const float* esc;    // [N]   its folded BN scale
+    const float* esh;    // [N]   its folded BN shift
+    float slope, eslope;
+    int M, N, K, ns;
+    int a_mode, e_mode;
+};
+
+__device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
+
+// ---- staging: global -> registers (with the fused transform) -> LDS -------------------------------------
+// Vector path (K % 4 == 0): thread t owns k4 = (t&7)*4 of rows (t>>3) + 32*i, i = 0..3.
+// Scalar path: thread t owns k = t&31 of rows (t>>5) + 8*i, i = 0..15.
+template <bool VEC>
+struct StageA {
+    static constexpr int NV = VEC ? 4 : 16;
+    float4 v[VEC ? 4 : 1];
+    float s[VEC ? 1 : 16];
+};
+
+template <bool VEC>
+__device__ __forceinline__ void load_a(const LinArgs& p, int m0, int k0, int tid, StageA<VEC>& st) {
+    if (VEC) {
+        const int k = k0 + (tid & 7) * 4;
+        const bool kin = k < p.K;
+        float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0), k2 = make_float4(0, 0, 0, 0);
+        if (p.a_mode != A_PLAIN && kin) {
+            sc = *reinterpret_cast<const float4*>(p.sc + k);
+            sh = *reinterpret_cast<const float4*>(p.sh + k);
+            if (p.a_mode >= A_DY) k2 = *reinterpret_cast<const float4*>(p.k2 + k);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = m0 + (tid >> 3) + 32 * i;
+            float4 a = make_float4(0, 0, 0, 0);
+            if (kin && r < p.M) {
+                const size_t off = (size_t)r * p.K + k;
+                if (p.a_mode == A_PLAIN) {
+                    a = *reinterpret_cast<const float4*>(p.A + off);
+                } else if (p.a_mode == A_BNACT) {
+                    const float4 x = *reinterpret_cast<const float4*>(p.A + off);
+                    a.x = lrelu(fmaf(sc.x, x.x, sh.x), p.slope); a.y = lrelu(fmaf(sc.y, x.y, sh.y), p.slope);
+                    a.z = lrelu(fmaf(sc.z, x.z, sh.z), p.slope); a.w = lrelu(fmaf(sc.w, x.w, sh.w), p.slope);
+                } else {
+                    float4 du;
+                    if (p.a_mode == A_DY) {
+                        du = *reinterpret_cast<const float4*>(p.A + off);
+                    } else {
+                        const int g = r / p.ns, srow = r - g * p.ns;
+                        const size_t go = (size_t)g * p.K + k;
+                        const int4 ar = *reinterpret_cast<const int4*>(p.arg + go);
+                        const float4 gz = *reinterpret_cast<const float4*>(p.gz + go);
+                        du.x = ar.x == srow ? gz.x : 0.f; du.y = ar.y == srow ? gz.y : 0.f;
+                        du.z = ar.z == srow ? gz.z : 0.f; du.w = ar.w == srow ? gz.w : 0.f;
+                    }
+                    const float4 y = *reinterpret_cast<const float4*>(p.A2 + off);
+                    a.x = fmaf(sc.x, du.x, -sh.x) - k2.x * y.x; a.y = fmaf(sc.y, du.y, -sh.y) - k2.y * y.y;
+                    a.z = fmaf(sc.z, du.z, -sh.z) - k2.z * y.z; a.w = fmaf(sc.w, du.w, -sh.w) - k2.w * y.w;
+                }
+            }
+            st.v[i] = a;
+        }
+    } else {
+        const int k = k0 + (tid & 31);
+        const bool kin = k < p.K;
+        float sc = 1.f, sh = 0.f, k2 = 0.f;
+        if (p.a_mode != A_PLAIN && kin) {
+            sc = p.sc[k]; sh = p.sh[k];
+            if (p.a_mode >= A_DY) k2 = p.k2[k];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = m0 + (tid >> 5) + 8 * i;
+            float a = 0.f;
+            if (kin && r < p.M) {
+                const size_t off = (size_t)r * p.K + k;
+                if (p.a_mode == A_PLAIN) a = p.A[off];
+                else if (p.a_mode == A_BNACT) a = lrelu(fmaf(sc, p.A[off], sh), p.slope);
+                else {
+                    float du;
+                    if (p.a_mode == A_DY) du = p.A[off];
+                    else {
+                        const int g = r / p.ns, srow = r - g * p.ns;
+                        const size_t go = (size_t)g * p.K + k;
+                        du = p.arg[go] == srow ? p.gz[go] : 0.f;
+                    }
+                    a = fmaf(sc, du, -sh) - k2 * p.A2[off];
+                }
+            }
+            st.s[i] = a;
+        }
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void store_a(float* sA, int tid, const StageA<VEC>& st) {
+    if (VEC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(&sA[((tid >> 3) + 32 * i) * LDS_LD + (tid & 7) * 4]) = st.v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sA[((tid >> 5) + 8 * i) * LDS_LD + (tid & 31)] = st.s[i];
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void load_b(const LinArgs& p, int n0, int k0, int tid, StageA<VEC>& st) {
+    if (VEC) {
+        const int k = k0 + (tid & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + (tid >> 3) + 32 * i;
+            st.v[i] = (k < p.K && n < p.N) ? *reinterpret_cast<const float4*>(p.B + (size_t)n * p.K + k) : make_float4(0, 0, 0, 0);
+        }
+    } else {
+        const int k = k0 + (tid & 31);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int n = n0 + (tid >> 5) + 8 * i;
+            st.s[i] = (k < p.K && n < p.N) ? p.B[(size_t)n * p.K + k] : 0.f;
+        }
+    }
+}
+
+// C[M,N] = A'[M,K] * B[N,K]^T with fused A transform and epilogue.
+template <bool VEC>
+__global__ __launch_bounds__(MLP_T) void linear_nt_kernel(const LinArgs p) {
+    __shared__ __attribute__((aligned(16))) float sA[BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float sB[BN * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int n0 = blockIdx.y * BN;
+    const int m_tiles = (p.M + BM - 1) / BM;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    // per-lane column statistics, reduced in registers across this workgroup's row tiles
+    double st_s[2] = {0.0, 0.0}, st_q[2] = {0.0, 0.0};
+
+    for (int mt = blockIdx.x; mt < m_tiles; mt += gridDim.x) {
+        const int m0 = mt * BM;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int k0 = 0; k0 < p.K; k0 += BK) {
+            StageA<VEC> ra, rb;
+            load_a<VEC>(p, m0, k0, tid, ra);
+            load_b<VEC>(p, n0, k0, tid, rb);
+            __syncthreads();                       // previous tile's fragment reads are done
+            store_a<VEC>(sA, tid, ra);
+            store_a<VEC>(sB, tid, rb);
+            __syncthreads();
+            const int kc = min(BK, p.K - k0);
+            const int nkk = (kc + 7) >> 3;
+            for (int kk = 0; kk < nkk; ++kk) {
+                float4 a4[2], b4[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a4[t] = *reinterpret_cast<const float4*>(&sA[(wr * 64 + t * 32 + lr) * LDS_LD + kk * 8 + lh * 4]);
+                    b4[t] = *reinterpret_cast<const float4*>(&sB[(wc * 64 + t * 32 + lr) * LDS_LD + kk * 8 + lh * 4]);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float av0 = s == 0 ? a4[0].x : s == 1 ? a4[0].y : s == 2 ? a4[0].z : a4[0].w;
+                    const float av1 = s == 0 ? a4[1].x : s == 1 ? a4[1].y : s == 2 ? a4[1].z : a4[1].w;
+                    const float bv0 = s == 0 ? b4[0].x : s == 1 ? b4[0].y : s == 2 ? b4[0].z : b4[0].w;
+                    const float bv1 = s == 0 ? b4[1].x : s == 1 ? b4[1].y : s == 2 ? b4[1].z : b4[1].w;
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1, acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = n0 + wc * 64 + tn * 32 + lr;
+            const bool cin = col < p.N;
+            const float bias = (p.bias && cin) ? p.bias[col] : 0.f;
+            float esc = 0.f, esh = 0.f;
+            if (p.e_mode == E_MASK_STORE_STATS && cin) { esc = p.esc[col]; esh = p.esh[col]; }
+            float ts = 0.f, tq = 0.f;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (cin && row < p.M) {
+                        const size_t off = (size_t)row * p.N + col;
+                        float c = acc[tm][tn][r] + bias;
+                        if (p.e_mode == E_MASK_STORE_STATS) {
+                            const float y = p.Yprev[off];
+                            c = fmaf(esc, y, esh) > 0.f ? c : c * p.eslope;
+                            ts += c; tq = fmaf(c, y, tq);
+                        } else if (p.e_mode == E_STORE_STATS) {
+                            ts += c; tq = fmaf(c, c, tq);
+                        }
+                        p.C[off] = c;
+                    }
+                }
+            }
+            st_s[tn] += (double)ts; st_q[tn] += (double)tq;
+        }
+    }
+
+    if (p.e_mode != E_STORE) {
+        // lanes l and l^32 hold the same column: fold, then combine the two waves that share a column range
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(sA);           // [4 waves][2 tn][32][2]
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            double s = st_s[tn], q = st_q[tn];
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+            if (lh == 0) { red[((wave * 2 + tn) * 32 + lr) * 2 + 0] = s; red[((wave * 2 + tn) * 32 + lr) * 2 + 1] = q; }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int c = tid, wcc = c >> 6, tn = (c >> 5) & 1, l = c & 31;
+            const int col = n0 + c;
+            if (col < p.N) {
+                double s = 0.0, q = 0.0;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {           // wr = 0,1 with this wc
+                    const int wv = w * 2 + wcc;
+                    s += red[((wv * 2 + tn) * 32 + l) * 2 + 0]; q += red[((wv * 2 + tn) * 32 + l) * 2 + 1];
+                }
+                double* dst = p.stats + (size_t)blockIdx.x * 2 * p.N;
+                dst[col] = s; dst[p.N + col] = q;
+            }
+        }
+    }
+}
+
+// ---- weight gradient: dW[I,J] = sum_p A'[p,I] * B'[p,J]  (A' = dy of this layer, B' = activation below) ----
+struct DwArgs {
+    const float* A; const float* A2;           // dU / Y of this layer            [P,I]
+    const float* sc; const float* sh; const float* k2;     // a, k1, k2           [I]
+    const int32_t* arg; const float* gz; int ns;            // sparse max-pool gradient [P/ns, I]
+    const float* Bsrc; const float* bsc; const float* bsh;  // Y_prev (or X) [P,J], folded BN of the layer below
+    float bslope;
+    float* part;                                // [gridDim.x][I][J] partial sums
+    int P, I, J;
+    int a_mode, b_mode;                         // a: A_DY / A_DY_SPARSE ; b: A_PLAIN / A_BNACT
+};
+
+constexpr int DW_BP = 32, DW_LD = 128 + 4;
+
+__device__ __forceinline__ float dw_load_a(const DwArgs& p, int r, int c, float sc, float sh, float k2) {
+    const size_t off = (size_t)r * p.I + c;
+    float du;
+    if (p.a_mode == A_DY) du = p.A[off];
+    else {
+        const int g = r / p.ns, srow = r - g * p.ns;
+        const size_t go = (size_t)g * p.I + c;
+        du = p.arg[go] == srow ? p.gz[go] : 0.f;
+    }
+    return fmaf(sc, du, -sh) - k2 * p.A2[off];
+}
+
+__global__ __launch_bounds__(MLP_T) void linear_dw_kernel(const DwArgs p) {
+    __shared__ __attribute__((aligned(16))) float sA[DW_BP * DW_LD];   // [p][i]
+    __shared__ __attribute__((aligned(16))) float sB[DW_BP * DW_LD];   // [p][j]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, lh = lane >> 5;
+    const int i0 = blockIdx.y * 128, j0 = blockIdx.z * 128;
+    const int chunks = (p.P + DW_BP - 1) / DW_BP;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // thread t stages channel c = t&127 of rows (t>>7) + 2*i, i = 0..15 (coalesced along channels)
+    const int ca = i0 + (tid & 127), cb = j0 + (tid & 127);
+    const bool ain = ca < p.I, bin = cb < p.J;
+    float asc = 0.f, ash = 0.f, ak2 = 0.f, bsc = 1.f, bsh = 0.f;
+    if (ain) { asc = p.sc[ca]; ash = p.sh[ca]; ak2 = p.k2[ca]; }
+    if (bin && p.b_mode == A_BNACT) { bsc = p.bsc[cb]; bsh = p.bsh[cb]; }
+
+    for (int ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+        const int p0 = ch * DW_BP;
+        float ra[16], rb[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = p0 + (tid >> 7) + 2 * i;
+            const bool rin = r < p.P;
+            ra[i] = (rin && ain) ? dw_load_a(p, r, ca, asc, ash, ak2) : 0.f;
+            float b = 0.f;
+            if (rin && bin) {
+                b = p.Bsrc[(size_t)r * p.J + cb];
+                if (p.b_mode == A_BNACT) b = lrelu(fmaf(bsc, b, bsh), p.bslope);
+            }
+            rb[i] = b;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            sA[((tid >> 7) + 2 * i) * DW_LD + (tid & 127)] = ra[i];
+            sB[((tid >> 7) + 2 * i) * DW_LD + (tid & 127)] = rb[i];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int ks = 0; ks < DW_BP / 2; ++ks) {
+            const int pr = ks * 2 + lh;                 // lanes 0-31: row 2ks, lanes 32-63: row 2ks+1
+            const float a0 = sA[pr * DW_LD + wr * 64 + lr], a1 = sA[pr * DW_LD + wr * 64 + 32 + lr];
+            const float b0 = sB[pr * DW_LD + wc * 64 + lr], b1 = sB[pr * DW_LD + wc * 64 + 32 + lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    float* out = p.part + (size_t)blockIdx.x * p.I * p.J;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = j0 + wc * 64 + tn * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < p.I && col < p.J) out[(size_t)row * p.J + col] = acc[tm][tn][r];
+            }
+        }
+}
+
+// out[e] = sum_r part[r][e]  (+ optional column sums of dy for the bias gradient are taken elsewhere)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int rows, size_t n,
+                                                          float* __restrict__ out) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s += part[(size_t)r * n + e];
+        out[e] = s;
+    }
+}
+
+// ---- BatchNorm bookkeeping (tiny kernels, one thread per channel) ---------------------------------------
+// mean/var from the fp64 partials; folded scale/shift; Jittor-style running statistics (biased variance).
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int rows, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, int P, int C, float eps, float momentum,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+                                   float* __restrict__ invstd_out, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int r = 0; r < rows; ++r) { s += stats[(size_t)r * 2 * C + c]; q += stats[(size_t)r * 2 * C + C + c]; }
+    const double mean = s / P;
+    double var = q / P - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float a = g * invstd;
+    scale[c] = a;
+    shift[c] = b - a * (float)mean;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = invstd;
+    if (running_mean) running_mean[c] += ((float)mean - running_mean[c]) * momentum;
+    if (running_var) running_var[c] += ((float)var - running_var[c]) * momentum;
+}
+
+// BatchNorm backward constants from sum(du) and sum(du*y):
+//   dbeta = S1, dgamma = (S2 - mean*S1)*invstd,  dy = a*du - k1 - k2*y with a = gamma*invstd,
+//   k2 = a*dgamma*invstd/P, k1 = a*dbeta/P - k2*mean.
+__global__ void bn_bwd_consts_kernel(const double* __restrict__ stats, int rows, const float* __restrict__ gamma,
+                                     const float* __restrict__ mean, const float* __restrict__ invstd, int P, int C,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ a_out,
+                                     float* __restrict__ k1, float* __restrict__ k2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < rows; ++r) { s1 += stats[(size_t)r * 2 * C + c]; s2 += stats[(size_t)r * 2 * C + C + c]; }
+    const double mu = mean[c], is = invstd[c];
+    const double g = gamma ? gamma[c] : 1.0;
+    const double dg = (s2 - mu * s1) * is;
+    const double a = g * is;
+    const double kk2 = a * dg * is / P;
+    if (dgamma) dgamma[c] = (float)dg;
+    if (dbeta) dbeta[c] = (float)s1;
+    a_out[c] = (float)a;
+    k2[c] = (float)kk2;
+    k1[c] = (float)(a * s1 / P - kk2 * mu);
+}
+
+// out[g,c] = max_s lrelu(scale*y+shift); arg = first s attaining it; ymax = y at arg.  One thread per (g,c),
+// lanes along c (coalesced 4 B x 64 = 256 B per row segment).
+__global__ __launch_bounds__(256) void bn_act_max_kernel(const float* __restrict__ Y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float slope, int G, int ns,
+                                                         int C, float* __restrict__ out, int32_t* __restrict__ arg,
+                                                         float* __restrict__ ymax) {
+    const size_t total = (size_t)G * C;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t g = e / C;
+        const int c = (int)(e - g * C);
+        const float a = scale[c], b = shift[c];
+        const float* y = Y + g * ns * C + c;
+        float best = -INFINITY, by = 0.f;
+        int bi = 0;
+        for (int s = 0; s < ns; ++s) {
+            const float yy = y[(size_t)s * C];
+            const float z = lrelu(fmaf(a, yy, b), slope);
+            if (z > best) { best = z; bi = s; by = yy; }
+        }
+        out[e] = best;
+        if (arg) arg[e] = bi;
+        if (ymax) ymax[e] = by;
+    }
+}
+
+// gz[g,c] = gout[g,c] * act'(out[g,c]); per-workgroup partial sums of gz and gz*ymax -> stats rows.
+__global__ __launch_bounds__(256) void maxgrad_prep_kernel(const float* __restrict__ gout, const float* __restrict__ out,
+                                                           const float* __restrict__ ymax, float slope, int G, int C,
+                                                           float* __restrict__ gz, double* __restrict__ stats) {
+    // grid.x = channel blocks of 256, grid.y = row slices (<= STAT_ROWS)
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int g = blockIdx.y; g < G; g += gridDim.y) {
+        const size_t e = (size_t)g * C + c;
+        const float v = gout[e] * (out[e] > 0.f ? 1.f : slope);
+        gz[e] = v;
+        s1 += v; s2 += (double)v * ymax[e];
+    }
+    stats[(size_t)blockIdx.y * 2 * C + c] = s1;
+    stats[(size_t)blockIdx.y * 2 * C + C + c] = s2;
+}
+
+// z = lrelu(scale*y+shift) on [P,C] (used where the activation itself is a module output)
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ Y, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, float slope, int C, size_t total,
+                                                     float* __restrict__ out) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        out[e] = lrelu(fmaf(scale[c], Y[e], shift[c]), slope);
+    }
+}
+
+// du = gz * act'(scale*y+shift) on [P,C] with per-workgroup partials of sum(du), sum(du*y)
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict__ gz, const float* __restrict__ Y,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         float slope, int P, int C, float* __restrict__ du,
+                                                         double* __restrict__ stats) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float a = scale[c], b = shift[c];
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = blockIdx.y; r < P; r += gridDim.y) {
+        const size_t e = (size_t)r * C + c;
+        const float y = Y[e];
+        const float v = gz[e] * (fmaf(a, y, b) > 0.f ? 1.f : slope);
+        du[e] = v;
+        s1 += v; s2 += (double)v * y;
+    }
+    stats[(size_t)blockIdx.y * 2 * C + c] = s1;
+    stats[(size_t)blockIdx.y * 2 * C + C + c] = s2;
+}
+
+static int launch_linear(const LinArgs& a, hipStream_t st) {
+    const int m_tiles = (a.M + BM - 1) / BM, n_tiles = (a.N + BN - 1) / BN;
+    const int gx = m_tiles < STAT_ROWS ? m_tiles : STAT_ROWS;
+    dim3 grid(gx, n_tiles);
+    const bool vec = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0) && (!a.A2 || (reinterpret_cast<uintptr_t>(a.A2) & 15) == 0);
+    if (vec) hipLaunchKernelGGL(linear_nt_kernel<true>, grid, dim3(MLP_T), 0, st, a);
+    else hipLaunchKernelGGL(linear_nt_kernel<false>, grid, dim3(MLP_T), 0, st, a);
+    return check_launch("pcl_linear");
+}
+
+}  // namespace pcl
+using namespace pcl;
+
+extern "C" int pcl_mlp_stat_rows(int rows) {
+    const int t = (rows + BM - 1) / BM;
+    return t < 1 ? 1 : (t < STAT_ROWS ? t : STAT_ROWS);
+}
+
+extern "C" int pcl_linear_fwd_f32(const float* X, const float* W, const float* bias, const float* in_scale,
+                                  const float* in_shift, float in_slope, int P, int Cin, int Cout, float* Y,
+                                  double* stats_ws, void* stream) {
+    PCL_REQUIRE(X && W && Y && stats_ws, "pcl_linear_fwd_f32: null pointer");
+    PCL_REQUIRE(P >= 1 && Cin >= 1 && Cout >= 1, "pcl_linear_fwd_f32: bad sizes P=%d Cin=%d Cout=%d", P, Cin, Cout);
+    PCL_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "pcl_linear_fwd_f32: in_scale/in_shift must come together");
+    LinArgs a = {};
+    a.A = X; a.B = W; a.bias = bias; a.sc = in_scale; a.sh = in_shift; a.slope = in_slope;
+    a.C = Y; a.stats = stats_ws; a.M = P; a.N = Cout; a.K = Cin;
+    a.a_mode = in_scale ? A_BNACT : A_PLAIN; a.e_mode = E_STORE_STATS;
+    return launch_linear(a, as_stream(stream));
+}
+
+extern "C" int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,
+                                     const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
+                                     int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
+                                     float prev_slope, float* dUprev, double* stats_ws, void* stream) {
+    PCL_REQUIRE(Y && a_ && k1 && k2 && Wt && dUprev, "pcl_linear_bwd_dx_f32: null pointer");
+    PCL_REQUIRE((dU != nullptr) != (arg != nullptr && gz != nullptr), "pcl_linear_bwd_dx_f32: pass dU or (arg,gz)");
+    PCL_REQUIRE(P >= 1 && Cin >= 1 && Cout >= 1 && (dU || ns >= 1), "pcl_linear_bwd_dx_f32: bad sizes");
+    PCL_REQUIRE(!Yprev || (prev_scale && prev_shift && stats_ws), "pcl_linear_bwd_dx_f32: masked mode needs scale/shift/stats");
+    LinArgs a = {};
+    a.A = dU; a.A2 = Y; a.B = Wt; a.sc = a_; a.sh = k1; a.k2 = k2; a.arg = arg; a.gz = gz; a.ns = ns;
+    a.C = dUprev; a.stats = stats_ws; a.Yprev = Yprev; a.esc = prev_scale; a.esh = prev_shift; a.eslope = prev_slope;
+    a.M = P; a.N = Cin; a.K = Cout;
+    a.a_mode = dU ? A_DY : A_DY_SPARSE; a.e_mode = Yprev ? E_MASK_STORE_STATS : E_STORE;
+    return launch_linear(a, as_stream(stream));
+}
+
+extern "C" size_t pcl_linear_bwd_dw_workspace_bytes(int P, int Cout, int Cin) {
+    if (P < 1 || Cout < 1 || Cin < 1) return 0;
+    const int tiles = ((Cout + 127) / 128) * ((Cin + 127) / 128);
+    const int chunks = (P + DW_BP - 1) / DW_BP;
+    int gx = (768 + tiles - 1) / tiles;
+    if (gx > chunks) gx = chunks;
+    if (gx < 1) gx = 1;
+    return sizeof(float) * (size_t)gx * Cout * Cin;
+}
+
+extern "C" int pcl_linear_bwd_dw_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,
+                                     const int32_t* arg, const float* gz, int ns, const float* Xprev,
+                                     const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
+                                     int Cin, float* dW, void* workspace, size_t workspace_bytes, void* stream) {
+    PCL_REQUIRE(Y && a_ && k1 && k2 && Xprev && dW, "pcl_linear_bwd_dw_f32: null pointer");
+    PCL_REQUIRE((dU != nullptr) != (arg != nullptr && gz != nullptr), "pcl_linear_bwd_dw_f32: pass dU or (arg,gz)");
+    PCL_REQUIRE((prev_scale == nullptr) == (prev_shift == nullptr), "pcl_linear_bwd_dw_f32: scale/shift together");
+    PCL_REQUIRE(P >= 1 && Cin >= 1 && Cout >= 1 && (dU || ns >= 1), "pcl_linear_bwd_dw_f32: bad sizes");
+    const size_t need = pcl_linear_bwd_dw_workspace_bytes(P, Cout, Cin);
+    if (!workspace || workspace_bytes < need) return fail(PCL_EWS, "pcl_linear_bwd_dw_f32: workspace %zu < %zu", workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    const int gx = (int)(need / (sizeof(float) * (size_t)Cout * Cin));
+    DwArgs d = {};
+    d.A = dU; d.A2 = Y; d.sc = a_; d.sh = k1; d.k2 = k2; d.arg = arg; d.gz = gz; d.ns = ns;
+    d.Bsrc = Xprev; d.bsc = prev_scale; d.bsh = prev_shift; d.bslope = prev_slope;
+    d.part = static_cast<float*>(workspace); d.P = P; d.I = Cout; d.J = Cin;
+    d.a_mode = dU ? A_DY : A_DY_SPARSE; d.b_mode = prev_scale ? A_BNACT : A_PLAIN;
+    dim3 grid(gx, (Cout + 127) / 128, (Cin + 127) / 128);
+    hipLaunchKernelGGL(linear_dw_kernel, grid, dim3(MLP_T), 0, st, d);
+    int rc = check_launch("pcl_linear_bwd_dw_f32");
+    if (rc) return rc;
+    const size_t n = (size_t)Cout * Cin;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(blocks), dim3(256), 0, st, d.part, gx, n, dW);
+    return check_launch("pcl_linear_bwd_dw_f32(reduce)");
+}
+
+extern "C" int pcl_bn_finalize_f32(const double* stats_ws, int stat_rows, const float* gamma, const float* beta, int P,
+                                   int C, float eps, float momentum, float* scale, float* shift, float* mean_out,
+                                   float* invstd_out, float* running_mean, float* running_var, void* stream) {
+    PCL_REQUIRE(stats_ws && scale && shift && mean_out && invstd_out, "pcl_bn_finalize_f32: null pointer");
+    PCL_REQUIRE(P >= 1 && C >= 1 && stat_rows >= 1, "pcl_bn_finalize_f32: bad sizes");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), stats_ws, stat_rows,
+                       gamma, beta, P, C, eps, momentum, scale, shift, mean_out, invstd_out, running_mean, running_var);
+    return check_launch("pcl_bn_finalize_f32");
+}
+
+extern "C" int pcl_bn_bwd_consts_f32(const double* stats_ws, int stat_rows, const float* gamma, const float* mean,
+                                     const float* invstd, int P, int C, float* dgamma, float* dbeta, float* a_out,
+                                     float* k1, float* k2, void* stream) {
+    PCL_REQUIRE(stats_ws && mean && invstd && a_out && k1 && k2, "pcl_bn_bwd_consts_f32: null pointer");
+    PCL_REQUIRE(P >= 1 && C >= 1 && stat_rows >= 1, "pcl_bn_bwd_consts_f32: bad sizes");
+    hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), stats_ws, stat_rows,
+                       gamma, mean, invstd, P, C, dgamma, dbeta, a_out, k1, k2);
+    return check_launch("pcl_bn_bwd_consts_f32");
+}
+
+extern "C" int pcl_bn_act_max_f32(const float* Y, const float* scale, const float* shift, float slope, int G, int ns,
+                                  int C, float* out, int32_t* arg, float* ymax, void* stream) {
+    PCL_REQUIRE(Y && scale && shift && out, "pcl_bn_act_max_f32: null pointer");
+    PCL_REQUIRE(G >= 1 && ns >= 1 && C >= 1, "pcl_bn_act_max_f32: bad sizes");
+    const size_t total = (size_t)G * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_act_max_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), Y, scale, shift, slope, G, ns, C,
+                       out, arg, ymax);
+    return check_launch("pcl_bn_act_max_f32");
+}
+
+extern "C" int pcl_maxgrad_prep_f32(const float* gout, const float* out, const float* ymax, float slope, int G, int C,
+                                    float* gz, double* stats_ws, int* stat_rows_out, void* stream) {
+    PCL_REQUIRE(gout && out && ymax && gz && stats_ws && stat_rows_out, "pcl_maxgrad_prep_f32: null pointer");
+    PCL_REQUIRE(G >= 1 && C >= 1, "pcl_maxgrad_prep_f32: bad sizes");
+    int rows = G < 64 ? G : 64;
+    *stat_rows_out = rows;
+    hipLaunchKernelGGL(maxgrad_prep_kernel, dim3((C + 255) / 256, rows), dim3(256), 0, as_stream(stream), gout, out, ymax,
+                       slope, G, C, gz, stats_ws);
+    return check_launch("pcl_maxgrad_prep_f32");
+}
+
+extern "C" int pcl_bn_act_f32(const float* Y, const float* scale, const float* shift, float slope, int P, int C,
+                              float* out, void* stream) {
+    PCL_REQUIRE(Y && scale && shift && out && P >= 1 && C >= 1, "pcl_bn_act_f32: bad arguments");
+    const size_t total = (size_t)P * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_act_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), Y, scale, shift, slope, C, total, out);
+    return check_launch("pcl_bn_act_f32");
+}
+
+extern "C" int pcl_bn_act_bwd_f32(const float* gz, const float* Y, const float* scale, const float* shift, float slope,
+                                  int P, int C, float* du, double* stats_ws, int* stat_rows_out, void* stream) {
+    PCL_REQUIRE(gz && Y && scale && shift && du && stats_ws && stat_rows_out && P >= 1 && C >= 1, "pcl_bn_act_bwd_f32: bad arguments");
+    int rows = P < STAT_ROWS ? P : STAT_ROWS;
+    *stat_rows_out = rows;
+    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3((C + 255) / 256, rows), dim3(256), 0, as_stream(stream), gz, Y, scale, shift,
+                       slope, P, C, du, stats_ws);
+    return check_launch("pcl_bn_act_bwd_f32");
+}

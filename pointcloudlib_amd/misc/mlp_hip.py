@@ -1,9 +1,181 @@
-"""Fused gfx950 pointwise-MLP path (filled in once the MFMA kernels land)."""
+"""Fused gfx950 path of ``PointwiseMLP``: one autograd node for the whole [Linear -> BatchNorm -> (Leaky)ReLU] x L
+(+ max over the group) stack, forward and backward, on the MFMA kernels of ``csrc/mlp.hip``.
+
+Per layer the only P-sized tensors that touch HBM are the pre-BatchNorm outputs ``y_l`` (kept for backward) and,
+in backward, the masked gradients ``du_l``; BatchNorm + activation are folded into operand staging, batch
+statistics and BatchNorm-backward sums come out of GEMM epilogues (see the header of mlp.hip).
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+_P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
 
 
 def available():
-    return False
+    return True
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _empty(shape, dev, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+class _FusedMLP(torch.autograd.Function):
+    """inputs: x [P,C0]; cfg = (group_ns|0, slope, eps, momentum, training, bn, last_act); then per layer
+    (W, bias|None, gamma|None, beta|None, running_mean|None, running_var|None)."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, *params):
+        ns, slope, eps, momentum, training, bn, last_act = cfg
+        L = len(params) // 6
+        dev = x.device
+        x = x.contiguous()
+        P, C0 = x.shape
+        st = _stream()
+        rows = _lib.lib().pcl_mlp_stat_rows(P)
+        Ys, scales, shifts, means, invstds = [], [], [], [], []
+        cur, in_scale, in_shift = x, None, None
+        cin = C0
+        for l in range(L):
+            W, bias, gamma, beta, rmean, rvar = params[6 * l:6 * l + 6]
+            cout = W.shape[0]
+            Y = _empty((P, cout), dev)
+            stats = _empty((rows, 2, cout), dev, torch.float64)
+            _lib.call("pcl_linear_fwd_f32", _P(cur), _P(W), _P(bias), _P(in_scale), _P(in_shift), slope, P, cin, cout,
+                      _P(Y), _P(stats), st, algo_bytes=4 * P * (cin + cout) + 4 * cin * cout,
+                      algo_flops=2 * P * cin * cout, tag=f"fwd{cin}x{cout}")
+            if bn and training:
+                scale, shift, mean, invstd = (_empty((cout,), dev) for _ in range(4))
+                _lib.call("pcl_bn_finalize_f32", _P(stats), rows, _P(gamma), _P(beta), P, cout, eps, momentum, _P(scale),
+                          _P(shift), _P(mean), _P(invstd), _P(rmean), _P(rvar), st)
+            elif bn:
+                invstd = torch.rsqrt(rvar + eps)
+                mean = rmean
+                scale = gamma * invstd
+                shift = beta - scale * rmean
+            else:
+                scale, shift = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+                mean, invstd = shift, scale
+            Ys.append(Y); scales.append(scale); shifts.append(shift); means.append(mean); invstds.append(invstd)
+            cur, in_scale, in_shift, cin = Y, scale, shift, cout
+        out_slope = slope if last_act else 1.0
+        if ns:
+            G = P // ns
+            out = _empty((G, cin), dev)
+            arg = _empty((G, cin), dev, torch.int32)
+            ymax = _empty((G, cin), dev)
+            _lib.call("pcl_bn_act_max_f32", _P(cur), _P(in_scale), _P(in_shift), out_slope, G, ns, cin, _P(out), _P(arg),
+                      _P(ymax), st, algo_bytes=4 * P * cin + 12 * G * cin, tag=f"max{cin}")
+        else:
+            out = _empty((P, cin), dev)
+            arg = ymax = None
+            _lib.call("pcl_bn_act_f32", _P(cur), _P(in_scale), _P(in_shift), out_slope, P, cin, _P(out), st)
+        ctx.cfg = (ns, slope, out_slope, training, bn, L, P, C0)
+        ctx.params = params
+        ctx.saved = (x, Ys, scales, shifts, means, invstds, out, arg, ymax)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        ns, slope, out_slope, training, bn, L, P, C0 = ctx.cfg
+        params = ctx.params
+        x, Ys, scales, shifts, means, invstds, out, arg, ymax = ctx.saved
+        dev = x.device
+        st = _stream()
+        lib = _lib.lib()
+        gout = gout.contiguous()
+        rows_c = ctypes.c_int(0)
+        cl = Ys[-1].shape[1]
+        stats = _empty((256, 2, cl), dev, torch.float64)
+        if ns:
+            G = P // ns
+            gz = _empty((G, cl), dev)
+            _lib.call("pcl_maxgrad_prep_f32", _P(gout), _P(out), _P(ymax), out_slope, G, cl, _P(gz), _P(stats),
+                      ctypes.byref(rows_c), st)
+            dU, sparse = None, True
+        else:
+            dU = _empty((P, cl), dev)
+            _lib.call("pcl_bn_act_bwd_f32", _P(gout), _P(Ys[-1]), _P(scales[-1]), _P(shifts[-1]), out_slope, P, cl, _P(dU),
+                      _P(stats), ctypes.byref(rows_c), st)
+            gz, sparse = None, False
+        rows = rows_c.value
+        grads = [None] * (6 * L)
+        need_x = ctx.needs_input_grad[0]
+        gx = None
+        for l in range(L - 1, -1, -1):
+            W, bias, gamma, beta, _, _ = params[6 * l:6 * l + 6]
+            cout, cin = W.shape
+            a, k1, k2 = (_empty((cout,), dev) for _ in range(3))
+            if bn and training:
+                dgamma, dbeta = _empty((cout,), dev), _empty((cout,), dev)
+                _lib.call("pcl_bn_bwd_consts_f32", _P(stats), rows, _P(gamma), _P(means[l]), _P(invstds[l]), P, cout,
+                          _P(dgamma), _P(dbeta), _P(a), _P(k1), _P(k2), st)
+                grads[6 * l + 2], grads[6 * l + 3] = dgamma, dbeta
+            else:
+                s = stats[:rows].sum(0)
+                a.copy_(scales[l]); k1.zero_(); k2.zero_()
+                if bn:   # eval-mode BatchNorm: affine with constant statistics
+                    grads[6 * l + 3] = s[0].float()
+                    grads[6 * l + 2] = ((s[1] - means[l].double() * s[0]) * invstds[l].double()).float()
+            if bias is not None:
+                # bias feeds BatchNorm -> its gradient is exactly zero; without BatchNorm it is sum(du)
+                grads[6 * l + 1] = torch.zeros_like(bias) if (bn and training) else stats[:rows, 0].sum(0).float() * a
+            Xprev = Ys[l - 1] if l > 0 else x
+            psc = scales[l - 1] if l > 0 else None
+            psh = shifts[l - 1] if l > 0 else None
+            nbytes = lib.pcl_linear_bwd_dw_workspace_bytes(P, cout, cin)
+            ws = _empty(((nbytes + 3) // 4,), dev)
+            dW = _empty((cout, cin), dev)
+            _lib.call("pcl_linear_bwd_dw_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(arg) if sparse else None,
+                      _P(gz) if sparse else None, ns or 1, _P(Xprev), _P(psc), _P(psh), slope, P, cout, cin, _P(dW), _P(ws),
+                      nbytes, st, algo_bytes=4 * P * (cin + (cout if sparse else 2 * cout)) + 4 * cin * cout,
+                      algo_flops=2 * P * cin * cout, tag=f"dw{cout}x{cin}")
+            grads[6 * l] = dW
+            if l > 0 or need_x:
+                Wt = W.t().contiguous()
+                dUp = _empty((P, cin), dev)
+                if l > 0:
+                    rows_n = lib.pcl_mlp_stat_rows(P)
+                    stats_n = _empty((rows_n, 2, cin), dev, torch.float64)
+                else:
+                    rows_n, stats_n = rows, None
+                _lib.call("pcl_linear_bwd_dx_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(arg) if sparse else None,
+                          _P(gz) if sparse else None, ns or 1, _P(Wt), P, cout, cin, _P(Xprev) if l > 0 else None, _P(psc),
+                          _P(psh), slope, _P(dUp), _P(stats_n), st,
+                          algo_bytes=4 * P * (cin * (2 if l > 0 else 1) + (cout if sparse else 2 * cout)) + 4 * cin * cout,
+                          algo_flops=2 * P * cin * cout, tag=f"dx{cout}x{cin}")
+                dU, sparse, stats, rows = dUp, False, stats_n, rows_n
+                if l == 0:
+                    gx = dUp
+        return (gx, None) + tuple(grads)
 
 
 def pointwise_mlp(module, x, group_max=None):
-    raise RuntimeError("fused HIP MLP kernels are not built")
+    """Run ``PointwiseMLP`` ``module`` on channel-last ``x`` [..., C0] through the fused HIP path."""
+    if not x.is_cuda:
+        raise RuntimeError("fused HIP MLP needs GPU tensors (no CPU fallback)")
+    if x.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {x.dtype}")
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    ns = 0
+    if group_max is not None:
+        assert x.shape[-2] == group_max, f"group_max={group_max} but group axis is {x.shape[-2]}"
+        ns = int(group_max)
+    params = []
+    for i in range(module.n_layers):
+        params += [module.weights[i], None if module.biases is None else module.biases[i],
+                   module.gammas[i] if module.bn else None, module.betas[i] if module.bn else None,
+                   getattr(module, f"running_mean_{i}") if module.bn else None,
+                   getattr(module, f"running_var_{i}") if module.bn else None]
+    cfg = (ns, module.slope, module.eps, module.momentum, module.training, module.bn, module.last_act)
+    out = _FusedMLP.apply(x2, cfg, *params)
+    if ns:
+        return out.reshape(*lead[:-1], out.shape[-1])
+    return out.reshape(*lead, out.shape[-1])

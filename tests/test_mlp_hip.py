@@ -1,0 +1,108 @@
+"""GPU: the fused MFMA MLP path (csrc/mlp.hip) against a plain PyTorch reference of the same op
+(fp64 on CPU as ground truth; fp32 tolerance stated per check).  Features: |err| <= 1e-5 * max(1, |ref|_max)
+(north_star: "within 1e-5 fp32 for features"); gradients: 1e-4 relative to the gradient's max-norm, and never
+worse than 4x the error of PyTorch's own fp32 GPU path against the same fp64 truth."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from pointcloudlib_amd.misc.layers import PointwiseMLP
+
+pytestmark = pytest.mark.gpu
+
+
+def run(module, x, ns, gout, backend):
+    module.backend = backend
+    module.zero_grad()
+    x = x.clone().requires_grad_(True)
+    out = module(x, group_max=ns)
+    out.backward(gout)
+    grads = {n: p.grad.detach().clone() for n, p in module.named_parameters()}
+    bufs = {n: b.detach().clone() for n, b in module.named_buffers()}
+    return out.detach(), x.grad.detach(), grads, bufs
+
+
+CASES = [
+    # spec, lead shape, group_max, bias, slope
+    ([6, 64, 64, 128], (2, 25, 16), 16, False, 0.0),        # SA1-like, K=6 (scalar staging), ragged P=800
+    ([131, 128, 128, 256], (2, 16, 32), 32, False, 0.0),    # SA2-like, K=131, N=256 (two column tiles)
+    ([259, 256, 512, 1024], (3, 1, 128), 128, False, 0.0),  # SA3-like (GroupAll), deep K
+    ([6, 64], (2, 40, 20), 20, False, 0.2),                 # DGCNN edge conv: LeakyReLU(0.2), max over k
+    ([64, 40, 24], (3, 70), None, True, 0.0),               # FP-style: bias + BN + ReLU, no max, N < 128
+    ([12, 8, 8, 16], (2, 33, 8), None, True, 0.0),          # WeightNet-sized
+]
+
+
+@pytest.mark.parametrize("spec,lead,ns,bias,slope", CASES)
+def test_fused_mlp_matches_reference(dev, spec, lead, ns, bias, slope):
+    torch.manual_seed(1234 + spec[0])
+    m64 = PointwiseMLP(spec, bias=bias, slope=slope).double()
+    with torch.no_grad():
+        for g, b in zip(m64.gammas, m64.betas):
+            g.uniform_(0.5, 1.5); b.uniform_(-0.3, 0.3)
+        for g in m64.gammas:
+            g[::3] *= -1.0                                   # negative gamma: max must not assume monotone BN
+    x64 = torch.randn(*lead, spec[0], dtype=torch.float64)
+    if ns:                                                   # padded duplicates inside groups (ball-query padding)
+        x64[..., ns // 2:, :] = x64[..., :1, :]
+    m64.backend = "torch"
+    out_shape = (*lead[:-1], spec[-1]) if ns else (*lead, spec[-1])
+    gout64 = torch.randn(out_shape, dtype=torch.float64)
+    ref = run(copy.deepcopy(m64), x64, ns, gout64, "torch")
+
+    m32 = copy.deepcopy(m64).float().to(dev)
+    x32, g32 = x64.float().to(dev), gout64.float().to(dev)
+    t32 = run(copy.deepcopy(m32), x32, ns, g32, "torch")
+    h32 = run(copy.deepcopy(m32), x32, ns, g32, "hip")
+
+    def err(a, b):
+        return (a.double().cpu() - b).abs().max().item()
+
+    scale = max(1.0, ref[0].abs().max().item())
+    e_h, e_t = err(h32[0], ref[0]), err(t32[0], ref[0])
+    assert e_h <= 1e-5 * scale, f"features: hip err {e_h:.3e} (torch fp32 {e_t:.3e}), scale {scale:.3f}"
+    gs = max(1e-6, ref[1].abs().max().item())
+    e_h, e_t = err(h32[1], ref[1]), err(t32[1], ref[1])
+    assert e_h <= max(1e-4 * gs, 4 * e_t), f"input grad: hip {e_h:.3e} torch {e_t:.3e} scale {gs:.3e}"
+    for name in ref[2]:
+        if "biases" in name:                                 # bias feeds BatchNorm: true gradient is 0
+            assert h32[2][name].abs().max().item() <= 1e-4
+            continue
+        gs = max(1e-6, ref[2][name].abs().max().item())
+        e_h, e_t = err(h32[2][name], ref[2][name]), err(t32[2][name], ref[2][name])
+        assert e_h <= max(1e-4 * gs, 4 * e_t), f"{name}: hip {e_h:.3e} torch {e_t:.3e} scale {gs:.3e}"
+    for name in ref[3]:                                      # running statistics (Jittor rule: biased variance)
+        assert err(h32[3][name], ref[3][name]) <= 1e-5 * max(1.0, ref[3][name].abs().max().item()), name
+
+
+def test_fused_mlp_eval_mode_and_no_input_grad(dev):
+    torch.manual_seed(0)
+    m = PointwiseMLP([6, 32, 64]).to(dev)
+    x = torch.randn(4, 10, 8, 6, device=dev)
+    m.train(); m.backend = "hip"; m(x, group_max=8)          # populate running stats
+    m.eval()
+    m.backend = "torch"; a = m(x, group_max=8)
+    m.backend = "hip"; b = m(x, group_max=8)
+    assert (a - b).abs().max().item() <= 1e-5 * max(1.0, a.abs().max().item())
+    m.train()
+    out = m(x, group_max=8)                                  # x does not require grad: no dX GEMM for layer 0
+    out.sum().backward()
+    assert all(p.grad is not None for p in m.parameters())
+
+
+def test_full_size_sa1_statistics_property(dev):
+    """BASELINE size (P = 32*512*64 rows): after BN the pre-activation has mean 0 / var 1 per channel, so the
+    reported batch statistics must reproduce those of an fp64 reduction of the stored pre-BN output."""
+    torch.manual_seed(3)
+    m = PointwiseMLP([6, 64, 64, 128]).to(dev).train()
+    m.backend = "hip"
+    x = torch.randn(32, 512, 64, 6, device=dev)
+    m(x, group_max=64)
+    y = torch.nn.functional.linear(x.reshape(-1, 6), m.weights[0])
+    mean = y.double().mean(0)
+    var = y.double().var(0, unbiased=False)
+    rm, rv = m.running_mean_0.double(), m.running_var_0.double()
+    assert (rm - 0.1 * mean).abs().max().item() < 1e-6
+    assert (rv - (0.9 + 0.1 * var)).abs().max().item() < 1e-5
