@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--npoints", type=int, default=1024, help="points per cloud (1024; 4096 is the north-star extra)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-kernel", default="auto")
+    ap.add_argument("--profile-all", action="store_true", help="print a per-entry-point event-timed table to stderr")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,6 +134,20 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    if args.profile_all and rank == 0:
+        _lib.PROFILER = _lib.KernelTimer()
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        summ = _lib.PROFILER.summary()
+        _lib.PROFILER = None
+        tot = sum(v["total_ms"] for v in summ.values()) / 3
+        print(f"--- own C-ABI calls, per step total {tot:.3f} ms", file=sys.stderr)
+        for (name, tag), v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
+            gbs = v["algo_bytes"] / (v["avg_ms"] * 1e-3) / 1e9 if v["algo_bytes"] else 0
+            tf = v["algo_flops"] / (v["avg_ms"] * 1e-3) / 1e12 if v["algo_flops"] else 0
+            print(f"{name:28s} {tag:14s} n/step={v['launches'] / 3:4.1f} avg={v['avg_ms']:8.4f} ms  {gbs:8.1f} GB/s {tf:7.2f} TF",
+                  file=sys.stderr)
     # pick the dominant own kernel (untimed 2-step pre-pass with every entry point bracketed by events)
     target = args.roofline_kernel
     if target == "auto":

@@ -117,9 +117,10 @@ int pcl_three_interp_bwd_f32(const float* gout, const int32_t* idx3, const float
  * batch statistics come out of the GEMM epilogues.  Notation per layer l: y = z_prev W^T (+bias) (stored),
  * u = scale*y + shift (BatchNorm, scale = gamma*invstd, shift = beta - scale*mean), z = lrelu(u).
  *
- * Statistics workspaces `stats_ws` are [rows][2][C] doubles with rows <= 256; the producer uses
- * pcl_mlp_stat_rows(P) rows for GEMM epilogues, or reports the count through *stat_rows_out. */
-int pcl_mlp_stat_rows(int P);
+ * Statistics workspaces `stats_ws` are [rows][2][C] doubles with rows <= 1024; a GEMM epilogue producing C
+ * channels over P rows writes pcl_mlp_stat_rows(P, C) rows, the elementwise producers report the count
+ * through *stat_rows_out. */
+int pcl_mlp_stat_rows(int P, int C);
 /* Y[P,Cout] = act_in(X[P,Cin]) W[Cout,Cin]^T (+bias);  act_in = identity (in_scale NULL) or
  * lrelu(in_scale*x+in_shift, in_slope).  stats_ws rows: (sum Y, sum Y^2) per channel. */
 int pcl_linear_fwd_f32(const float* X, const float* W, const float* bias, const float* in_scale,

@@ -57,7 +57,7 @@ _SIGS = {
     "pcl_three_nn_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "pcl_three_interp_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_three_interp_bwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
-    "pcl_mlp_stat_rows": (c_int, [c_int]),
+    "pcl_mlp_stat_rows": (c_int, [c_int, c_int]),
     "pcl_linear_fwd_f32": (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P]),
     "pcl_bn_finalize_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "pcl_bn_act_max_f32": (c_int, [_P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P]),
@@ -80,6 +80,11 @@ def lib():
         if not os.path.exists(_SO):
             raise PclError(f"{_SO} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch-ROCm bundles its own libamdhip64 (same SONAME).  Kernels launched here must run in the SAME HIP
+        # runtime instance that owns torch's device buffers and streams, so torch's copy has to be the one the
+        # dynamic linker resolves for us: load torch first, then dlopen (otherwise /opt/rocm's copy is pulled in as
+        # a second runtime and every launch fails with hipErrorNoDevice).
+        import torch  # noqa: F401
         L = ctypes.CDLL(_SO)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)

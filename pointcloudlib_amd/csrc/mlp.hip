@@ -26,9 +26,9 @@ namespace pcl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = BK + 4;
+constexpr int BK = 32, LDS_LD = BK + 4;
 constexpr int MLP_T = 256;
-constexpr int STAT_ROWS = 256;   // max workgroups along the row axis == rows of the stats workspace
+constexpr int STAT_ROWS = 1024;  // max workgroups along the row axis == max rows of a stats workspace
 
 enum AMode { A_PLAIN = 0, A_BNACT = 1, A_DY = 2, A_DY_SPARSE = 3 };
 enum EMode { E_STORE_STATS = 0, E_MASK_STORE_STATS = 1, E_STORE = 2 };
@@ -55,184 +55,257 @@ struct LinArgs {
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
 
-// ---- staging: global -> registers (with the fused transform) -> LDS -------------------------------------
-// Vector path (K % 4 == 0): thread t owns k4 = (t&7)*4 of rows (t>>3) + 32*i, i = 0..3.
-// Scalar path: thread t owns k = t&31 of rows (t>>5) + 8*i, i = 0..15.
-template <bool VEC>
-struct StageA {
-    static constexpr int NV = VEC ? 4 : 16;
-    float4 v[VEC ? 4 : 1];
-    float s[VEC ? 1 : 16];
+// ---- staging: global -> registers (raw) ... MFMAs of the current step ... -> transform -> LDS ------------
+// The raw operands of step i+1 are requested before the MFMAs of step i and only touched (fused transform +
+// LDS store) after them, so HBM/L2 latency hides under the matrix pipe.
+// Vector path (K % 4 == 0): thread t owns k4 = (t&7)*4 of rows (t>>3) + 32*i.
+// Scalar path: thread t owns k = t&31 of rows (t>>5) + 8*i.
+template <bool VEC, int ROWS>
+struct Stage {
+    static constexpr int NI = VEC ? ROWS / 32 : ROWS / 8;
+    float4 v[VEC ? NI : 1], v2[VEC ? NI : 1], vg[VEC ? NI : 1];
+    int4 vi[VEC ? NI : 1];
+    float s[VEC ? 1 : NI], s2[VEC ? 1 : NI], sg[VEC ? 1 : NI];
+    int si[VEC ? 1 : NI];
+    float4 c_sc, c_sh, c_k2;       // per-k constants of this step (vector path)
+    float f_sc, f_sh, f_k2;        // (scalar path)
+    int m0;                        // first row of the staged tile (for the sparse row-in-group test)
 };
 
-template <bool VEC>
-__device__ __forceinline__ void load_a(const LinArgs& p, int m0, int k0, int tid, StageA<VEC>& st) {
-    if (VEC) {
+template <int AM, bool VEC, int ROWS>
+__device__ __forceinline__ void load_a(const LinArgs& p, int m0, int k0, int tid, Stage<VEC, ROWS>& st) {
+    st.m0 = m0;
+    if constexpr (VEC) {
         const int k = k0 + (tid & 7) * 4;
         const bool kin = k < p.K;
-        float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0), k2 = make_float4(0, 0, 0, 0);
-        if (p.a_mode != A_PLAIN && kin) {
-            sc = *reinterpret_cast<const float4*>(p.sc + k);
-            sh = *reinterpret_cast<const float4*>(p.sh + k);
-            if (p.a_mode >= A_DY) k2 = *reinterpret_cast<const float4*>(p.k2 + k);
+        st.c_sc = make_float4(1, 1, 1, 1); st.c_sh = make_float4(0, 0, 0, 0); st.c_k2 = make_float4(0, 0, 0, 0);
+        if (AM != A_PLAIN && kin) {
+            st.c_sc = *reinterpret_cast<const float4*>(p.sc + k);
+            st.c_sh = *reinterpret_cast<const float4*>(p.sh + k);
+            if (AM >= A_DY) st.c_k2 = *reinterpret_cast<const float4*>(p.k2 + k);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < ROWS / 32; ++i) {
             const int r = m0 + (tid >> 3) + 32 * i;
-            float4 a = make_float4(0, 0, 0, 0);
-            if (kin && r < p.M) {
-                const size_t off = (size_t)r * p.K + k;
-                if (p.a_mode == A_PLAIN) {
-                    a = *reinterpret_cast<const float4*>(p.A + off);
-                } else if (p.a_mode == A_BNACT) {
-                    const float4 x = *reinterpret_cast<const float4*>(p.A + off);
-                    a.x = lrelu(fmaf(sc.x, x.x, sh.x), p.slope); a.y = lrelu(fmaf(sc.y, x.y, sh.y), p.slope);
-                    a.z = lrelu(fmaf(sc.z, x.z, sh.z), p.slope); a.w = lrelu(fmaf(sc.w, x.w, sh.w), p.slope);
-                } else {
-                    float4 du;
-                    if (p.a_mode == A_DY) {
-                        du = *reinterpret_cast<const float4*>(p.A + off);
-                    } else {
-                        const int g = r / p.ns, srow = r - g * p.ns;
-                        const size_t go = (size_t)g * p.K + k;
-                        const int4 ar = *reinterpret_cast<const int4*>(p.arg + go);
-                        const float4 gz = *reinterpret_cast<const float4*>(p.gz + go);
-                        du.x = ar.x == srow ? gz.x : 0.f; du.y = ar.y == srow ? gz.y : 0.f;
-                        du.z = ar.z == srow ? gz.z : 0.f; du.w = ar.w == srow ? gz.w : 0.f;
-                    }
-                    const float4 y = *reinterpret_cast<const float4*>(p.A2 + off);
-                    a.x = fmaf(sc.x, du.x, -sh.x) - k2.x * y.x; a.y = fmaf(sc.y, du.y, -sh.y) - k2.y * y.y;
-                    a.z = fmaf(sc.z, du.z, -sh.z) - k2.z * y.z; a.w = fmaf(sc.w, du.w, -sh.w) - k2.w * y.w;
-                }
+            const bool in = kin && r < p.M;
+            const size_t off = (size_t)r * p.K + k;
+            const float4 z4 = make_float4(0, 0, 0, 0);
+            if constexpr (AM == A_PLAIN || AM == A_BNACT) {
+                st.v[i] = in ? *reinterpret_cast<const float4*>(p.A + off) : z4;
+            } else if constexpr (AM == A_DY) {
+                st.v[i] = in ? *reinterpret_cast<const float4*>(p.A + off) : z4;
+                st.v2[i] = in ? *reinterpret_cast<const float4*>(p.A2 + off) : z4;
+            } else {
+                const int g = r / p.ns;
+                const size_t go = (size_t)g * p.K + k;
+                st.vi[i] = in ? *reinterpret_cast<const int4*>(p.arg + go) : make_int4(-1, -1, -1, -1);
+                st.vg[i] = in ? *reinterpret_cast<const float4*>(p.gz + go) : z4;
+                st.v2[i] = in ? *reinterpret_cast<const float4*>(p.A2 + off) : z4;
             }
-            st.v[i] = a;
         }
     } else {
         const int k = k0 + (tid & 31);
         const bool kin = k < p.K;
-        float sc = 1.f, sh = 0.f, k2 = 0.f;
-        if (p.a_mode != A_PLAIN && kin) {
-            sc = p.sc[k]; sh = p.sh[k];
-            if (p.a_mode >= A_DY) k2 = p.k2[k];
+        st.f_sc = 1.f; st.f_sh = 0.f; st.f_k2 = 0.f;
+        if (AM != A_PLAIN && kin) {
+            st.f_sc = p.sc[k]; st.f_sh = p.sh[k];
+            if (AM >= A_DY) st.f_k2 = p.k2[k];
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < ROWS / 8; ++i) {
             const int r = m0 + (tid >> 5) + 8 * i;
-            float a = 0.f;
+            const bool in = kin && r < p.M;
+            const size_t off = (size_t)r * p.K + k;
+            if constexpr (AM == A_PLAIN || AM == A_BNACT) {
+                st.s[i] = in ? p.A[off] : 0.f;
+            } else if constexpr (AM == A_DY) {
+                st.s[i] = in ? p.A[off] : 0.f;
+                st.s2[i] = in ? p.A2[off] : 0.f;
+            } else {
+                const int g = r / p.ns;
+                const size_t go = (size_t)g * p.K + k;
+                st.si[i] = in ? p.arg[go] : -1;
+                st.sg[i] = in ? p.gz[go] : 0.f;
+                st.s2[i] = in ? p.A2[off] : 0.f;
+            }
+        }
+    }
+}
+
+// fused transform + LDS store of a staged A tile.  Rows/columns outside the matrix were loaded as zeros and
+// must stay exactly zero (they feed MFMAs whose results are discarded or masked, but k-padding feeds real
+// outputs), so the affine modes are applied only to in-range elements.
+template <int AM, bool VEC, int ROWS>
+__device__ __forceinline__ void store_a(const LinArgs& p, float* sX, int k0, int tid, const Stage<VEC, ROWS>& st) {
+    if constexpr (VEC) {
+        const bool kin = k0 + (tid & 7) * 4 < p.K;
+        const float4 sc = st.c_sc, sh = st.c_sh, k2 = st.c_k2;
+#pragma unroll
+        for (int i = 0; i < ROWS / 32; ++i) {
+            const int rl = (tid >> 3) + 32 * i;
+            const int r = st.m0 + rl;
+            float4 a = make_float4(0, 0, 0, 0);
             if (kin && r < p.M) {
-                const size_t off = (size_t)r * p.K + k;
-                if (p.a_mode == A_PLAIN) a = p.A[off];
-                else if (p.a_mode == A_BNACT) a = lrelu(fmaf(sc, p.A[off], sh), p.slope);
-                else {
-                    float du;
-                    if (p.a_mode == A_DY) du = p.A[off];
+                if constexpr (AM == A_PLAIN) {
+                    a = st.v[i];
+                } else if constexpr (AM == A_BNACT) {
+                    const float4 x = st.v[i];
+                    a.x = lrelu(fmaf(sc.x, x.x, sh.x), p.slope); a.y = lrelu(fmaf(sc.y, x.y, sh.y), p.slope);
+                    a.z = lrelu(fmaf(sc.z, x.z, sh.z), p.slope); a.w = lrelu(fmaf(sc.w, x.w, sh.w), p.slope);
+                } else {
+                    float4 du;
+                    if constexpr (AM == A_DY) du = st.v[i];
                     else {
-                        const int g = r / p.ns, srow = r - g * p.ns;
-                        const size_t go = (size_t)g * p.K + k;
-                        du = p.arg[go] == srow ? p.gz[go] : 0.f;
+                        const int srow = r % p.ns;
+                        const int4 ar = st.vi[i];
+                        const float4 gz = st.vg[i];
+                        du.x = ar.x == srow ? gz.x : 0.f; du.y = ar.y == srow ? gz.y : 0.f;
+                        du.z = ar.z == srow ? gz.z : 0.f; du.w = ar.w == srow ? gz.w : 0.f;
                     }
-                    a = fmaf(sc, du, -sh) - k2 * p.A2[off];
+                    const float4 y = st.v2[i];
+                    a.x = fmaf(sc.x, du.x, -sh.x) - k2.x * y.x; a.y = fmaf(sc.y, du.y, -sh.y) - k2.y * y.y;
+                    a.z = fmaf(sc.z, du.z, -sh.z) - k2.z * y.z; a.w = fmaf(sc.w, du.w, -sh.w) - k2.w * y.w;
                 }
             }
-            st.s[i] = a;
+            *reinterpret_cast<float4*>(&sX[rl * LDS_LD + (tid & 7) * 4]) = a;
+        }
+    } else {
+        const bool kin = k0 + (tid & 31) < p.K;
+        const float sc = st.f_sc, sh = st.f_sh, k2 = st.f_k2;
+#pragma unroll
+        for (int i = 0; i < ROWS / 8; ++i) {
+            const int rl = (tid >> 5) + 8 * i;
+            const int r = st.m0 + rl;
+            float a = 0.f;
+            if (kin && r < p.M) {
+                if constexpr (AM == A_PLAIN) a = st.s[i];
+                else if constexpr (AM == A_BNACT) a = lrelu(fmaf(sc, st.s[i], sh), p.slope);
+                else {
+                    float du;
+                    if constexpr (AM == A_DY) du = st.s[i];
+                    else du = st.si[i] == (r % p.ns) ? st.sg[i] : 0.f;
+                    a = fmaf(sc, du, -sh) - k2 * st.s2[i];
+                }
+            }
+            sX[rl * LDS_LD + (tid & 31)] = a;
         }
     }
 }
 
-template <bool VEC>
-__device__ __forceinline__ void store_a(float* sA, int tid, const StageA<VEC>& st) {
-    if (VEC) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(&sA[((tid >> 3) + 32 * i) * LDS_LD + (tid & 7) * 4]) = st.v[i];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sA[((tid >> 5) + 8 * i) * LDS_LD + (tid & 31)] = st.s[i];
-    }
-}
-
-template <bool VEC>
-__device__ __forceinline__ void load_b(const LinArgs& p, int n0, int k0, int tid, StageA<VEC>& st) {
-    if (VEC) {
+template <bool VEC, int ROWS>
+__device__ __forceinline__ void load_b(const LinArgs& p, int n0, int k0, int tid, Stage<VEC, ROWS>& st) {
+    if constexpr (VEC) {
         const int k = k0 + (tid & 7) * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < ROWS / 32; ++i) {
             const int n = n0 + (tid >> 3) + 32 * i;
             st.v[i] = (k < p.K && n < p.N) ? *reinterpret_cast<const float4*>(p.B + (size_t)n * p.K + k) : make_float4(0, 0, 0, 0);
         }
     } else {
         const int k = k0 + (tid & 31);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < ROWS / 8; ++i) {
             const int n = n0 + (tid >> 5) + 8 * i;
             st.s[i] = (k < p.K && n < p.N) ? p.B[(size_t)n * p.K + k] : 0.f;
         }
     }
 }
 
-// C[M,N] = A'[M,K] * B[N,K]^T with fused A transform and epilogue.
-template <bool VEC>
-__global__ __launch_bounds__(MLP_T) void linear_nt_kernel(const LinArgs p) {
-    __shared__ __attribute__((aligned(16))) float sA[BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float sB[BN * LDS_LD];
+template <bool VEC, int ROWS>
+__device__ __forceinline__ void store_b(float* sX, int tid, const Stage<VEC, ROWS>& st) {
+    if constexpr (VEC) {
+#pragma unroll
+        for (int i = 0; i < ROWS / 32; ++i)
+            *reinterpret_cast<float4*>(&sX[((tid >> 3) + 32 * i) * LDS_LD + (tid & 7) * 4]) = st.v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < ROWS / 8; ++i) sX[((tid >> 5) + 8 * i) * LDS_LD + (tid & 31)] = st.s[i];
+    }
+}
+
+// C[M,N] = A'[M,K] * B[N,K]^T with fused A transform (AM) and epilogue (EM).
+// 2 x 2 waves, each owning a 64 x (32*TN) tile: block tile 128 x (64*TN); TN = 1 for N <= 64.
+template <int AM, int EM, bool VEC, int TN>
+__global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p) {
+    constexpr int TBM = 128, TBN = 64 * TN;
+    __shared__ __attribute__((aligned(16))) float sA[TBM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float sB[TBN * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int n0 = blockIdx.y * BN;
-    const int m_tiles = (p.M + BM - 1) / BM;
+    const int n0 = blockIdx.y * TBN;
+    const int m_tiles = (p.M + TBM - 1) / TBM;
     const int lr = lane & 31, lh = lane >> 5;
 
-    // per-lane column statistics, reduced in registers across this workgroup's row tiles
-    double st_s[2] = {0.0, 0.0}, st_q[2] = {0.0, 0.0};
+    double st_s[TN], st_q[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) { st_s[t] = 0.0; st_q[t] = 0.0; }
 
-    for (int mt = blockIdx.x; mt < m_tiles; mt += gridDim.x) {
-        const int m0 = mt * BM;
-        f32x16 acc[2][2];
+    Stage<VEC, TBM> ra;
+    Stage<VEC, TBN> rb;
+    int mt = blockIdx.x;
+    int staged_k0 = 0;
+    if (mt < m_tiles) {
+        load_a<AM, VEC, TBM>(p, mt * TBM, 0, tid, ra);
+        load_b<VEC, TBN>(p, n0, 0, tid, rb);
+    }
+    for (; mt < m_tiles; mt += gridDim.x) {
+        const int m0 = mt * TBM;
+        f32x16 acc[2][TN];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         for (int k0 = 0; k0 < p.K; k0 += BK) {
-            StageA<VEC> ra, rb;
-            load_a<VEC>(p, m0, k0, tid, ra);
-            load_b<VEC>(p, n0, k0, tid, rb);
-            __syncthreads();                       // previous tile's fragment reads are done
-            store_a<VEC>(sA, tid, ra);
-            store_a<VEC>(sB, tid, rb);
+            __syncthreads();                       // previous step's fragment reads are done
+            store_a<AM, VEC, TBM>(p, sA, staged_k0, tid, ra);
+            store_b<VEC, TBN>(sB, tid, rb);
             __syncthreads();
+            // request the next step's operands (next k block, or the first k block of this workgroup's next tile)
+            {
+                int nk = k0 + BK, nmt = mt;
+                if (nk >= p.K) { nk = 0; nmt = mt + gridDim.x; }
+                staged_k0 = nk;
+                if (nmt < m_tiles) {
+                    load_a<AM, VEC, TBM>(p, nmt * TBM, nk, tid, ra);
+                    load_b<VEC, TBN>(p, n0, nk, tid, rb);
+                }
+            }
             const int kc = min(BK, p.K - k0);
             const int nkk = (kc + 7) >> 3;
             for (int kk = 0; kk < nkk; ++kk) {
-                float4 a4[2], b4[2];
+                float4 a4[2], b4[TN];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < 2; ++t)
                     a4[t] = *reinterpret_cast<const float4*>(&sA[(wr * 64 + t * 32 + lr) * LDS_LD + kk * 8 + lh * 4]);
-                    b4[t] = *reinterpret_cast<const float4*>(&sB[(wc * 64 + t * 32 + lr) * LDS_LD + kk * 8 + lh * 4]);
-                }
+#pragma unroll
+                for (int t = 0; t < TN; ++t)
+                    b4[t] = *reinterpret_cast<const float4*>(&sB[(wc * 32 * TN + t * 32 + lr) * LDS_LD + kk * 8 + lh * 4]);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const float av0 = s == 0 ? a4[0].x : s == 1 ? a4[0].y : s == 2 ? a4[0].z : a4[0].w;
-                    const float av1 = s == 0 ? a4[1].x : s == 1 ? a4[1].y : s == 2 ? a4[1].z : a4[1].w;
-                    const float bv0 = s == 0 ? b4[0].x : s == 1 ? b4[0].y : s == 2 ? b4[0].z : b4[0].w;
-                    const float bv1 = s == 0 ? b4[1].x : s == 1 ? b4[1].y : s == 2 ? b4[1].z : b4[1].w;
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv1, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv0, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1, acc[1][1], 0, 0, 0);
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm) {
+                        const float av = s == 0 ? a4[tm].x : s == 1 ? a4[tm].y : s == 2 ? a4[tm].z : a4[tm].w;
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) {
+                            const float bv = s == 0 ? b4[tn].x : s == 1 ? b4[tn].y : s == 2 ? b4[tn].z : b4[tn].w;
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tm][tn], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
 
         // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int col = n0 + wc * 64 + tn * 32 + lr;
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = n0 + wc * 32 * TN + tn * 32 + lr;
             const bool cin = col < p.N;
             const float bias = (p.bias && cin) ? p.bias[col] : 0.f;
             float esc = 0.f, esh = 0.f;
-            if (p.e_mode == E_MASK_STORE_STATS && cin) { esc = p.esc[col]; esh = p.esh[col]; }
+            if (EM == E_MASK_STORE_STATS && cin) { esc = p.esc[col]; esh = p.esh[col]; }
             float ts = 0.f, tq = 0.f;
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
@@ -242,11 +315,11 @@ __global__ __launch_bounds__(MLP_T) void linear_nt_kernel(const LinArgs p) {
                     if (cin && row < p.M) {
                         const size_t off = (size_t)row * p.N + col;
                         float c = acc[tm][tn][r] + bias;
-                        if (p.e_mode == E_MASK_STORE_STATS) {
+                        if constexpr (EM == E_MASK_STORE_STATS) {
                             const float y = p.Yprev[off];
                             c = fmaf(esc, y, esh) > 0.f ? c : c * p.eslope;
                             ts += c; tq = fmaf(c, y, tq);
-                        } else if (p.e_mode == E_STORE_STATS) {
+                        } else if constexpr (EM == E_STORE_STATS) {
                             ts += c; tq = fmaf(c, c, tq);
                         }
                         p.C[off] = c;
@@ -257,26 +330,26 @@ __global__ __launch_bounds__(MLP_T) void linear_nt_kernel(const LinArgs p) {
         }
     }
 
-    if (p.e_mode != E_STORE) {
-        // lanes l and l^32 hold the same column: fold, then combine the two waves that share a column range
+    if constexpr (EM != E_STORE) {
+        // lanes l and l^32 hold the same column: fold, then combine the two waves (wr = 0,1) sharing the columns
         __syncthreads();
-        double* red = reinterpret_cast<double*>(sA);           // [4 waves][2 tn][32][2]
+        double* red = reinterpret_cast<double*>(sA);           // [4 waves][TN][32][2]
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
+        for (int tn = 0; tn < TN; ++tn) {
             double s = st_s[tn], q = st_q[tn];
             s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-            if (lh == 0) { red[((wave * 2 + tn) * 32 + lr) * 2 + 0] = s; red[((wave * 2 + tn) * 32 + lr) * 2 + 1] = q; }
+            if (lh == 0) { red[((wave * TN + tn) * 32 + lr) * 2 + 0] = s; red[((wave * TN + tn) * 32 + lr) * 2 + 1] = q; }
         }
         __syncthreads();
-        if (tid < BN) {
-            const int c = tid, wcc = c >> 6, tn = (c >> 5) & 1, l = c & 31;
+        if (tid < TBN) {
+            const int c = tid, wcc = c / (32 * TN), tn = (c >> 5) % TN, l = c & 31;
             const int col = n0 + c;
             if (col < p.N) {
                 double s = 0.0, q = 0.0;
 #pragma unroll
-                for (int w = 0; w < 2; ++w) {           // wr = 0,1 with this wc
+                for (int w = 0; w < 2; ++w) {
                     const int wv = w * 2 + wcc;
-                    s += red[((wv * 2 + tn) * 32 + l) * 2 + 0]; q += red[((wv * 2 + tn) * 32 + l) * 2 + 1];
+                    s += red[((wv * TN + tn) * 32 + l) * 2 + 0]; q += red[((wv * TN + tn) * 32 + l) * 2 + 1];
                 }
                 double* dst = p.stats + (size_t)blockIdx.x * 2 * p.N;
                 dst[col] = s; dst[p.N + col] = q;
@@ -297,87 +370,230 @@ struct DwArgs {
     int a_mode, b_mode;                         // a: A_DY / A_DY_SPARSE ; b: A_PLAIN / A_BNACT
 };
 
-constexpr int DW_BP = 32, DW_LD = 128 + 4;
+constexpr int DW_BP = 32;
 
-__device__ __forceinline__ float dw_load_a(const DwArgs& p, int r, int c, float sc, float sh, float k2) {
-    const size_t off = (size_t)r * p.I + c;
-    float du;
-    if (p.a_mode == A_DY) du = p.A[off];
-    else {
-        const int g = r / p.ns, srow = r - g * p.ns;
-        const size_t go = (size_t)g * p.I + c;
-        du = p.arg[go] == srow ? p.gz[go] : 0.f;
+// Staged [32 rows][W channels] operand tile of the dW GEMM.  Vector path: thread t owns channels
+// c4 = (t % (W/4))*4 of rows t/(W/4) + RP*i; scalar path: channel t % W of rows t/W + RP*i.
+template <bool VEC, int W>
+struct DwStage {
+    static constexpr int CPR = VEC ? W / 4 : W;          // threads per row
+    static constexpr int RP = MLP_T / CPR;               // rows per pass
+    static constexpr int NI = DW_BP / RP;
+    float4 v[VEC ? NI : 1], v2[VEC ? NI : 1], vg[VEC ? NI : 1];
+    int4 vi[VEC ? NI : 1];
+    float s[VEC ? 1 : NI], s2[VEC ? 1 : NI], sg[VEC ? 1 : NI];
+    int si[VEC ? 1 : NI];
+    int p0;
+};
+
+template <int AM, bool VEC, int W>
+__device__ __forceinline__ void dw_load_a(const DwArgs& p, int p0, int c0, int tid, DwStage<VEC, W>& st) {
+    using S = DwStage<VEC, W>;
+    st.p0 = p0;
+    const int c = c0 + (tid % S::CPR) * (VEC ? 4 : 1);
+    const bool cin = c < p.I;
+#pragma unroll
+    for (int i = 0; i < S::NI; ++i) {
+        const int r = p0 + tid / S::CPR + S::RP * i;
+        const bool in = cin && r < p.P;
+        const size_t off = (size_t)r * p.I + c;
+        if constexpr (VEC) {
+            const float4 z4 = make_float4(0, 0, 0, 0);
+            st.v2[i] = in ? *reinterpret_cast<const float4*>(p.A2 + off) : z4;
+            if constexpr (AM == A_DY) st.v[i] = in ? *reinterpret_cast<const float4*>(p.A + off) : z4;
+            else {
+                const size_t go = (size_t)(r / p.ns) * p.I + c;
+                st.vi[i] = in ? *reinterpret_cast<const int4*>(p.arg + go) : make_int4(-1, -1, -1, -1);
+                st.vg[i] = in ? *reinterpret_cast<const float4*>(p.gz + go) : z4;
+            }
+        } else {
+            st.s2[i] = in ? p.A2[off] : 0.f;
+            if constexpr (AM == A_DY) st.s[i] = in ? p.A[off] : 0.f;
+            else {
+                const size_t go = (size_t)(r / p.ns) * p.I + c;
+                st.si[i] = in ? p.arg[go] : -1;
+                st.sg[i] = in ? p.gz[go] : 0.f;
+            }
+        }
     }
-    return fmaf(sc, du, -sh) - k2 * p.A2[off];
 }
 
-__global__ __launch_bounds__(MLP_T) void linear_dw_kernel(const DwArgs p) {
-    __shared__ __attribute__((aligned(16))) float sA[DW_BP * DW_LD];   // [p][i]
-    __shared__ __attribute__((aligned(16))) float sB[DW_BP * DW_LD];   // [p][j]
+template <int AM, bool VEC, int W>
+__device__ __forceinline__ void dw_store_a(const DwArgs& p, float* sX, int c0, int tid, const DwStage<VEC, W>& st,
+                                           float4 sc, float4 sh, float4 k2) {
+    using S = DwStage<VEC, W>;
+    const int cl = (tid % S::CPR) * (VEC ? 4 : 1);
+    const bool cin = c0 + cl < p.I;
+#pragma unroll
+    for (int i = 0; i < S::NI; ++i) {
+        const int rl = tid / S::CPR + S::RP * i;
+        const int r = st.p0 + rl;
+        const bool in = cin && r < p.P;
+        if constexpr (VEC) {
+            float4 a = make_float4(0, 0, 0, 0);
+            if (in) {
+                float4 du;
+                if constexpr (AM == A_DY) du = st.v[i];
+                else {
+                    const int srow = r % p.ns;
+                    const int4 ar = st.vi[i];
+                    const float4 gz = st.vg[i];
+                    du.x = ar.x == srow ? gz.x : 0.f; du.y = ar.y == srow ? gz.y : 0.f;
+                    du.z = ar.z == srow ? gz.z : 0.f; du.w = ar.w == srow ? gz.w : 0.f;
+                }
+                const float4 y = st.v2[i];
+                a.x = fmaf(sc.x, du.x, -sh.x) - k2.x * y.x; a.y = fmaf(sc.y, du.y, -sh.y) - k2.y * y.y;
+                a.z = fmaf(sc.z, du.z, -sh.z) - k2.z * y.z; a.w = fmaf(sc.w, du.w, -sh.w) - k2.w * y.w;
+            }
+            *reinterpret_cast<float4*>(&sX[rl * (W + 4) + cl]) = a;
+        } else {
+            float a = 0.f;
+            if (in) {
+                float du;
+                if constexpr (AM == A_DY) du = st.s[i];
+                else du = st.si[i] == (r % p.ns) ? st.sg[i] : 0.f;
+                a = fmaf(sc.x, du, -sh.x) - k2.x * st.s2[i];
+            }
+            sX[rl * (W + 4) + cl] = a;
+        }
+    }
+}
+
+template <bool VEC, int W>
+__device__ __forceinline__ void dw_load_b(const DwArgs& p, int p0, int c0, int tid, DwStage<VEC, W>& st) {
+    using S = DwStage<VEC, W>;
+    st.p0 = p0;
+    const int c = c0 + (tid % S::CPR) * (VEC ? 4 : 1);
+    const bool cin = c < p.J;
+#pragma unroll
+    for (int i = 0; i < S::NI; ++i) {
+        const int r = p0 + tid / S::CPR + S::RP * i;
+        const bool in = cin && r < p.P;
+        const size_t off = (size_t)r * p.J + c;
+        if constexpr (VEC) st.v[i] = in ? *reinterpret_cast<const float4*>(p.Bsrc + off) : make_float4(0, 0, 0, 0);
+        else st.s[i] = in ? p.Bsrc[off] : 0.f;
+    }
+}
+
+template <bool VEC, int W>
+__device__ __forceinline__ void dw_store_b(const DwArgs& p, float* sX, int c0, int tid, const DwStage<VEC, W>& st,
+                                           float4 sc, float4 sh) {
+    using S = DwStage<VEC, W>;
+    const int cl = (tid % S::CPR) * (VEC ? 4 : 1);
+    const bool cin = c0 + cl < p.J;
+    const bool act = p.b_mode == A_BNACT;
+#pragma unroll
+    for (int i = 0; i < S::NI; ++i) {
+        const int rl = tid / S::CPR + S::RP * i;
+        const bool in = cin && st.p0 + rl < p.P;
+        if constexpr (VEC) {
+            float4 b = make_float4(0, 0, 0, 0);
+            if (in) {
+                b = st.v[i];
+                if (act) {
+                    b.x = lrelu(fmaf(sc.x, b.x, sh.x), p.bslope); b.y = lrelu(fmaf(sc.y, b.y, sh.y), p.bslope);
+                    b.z = lrelu(fmaf(sc.z, b.z, sh.z), p.bslope); b.w = lrelu(fmaf(sc.w, b.w, sh.w), p.bslope);
+                }
+            }
+            *reinterpret_cast<float4*>(&sX[rl * (W + 4) + cl]) = b;
+        } else {
+            float b = 0.f;
+            if (in) { b = st.s[i]; if (act) b = lrelu(fmaf(sc.x, b, sh.x), p.bslope); }
+            sX[rl * (W + 4) + cl] = b;
+        }
+    }
+}
+
+// dW tile (64*TM) x (64*TN) per workgroup (2 x 2 waves, wave tile (32*TM) x (32*TN)); persistent over
+// 32-row chunks of P with register prefetch of the next chunk; partial tiles go to `part`.
+template <int AM, bool VEC, int TM, int TN>
+__global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p) {
+    constexpr int WI = 64 * TM, WJ = 64 * TN;
+    __shared__ __attribute__((aligned(16))) float sA[DW_BP * (WI + 4)];   // [p][i]
+    __shared__ __attribute__((aligned(16))) float sB[DW_BP * (WJ + 4)];   // [p][j]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, lh = lane >> 5;
-    const int i0 = blockIdx.y * 128, j0 = blockIdx.z * 128;
+    const int i0 = blockIdx.y * WI, j0 = blockIdx.z * WJ;
     const int chunks = (p.P + DW_BP - 1) / DW_BP;
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // thread t stages channel c = t&127 of rows (t>>7) + 2*i, i = 0..15 (coalesced along channels)
-    const int ca = i0 + (tid & 127), cb = j0 + (tid & 127);
-    const bool ain = ca < p.I, bin = cb < p.J;
-    float asc = 0.f, ash = 0.f, ak2 = 0.f, bsc = 1.f, bsh = 0.f;
-    if (ain) { asc = p.sc[ca]; ash = p.sh[ca]; ak2 = p.k2[ca]; }
-    if (bin && p.b_mode == A_BNACT) { bsc = p.bsc[cb]; bsh = p.bsh[cb]; }
+    // per-thread channel constants (the thread's channels are the same for every chunk)
+    float4 asc = make_float4(0, 0, 0, 0), ash = asc, ak2 = asc, bsc = make_float4(1, 1, 1, 1), bsh = asc;
+    {
+        using SA = DwStage<VEC, WI>;
+        using SB = DwStage<VEC, WJ>;
+        const int ca = i0 + (tid % SA::CPR) * (VEC ? 4 : 1), cb = j0 + (tid % SB::CPR) * (VEC ? 4 : 1);
+        if constexpr (VEC) {
+            if (ca < p.I) { asc = *reinterpret_cast<const float4*>(p.sc + ca); ash = *reinterpret_cast<const float4*>(p.sh + ca);
+                            ak2 = *reinterpret_cast<const float4*>(p.k2 + ca); }
+            if (cb < p.J && p.b_mode == A_BNACT) { bsc = *reinterpret_cast<const float4*>(p.bsc + cb); bsh = *reinterpret_cast<const float4*>(p.bsh + cb); }
+        } else {
+            if (ca < p.I) { asc.x = p.sc[ca]; ash.x = p.sh[ca]; ak2.x = p.k2[ca]; }
+            if (cb < p.J && p.b_mode == A_BNACT) { bsc.x = p.bsc[cb]; bsh.x = p.bsh[cb]; }
+        }
+    }
 
-    for (int ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
-        const int p0 = ch * DW_BP;
-        float ra[16], rb[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = p0 + (tid >> 7) + 2 * i;
-            const bool rin = r < p.P;
-            ra[i] = (rin && ain) ? dw_load_a(p, r, ca, asc, ash, ak2) : 0.f;
-            float b = 0.f;
-            if (rin && bin) {
-                b = p.Bsrc[(size_t)r * p.J + cb];
-                if (p.b_mode == A_BNACT) b = lrelu(fmaf(bsc, b, bsh), p.bslope);
-            }
-            rb[i] = b;
-        }
+    DwStage<VEC, WI> ra;
+    DwStage<VEC, WJ> rb;
+    int ch = blockIdx.x;
+    if (ch < chunks) { dw_load_a<AM, VEC, WI>(p, ch * DW_BP, i0, tid, ra); dw_load_b<VEC, WJ>(p, ch * DW_BP, j0, tid, rb); }
+    for (; ch < chunks; ch += gridDim.x) {
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            sA[((tid >> 7) + 2 * i) * DW_LD + (tid & 127)] = ra[i];
-            sB[((tid >> 7) + 2 * i) * DW_LD + (tid & 127)] = rb[i];
-        }
+        dw_store_a<AM, VEC, WI>(p, sA, i0, tid, ra, asc, ash, ak2);
+        dw_store_b<VEC, WJ>(p, sB, j0, tid, rb, bsc, bsh);
         __syncthreads();
+        const int nch = ch + gridDim.x;
+        if (nch < chunks) { dw_load_a<AM, VEC, WI>(p, nch * DW_BP, i0, tid, ra); dw_load_b<VEC, WJ>(p, nch * DW_BP, j0, tid, rb); }
 #pragma unroll 4
         for (int ks = 0; ks < DW_BP / 2; ++ks) {
             const int pr = ks * 2 + lh;                 // lanes 0-31: row 2ks, lanes 32-63: row 2ks+1
-            const float a0 = sA[pr * DW_LD + wr * 64 + lr], a1 = sA[pr * DW_LD + wr * 64 + 32 + lr];
-            const float b0 = sB[pr * DW_LD + wc * 64 + lr], b1 = sB[pr * DW_LD + wc * 64 + 32 + lr];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) av[t] = sA[pr * (WI + 4) + wr * 32 * TM + t * 32 + lr];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) bv[t] = sB[pr * (WJ + 4) + wc * 32 * TN + t * 32 + lr];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
         }
     }
     float* out = p.part + (size_t)blockIdx.x * p.I * p.J;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int col = j0 + wc * 64 + tn * 32 + lr;
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = j0 + wc * 32 * TN + tn * 32 + lr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = i0 + wr * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < p.I && col < p.J) out[(size_t)row * p.J + col] = acc[tm][tn][r];
             }
         }
+}
+
+static void dw_grid(int P, int I, int J, int& gx, int& ti, int& tj, int& tm, int& tn) {
+    tm = I > 64 ? 2 : 1; tn = J > 64 ? 2 : 1;
+    ti = (I + 64 * tm - 1) / (64 * tm); tj = (J + 64 * tn - 1) / (64 * tn);
+    const int chunks = (P + DW_BP - 1) / DW_BP;
+    gx = (1024 + ti * tj - 1) / (ti * tj);
+    if (gx > chunks) gx = chunks;
+    if (gx < 1) gx = 1;
+}
+
+template <int AM, bool VEC>
+static void launch_dw_t(const DwArgs& d, dim3 grid, int tm, int tn, hipStream_t st) {
+    if (tm == 1 && tn == 1) hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 1, 1>), grid, dim3(MLP_T), 0, st, d);
+    else if (tm == 2 && tn == 1) hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 2, 1>), grid, dim3(MLP_T), 0, st, d);
+    else if (tm == 1 && tn == 2) hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 1, 2>), grid, dim3(MLP_T), 0, st, d);
+    else hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 2, 2>), grid, dim3(MLP_T), 0, st, d);
 }
 
 // out[e] = sum_r part[r][e]  (+ optional column sums of dy for the bias gradient are taken elsewhere)
@@ -392,15 +608,32 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 
 // ---- BatchNorm bookkeeping (tiny kernels, one thread per channel) ---------------------------------------
 // mean/var from the fp64 partials; folded scale/shift; Jittor-style running statistics (biased variance).
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, int rows, const float* __restrict__ gamma,
+// column sums of a [rows][2][C] fp64 partial workspace: 4 channels x 64 row-lanes per 256-thread block
+__device__ __forceinline__ void stat_colsum(const double* __restrict__ stats, int rows, int C, int c, int ry, double& s,
+                                            double& q, double* red /*[2][64][4]*/) {
+    s = 0.0; q = 0.0;
+    if (c < C)
+        for (int r = ry; r < rows; r += 64) { s += stats[(size_t)r * 2 * C + c]; q += stats[(size_t)r * 2 * C + C + c]; }
+    const int cl = threadIdx.x & 3;
+    red[(0 * 64 + ry) * 4 + cl] = s; red[(1 * 64 + ry) * 4 + cl] = q;
+    __syncthreads();
+    for (int h = 32; h >= 1; h >>= 1) {
+        if (ry < h) { red[(0 * 64 + ry) * 4 + cl] += red[(0 * 64 + ry + h) * 4 + cl]; red[(1 * 64 + ry) * 4 + cl] += red[(1 * 64 + ry + h) * 4 + cl]; }
+        __syncthreads();
+    }
+    s = red[cl]; q = red[64 * 4 + cl];
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ stats, int rows, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, int P, int C, float eps, float momentum,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out, float* __restrict__ running_mean,
                                    float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int r = 0; r < rows; ++r) { s += stats[(size_t)r * 2 * C + c]; q += stats[(size_t)r * 2 * C + C + c]; }
+    __shared__ double red[2 * 64 * 4];
+    const int c = blockIdx.x * 4 + (threadIdx.x & 3), ry = threadIdx.x >> 2;
+    double s, q;
+    stat_colsum(stats, rows, C, c, ry, s, q, red);
+    if (ry != 0 || c >= C) return;
     const double mean = s / P;
     double var = q / P - mean * mean;
     var = var > 0.0 ? var : 0.0;
@@ -418,14 +651,15 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int rows, c
 // BatchNorm backward constants from sum(du) and sum(du*y):
 //   dbeta = S1, dgamma = (S2 - mean*S1)*invstd,  dy = a*du - k1 - k2*y with a = gamma*invstd,
 //   k2 = a*dgamma*invstd/P, k1 = a*dbeta/P - k2*mean.
-__global__ void bn_bwd_consts_kernel(const double* __restrict__ stats, int rows, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void bn_bwd_consts_kernel(const double* __restrict__ stats, int rows, const float* __restrict__ gamma,
                                      const float* __restrict__ mean, const float* __restrict__ invstd, int P, int C,
                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ a_out,
                                      float* __restrict__ k1, float* __restrict__ k2) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < rows; ++r) { s1 += stats[(size_t)r * 2 * C + c]; s2 += stats[(size_t)r * 2 * C + C + c]; }
+    __shared__ double red[2 * 64 * 4];
+    const int c = blockIdx.x * 4 + (threadIdx.x & 3), ry = threadIdx.x >> 2;
+    double s1, s2;
+    stat_colsum(stats, rows, C, c, ry, s1, s2, red);
+    if (ry != 0 || c >= C) return;
     const double mu = mean[c], is = invstd[c];
     const double g = gamma ? gamma[c] : 1.0;
     const double dg = (s2 - mu * s1) * is;
@@ -511,23 +745,56 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
     stats[(size_t)blockIdx.y * 2 * C + C + c] = s2;
 }
 
-static int launch_linear(const LinArgs& a, hipStream_t st) {
-    const int m_tiles = (a.M + BM - 1) / BM, n_tiles = (a.N + BN - 1) / BN;
-    const int gx = m_tiles < STAT_ROWS ? m_tiles : STAT_ROWS;
-    dim3 grid(gx, n_tiles);
+static void linear_grid(int M, int N, int& gx, int& n_tiles, bool& narrow) {
+    narrow = N <= 64;                                  // 128x64 block tile instead of 128x128
+    const int tbn = narrow ? 64 : 128;
+    const int m_tiles = (M + 127) / 128;
+    n_tiles = (N + tbn - 1) / tbn;
+    gx = m_tiles < STAT_ROWS ? m_tiles : STAT_ROWS;
+    const int want = (1024 + n_tiles - 1) / n_tiles;   // ~4 workgroups per CU in total
+    if (gx > want) gx = want;
+}
+
+template <int AM, int EM>
+static int launch_linear_t(const LinArgs& a, hipStream_t st) {
     const bool vec = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0) && (!a.A2 || (reinterpret_cast<uintptr_t>(a.A2) & 15) == 0);
-    if (vec) hipLaunchKernelGGL(linear_nt_kernel<true>, grid, dim3(MLP_T), 0, st, a);
-    else hipLaunchKernelGGL(linear_nt_kernel<false>, grid, dim3(MLP_T), 0, st, a);
+    int gx, n_tiles; bool narrow;
+    linear_grid(a.M, a.N, gx, n_tiles, narrow);
+    dim3 grid(gx, n_tiles);
+    if (narrow) {
+        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1>), grid, dim3(MLP_T), 0, st, a);
+        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1>), grid, dim3(MLP_T), 0, st, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 2>), grid, dim3(MLP_T), 0, st, a);
+        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 2>), grid, dim3(MLP_T), 0, st, a);
+    }
     return check_launch("pcl_linear");
+}
+
+// number of stats rows a launch_linear_t call with M rows and N columns writes
+static int linear_stat_rows(int M, int N) {
+    int gx, n_tiles; bool narrow;
+    linear_grid(M, N, gx, n_tiles, narrow);
+    return gx;
+}
+
+static int launch_linear(const LinArgs& a, hipStream_t st) {
+    if (a.a_mode == A_PLAIN && a.e_mode == E_STORE_STATS) return launch_linear_t<A_PLAIN, E_STORE_STATS>(a, st);
+    if (a.a_mode == A_BNACT && a.e_mode == E_STORE_STATS) return launch_linear_t<A_BNACT, E_STORE_STATS>(a, st);
+    if (a.a_mode == A_DY && a.e_mode == E_MASK_STORE_STATS) return launch_linear_t<A_DY, E_MASK_STORE_STATS>(a, st);
+    if (a.a_mode == A_DY && a.e_mode == E_STORE) return launch_linear_t<A_DY, E_STORE>(a, st);
+    if (a.a_mode == A_DY_SPARSE && a.e_mode == E_MASK_STORE_STATS) return launch_linear_t<A_DY_SPARSE, E_MASK_STORE_STATS>(a, st);
+    if (a.a_mode == A_DY_SPARSE && a.e_mode == E_STORE) return launch_linear_t<A_DY_SPARSE, E_STORE>(a, st);
+    return fail(PCL_EINVAL, "pcl_linear: unsupported mode combination %d/%d", a.a_mode, a.e_mode);
 }
 
 }  // namespace pcl
 using namespace pcl;
 
-extern "C" int pcl_mlp_stat_rows(int rows) {
-    const int t = (rows + BM - 1) / BM;
-    return t < 1 ? 1 : (t < STAT_ROWS ? t : STAT_ROWS);
+extern "C" int pcl_mlp_stat_rows(int P, int C) {
+    if (P < 1 || C < 1) return 1;
+    return linear_stat_rows(P, C);
 }
 
 extern "C" int pcl_linear_fwd_f32(const float* X, const float* W, const float* bias, const float* in_scale,
@@ -561,11 +828,8 @@ extern "C" int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const floa
 
 extern "C" size_t pcl_linear_bwd_dw_workspace_bytes(int P, int Cout, int Cin) {
     if (P < 1 || Cout < 1 || Cin < 1) return 0;
-    const int tiles = ((Cout + 127) / 128) * ((Cin + 127) / 128);
-    const int chunks = (P + DW_BP - 1) / DW_BP;
-    int gx = (768 + tiles - 1) / tiles;
-    if (gx > chunks) gx = chunks;
-    if (gx < 1) gx = 1;
+    int gx, ti, tj, tm, tn;
+    dw_grid(P, Cout, Cin, gx, ti, tj, tm, tn);
     return sizeof(float) * (size_t)gx * Cout * Cin;
 }
 
@@ -580,14 +844,18 @@ extern "C" int pcl_linear_bwd_dw_f32(const float* dU, const float* Y, const floa
     const size_t need = pcl_linear_bwd_dw_workspace_bytes(P, Cout, Cin);
     if (!workspace || workspace_bytes < need) return fail(PCL_EWS, "pcl_linear_bwd_dw_f32: workspace %zu < %zu", workspace_bytes, need);
     hipStream_t st = as_stream(stream);
-    const int gx = (int)(need / (sizeof(float) * (size_t)Cout * Cin));
+    int gx, ti, tj, tm, tn;
+    dw_grid(P, Cout, Cin, gx, ti, tj, tm, tn);
     DwArgs d = {};
     d.A = dU; d.A2 = Y; d.sc = a_; d.sh = k1; d.k2 = k2; d.arg = arg; d.gz = gz; d.ns = ns;
     d.Bsrc = Xprev; d.bsc = prev_scale; d.bsh = prev_shift; d.bslope = prev_slope;
     d.part = static_cast<float*>(workspace); d.P = P; d.I = Cout; d.J = Cin;
     d.a_mode = dU ? A_DY : A_DY_SPARSE; d.b_mode = prev_scale ? A_BNACT : A_PLAIN;
-    dim3 grid(gx, (Cout + 127) / 128, (Cin + 127) / 128);
-    hipLaunchKernelGGL(linear_dw_kernel, grid, dim3(MLP_T), 0, st, d);
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool vec = (Cout % 4 == 0) && (Cin % 4 == 0) && al16(Y) && al16(Xprev) && (!dU || al16(dU)) && (!gz || (al16(gz) && al16(arg)));
+    dim3 grid(gx, ti, tj);
+    if (dU) { if (vec) launch_dw_t<A_DY, true>(d, grid, tm, tn, st); else launch_dw_t<A_DY, false>(d, grid, tm, tn, st); }
+    else { if (vec) launch_dw_t<A_DY_SPARSE, true>(d, grid, tm, tn, st); else launch_dw_t<A_DY_SPARSE, false>(d, grid, tm, tn, st); }
     int rc = check_launch("pcl_linear_bwd_dw_f32");
     if (rc) return rc;
     const size_t n = (size_t)Cout * Cin;
@@ -602,7 +870,7 @@ extern "C" int pcl_bn_finalize_f32(const double* stats_ws, int stat_rows, const 
                                    float* invstd_out, float* running_mean, float* running_var, void* stream) {
     PCL_REQUIRE(stats_ws && scale && shift && mean_out && invstd_out, "pcl_bn_finalize_f32: null pointer");
     PCL_REQUIRE(P >= 1 && C >= 1 && stat_rows >= 1, "pcl_bn_finalize_f32: bad sizes");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), stats_ws, stat_rows,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), stats_ws, stat_rows,
                        gamma, beta, P, C, eps, momentum, scale, shift, mean_out, invstd_out, running_mean, running_var);
     return check_launch("pcl_bn_finalize_f32");
 }
@@ -612,7 +880,7 @@ extern "C" int pcl_bn_bwd_consts_f32(const double* stats_ws, int stat_rows, cons
                                      float* k1, float* k2, void* stream) {
     PCL_REQUIRE(stats_ws && mean && invstd && a_out && k1 && k2, "pcl_bn_bwd_consts_f32: null pointer");
     PCL_REQUIRE(P >= 1 && C >= 1 && stat_rows >= 1, "pcl_bn_bwd_consts_f32: bad sizes");
-    hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), stats_ws, stat_rows,
+    hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), stats_ws, stat_rows,
                        gamma, mean, invstd, P, C, dgamma, dbeta, a_out, k1, k2);
     return check_launch("pcl_bn_bwd_consts_f32");
 }

@@ -38,7 +38,6 @@ class _FusedMLP(torch.autograd.Function):
         x = x.contiguous()
         P, C0 = x.shape
         st = _stream()
-        rows = _lib.lib().pcl_mlp_stat_rows(P)
         Ys, scales, shifts, means, invstds = [], [], [], [], []
         cur, in_scale, in_shift = x, None, None
         cin = C0
@@ -46,6 +45,7 @@ class _FusedMLP(torch.autograd.Function):
             W, bias, gamma, beta, rmean, rvar = params[6 * l:6 * l + 6]
             cout = W.shape[0]
             Y = _empty((P, cout), dev)
+            rows = _lib.lib().pcl_mlp_stat_rows(P, cout)
             stats = _empty((rows, 2, cout), dev, torch.float64)
             _lib.call("pcl_linear_fwd_f32", _P(cur), _P(W), _P(bias), _P(in_scale), _P(in_shift), slope, P, cin, cout,
                       _P(Y), _P(stats), st, algo_bytes=4 * P * (cin + cout) + 4 * cin * cout,
@@ -92,7 +92,7 @@ class _FusedMLP(torch.autograd.Function):
         gout = gout.contiguous()
         rows_c = ctypes.c_int(0)
         cl = Ys[-1].shape[1]
-        stats = _empty((256, 2, cl), dev, torch.float64)
+        stats = _empty((1024, 2, cl), dev, torch.float64)
         if ns:
             G = P // ns
             gz = _empty((G, cl), dev)
@@ -141,7 +141,7 @@ class _FusedMLP(torch.autograd.Function):
                 Wt = W.t().contiguous()
                 dUp = _empty((P, cin), dev)
                 if l > 0:
-                    rows_n = lib.pcl_mlp_stat_rows(P)
+                    rows_n = lib.pcl_mlp_stat_rows(P, cin)
                     stats_n = _empty((rows_n, 2, cin), dev, torch.float64)
                 else:
                     rows_n, stats_n = rows, None
