@@ -72,61 +72,55 @@ struct Stage {
     int m0;                        // first row of the staged tile (for the sparse row-in-group test)
 };
 
+// All staging loads are UNCONDITIONAL with clamped (always valid) addresses: a load under a divergent branch
+// makes hipcc drain vmcnt(0) at the branch join, which would serialise the prefetch against the MFMAs.
+// Out-of-range elements are zeroed later, in the transform/store stage.
 template <int AM, bool VEC, int ROWS>
 __device__ __forceinline__ void load_a(const LinArgs& p, int m0, int k0, int tid, Stage<VEC, ROWS>& st) {
     st.m0 = m0;
     if constexpr (VEC) {
-        const int k = k0 + (tid & 7) * 4;
-        const bool kin = k < p.K;
-        st.c_sc = make_float4(1, 1, 1, 1); st.c_sh = make_float4(0, 0, 0, 0); st.c_k2 = make_float4(0, 0, 0, 0);
-        if (AM != A_PLAIN && kin) {
+        const int k = min(k0 + (tid & 7) * 4, p.K - 4);
+        if constexpr (AM != A_PLAIN) {
             st.c_sc = *reinterpret_cast<const float4*>(p.sc + k);
             st.c_sh = *reinterpret_cast<const float4*>(p.sh + k);
-            if (AM >= A_DY) st.c_k2 = *reinterpret_cast<const float4*>(p.k2 + k);
+            if constexpr (AM >= A_DY) st.c_k2 = *reinterpret_cast<const float4*>(p.k2 + k);
         }
 #pragma unroll
         for (int i = 0; i < ROWS / 32; ++i) {
-            const int r = m0 + (tid >> 3) + 32 * i;
-            const bool in = kin && r < p.M;
+            const int r = min(m0 + (tid >> 3) + 32 * i, p.M - 1);
             const size_t off = (size_t)r * p.K + k;
-            const float4 z4 = make_float4(0, 0, 0, 0);
             if constexpr (AM == A_PLAIN || AM == A_BNACT) {
-                st.v[i] = in ? *reinterpret_cast<const float4*>(p.A + off) : z4;
+                st.v[i] = *reinterpret_cast<const float4*>(p.A + off);
             } else if constexpr (AM == A_DY) {
-                st.v[i] = in ? *reinterpret_cast<const float4*>(p.A + off) : z4;
-                st.v2[i] = in ? *reinterpret_cast<const float4*>(p.A2 + off) : z4;
+                st.v[i] = *reinterpret_cast<const float4*>(p.A + off);
+                st.v2[i] = *reinterpret_cast<const float4*>(p.A2 + off);
             } else {
-                const int g = r / p.ns;
-                const size_t go = (size_t)g * p.K + k;
-                st.vi[i] = in ? *reinterpret_cast<const int4*>(p.arg + go) : make_int4(-1, -1, -1, -1);
-                st.vg[i] = in ? *reinterpret_cast<const float4*>(p.gz + go) : z4;
-                st.v2[i] = in ? *reinterpret_cast<const float4*>(p.A2 + off) : z4;
+                const size_t go = (size_t)(r / p.ns) * p.K + k;
+                st.vi[i] = *reinterpret_cast<const int4*>(p.arg + go);
+                st.vg[i] = *reinterpret_cast<const float4*>(p.gz + go);
+                st.v2[i] = *reinterpret_cast<const float4*>(p.A2 + off);
             }
         }
     } else {
-        const int k = k0 + (tid & 31);
-        const bool kin = k < p.K;
-        st.f_sc = 1.f; st.f_sh = 0.f; st.f_k2 = 0.f;
-        if (AM != A_PLAIN && kin) {
+        const int k = min(k0 + (tid & 31), p.K - 1);
+        if constexpr (AM != A_PLAIN) {
             st.f_sc = p.sc[k]; st.f_sh = p.sh[k];
-            if (AM >= A_DY) st.f_k2 = p.k2[k];
+            if constexpr (AM >= A_DY) st.f_k2 = p.k2[k];
         }
 #pragma unroll
         for (int i = 0; i < ROWS / 8; ++i) {
-            const int r = m0 + (tid >> 5) + 8 * i;
-            const bool in = kin && r < p.M;
+            const int r = min(m0 + (tid >> 5) + 8 * i, p.M - 1);
             const size_t off = (size_t)r * p.K + k;
             if constexpr (AM == A_PLAIN || AM == A_BNACT) {
-                st.s[i] = in ? p.A[off] : 0.f;
+                st.s[i] = p.A[off];
             } else if constexpr (AM == A_DY) {
-                st.s[i] = in ? p.A[off] : 0.f;
-                st.s2[i] = in ? p.A2[off] : 0.f;
+                st.s[i] = p.A[off];
+                st.s2[i] = p.A2[off];
             } else {
-                const int g = r / p.ns;
-                const size_t go = (size_t)g * p.K + k;
-                st.si[i] = in ? p.arg[go] : -1;
-                st.sg[i] = in ? p.gz[go] : 0.f;
-                st.s2[i] = in ? p.A2[off] : 0.f;
+                const size_t go = (size_t)(r / p.ns) * p.K + k;
+                st.si[i] = p.arg[go];
+                st.sg[i] = p.gz[go];
+                st.s2[i] = p.A2[off];
             }
         }
     }
@@ -195,31 +189,39 @@ __device__ __forceinline__ void store_a(const LinArgs& p, float* sX, int k0, int
 template <bool VEC, int ROWS>
 __device__ __forceinline__ void load_b(const LinArgs& p, int n0, int k0, int tid, Stage<VEC, ROWS>& st) {
     if constexpr (VEC) {
-        const int k = k0 + (tid & 7) * 4;
+        const int k = min(k0 + (tid & 7) * 4, p.K - 4);
 #pragma unroll
         for (int i = 0; i < ROWS / 32; ++i) {
-            const int n = n0 + (tid >> 3) + 32 * i;
-            st.v[i] = (k < p.K && n < p.N) ? *reinterpret_cast<const float4*>(p.B + (size_t)n * p.K + k) : make_float4(0, 0, 0, 0);
+            const int n = min(n0 + (tid >> 3) + 32 * i, p.N - 1);
+            st.v[i] = *reinterpret_cast<const float4*>(p.B + (size_t)n * p.K + k);
         }
     } else {
-        const int k = k0 + (tid & 31);
+        const int k = min(k0 + (tid & 31), p.K - 1);
 #pragma unroll
         for (int i = 0; i < ROWS / 8; ++i) {
-            const int n = n0 + (tid >> 5) + 8 * i;
-            st.s[i] = (k < p.K && n < p.N) ? p.B[(size_t)n * p.K + k] : 0.f;
+            const int n = min(n0 + (tid >> 5) + 8 * i, p.N - 1);
+            st.s[i] = p.B[(size_t)n * p.K + k];
         }
     }
 }
 
 template <bool VEC, int ROWS>
-__device__ __forceinline__ void store_b(float* sX, int tid, const Stage<VEC, ROWS>& st) {
+__device__ __forceinline__ void store_b(const LinArgs& p, float* sX, int n0, int k0, int tid, const Stage<VEC, ROWS>& st) {
     if constexpr (VEC) {
+        const bool kin = k0 + (tid & 7) * 4 < p.K;
 #pragma unroll
-        for (int i = 0; i < ROWS / 32; ++i)
-            *reinterpret_cast<float4*>(&sX[((tid >> 3) + 32 * i) * LDS_LD + (tid & 7) * 4]) = st.v[i];
+        for (int i = 0; i < ROWS / 32; ++i) {
+            const int rl = (tid >> 3) + 32 * i;
+            const bool in = kin && n0 + rl < p.N;
+            *reinterpret_cast<float4*>(&sX[rl * LDS_LD + (tid & 7) * 4]) = in ? st.v[i] : make_float4(0, 0, 0, 0);
+        }
     } else {
+        const bool kin = k0 + (tid & 31) < p.K;
 #pragma unroll
-        for (int i = 0; i < ROWS / 8; ++i) sX[((tid >> 5) + 8 * i) * LDS_LD + (tid & 31)] = st.s[i];
+        for (int i = 0; i < ROWS / 8; ++i) {
+            const int rl = (tid >> 5) + 8 * i;
+            sX[rl * LDS_LD + (tid & 31)] = (kin && n0 + rl < p.N) ? st.s[i] : 0.f;
+        }
     }
 }
 
@@ -239,6 +241,14 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p) {
     double st_s[TN], st_q[TN];
 #pragma unroll
     for (int t = 0; t < TN; ++t) { st_s[t] = 0.0; st_q[t] = 0.0; }
+    float ep_bias[TN], ep_sc[TN], ep_sh[TN];        // per-column epilogue constants (this lane's columns)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int col = min(n0 + wc * 32 * TN + t * 32 + lr, p.N - 1);
+        ep_bias[t] = p.bias ? p.bias[col] : 0.f;
+        ep_sc[t] = EM == E_MASK_STORE_STATS ? p.esc[col] : 0.f;
+        ep_sh[t] = EM == E_MASK_STORE_STATS ? p.esh[col] : 0.f;
+    }
 
     Stage<VEC, TBM> ra;
     Stage<VEC, TBN> rb;
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p) {
         for (int k0 = 0; k0 < p.K; k0 += BK) {
             __syncthreads();                       // previous step's fragment reads are done
             store_a<AM, VEC, TBM>(p, sA, staged_k0, tid, ra);
-            store_b<VEC, TBN>(sB, tid, rb);
+            store_b<VEC, TBN>(p, sB, n0, staged_k0, tid, rb);
             __syncthreads();
             // request the next step's operands (next k block, or the first k block of this workgroup's next tile)
             {
@@ -299,32 +309,60 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p) {
         }
 
         // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        // Full tiles take a branch-free path (a store or load under a per-element branch makes hipcc wait
+        // vmcnt(0) at every join, serialising the 64 stores of a lane).
+        const bool full = (m0 + TBM <= p.M) && (n0 + TBN <= p.N);
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int col = n0 + wc * 32 * TN + tn * 32 + lr;
             const bool cin = col < p.N;
-            const float bias = (p.bias && cin) ? p.bias[col] : 0.f;
-            float esc = 0.f, esh = 0.f;
-            if (EM == E_MASK_STORE_STATS && cin) { esc = p.esc[col]; esh = p.esh[col]; }
+            const float bias = ep_bias[tn], esc = ep_sc[tn], esh = ep_sh[tn];
             float ts = 0.f, tq = 0.f;
+            if (full) {
+                float yv[2][16];
+                if constexpr (EM == E_MASK_STORE_STATS) {
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
+                    for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (cin && row < p.M) {
-                        const size_t off = (size_t)row * p.N + col;
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            yv[tm][r] = p.Yprev[(size_t)row * p.N + col];
+                        }
+                }
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                         float c = acc[tm][tn][r] + bias;
                         if constexpr (EM == E_MASK_STORE_STATS) {
-                            const float y = p.Yprev[off];
+                            const float y = yv[tm][r];
                             c = fmaf(esc, y, esh) > 0.f ? c : c * p.eslope;
                             ts += c; tq = fmaf(c, y, tq);
                         } else if constexpr (EM == E_STORE_STATS) {
                             ts += c; tq = fmaf(c, c, tq);
                         }
-                        p.C[off] = c;
+                        p.C[(size_t)row * p.N + col] = c;
                     }
-                }
+            } else {
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (cin && row < p.M) {
+                            const size_t off = (size_t)row * p.N + col;
+                            float c = acc[tm][tn][r] + bias;
+                            if constexpr (EM == E_MASK_STORE_STATS) {
+                                const float y = p.Yprev[off];
+                                c = fmaf(esc, y, esh) > 0.f ? c : c * p.eslope;
+                                ts += c; tq = fmaf(c, y, tq);
+                            } else if constexpr (EM == E_STORE_STATS) {
+                                ts += c; tq = fmaf(c, c, tq);
+                            }
+                            p.C[off] = c;
+                        }
+                    }
             }
             st_s[tn] += (double)ts; st_q[tn] += (double)tq;
         }
@@ -390,29 +428,26 @@ template <int AM, bool VEC, int W>
 __device__ __forceinline__ void dw_load_a(const DwArgs& p, int p0, int c0, int tid, DwStage<VEC, W>& st) {
     using S = DwStage<VEC, W>;
     st.p0 = p0;
-    const int c = c0 + (tid % S::CPR) * (VEC ? 4 : 1);
-    const bool cin = c < p.I;
+    const int c = min(c0 + (tid % S::CPR) * (VEC ? 4 : 1), p.I - (VEC ? 4 : 1));     // clamped, always valid
 #pragma unroll
     for (int i = 0; i < S::NI; ++i) {
-        const int r = p0 + tid / S::CPR + S::RP * i;
-        const bool in = cin && r < p.P;
+        const int r = min(p0 + tid / S::CPR + S::RP * i, p.P - 1);
         const size_t off = (size_t)r * p.I + c;
         if constexpr (VEC) {
-            const float4 z4 = make_float4(0, 0, 0, 0);
-            st.v2[i] = in ? *reinterpret_cast<const float4*>(p.A2 + off) : z4;
-            if constexpr (AM == A_DY) st.v[i] = in ? *reinterpret_cast<const float4*>(p.A + off) : z4;
+            st.v2[i] = *reinterpret_cast<const float4*>(p.A2 + off);
+            if constexpr (AM == A_DY) st.v[i] = *reinterpret_cast<const float4*>(p.A + off);
             else {
                 const size_t go = (size_t)(r / p.ns) * p.I + c;
-                st.vi[i] = in ? *reinterpret_cast<const int4*>(p.arg + go) : make_int4(-1, -1, -1, -1);
-                st.vg[i] = in ? *reinterpret_cast<const float4*>(p.gz + go) : z4;
+                st.vi[i] = *reinterpret_cast<const int4*>(p.arg + go);
+                st.vg[i] = *reinterpret_cast<const float4*>(p.gz + go);
             }
         } else {
-            st.s2[i] = in ? p.A2[off] : 0.f;
-            if constexpr (AM == A_DY) st.s[i] = in ? p.A[off] : 0.f;
+            st.s2[i] = p.A2[off];
+            if constexpr (AM == A_DY) st.s[i] = p.A[off];
             else {
                 const size_t go = (size_t)(r / p.ns) * p.I + c;
-                st.si[i] = in ? p.arg[go] : -1;
-                st.sg[i] = in ? p.gz[go] : 0.f;
+                st.si[i] = p.arg[go];
+                st.sg[i] = p.gz[go];
             }
         }
     }
@@ -463,15 +498,13 @@ template <bool VEC, int W>
 __device__ __forceinline__ void dw_load_b(const DwArgs& p, int p0, int c0, int tid, DwStage<VEC, W>& st) {
     using S = DwStage<VEC, W>;
     st.p0 = p0;
-    const int c = c0 + (tid % S::CPR) * (VEC ? 4 : 1);
-    const bool cin = c < p.J;
+    const int c = min(c0 + (tid % S::CPR) * (VEC ? 4 : 1), p.J - (VEC ? 4 : 1));
 #pragma unroll
     for (int i = 0; i < S::NI; ++i) {
-        const int r = p0 + tid / S::CPR + S::RP * i;
-        const bool in = cin && r < p.P;
+        const int r = min(p0 + tid / S::CPR + S::RP * i, p.P - 1);
         const size_t off = (size_t)r * p.J + c;
-        if constexpr (VEC) st.v[i] = in ? *reinterpret_cast<const float4*>(p.Bsrc + off) : make_float4(0, 0, 0, 0);
-        else st.s[i] = in ? p.Bsrc[off] : 0.f;
+        if constexpr (VEC) st.v[i] = *reinterpret_cast<const float4*>(p.Bsrc + off);
+        else st.s[i] = p.Bsrc[off];
     }
 }
 
@@ -529,13 +562,14 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p) {
         using SA = DwStage<VEC, WI>;
         using SB = DwStage<VEC, WJ>;
         const int ca = i0 + (tid % SA::CPR) * (VEC ? 4 : 1), cb = j0 + (tid % SB::CPR) * (VEC ? 4 : 1);
+        const int cac = min(ca, p.I - (VEC ? 4 : 1)), cbc = min(cb, p.J - (VEC ? 4 : 1));
         if constexpr (VEC) {
-            if (ca < p.I) { asc = *reinterpret_cast<const float4*>(p.sc + ca); ash = *reinterpret_cast<const float4*>(p.sh + ca);
-                            ak2 = *reinterpret_cast<const float4*>(p.k2 + ca); }
-            if (cb < p.J && p.b_mode == A_BNACT) { bsc = *reinterpret_cast<const float4*>(p.bsc + cb); bsh = *reinterpret_cast<const float4*>(p.bsh + cb); }
+            asc = *reinterpret_cast<const float4*>(p.sc + cac); ash = *reinterpret_cast<const float4*>(p.sh + cac);
+            ak2 = *reinterpret_cast<const float4*>(p.k2 + cac);
+            if (p.b_mode == A_BNACT) { bsc = *reinterpret_cast<const float4*>(p.bsc + cbc); bsh = *reinterpret_cast<const float4*>(p.bsh + cbc); }
         } else {
-            if (ca < p.I) { asc.x = p.sc[ca]; ash.x = p.sh[ca]; ak2.x = p.k2[ca]; }
-            if (cb < p.J && p.b_mode == A_BNACT) { bsc.x = p.bsc[cb]; bsh.x = p.bsh[cb]; }
+            asc.x = p.sc[cac]; ash.x = p.sh[cac]; ak2.x = p.k2[cac];
+            if (p.b_mode == A_BNACT) { bsc.x = p.bsc[cbc]; bsh.x = p.bsh[cbc]; }
         }
     }
 
@@ -583,7 +617,7 @@ static void dw_grid(int P, int I, int J, int& gx, int& ti, int& tj, int& tm, int
     tm = I > 64 ? 2 : 1; tn = J > 64 ? 2 : 1;
     ti = (I + 64 * tm - 1) / (64 * tm); tj = (J + 64 * tn - 1) / (64 * tn);
     const int chunks = (P + DW_BP - 1) / DW_BP;
-    gx = (1024 + ti * tj - 1) / (ti * tj);
+    gx = (768 + ti * tj - 1) / (ti * tj);
     if (gx > chunks) gx = chunks;
     if (gx < 1) gx = 1;
 }
@@ -596,13 +630,24 @@ static void launch_dw_t(const DwArgs& d, dim3 grid, int tm, int tn, hipStream_t 
     else hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 2, 2>), grid, dim3(MLP_T), 0, st, d);
 }
 
-// out[e] = sum_r part[r][e]  (+ optional column sums of dy for the bias gradient are taken elsewhere)
+// out[e] = sum_r part[r][e]: 32 outputs x 8 row-lanes per 256-thread block (partials are L2-resident).
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int rows, size_t n,
                                                           float* __restrict__ out) {
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
-        float s = 0.f;
-        for (int r = 0; r < rows; ++r) s += part[(size_t)r * n + e];
-        out[e] = s;
+    __shared__ float red[8][33];
+    const int el = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const size_t e = (size_t)blockIdx.x * 32 + el;
+    float s = 0.f;
+    if (e < n) {
+#pragma unroll 8
+        for (int r = ry; r < rows; r += 8) s += part[(size_t)r * n + e];
+    }
+    red[ry][el] = s;
+    __syncthreads();
+    if (ry == 0 && e < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += red[j][el];
+        out[e] = t;
     }
 }
 
@@ -859,8 +904,7 @@ extern "C" int pcl_linear_bwd_dw_f32(const float* dU, const float* Y, const floa
     int rc = check_launch("pcl_linear_bwd_dw_f32");
     if (rc) return rc;
     const size_t n = (size_t)Cout * Cin;
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    const int blocks = (int)((n + 31) / 32);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(blocks), dim3(256), 0, st, d.part, gx, n, dW);
     return check_launch("pcl_linear_bwd_dw_f32(reduce)");
 }
@@ -901,7 +945,7 @@ extern "C" int pcl_maxgrad_prep_f32(const float* gout, const float* out, const f
                                     float* gz, double* stats_ws, int* stat_rows_out, void* stream) {
     PCL_REQUIRE(gout && out && ymax && gz && stats_ws && stat_rows_out, "pcl_maxgrad_prep_f32: null pointer");
     PCL_REQUIRE(G >= 1 && C >= 1, "pcl_maxgrad_prep_f32: bad sizes");
-    int rows = G < 64 ? G : 64;
+    int rows = G < 512 ? G : 512;
     *stat_rows_out = rows;
     hipLaunchKernelGGL(maxgrad_prep_kernel, dim3((C + 255) / 256, rows), dim3(256), 0, as_stream(stream), gout, out, ymax,
                        slope, G, C, gz, stats_ws);
