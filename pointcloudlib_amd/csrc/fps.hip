@@ -6,21 +6,63 @@
 //     LDS as float4 (x,y,z,_) so the "last winner" lookup is one broadcast ds_read_b128;
 //   * every lane keeps PPT points (xyz + running min-distance) in VGPRs for the whole
 //     m-step chain -- no global or LDS traffic for the O(m*N) part;
-//   * per step: lane-local arg-max, a DPP row reduction + 4 readlanes for the wave maximum, a
-//     ballot to find the winning lane (the common no-tie case costs one readlane; exact ties fall
-//     back to a wave min over the tie rank), one LDS slot per wave and ONE barrier per step
-//     (double-buffered slots) to combine waves.
+//   * per step: lane-local max of a 64-bit key (distance bits | inverted tie rank) with one v_max_f64 per
+//     point, a 6-step DPP reduction for the wave maximum, one 8-byte LDS slot per wave and ONE barrier per
+//     step (double-buffered slots) to combine waves; the winner's index is recovered from the key by shifts;
+//   * nothing is written to global memory inside the chain (indices are buffered in LDS).
 //   The op is a chain of m-1 dependent arg-max steps with only B independent problems: it is
-//   latency-bound (reported as cycles/step in DESIGN.md), not HBM-bound.
+//   latency-bound (~940 shader cycles per step at N=1024, of which ~45 % are LDS/barrier waits; PMC in
+//   profiles/), not HBM-bound.
 //
 // Tie rule (exact ties only): the reference's S-thread strided scan + tree reduction picks, among
 // equal distances, the smallest (bitreverse_{log2 S}(k mod S), k).  We carry that as a 32-bit rank
-// rank(k) = bitrev(k mod S) * ceil(N/S) + k div S, smaller wins.
+// rank'(k) = (bitrev(k mod S) << sh) | (k div S), smaller wins (see the key layout below).
 #include "common.h"
 
 namespace pcl {
 
 struct FpsSlot { unsigned key, rank, k, pad; };
+
+// 64-bit arg-max key: high word = bits of the (non-negative) running min-distance, low word = ~rank'(k), so
+// one unsigned 64-bit max picks the largest distance and, among exactly equal distances, the smallest rank.
+//   rank'(k) = (bitrev_{log2 S}(k mod S) << sh) | (k div S),  sh = bits of ((N-1) div S)
+// is order-isomorphic to the reference's (bitrev(k mod S), k) priority and invertible with shifts only.
+// Points that may never be sampled carry key 0 (distance 0, low word 0) and lose to every live point;
+// a cloud without live points reduces to key 0 -> index 0 (misc/ops.py:152-153).
+// The keys are compared as IEEE doubles: for bit patterns with a clear sign bit and a non-NaN exponent (high
+// word = bits of a finite non-negative float, so the f64 exponent field is < 0x7F8) numeric order == unsigned
+// integer order, and v_max_f64 does in ONE instruction what a 64-bit integer max needs five for.  The step
+// chain is latency-bound, so instruction count on the dependent path is what matters.
+__device__ __forceinline__ double key_max(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)u, (int)(unsigned)u, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(u >> 32), (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// wave-wide max of a key: 4 DPP butterfly steps inside each row of 16 lanes, row_bcast:15 / row_bcast:31 fold
+// the four rows, the total is read from lane 63 (wave-uniform).  Measured on MI355X: 382 ns/step at N=1024
+// with 4 waves; a two-pass 32-bit variant with the DPP modifier fused into v_max_u32 (fewer instructions, two
+// VALU->SGPR hops) measured 401 ns/step, the original compare/select/ballot form 582 ns/step.
+__device__ __forceinline__ unsigned long long wave_key_max(double v) {
+    v = key_max(v, dpp_f64<0xB1, 0xf>(v));      // quad_perm [1,0,3,2]
+    v = key_max(v, dpp_f64<0x4E, 0xf>(v));      // quad_perm [2,3,0,1]
+    v = key_max(v, dpp_f64<0x141, 0xf>(v));     // row_half_mirror
+    v = key_max(v, dpp_f64<0x140, 0xf>(v));     // row_mirror  -> every lane holds its row's max
+    v = key_max(v, dpp_f64<0x142, 0xa>(v));     // row_bcast:15 into rows 1,3
+    v = key_max(v, dpp_f64<0x143, 0xc>(v));     // row_bcast:31 into rows 2,3 -> lane 63 has the wave max
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
 
 template <int T, int PPT>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int N, int m, int log2S,
@@ -28,8 +70,9 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                                                 int32_t* __restrict__ idx_out, float* __restrict__ new_xyz_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = T / 64;
-    FpsSlot* slots = reinterpret_cast<FpsSlot*>(smem);                       // [2][NW]
-    float4* s_xyz = reinterpret_cast<float4*>(smem + sizeof(FpsSlot) * 2 * (NW > 1 ? NW : 1));
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(smem);      // [2][NW] (NW > 1)
+    float4* s_xyz = reinterpret_cast<float4*>(smem + 256);
+    int* s_out = reinterpret_cast<int*>(smem + 256 + sizeof(float4) * (size_t)N);  // [m] sampled indices
 
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* p = xyz + (size_t)b * N * 3;
@@ -45,94 +88,67 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     __syncthreads();
 
     const unsigned S = 1u << log2S;
-    const unsigned cnt = ((unsigned)N + S - 1) >> log2S;
-    auto rank_of = [&](unsigned k) -> unsigned {
-        const unsigned br = log2S ? (__brev(k & (S - 1)) >> (32 - log2S)) : 0u;
-        return br * cnt + (k >> log2S);
-    };
-    float px[PPT], py[PPT], pz[PPT], md[PPT];     // md: running min distance, -1 = never a candidate
+    int sh = 0;
+    while ((((unsigned)N - 1) >> log2S) >> sh) ++sh;                    // bits of (N-1) div S
+    float px[PPT], py[PPT], pz[PPT], md[PPT];
+    unsigned lo[PPT];                                                    // ~rank'(k), 0 = never a candidate
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        const int k = tid + j * T;
-        if (k < N) {
+        const unsigned k = (unsigned)(tid + j * T);
+        px[j] = py[j] = pz[j] = 0.f; md[j] = 0.f; lo[j] = 0u;
+        if (k < (unsigned)N) {
             const float4 v = s_xyz[k];
             px[j] = v.x; py[j] = v.y; pz[j] = v.z;
             const float mag = __fadd_rn(__fadd_rn(__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y)), __fmul_rn(v.z, v.z));
-            md[j] = ((double)mag <= skip_thr) ? -1.0f : 1e10f;    // skip_thr < 0 disables the rule
-        } else {
-            px[j] = py[j] = pz[j] = 0.f; md[j] = -1.0f;
+            if (!((double)mag <= skip_thr)) {                            // skip_thr < 0 disables the rule
+                const unsigned br = log2S ? (__brev(k & (S - 1)) >> (32 - log2S)) : 0u;
+                lo[j] = ~((br << sh) | (k >> log2S));
+                md[j] = 1e10f;
+            }
         }
     }
 
+    // NOTE: nothing is stored to global memory inside the chain: a global store per step would be drained
+    // (vmcnt(0)) by every __syncthreads(), adding an HBM round trip to each of the m-1 dependent steps.
     int old = start_idx ? start_idx[b] : 0;
-    if (tid == 0) out[0] = old;
+    if (tid == 0) s_out[0] = old;
     const int lane = tid & 63, wid = tid >> 6;
 
     for (int step = 1; step < m; ++step) {
         const float4 c = s_xyz[old];
-        if (tid == 0 && oxyz) { oxyz[(step - 1) * 3 + 0] = c.x; oxyz[(step - 1) * 3 + 1] = c.y; oxyz[(step - 1) * 3 + 2] = c.z; }
-        // lane-local arg-max of the updated min-distances (first maximum; exact ties are fixed up below)
-        float best = -1.0f;
-        unsigned bestk = 0;
+        double best = 0.0;
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             const float d = sq_dist3(px[j], py[j], pz[j], c.x, c.y, c.z);
-            const float d2 = fminf(d, md[j]);                     // dead points stay at -1 forever
+            const float d2 = fminf(d, md[j]);                     // never-candidates stay at 0 forever
             md[j] = d2;
-            const bool gt = d2 > best;
-            bestk = gt ? (unsigned)(tid + j * T) : bestk;
-            best = gt ? d2 : best;
+            best = key_max(best, __longlong_as_double(((unsigned long long)__float_as_uint(d2) << 32) | lo[j]));
         }
-        // wave arg-max: key is monotone in best for best >= 0; 0 means "no live point"
-        const unsigned key = best >= 0.0f ? __float_as_uint(best) + 1u : 0u;
-        const unsigned wmax = wave_max_u32(key);
-        unsigned wr = 0xFFFFFFFFu, wk = 0;
-        if (wmax) {
-            const float wbest = __uint_as_float(wmax - 1u);
-            int ntied = 0;
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) ntied += __popcll(__ballot(md[j] == wbest));
-            if (ntied == 1) {                                      // the common case: one point attains the max
-                const unsigned long long w = __ballot(key == wmax);
-                const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)w) - 1);
-                wk = __builtin_amdgcn_readlane(bestk, l);
-                wr = rank_of(wk);
-            } else {                                               // exact tie: smallest rank wins
-                unsigned r = 0xFFFFFFFFu, rkk = 0;
-#pragma unroll
-                for (int j = 0; j < PPT; ++j) {
-                    const unsigned kj = (unsigned)(tid + j * T);
-                    const unsigned rj = rank_of(kj);
-                    const bool take = (md[j] == wbest) & (rj < r);
-                    r = take ? rj : r; rkk = take ? kj : rkk;
-                }
-                wr = wave_min_u32(r);
-                const unsigned long long w = __ballot(r == wr);
-                const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)w) - 1);
-                wk = __builtin_amdgcn_readlane(rkk, l);
-            }
-        }
-        if (NW == 1) {
-            old = wmax ? (int)wk : 0;
-        } else {
-            FpsSlot* sl = slots + (step & 1) * NW;
-            if (lane == 0) { FpsSlot s; s.key = wmax; s.rank = wr; s.k = wk; s.pad = 0; sl[wid] = s; }
+        unsigned long long w = wave_key_max(best);               // wave-uniform
+        if (NW > 1) {
+            unsigned long long* sl = slots + (step & 1) * NW;
+            if (lane == 0) sl[wid] = w;
             __syncthreads();
-            unsigned bk = 0, br = 0xFFFFFFFFu, bi = 0;
+            double wd = __longlong_as_double(sl[0]);
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const FpsSlot s = sl[w];
-                const bool take = (s.key > bk) | ((s.key == bk) & (s.rank < br));
-                bk = take ? s.key : bk; br = take ? s.rank : br; bi = take ? s.k : bi;
-            }
-            old = bk ? (int)bi : 0;
+            for (int i = 1; i < NW; ++i) wd = key_max(wd, __longlong_as_double(sl[i]));
+            w = __double_as_longlong(wd);
         }
-        if (tid == 0) out[step] = old;
+        // invert the rank: low word 0 can only win when no point is live -> index 0
+        const unsigned r = ~(unsigned)w;
+        const unsigned kdiv = r & ((1u << sh) - 1u);
+        const unsigned br = r >> sh;
+        const unsigned kk = (kdiv << log2S) | (log2S ? (__brev(br) >> (32 - log2S)) : 0u);
+        old = (unsigned)w ? (int)kk : 0;
+        if (tid == 0) s_out[step] = old;
     }
-    if (tid == 0 && oxyz) {
-        const float4 c = s_xyz[old];
-        oxyz[(m - 1) * 3 + 0] = c.x; oxyz[(m - 1) * 3 + 1] = c.y; oxyz[(m - 1) * 3 + 2] = c.z;
-    }
+    __syncthreads();
+    for (int j = tid; j < m; j += T) out[j] = s_out[j];
+    if (oxyz)
+        for (int i = tid; i < 3 * m; i += T) {
+            const int j = i / 3, cc = i - 3 * j;
+            oxyz[i] = s_flat[4 * s_out[j] + cc];
+        }
 }
 
 // Large-cloud variant (N*16 B does not fit LDS next to the slots): only the running min-distance
@@ -204,8 +220,7 @@ __global__ __launch_bounds__(T) void fps_kernel_lds(const float* __restrict__ xy
 template <int T, int PPT>
 static int launch_fps(const float* xyz, int B, int N, int m, int log2S, double thr, const int32_t* start,
                       int32_t* idx, float* nx, hipStream_t st) {
-    constexpr int NW = T / 64;
-    const size_t lds = sizeof(FpsSlot) * 2 * (NW > 1 ? NW : 1) + sizeof(float4) * (size_t)N;
+    const size_t lds = 256 + sizeof(float4) * (size_t)N + sizeof(int) * (size_t)m;   // slots + xyz + indices
     auto kern = fps_kernel<T, PPT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -236,7 +251,7 @@ extern "C" int pcl_fps_f32(const float* xyz, int B, int N, int m, int tie_stride
     const int ppt = (N + T - 1) / T;
 #define PCL_FPS_CASE(TT, PP) \
     if (T == TT && ppt <= PP) return launch_fps<TT, PP>(xyz, B, N, m, log2S, skip_sqnorm_le, start_idx, idx_out, new_xyz_out, st);
-    if ((size_t)N * 16 <= 150 * 1024) {
+    if ((size_t)N * 16 + (size_t)m * 4 + 256 <= 158 * 1024) {
         PCL_FPS_CASE(64, 1) PCL_FPS_CASE(64, 2) PCL_FPS_CASE(64, 4) PCL_FPS_CASE(64, 8) PCL_FPS_CASE(64, 16) PCL_FPS_CASE(64, 32)
         PCL_FPS_CASE(128, 1) PCL_FPS_CASE(128, 2) PCL_FPS_CASE(128, 4) PCL_FPS_CASE(128, 8) PCL_FPS_CASE(128, 16)
         PCL_FPS_CASE(256, 1) PCL_FPS_CASE(256, 2) PCL_FPS_CASE(256, 4) PCL_FPS_CASE(256, 8) PCL_FPS_CASE(256, 16)
