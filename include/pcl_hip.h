@@ -87,6 +87,12 @@ int pcl_gather_rows_f32(const float* src, const int32_t* idx, int B, int N, int 
 int pcl_gather_rows_bwd_f32(const float* gout, const int32_t* idx, int B, int N, int M, int C,
                             float* gsrc, void* stream);
 
+/* DGCNN edge features, get_graph_feature (networks/cls/dgcnn.py:29-50):
+ *   x [B,N,C] channel-last, idx [B,N,k] -> out [B,N,k,2C] = concat(x[idx]-x[n], x[n]);  bwd defines all of gx. */
+int pcl_edge_feature_f32(const float* x, const int32_t* idx, int B, int N, int k, int C, float* out, void* stream);
+int pcl_edge_feature_bwd_f32(const float* gout, const int32_t* idx, int B, int N, int k, int C, float* gx,
+                             void* stream);
+
 /* ---- brute-force k-NN -------------------------------------------------------------------------
  * Replaces knn_cuda_global (compute_distances + modified_insertion_sort), misc/ops.py:429-638.
  *   ref [B,C,Nr] (the reference's in0 = x_r), qry [B,C,Nq] (in1 = x_q), channel-major

@@ -52,6 +52,8 @@ _SIGS = {
     "pcl_group_all_bwd_f32": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_gather_rows_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_gather_rows_bwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcl_edge_feature_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcl_edge_feature_bwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "pcl_knn_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     "pcl_three_nn_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),

@@ -87,6 +87,48 @@ __global__ __launch_bounds__(GT) void gather_rows_bwd_kernel(const float* __rest
     }
 }
 
+
+// DGCNN edge features, get_graph_feature (/root/reference/networks/cls/dgcnn.py:29-50) without the k-fold
+// `repeat` of the centres: out[b,n,j,:] = concat(x[b,idx[b,n,j],:] - x[b,n,:], x[b,n,:])  -> [B,N,k,2C].
+__global__ __launch_bounds__(GT) void edge_feature_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                          int N, int k, int C, size_t total, float* __restrict__ out) {
+    const int D = 2 * C;
+    for (size_t g = (size_t)blockIdx.x * GT + threadIdx.x; g < total; g += (size_t)gridDim.x * GT) {
+        const size_t row = g / D;                // (b*N + n)*k + j
+        const int c = (int)(g - row * D);
+        const size_t bn = row / k;               // b*N + n
+        const size_t b = bn / N;
+        if (c < C) out[g] = __fsub_rn(x[(b * N + idx[row]) * C + c], x[bn * C + c]);
+        else out[g] = x[bn * C + (c - C)];
+    }
+}
+
+// gradient, centre part: gx[b,n,c] = sum_j (g[b,n,j,C+c] - g[b,n,j,c])   (plain store: initialises gx)
+__global__ __launch_bounds__(GT) void edge_feature_bwd_center_kernel(const float* __restrict__ gout, int k, int C,
+                                                                     size_t total, float* __restrict__ gx) {
+    const int D = 2 * C;
+    for (size_t g = (size_t)blockIdx.x * GT + threadIdx.x; g < total; g += (size_t)gridDim.x * GT) {
+        const size_t bn = g / C;
+        const int c = (int)(g - bn * C);
+        const float* base = gout + bn * k * D;
+        float s = 0.f;
+        for (int j = 0; j < k; ++j) s += base[(size_t)j * D + C + c] - base[(size_t)j * D + c];
+        gx[g] = s;
+    }
+}
+
+// gradient, neighbour part: gx[b,idx[b,n,j],c] += g[b,n,j,c]
+__global__ __launch_bounds__(GT) void edge_feature_bwd_nbr_kernel(const float* __restrict__ gout, const int32_t* __restrict__ idx,
+                                                                  int N, int k, int C, size_t total, float* __restrict__ gx) {
+    const int D = 2 * C;
+    for (size_t g = (size_t)blockIdx.x * GT + threadIdx.x; g < total; g += (size_t)gridDim.x * GT) {
+        const size_t row = g / C;
+        const int c = (int)(g - row * C);
+        const size_t b = row / ((size_t)N * k);
+        unsafeAtomicAdd(&gx[(b * N + idx[row]) * C + c], gout[row * D + c]);
+    }
+}
+
 static inline int grid_for(size_t total) {
     size_t blocks = (total + GT - 1) / GT;
     if (blocks > 256 * 16) blocks = 256 * 16;   // 16 resident blocks per CU, grid-stride the rest
@@ -164,4 +206,26 @@ extern "C" int pcl_gather_rows_bwd_f32(const float* gout, const int32_t* idx, in
     if (!total) return PCL_OK;
     hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3(grid_for(total)), dim3(GT), 0, st, gout, idx, N, M, C, total, gsrc);
     return check_launch("pcl_gather_rows_bwd_f32");
+}
+
+extern "C" int pcl_edge_feature_f32(const float* x, const int32_t* idx, int B, int N, int k, int C, float* out, void* stream) {
+    PCL_REQUIRE(x && idx && out && B >= 0 && N >= 1 && k >= 1 && C >= 1, "pcl_edge_feature_f32: bad arguments");
+    const size_t total = (size_t)B * N * k * 2 * C;
+    if (!total) return PCL_OK;
+    hipLaunchKernelGGL(edge_feature_kernel, dim3(grid_for(total)), dim3(GT), 0, as_stream(stream), x, idx, N, k, C, total, out);
+    return check_launch("pcl_edge_feature_f32");
+}
+
+extern "C" int pcl_edge_feature_bwd_f32(const float* gout, const int32_t* idx, int B, int N, int k, int C, float* gx,
+                                        void* stream) {
+    PCL_REQUIRE(gout && idx && gx && B >= 0 && N >= 1 && k >= 1 && C >= 1, "pcl_edge_feature_bwd_f32: bad arguments");
+    hipStream_t st = as_stream(stream);
+    const size_t tc = (size_t)B * N * C;
+    if (!tc) return PCL_OK;
+    hipLaunchKernelGGL(edge_feature_bwd_center_kernel, dim3(grid_for(tc)), dim3(GT), 0, st, gout, k, C, tc, gx);
+    int rc = check_launch("pcl_edge_feature_bwd_f32(center)");
+    if (rc) return rc;
+    const size_t tn = tc * k;
+    hipLaunchKernelGGL(edge_feature_bwd_nbr_kernel, dim3(grid_for(tn)), dim3(GT), 0, st, gout, idx, N, k, C, tn, gx);
+    return check_launch("pcl_edge_feature_bwd_f32(nbr)");
 }

@@ -16,7 +16,7 @@ from .. import _lib
 
 __all__ = [
     "optimal_block", "furthest_point_sample", "ball_query", "group_points", "group_all", "index_points",
-    "knn_indices", "three_nn", "three_interpolate", "FurthestPointSampler", "BallQueryGrouper", "GroupAll",
+    "knn_indices", "edge_features", "three_nn", "three_interpolate", "FurthestPointSampler", "BallQueryGrouper", "GroupAll",
     "KNN", "PointNetFeaturePropagation",
 ]
 
@@ -209,6 +209,36 @@ class _GatherRows(torch.autograd.Function):
 def index_points(points, idx):
     """points [B,N,C], idx [B,S] or [B,S,K] (int32) -> [B,S,(K,)C].  misc/ops.py:12-27."""
     return _GatherRows.apply(points, idx.to(torch.int32))
+
+
+class _EdgeFeature(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        x = _dev(x, "x")
+        idx = _dev(idx, "idx", torch.int32)
+        B, N, C = x.shape
+        k = idx.shape[2]
+        out = torch.empty((B, N, k, 2 * C), dtype=torch.float32, device=x.device)
+        _lib.call("pcl_edge_feature_f32", _p(x), _p(idx), B, N, k, C, _p(out), _stream(),
+                  algo_bytes=4 * B * N * (C + k + 2 * C * k))
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, k, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (idx,) = ctx.saved_tensors
+        B, N, k, C = ctx.dims
+        gout = _dev(gout, "grad")
+        gx = torch.empty((B, N, C), dtype=torch.float32, device=gout.device)
+        _lib.call("pcl_edge_feature_bwd_f32", _p(gout), _p(idx), B, N, k, C, _p(gx), _stream(),
+                  algo_bytes=4 * B * N * (C + k + 2 * C * k))
+        return gx, None
+
+
+def edge_features(x, idx):
+    """x [B,N,C] channel-last, idx [B,N,k] int32 -> [B,N,k,2C] = concat(x[idx]-x, x).  dgcnn.py:29-50."""
+    return _EdgeFeature.apply(x, idx)
 
 
 class _ThreeInterpolate(torch.autograd.Function):

@@ -1,0 +1,63 @@
+"""DGCNN classification -- counterpart of /root/reference/networks/cls/dgcnn.py (DGCNN :61-122,
+get_graph_feature :29-50).
+
+Same layer widths, k and activations: four EdgeConv stages (kNN in the CURRENT feature space -> edge features
+concat(nbr - ctr, ctr) -> Conv2d 1x1 (bias=False) + BN + LeakyReLU(0.2) -> max over k) :72-83,:100-111;
+concat(x1..x4) -> Conv1d 512->1024 + BN1d + LeakyReLU :84-86,:113; global max || global mean :114-116; FC head
+:87-93,:117-121.  Input is [B,3,N] like the reference; internally activations are channel-last [B,N,C].
+
+kNN runs in the HIP KNN kernel (index-exact vs the oracle), the gather/concat in pcl_edge_feature_f32 (no k-fold
+`repeat` of the centres), the conv+BN+LeakyReLU+max in the fused MFMA MLP path.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ...misc.layers import PointwiseMLP
+from ...misc.ops import KNN, edge_features
+
+
+def get_graph_feature(x, knn=None, k=None, idx=None):
+    """x [B,N,C] channel-last -> [B,N,k,2C]  (dgcnn.py:29-50; the reference returns [B,2C,N,k])."""
+    if idx is None:
+        xt = x.transpose(1, 2).contiguous()           # [B,C,N] as KNN expects (misc/ops.py:651)
+        idx = knn(xt, xt).permute(0, 2, 1).contiguous()   # [B,k,N] -> [B,N,k]   dgcnn.py:34-35
+    return edge_features(x, idx)
+
+
+class DGCNN(nn.Module):
+    def __init__(self, n_classes=40):
+        super().__init__()
+        self.k = 20
+        self.knn = KNN(self.k)
+        self.conv1 = PointwiseMLP([6, 64], slope=0.2)
+        self.conv2 = PointwiseMLP([64 * 2, 64], slope=0.2)
+        self.conv3 = PointwiseMLP([64 * 2, 128], slope=0.2)
+        self.conv4 = PointwiseMLP([128 * 2, 256], slope=0.2)
+        self.conv5 = PointwiseMLP([512, 1024], slope=0.2)
+        self.linear1 = nn.Linear(1024 * 2, 512, bias=False)
+        self.bn6 = nn.BatchNorm1d(512)
+        self.dp1 = nn.Dropout(p=0.5)
+        self.linear2 = nn.Linear(512, 256)
+        self.bn7 = nn.BatchNorm1d(256)
+        self.dp2 = nn.Dropout(p=0.5)
+        self.linear3 = nn.Linear(256, n_classes)
+
+    def forward(self, x):
+        """x [B,3,N] -> logits [B,n_classes]."""
+        x = x.transpose(1, 2).contiguous()                                 # channel-last
+        x1 = self.conv1(get_graph_feature(x, self.knn), group_max=self.k)   # :100-102
+        x2 = self.conv2(get_graph_feature(x1, self.knn), group_max=self.k)  # :103-105
+        x3 = self.conv3(get_graph_feature(x2, self.knn), group_max=self.k)  # :106-108
+        x4 = self.conv4(get_graph_feature(x3, self.knn), group_max=self.k)  # :109-111
+        x = torch.cat((x1, x2, x3, x4), dim=2)                              # [B,N,512]   :112
+        x = self.conv5(x)                                                   # [B,N,1024]  :113
+        x = torch.cat((x.max(dim=1)[0], x.mean(dim=1)), dim=1)              # :114-116
+        x = F.leaky_relu(self.bn6(self.linear1(x)), 0.2)
+        x = self.dp1(x)
+        x = F.leaky_relu(self.bn7(self.linear2(x)), 0.2)
+        x = self.dp2(x)
+        return self.linear3(x)
+
+    def execute(self, *a, **k):
+        return self(*a, **k)

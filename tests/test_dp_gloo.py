@@ -1,0 +1,85 @@
+"""CPU, world_size = 2 over gloo: the data-parallel layer (flat gradient bucket + one all-reduce) reproduces the
+single-process gradient of the concatenated batch, parameters stay replicated, and batches shard by cloud."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_model():
+    from pointcloudlib_amd.misc.layers import PointwiseMLP
+    torch.manual_seed(7)
+    m = PointwiseMLP([5, 16, 8], bias=True, bn=False, backend="torch")     # no BatchNorm: grads are batch-additive
+    return m
+
+
+def _worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pointcloudlib_amd.dp import FlatBucketDP, shard_batch
+    model = _make_model()
+    if rank == 1:                                   # rank 1 starts from different weights: broadcast must fix it
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    dp = FlatBucketDP(model)
+    torch.manual_seed(0)
+    x = torch.randn(8, 12, 5)
+    y = torch.randn(8, 12, 8)
+    (xs, ys) = shard_batch([x, y], rank, world)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    for _ in range(2):
+        dp.zero_grad()
+        ((model(xs) - ys) ** 2).mean().backward()
+        dp.all_reduce()
+        opt.step()
+    out_q.put((rank, [p.detach().numpy().copy() for p in model.parameters()], dp.flat.numpy().copy(), dp.nbytes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_dp_matches_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference on the full batch
+    model = _make_model()
+    torch.manual_seed(0)
+    x = torch.randn(8, 12, 5)
+    y = torch.randn(8, 12, 8)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    for _ in range(2):
+        opt.zero_grad()
+        ((model(x) - y) ** 2).mean().backward()
+        opt.step()
+    ref = [p.detach() for p in model.parameters()]
+    for r in range(world):
+        assert res[r][3] == sum(p.numel() for p in ref) * 4
+        for a, b in zip(res[r][1], ref):
+            assert torch.allclose(torch.from_numpy(a), b, rtol=1e-5, atol=1e-6)
+    assert (res[0][2] == res[1][2]).all()               # identical averaged gradient buckets on both ranks
+
+
+def test_shard_batch_by_cloud():
+    from pointcloudlib_amd.dp import shard_batch
+    x = torch.arange(24).reshape(8, 3)
+    a, = shard_batch([x], 1, 4)
+    assert a.tolist() == x[2:4].tolist()

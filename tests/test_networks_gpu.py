@@ -1,0 +1,126 @@
+"""GPU: whole networks built from the HIP ops -- shapes, backend agreement (fused HIP MLP vs plain-PyTorch MLP on
+the same HIP indices) and, for PointNet++ SSG, feature parity with the CPU restatement level by level."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from pointcloudlib_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def set_backend(model, backend):
+    for m in model.modules():
+        if hasattr(m, "backend"):
+            m.backend = backend
+    return model
+
+
+def no_dropout(model):
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return model
+
+
+def fwd_bwd(model, args, backend):
+    m = set_backend(copy.deepcopy(model), backend).train()
+    out = m(*args)
+    out.square().mean().backward()
+    return out.detach(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+
+def test_pointnet2_cls_matches_cpu_restatement(oracle, dev):
+    from oracle.cpu_model import PointNet2ClsCPU
+    from pointcloudlib_amd.misc import ops
+    from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
+    torch.manual_seed(0)
+    B, N = 8, 1024
+    pts, nrm = synth.gauss_ball(B, N, 11), synth.unit_normals(B, N, 12)
+    net = no_dropout(PointNet2_cls().to(dev)).train()
+    ref = PointNet2ClsCPU(net.state_dict(), tie_stride=ops.optimal_block(B)).train()
+    x, f = torch.from_numpy(pts).to(dev), torch.from_numpy(nrm).to(dev)
+    # level by level: sampled xyz bit-exact, pooled features within 1e-5 (relative to the level's max)
+    with torch.no_grad():
+        logits_ref, aux = ref(torch.from_numpy(pts), torch.from_numpy(nrm), return_aux=True)
+        cur_xyz, cur_f = x, f
+        for lvl, mod in enumerate(net.pointnet_modules):
+            new_xyz, cur_f = mod(cur_xyz, cur_f)
+            want = aux[lvl]["feat"]
+            scale = max(1.0, want.abs().max().item())
+            err = (cur_f.cpu() - want).abs().max().item()
+            assert err <= 1e-5 * scale, f"SA{lvl + 1}: {err:.3e} vs scale {scale:.3f}"
+            if new_xyz is not None:
+                assert np.array_equal(new_xyz.cpu().numpy()[:, :, 0], pts[np.arange(B)[:, None], aux[lvl]["fps_idx"]][:, :, 0]) \
+                    if lvl == 0 else True
+                cur_xyz = new_xyz
+        logits = net.fc_layer(cur_f.squeeze(1))
+        assert (logits.cpu() - logits_ref).abs().max().item() <= 1e-4 * max(1.0, logits_ref.abs().max().item())
+
+
+def test_pointnet2_cls_backends_agree_with_grads(dev):
+    from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
+    torch.manual_seed(1)
+    B, N = 4, 1024
+    x = torch.from_numpy(synth.gauss_ball(B, N, 3)).to(dev)
+    f = torch.from_numpy(synth.unit_normals(B, N, 4)).to(dev)
+    net = no_dropout(PointNet2_cls().to(dev))
+    o_h, g_h = fwd_bwd(net, (x, f), "hip")
+    o_t, g_t = fwd_bwd(net, (x, f), "torch")
+    assert (o_h - o_t).abs().max().item() <= 1e-4 * max(1.0, o_t.abs().max().item())
+    for n in g_t:
+        s = max(1e-6, g_t[n].abs().max().item())
+        assert (g_h[n] - g_t[n]).abs().max().item() <= 2e-3 * s, n     # two fp32 paths; BN backward amplifies
+
+
+def test_pointnet_and_partseg_shapes_and_backends(dev):
+    from pointcloudlib_amd.networks.cls.pointnet import PointNet
+    from pointcloudlib_amd.networks.seg.pointnet2_partseg import PointNet2_partseg, PointNetMSG
+    torch.manual_seed(2)
+    B, N = 4, 2048
+    x = torch.from_numpy(synth.gauss_ball(B, N, 5)).to(dev)
+    net = no_dropout(PointNet().to(dev))
+    o_h, g_h = fwd_bwd(net, (x.transpose(1, 2).contiguous(),), "hip")
+    o_t, g_t = fwd_bwd(net, (x.transpose(1, 2).contiguous(),), "torch")
+    assert o_h.shape == (B, 40) and (o_h - o_t).abs().max().item() <= 1e-4 * max(1.0, o_t.abs().max().item())
+    onehot = torch.zeros(B, 16, device=dev)
+    onehot[torch.arange(B), torch.arange(B) % 16] = 1
+    for cls in (PointNet2_partseg, PointNetMSG):
+        seg = no_dropout(cls().to(dev))
+        o_h, g_h = fwd_bwd(seg, (x, x, onehot), "hip")              # train_partseg.py:110: model(data, data, onehot)
+        o_t, g_t = fwd_bwd(seg, (x, x, onehot), "torch")
+        assert o_h.shape == (B, 50, N)
+        assert (o_h - o_t).abs().max().item() <= 1e-3 * max(1.0, o_t.abs().max().item())
+        assert set(g_h) == set(g_t) and all(torch.isfinite(v).all() for v in g_h.values())
+
+
+def test_dgcnn_forward_backward(oracle, dev):
+    from pointcloudlib_amd.misc import ops
+    from pointcloudlib_amd.networks.cls.dgcnn import DGCNN, get_graph_feature
+    torch.manual_seed(3)
+    B, N = 4, 512
+    pts = synth.gauss_ball(B, N, 6)
+    x = torch.from_numpy(pts).to(dev)
+    # edge features of the first stage against the oracle's kNN + a NumPy gather
+    idx = oracle.knn(np.ascontiguousarray(pts.transpose(0, 2, 1)), np.ascontiguousarray(pts.transpose(0, 2, 1)), 20)
+    idx = idx.transpose(0, 2, 1)
+    ef = get_graph_feature(x, ops.KNN(20)).cpu().numpy()
+    nb = pts[np.arange(B)[:, None, None], idx]
+    want = np.concatenate([nb - pts[:, :, None, :], np.broadcast_to(pts[:, :, None, :], nb.shape)], -1)
+    assert np.array_equal(ef, want)
+    net = no_dropout(DGCNN().to(dev)).train()
+    out = net(x.transpose(1, 2).contiguous())
+    assert out.shape == (B, 40)
+    out.square().mean().backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+    # gradient of the edge-feature op against autograd on plain indexing
+    xr = x[:, :64].clone().requires_grad_(True)
+    ii = torch.from_numpy(np.ascontiguousarray(idx[:, :64, :8] % 64)).to(dev).int()
+    g = torch.randn(B, 64, 8, 6, device=dev)
+    ops.edge_features(xr, ii).backward(g)
+    xr2 = x[:, :64].clone().requires_grad_(True)
+    nbr = xr2[torch.arange(B, device=dev)[:, None, None], ii.long()]
+    torch.cat([nbr - xr2[:, :, None, :], xr2[:, :, None, :].expand_as(nbr)], -1).backward(g)
+    assert (xr.grad - xr2.grad).abs().max().item() <= 1e-5 * max(1.0, xr2.grad.abs().max().item())
