@@ -70,8 +70,9 @@ def test_pointnet2_cls_backends_agree_with_grads(dev):
     o_h, g_h = fwd_bwd(net, (x, f), "hip")
     o_t, g_t = fwd_bwd(net, (x, f), "torch")
     assert (o_h - o_t).abs().max().item() <= 1e-4 * max(1.0, o_t.abs().max().item())
+    gmax = max(v.abs().max().item() for v in g_t.values())
     for n in g_t:
-        s = max(1e-6, g_t[n].abs().max().item())
+        s = max(1e-3 * gmax, g_t[n].abs().max().item())                # some gradients are exactly 0 in theory
         assert (g_h[n] - g_t[n]).abs().max().item() <= 2e-3 * s, n     # two fp32 paths; BN backward amplifies
 
 
