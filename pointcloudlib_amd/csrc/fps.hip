@@ -78,6 +78,8 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     const float* p = xyz + (size_t)b * N * 3;
     int32_t* out = idx_out + (size_t)b * m;
     float* oxyz = new_xyz_out ? new_xyz_out + (size_t)b * m * 3 : nullptr;
+    // latency-critical serial chain: when co-resident with throughput kernels (side stream), win issue arbitration
+    __builtin_amdgcn_s_setprio(3);
 
     // stage the cloud: coalesced dword reads of the AoS xyz, scattered into float4 slots
     float* s_flat = reinterpret_cast<float*>(s_xyz);

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from ...misc.layers import PointwiseMLP
-from ...misc.ops import BallQueryGrouper, FurthestPointSampler, GroupAll
+from ...misc.ops import BallQueryGrouper, FurthestPointSampler, GroupAll, ball_query, group_points
 
 
 class PointNetModuleBase(nn.Module):
@@ -31,12 +31,24 @@ class PointNetModuleBase(nn.Module):
             spec[0] += 3
         return PointwiseMLP(spec, bias=not bn, bn=bn, slope=0.0)
 
-    def forward(self, xyz: torch.Tensor, feature: Optional[torch.Tensor]):
-        """xyz [B,N,3], feature [B,N,C] -> (new_xyz [B,n_points,3] | None, new_feature [B,n_points,C'])."""
-        new_xyz = self.sampler(xyz) if self.n_points is not None else None      # :45
+    def sample(self, xyz: torch.Tensor):
+        """The index-producing half of ``forward`` (no gradients, depends on xyz only): FPS centres and the
+        ball-query neighbour lists of every grouper.  Returns (new_xyz, [idx per grouper])."""
+        if self.n_points is None:
+            return None, [None] * len(self.groupers)
+        new_xyz = self.sampler(xyz)                                             # :45
+        return new_xyz, [ball_query(new_xyz, xyz, g.radius, g.n_samples) for g in self.groupers]
+
+    def forward(self, xyz: torch.Tensor, feature: Optional[torch.Tensor], sampling=None):
+        """xyz [B,N,3], feature [B,N,C] -> (new_xyz [B,n_points,3] | None, new_feature [B,n_points,C']).
+        ``sampling`` = a precomputed result of ``sample(xyz)`` (see PointNet2_cls.precompute_sampling)."""
+        new_xyz, idxs = sampling if sampling is not None else self.sample(xyz)
         new_feature_list = []
-        for grouper, mlp in zip(self.groupers, self.mlps):
-            grouped = grouper(new_xyz, xyz, feature)                            # [B, m, ns, C]      :51
+        for grouper, mlp, idx in zip(self.groupers, self.mlps, idxs):
+            if idx is None:
+                grouped = grouper(new_xyz, xyz, feature)                        # GroupAll
+            else:
+                grouped = group_points(xyz, new_xyz, feature, idx, grouper.use_xyz)   # [B, m, ns, C]   :51
             ns = grouped.shape[2]
             new_feature_list.append(mlp(grouped, group_max=ns))                 # conv/bn/relu x3 + max  :54-57
         new_feature = new_feature_list[0] if len(new_feature_list) == 1 else torch.cat(new_feature_list, dim=-1)
@@ -94,9 +106,39 @@ class PointNet2_cls(nn.Module):
             nn.Dropout(0.5), nn.Linear(256, self.n_classes),
         )
 
-    def forward(self, xyz, feature):
-        for module in self.pointnet_modules:
-            xyz, feature = module(xyz, feature)
+    def precompute_sampling(self, xyz, stream=None):
+        """Run every index-producing op of the network (FPS + ball query per level: they depend on xyz only) for a
+        batch, optionally on a side stream so that it overlaps other work -- the sampling of batch t+1 hides under
+        the backward pass of batch t, the way an input pipeline would prepare it.  Returns a handle for
+        ``forward(xyz, feature, sampling=handle)``.  The chain of m-1 dependent FPS steps occupies only B
+        workgroups, so it costs nothing to run it beside the MFMA kernels."""
+        cur = torch.cuda.current_stream()
+        if stream is None:
+            stream = cur
+        if stream is not cur:
+            stream.wait_stream(cur)                       # xyz may have just been produced on the current stream
+        out = []
+        with torch.cuda.stream(stream), torch.no_grad():
+            for module in self.pointnet_modules:
+                s = module.sample(xyz)
+                out.append(s)
+                if s[0] is not None:
+                    xyz = s[0]
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return {"levels": out, "event": ev, "stream": stream}
+
+    def forward(self, xyz, feature, sampling=None):
+        if sampling is not None:
+            cur = torch.cuda.current_stream()
+            if sampling["stream"] is not cur:
+                cur.wait_event(sampling["event"])
+                for new_xyz, idxs in sampling["levels"]:              # allocator safety across streams
+                    for t in [new_xyz] + list(idxs):
+                        if t is not None:
+                            t.record_stream(cur)
+        for i, module in enumerate(self.pointnet_modules):
+            xyz, feature = module(xyz, feature, None if sampling is None else sampling["levels"][i])
         feature = feature.squeeze(dim=1)                                                         # :157
         return self.fc_layer(feature)
 
