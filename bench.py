@@ -214,8 +214,16 @@ def main():
             else:
                 ach = r["algo_flops"] / (r["avg_ms"] * 1e-3) / 1e12
                 peak, unit = FP32_PEAK_TFLOPS, "TFLOP/s"
-            roofline = {"kernel": key[0], "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
-                        "frac": round(ach / peak, 5), "traffic": None, "avg_launch_ms": round(r["avg_ms"], 5),
+            traffic, traffic_src = None, None          # PMC HBM bytes per launch, from the committed profile (a separate
+            try:                                       # rocprofv3 --pmc pass of this same command; see profiles/)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+                traffic = tj["per_launch_hbm_bytes"].get(f"{key[0]}:{key[1]}")
+                traffic_src = tj["source"] if traffic is not None else None
+            except Exception:
+                pass
+            roofline = {"kernel": key[0], "shape": key[1], "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
+                        "frac": round(ach / peak, 5), "traffic": traffic, "traffic_source": traffic_src,
+                        "avg_launch_ms": round(r["avg_ms"], 5),
                         "launches": r["launches"], "algo_bytes_per_launch": r["algo_bytes"],
                         "algo_flops_per_launch": r["algo_flops"]}
         cpu = None
