@@ -115,6 +115,10 @@ int pcl_three_interp_f32(const float* points2, const int32_t* idx3, const float*
 int pcl_three_interp_bwd_f32(const float* gout, const int32_t* idx3, const float* w3, int B, int N,
                              int S, int D, float* gpoints2, void* stream);
 
+/* ---- Gaussian kernel density (PointConv compute_density, misc/pointconv_utils.py:174-184) ----------------
+ *   density[b,i] = mean_j exp(-|x_i-x_j|^2 / (2 bw^2)) / (2.5 bw), without the [B,N,N] matrix (direct-form d2). */
+int pcl_density_f32(const float* xyz, int B, int N, float bandwidth, float* density_out, void* stream);
+
 /* ---- per-group pointwise MLP: 1x1 conv + BatchNorm(train) + (Leaky)ReLU [+ max over the group] ---------
  * Replaces the nn.Conv(k=1)+nn.BatchNorm+nn.ReLU stacks of build_mlps (networks/cls/pointnet2.py:18-31;
  * DGCNN conv1-4 networks/cls/dgcnn.py:72-83; FP stacks misc/ops.py:54-64) and the max over the group

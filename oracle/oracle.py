@@ -158,3 +158,12 @@ def three_interp(points2, idx3, w3):
     out = np.empty((B, N, D), np.float32)
     _check(_lib().pclo_three_interp_f32(pp, pi, pw, B, N, S, D, out.ctypes.data_as(c_float_p)), "three_interp")
     return out
+
+
+def density(xyz, bandwidth):
+    """PointConv compute_density (misc/pointconv_utils.py:174-184), direct-form distances, fp64 accumulation."""
+    xyz, px = _f(xyz)
+    B, N, _ = xyz.shape
+    out = np.empty((B, N), np.float32)
+    _check(_lib().pclo_density_f32(px, B, N, ctypes.c_float(bandwidth), out.ctypes.data_as(c_float_p)), "density")
+    return out

@@ -340,3 +340,27 @@ int pclo_three_interp_f32(const float* points2, const int32_t* idx3, const float
         }
     return PCLO_OK;
 }
+
+/* ------------------------------------------------------------------------- *
+ * PointConv Gaussian KDE: compute_density, misc/pointconv_utils.py:174-184.
+ * density[b,i] = mean_j exp(-d2(i,j)/(2 bw^2)) / (2.5 bw).  The reference uses the
+ * matmul-form distance matrix (:34-53); DEFINED here in direct form, j ascending,
+ * accumulation in double (the HIP kernel accumulates in fp32: parity to 1e-5 rel).
+ * ------------------------------------------------------------------------- */
+int pclo_density_f32(const float* xyz, int B, int N, float bandwidth, float* out) {
+    if (!xyz || !out || N < 1 || bandwidth <= 0.f) return PCLO_EINVAL;
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        const float* P = xyz + (size_t)b * N * 3;
+        for (int i = 0; i < N; ++i) {
+            double acc = 0.0;
+            for (int j = 0; j < N; ++j) {
+                const float d = (P[3 * i] - P[3 * j]) * (P[3 * i] - P[3 * j]) + (P[3 * i + 1] - P[3 * j + 1]) * (P[3 * i + 1] - P[3 * j + 1]) +
+                                (P[3 * i + 2] - P[3 * j + 2]) * (P[3 * i + 2] - P[3 * j + 2]);
+                acc += exp(-(double)d / (2.0 * (double)bandwidth * (double)bandwidth));
+            }
+            out[(size_t)b * N + i] = (float)(acc / N / (2.5 * (double)bandwidth));
+        }
+    }
+    return PCLO_OK;
+}

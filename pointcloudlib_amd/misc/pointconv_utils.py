@@ -1,0 +1,136 @@
+"""PointConv building blocks -- host-side mirror of /root/reference/misc/pointconv_utils.py.
+
+Same function/class names and argument meaning: ``farthest_point_sample`` :74, ``knn_point`` :120,
+``sample_and_group`` :133, ``compute_density`` :174, ``DensityNet`` :186, ``WeightNet`` :220,
+``PointConvDensitySetAbstraction`` :340.  All tensors channel-last ([B,N,C]); the reference's permutes to
+[B,C,ns,npoint] around its Conv2d(k=1) stacks disappear (1x1 conv == row-wise linear map).
+
+What runs where: FPS (no origin skip, caller-supplied start index -- the reference draws it with
+np.random.randint, :88), k-NN grouping (HIP KNN kernel, direct-form distances, ties -> lower index; the reference
+uses matmul-form distances + a full argsort, :120-131 -- parity unpinned, documented), gathers, Gaussian KDE
+(pcl_density_f32, no [B,N,N] matrix) and every Conv+BN+ReLU stack (fused MFMA MLP) are HIP; the per-point
+(C x ns)(ns x 16) contraction and the density multiply are small PyTorch ops (rocBLAS batched GEMM).
+
+Upstream bugs handled: ``sample_and_group_all`` is called at :380 but defined nowhere --
+implemented here with the original PointConv semantics (one group of all N points, xyz relative to the cloud
+centroid, density reshaped [B,1,N,1]); ``DensityNet``'s sigmoid branch (:213) is unreachable upstream (``i == len``)
+so every layer is BN+ReLU, reproduced as such.
+"""
+import torch
+from torch import nn
+
+from .. import _lib
+from .layers import PointwiseMLP
+from .ops import _dev, _p, _stream, furthest_point_sample, index_points, knn_indices
+
+
+def farthest_point_sample(xyz, npoint, start_idx=None):
+    """xyz [B,N,3] -> int32 [B,npoint] (:74-116).  ``start_idx`` [B] int32; default: random like :88."""
+    B, N, _ = xyz.shape
+    if start_idx is None:
+        start_idx = torch.randint(0, N, (B,), device=xyz.device, dtype=torch.int32)
+    idx, _ = furthest_point_sample(xyz, npoint, tie_stride=1, skip_sqnorm_le=None, start_idx=start_idx)
+    return idx
+
+
+def knn_point(nsample, xyz, new_xyz):
+    """k nearest points of xyz [B,N,3] for each new_xyz [B,S,3] -> int32 [B,S,nsample], ascending distance (:120-131)."""
+    idx = knn_indices(new_xyz.transpose(1, 2).contiguous(), xyz.transpose(1, 2).contiguous(), nsample)   # [B,k,S]
+    return idx.permute(0, 2, 1).contiguous()
+
+
+def compute_density(xyz, bandwidth):
+    """xyz [B,N,3] -> [B,N] (:174-184)."""
+    xyz = _dev(xyz, "xyz")
+    B, N, _ = xyz.shape
+    out = torch.empty((B, N), dtype=torch.float32, device=xyz.device)
+    _lib.call("pcl_density_f32", _p(xyz), B, N, float(bandwidth), _p(out), _stream())
+    return out
+
+
+def sample_and_group(npoint, nsample, xyz, points, density_scale=None, start_idx=None):
+    """(:133-170) -> new_xyz [B,S,3], new_points [B,S,ns,3+D], grouped_xyz_norm [B,S,ns,3], idx, grouped_density."""
+    B, N, C = xyz.shape
+    fps_idx = farthest_point_sample(xyz, npoint, start_idx)
+    new_xyz = index_points(xyz, fps_idx)
+    idx = knn_point(nsample, xyz, new_xyz)
+    grouped_xyz_norm = index_points(xyz, idx) - new_xyz.view(B, npoint, 1, C)
+    if points is not None:
+        new_points = torch.cat([grouped_xyz_norm, index_points(points, idx)], dim=-1)
+    else:
+        new_points = grouped_xyz_norm
+    if density_scale is None:
+        return new_xyz, new_points, grouped_xyz_norm, idx
+    return new_xyz, new_points, grouped_xyz_norm, idx, index_points(density_scale, idx)
+
+
+def sample_and_group_all(xyz, points, density_scale=None):
+    """Missing upstream (:380).  One group of all N points; xyz relative to the centroid; density [B,1,N,1]."""
+    B, N, C = xyz.shape
+    new_xyz = xyz.mean(dim=1, keepdim=True)
+    grouped_xyz = xyz.view(B, 1, N, C) - new_xyz.view(B, 1, 1, C)
+    new_points = torch.cat([grouped_xyz, points.view(B, 1, N, -1)], dim=-1) if points is not None else grouped_xyz
+    if density_scale is None:
+        return new_xyz, new_points, grouped_xyz
+    return new_xyz, new_points, grouped_xyz, density_scale.view(B, 1, N, 1)
+
+
+class DensityNet(nn.Module):
+    """Conv1d 1->8->8->1, each + BatchNorm1d + ReLU (:186-218; the sigmoid branch never fires upstream)."""
+
+    def __init__(self, hidden_unit=(8, 8)):
+        super().__init__()
+        self.mlp = PointwiseMLP([1] + list(hidden_unit) + [1], bias=True)
+
+    def forward(self, xyz_density):
+        """[B,N] -> [B,N,1]."""
+        return self.mlp(xyz_density.unsqueeze(-1))
+
+
+class WeightNet(nn.Module):
+    """Conv2d in->8->8->out, each + BatchNorm + ReLU (:220-250)."""
+
+    def __init__(self, in_channel, out_channel, hidden_unit=(8, 8)):
+        super().__init__()
+        self.mlp = PointwiseMLP([in_channel] + list(hidden_unit or []) + [out_channel], bias=True)
+
+    def forward(self, localized_xyz):
+        """[B,S,ns,3] -> [B,S,ns,out]."""
+        return self.mlp(localized_xyz)
+
+
+class PointConvDensitySetAbstraction(nn.Module):
+    """(:340-400).  ``forward(xyz [B,3,N], points [B,D,N] | None) -> (new_xyz [B,3,S], new_points [B,D',S])``."""
+
+    def __init__(self, npoint, nsample, in_channel, mlp, bandwidth, group_all):
+        super().__init__()
+        self.npoint = npoint
+        self.nsample = nsample
+        self.mlp = PointwiseMLP([in_channel] + list(mlp), bias=True)        # mlp_convs + mlp_bns + relu  :348-351
+        self.weightnet = WeightNet(3, 16)
+        self.densitynet = DensityNet()
+        self.linear = PointwiseMLP([16 * mlp[-1], mlp[-1]], bias=True)       # Linear + BatchNorm1d + ReLU  :395-397
+        self.group_all = group_all
+        self.bandwidth = bandwidth
+
+    def forward(self, xyz, points, start_idx=None):
+        B, _, N = xyz.shape
+        xyz = xyz.permute(0, 2, 1).contiguous()
+        if points is not None:
+            points = points.permute(0, 2, 1).contiguous()
+        density_scale = self.densitynet(compute_density(xyz, self.bandwidth))            # :376-377  [B,N,1]
+        if self.group_all:
+            new_xyz, new_points, grouped_xyz_norm, grouped_density = sample_and_group_all(xyz, points, density_scale)
+        else:
+            new_xyz, new_points, grouped_xyz_norm, _, grouped_density = sample_and_group(
+                self.npoint, self.nsample, xyz, points, density_scale, start_idx)
+        new_points = self.mlp(new_points.contiguous())                                   # [B,S,ns,C]   :384-389
+        weights = self.weightnet(grouped_xyz_norm.contiguous())                          # [B,S,ns,16]  :391-392
+        new_points = new_points * grouped_density                                         # :393
+        S = new_points.shape[1]
+        new_points = torch.matmul(new_points.transpose(2, 3), weights).reshape(B, S, -1)   # [B,S,C*16]   :394
+        new_points = self.linear(new_points)                                              # :395-397
+        return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
+
+    def execute(self, *a, **k):
+        return self(*a, **k)
