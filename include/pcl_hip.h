@@ -136,6 +136,16 @@ int pcl_mlp_stat_rows(int P, int C);
 int pcl_linear_fwd_f32(const float* X, const float* W, const float* bias, const float* in_scale,
                        const float* in_shift, float in_slope, int P, int Cin, int Cout, float* Y,
                        double* stats_ws, void* stream);
+/* Same, for the LAST layer of a stack that is max-pooled over groups of ns (32 or 64) consecutive rows: the
+ * epilogue also emits per-group max / min of Y and the row-in-group attaining them (first occurrence);
+ * pcl_group_minmax_finalize_f32 then yields out = max_s lrelu(scale*y+shift) (max for scale >= 0, min otherwise),
+ * arg and ymax without re-reading Y. */
+int pcl_linear_fwd_gmax_f32(const float* X, const float* W, const float* bias, const float* in_scale,
+                            const float* in_shift, float in_slope, int P, int Cin, int Cout, int ns, float* Y,
+                            double* stats_ws, float* gmax, float* gmin, int32_t* gamax, int32_t* gamin, void* stream);
+int pcl_group_minmax_finalize_f32(const float* gmax, const float* gmin, const int32_t* gamax, const int32_t* gamin,
+                                  const float* scale, const float* shift, float slope, int G, int C, float* out,
+                                  int32_t* arg, float* ymax, void* stream);
 /* mean/var (biased, max(E[y^2]-E[y]^2,0)) from the partials -> scale, shift, mean, invstd; running stats
  * r += (batch - r)*momentum with the biased variance (nullable). */
 int pcl_bn_finalize_f32(const double* stats_ws, int stat_rows, const float* gamma, const float* beta, int P,

@@ -62,6 +62,8 @@ _SIGS = {
     "pcl_density_f32": (c_int, [_P, c_int, c_int, c_float, _P, _P]),
     "pcl_mlp_stat_rows": (c_int, [c_int, c_int]),
     "pcl_linear_fwd_f32": (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P]),
+    "pcl_linear_fwd_gmax_f32": (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "pcl_group_minmax_finalize_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P, _P]),
     "pcl_bn_finalize_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "pcl_bn_act_max_f32": (c_int, [_P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P]),
     "pcl_bn_act_f32": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P]),

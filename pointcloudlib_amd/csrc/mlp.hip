@@ -48,6 +48,10 @@ struct LinArgs {
     const float* Yprev;  // [M,N] E_MASK_STORE_STATS: pre-BN output of the layer below
     const float* esc;    // [N]   its folded BN scale
     const float* esh;    // [N]   its folded BN shift
+    float* gmax;         // [M/ns, N] E_STORE_STATS + GM: per-group max / min of the stored rows and the row-in-group
+    float* gmin;         //           attaining them (first occurrence), for the fused max-pool
+    int32_t* gamax;
+    int32_t* gamin;
     float slope, eslope;
     int M, N, K, ns;
     int a_mode, e_mode;
@@ -227,7 +231,10 @@ __device__ __forceinline__ void store_b(const LinArgs& p, float* sX, int n0, int
 
 // C[M,N] = A'[M,K] * B[N,K]^T with fused A transform (AM) and epilogue (EM).
 // 2 x 2 waves, each owning a 64 x (32*TN) tile: block tile 128 x (64*TN); TN = 1 for N <= 64.
-template <int AM, int EM, bool VEC, int TN>
+// GM (E_STORE_STATS only): 0 = off; 32 / 64 = also emit per-group (ns = GM rows) max/min/argmax/argmin of the
+// raw outputs -- BatchNorm's scale is not known yet, so both extremes are kept and the tiny finalize kernel
+// picks max for scale >= 0 and min for scale < 0 (the activation is monotone).
+template <int AM, int EM, bool VEC, int TN, int GM>
 __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p) {
     constexpr int TBM = 128, TBN = 64 * TN;
     __shared__ __attribute__((aligned(16))) float sA[TBM * LDS_LD];
@@ -365,6 +372,33 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p) {
                     }
             }
             st_s[tn] += (double)ts; st_q[tn] += (double)tq;
+            if constexpr (GM != 0) {
+                // rows of this lane, ascending: s = tm*32 + (r&3) + 8*(r>>2) + 4*lh; a group is GM consecutive rows
+                constexpr int NG = 64 / GM;                      // groups per 64-row wave slab (1 or 2)
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi) {
+                    float vmax = -INFINITY, vmin = INFINITY;
+                    int imax = 0, imin = 0;
+#pragma unroll
+                    for (int tm = gi * (2 / NG); tm < (gi + 1) * (2 / NG); ++tm)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int sl = (tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) - gi * GM;   // row in group
+                            const float c = acc[tm][tn][r] + bias;
+                            if (c > vmax) { vmax = c; imax = sl; }
+                            if (c < vmin) { vmin = c; imin = sl; }
+                        }
+                    const float omax = __shfl_xor(vmax, 32), omin = __shfl_xor(vmin, 32);
+                    const int oimax = __shfl_xor(imax, 32), oimin = __shfl_xor(imin, 32);
+                    if (omax > vmax || (omax == vmax && oimax < imax)) { vmax = omax; imax = oimax; }
+                    if (omin < vmin || (omin == vmin && oimin < imin)) { vmin = omin; imin = oimin; }
+                    const int row0 = m0 + wr * 64 + gi * GM;
+                    if (lh == 0 && cin && row0 < p.M) {
+                        const size_t o = (size_t)(row0 / GM) * p.N + col;
+                        p.gmax[o] = vmax; p.gmin[o] = vmin; p.gamax[o] = imax; p.gamin[o] = imin;
+                    }
+                }
+            }
         }
     }
 
@@ -742,6 +776,23 @@ __global__ __launch_bounds__(256) void bn_act_max_kernel(const float* __restrict
     }
 }
 
+// fused max-pool finish: pick the extreme that maximises lrelu(scale*y+shift) (max for scale >= 0, min otherwise)
+__global__ __launch_bounds__(256) void group_minmax_finalize_kernel(const float* __restrict__ gmax, const float* __restrict__ gmin,
+                                                                    const int32_t* __restrict__ gamax, const int32_t* __restrict__ gamin,
+                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                    float slope, int C, size_t total, float* __restrict__ out,
+                                                                    int32_t* __restrict__ arg, float* __restrict__ ymax) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const float a = scale[c];
+        const bool up = a >= 0.f;
+        const float y = up ? gmax[e] : gmin[e];
+        out[e] = lrelu(fmaf(a, y, shift[c]), slope);
+        arg[e] = up ? gamax[e] : gamin[e];
+        ymax[e] = y;
+    }
+}
+
 // gz[g,c] = gout[g,c] * act'(out[g,c]); per-workgroup partial sums of gz and gz*ymax -> stats rows.
 __global__ __launch_bounds__(256) void maxgrad_prep_kernel(const float* __restrict__ gout, const float* __restrict__ out,
                                                            const float* __restrict__ ymax, float slope, int G, int C,
@@ -800,7 +851,7 @@ static void linear_grid(int M, int N, int& gx, int& n_tiles, bool& narrow) {
     if (gx > want) gx = want;
 }
 
-template <int AM, int EM>
+template <int AM, int EM, int GM = 0>
 static int launch_linear_t(const LinArgs& a, hipStream_t st) {
     const bool vec = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0) && (!a.A2 || (reinterpret_cast<uintptr_t>(a.A2) & 15) == 0);
@@ -808,11 +859,11 @@ static int launch_linear_t(const LinArgs& a, hipStream_t st) {
     linear_grid(a.M, a.N, gx, n_tiles, narrow);
     dim3 grid(gx, n_tiles);
     if (narrow) {
-        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1>), grid, dim3(MLP_T), 0, st, a);
-        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1>), grid, dim3(MLP_T), 0, st, a);
+        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, GM>), grid, dim3(MLP_T), 0, st, a);
+        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1, GM>), grid, dim3(MLP_T), 0, st, a);
     } else {
-        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 2>), grid, dim3(MLP_T), 0, st, a);
-        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 2>), grid, dim3(MLP_T), 0, st, a);
+        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 2, GM>), grid, dim3(MLP_T), 0, st, a);
+        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 2, GM>), grid, dim3(MLP_T), 0, st, a);
     }
     return check_launch("pcl_linear");
 }
@@ -825,6 +876,13 @@ static int linear_stat_rows(int M, int N) {
 }
 
 static int launch_linear(const LinArgs& a, hipStream_t st) {
+    if (a.e_mode == E_STORE_STATS && a.gmax) {
+        if (a.a_mode == A_PLAIN && a.ns == 64) return launch_linear_t<A_PLAIN, E_STORE_STATS, 64>(a, st);
+        if (a.a_mode == A_BNACT && a.ns == 64) return launch_linear_t<A_BNACT, E_STORE_STATS, 64>(a, st);
+        if (a.a_mode == A_PLAIN && a.ns == 32) return launch_linear_t<A_PLAIN, E_STORE_STATS, 32>(a, st);
+        if (a.a_mode == A_BNACT && a.ns == 32) return launch_linear_t<A_BNACT, E_STORE_STATS, 32>(a, st);
+        return fail(PCL_EINVAL, "pcl_linear_fwd_gmax_f32: group size %d not supported (32 or 64)", a.ns);
+    }
     if (a.a_mode == A_PLAIN && a.e_mode == E_STORE_STATS) return launch_linear_t<A_PLAIN, E_STORE_STATS>(a, st);
     if (a.a_mode == A_BNACT && a.e_mode == E_STORE_STATS) return launch_linear_t<A_BNACT, E_STORE_STATS>(a, st);
     if (a.a_mode == A_DY && a.e_mode == E_MASK_STORE_STATS) return launch_linear_t<A_DY, E_MASK_STORE_STATS>(a, st);
@@ -853,6 +911,35 @@ extern "C" int pcl_linear_fwd_f32(const float* X, const float* W, const float* b
     a.C = Y; a.stats = stats_ws; a.M = P; a.N = Cout; a.K = Cin;
     a.a_mode = in_scale ? A_BNACT : A_PLAIN; a.e_mode = E_STORE_STATS;
     return launch_linear(a, as_stream(stream));
+}
+
+extern "C" int pcl_linear_fwd_gmax_f32(const float* X, const float* W, const float* bias, const float* in_scale,
+                                       const float* in_shift, float in_slope, int P, int Cin, int Cout, int ns, float* Y,
+                                       double* stats_ws, float* gmax, float* gmin, int32_t* gamax, int32_t* gamin,
+                                       void* stream) {
+    PCL_REQUIRE(X && W && Y && stats_ws && gmax && gmin && gamax && gamin, "pcl_linear_fwd_gmax_f32: null pointer");
+    PCL_REQUIRE(P >= 1 && Cin >= 1 && Cout >= 1 && (ns == 32 || ns == 64) && P % ns == 0,
+                "pcl_linear_fwd_gmax_f32: bad sizes P=%d Cin=%d Cout=%d ns=%d (ns must be 32 or 64 and divide P)", P, Cin, Cout, ns);
+    PCL_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "pcl_linear_fwd_gmax_f32: in_scale/in_shift must come together");
+    LinArgs a = {};
+    a.A = X; a.B = W; a.bias = bias; a.sc = in_scale; a.sh = in_shift; a.slope = in_slope;
+    a.C = Y; a.stats = stats_ws; a.M = P; a.N = Cout; a.K = Cin; a.ns = ns;
+    a.gmax = gmax; a.gmin = gmin; a.gamax = gamax; a.gamin = gamin;
+    a.a_mode = in_scale ? A_BNACT : A_PLAIN; a.e_mode = E_STORE_STATS;
+    return launch_linear(a, as_stream(stream));
+}
+
+extern "C" int pcl_group_minmax_finalize_f32(const float* gmax, const float* gmin, const int32_t* gamax, const int32_t* gamin,
+                                             const float* scale, const float* shift, float slope, int G, int C, float* out,
+                                             int32_t* arg, float* ymax, void* stream) {
+    PCL_REQUIRE(gmax && gmin && gamax && gamin && scale && shift && out && arg && ymax && G >= 1 && C >= 1,
+                "pcl_group_minmax_finalize_f32: bad arguments");
+    const size_t total = (size_t)G * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(group_minmax_finalize_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gmax, gmin, gamax, gamin, scale,
+                       shift, slope, C, total, out, arg, ymax);
+    return check_launch("pcl_group_minmax_finalize_f32");
 }
 
 extern "C" int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,

@@ -47,9 +47,19 @@ class _FusedMLP(torch.autograd.Function):
             Y = _empty((P, cout), dev)
             rows = _lib.lib().pcl_mlp_stat_rows(P, cout)
             stats = _empty((rows, 2, cout), dev, torch.float64)
-            _lib.call("pcl_linear_fwd_f32", _P(cur), _P(W), _P(bias), _P(in_scale), _P(in_shift), slope, P, cin, cout,
-                      _P(Y), _P(stats), st, algo_bytes=4 * P * (cin + cout) + 4 * cin * cout,
-                      algo_flops=2 * P * cin * cout, tag=f"fwd{cin}x{cout}")
+            fused_max = (l == L - 1) and ns in (32, 64)
+            if fused_max:      # last layer of a max-pooled stack: per-group min/max come out of the GEMM epilogue
+                G = P // ns
+                gmax, gmin = _empty((G, cout), dev), _empty((G, cout), dev)
+                gamax, gamin = _empty((G, cout), dev, torch.int32), _empty((G, cout), dev, torch.int32)
+                _lib.call("pcl_linear_fwd_gmax_f32", _P(cur), _P(W), _P(bias), _P(in_scale), _P(in_shift), slope, P, cin,
+                          cout, ns, _P(Y), _P(stats), _P(gmax), _P(gmin), _P(gamax), _P(gamin), st,
+                          algo_bytes=4 * P * (cin + cout) + 4 * cin * cout, algo_flops=2 * P * cin * cout,
+                          tag=f"fwd{cin}x{cout}")
+            else:
+                _lib.call("pcl_linear_fwd_f32", _P(cur), _P(W), _P(bias), _P(in_scale), _P(in_shift), slope, P, cin, cout,
+                          _P(Y), _P(stats), st, algo_bytes=4 * P * (cin + cout) + 4 * cin * cout,
+                          algo_flops=2 * P * cin * cout, tag=f"fwd{cin}x{cout}")
             if bn and training:
                 scale, shift, mean, invstd = (_empty((cout,), dev) for _ in range(4))
                 _lib.call("pcl_bn_finalize_f32", _P(stats), rows, _P(gamma), _P(beta), P, cout, eps, momentum, _P(scale),
@@ -70,8 +80,12 @@ class _FusedMLP(torch.autograd.Function):
             out = _empty((G, cin), dev)
             arg = _empty((G, cin), dev, torch.int32)
             ymax = _empty((G, cin), dev)
-            _lib.call("pcl_bn_act_max_f32", _P(cur), _P(in_scale), _P(in_shift), out_slope, G, ns, cin, _P(out), _P(arg),
-                      _P(ymax), st, algo_bytes=4 * P * cin + 12 * G * cin, tag=f"max{cin}")
+            if fused_max:
+                _lib.call("pcl_group_minmax_finalize_f32", _P(gmax), _P(gmin), _P(gamax), _P(gamin), _P(in_scale),
+                          _P(in_shift), out_slope, G, cin, _P(out), _P(arg), _P(ymax), st)
+            else:
+                _lib.call("pcl_bn_act_max_f32", _P(cur), _P(in_scale), _P(in_shift), out_slope, G, ns, cin, _P(out), _P(arg),
+                          _P(ymax), st, algo_bytes=4 * P * cin + 12 * G * cin, tag=f"max{cin}")
         else:
             out = _empty((P, cin), dev)
             arg = ymax = None

@@ -29,6 +29,8 @@ CASES = [
     ([6, 64, 64, 128], (2, 25, 16), 16, False, 0.0),        # SA1-like, K=6 (scalar staging), ragged P=800
     ([131, 128, 128, 256], (2, 16, 32), 32, False, 0.0),    # SA2-like, K=131, N=256 (two column tiles)
     ([259, 256, 512, 1024], (3, 1, 128), 128, False, 0.0),  # SA3-like (GroupAll), deep K
+    ([6, 64, 64, 128], (3, 5, 64), 64, False, 0.0),         # ns = 64: max/min fused into the last GEMM epilogue
+    ([35, 48], (2, 9, 64), 64, True, 0.2),                  # fused max, single layer, bias, LeakyReLU, ragged tiles
     ([6, 64], (2, 40, 20), 20, False, 0.2),                 # DGCNN edge conv: LeakyReLU(0.2), max over k
     ([64, 40, 24], (3, 70), None, True, 0.0),               # FP-style: bias + BN + ReLU, no max, N < 128
     ([12, 8, 8, 16], (2, 33, 8), None, True, 0.0),          # WeightNet-sized

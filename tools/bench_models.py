@@ -1,0 +1,66 @@
+"""Throughput of the other BASELINE configs on one MI355X (train step: fwd + bwd + SGD, synthetic data).
+    python tools/bench_models.py [--steps 10] [--out profiles/r01_other_configs.json]"""
+import argparse, json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pointcloudlib_amd import synth
+from pointcloudlib_amd.train_utils import soft_cross_entropy_loss
+
+
+def run(name, make, inputs, loss_fn, steps, warmup=3):
+    torch.manual_seed(0)
+    net = make().cuda().train()
+    opt = torch.optim.SGD(net.parameters(), lr=0.02, momentum=0.9)
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss_fn(net(*inputs)).backward()
+        opt.step()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    B = inputs[0].shape[0]
+    r = {"config": name, "ms_per_step": round(dt * 1e3, 3), "clouds_per_s": round(B / dt, 1), "batch": B,
+         "params": sum(p.numel() for p in net.parameters())}
+    print(json.dumps(r), flush=True)
+    return r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    from pointcloudlib_amd.networks.cls.pointnet import PointNet
+    from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
+    from pointcloudlib_amd.networks.cls.dgcnn import DGCNN
+    from pointcloudlib_amd.networks.cls.pointconv import PointConvDensityClsSsg
+    from pointcloudlib_amd.networks.seg.pointnet2_partseg import PointNet2_partseg
+    dev = "cuda"
+    def cloud(B, N, seed): return torch.from_numpy(synth.gauss_ball(B, N, seed)).to(dev)
+    def nrm(B, N, seed): return torch.from_numpy(synth.unit_normals(B, N, seed)).to(dev)
+    def lab(B, seed): return torch.from_numpy(synth.labels(B, 40, seed)).to(dev)
+    res = []
+    y8, y32 = lab(8, 1), lab(32, 1)
+    x = cloud(8, 1024, 20241)
+    res.append(run("cfg1 PointNet cls B=8 N=1024", PointNet, (x.transpose(1, 2).contiguous(),), lambda o: soft_cross_entropy_loss(o, y8), a.steps))
+    x = cloud(32, 1024, 20242)
+    res.append(run("cfg2 PointNet++ SSG cls B=32 N=1024 (no sampling prefetch)", PointNet2_cls, (x, nrm(32, 1024, 7)), lambda o: soft_cross_entropy_loss(o, y32), a.steps))
+    x4 = cloud(32, 4096, 20242)
+    res.append(run("cfg2' PointNet++ SSG cls B=32 N=4096", PointNet2_cls, (x4, nrm(32, 4096, 7)), lambda o: soft_cross_entropy_loss(o, y32), a.steps))
+    res.append(run("cfg3 DGCNN cls B=32 N=1024 k=20", DGCNN, (x.transpose(1, 2).contiguous(),), lambda o: soft_cross_entropy_loss(o, y32), a.steps))
+    xs = cloud(16, 2048, 20244)
+    oh = torch.zeros(16, 16, device=dev); oh[torch.arange(16), torch.arange(16) % 16] = 1
+    seg = torch.randint(0, 50, (16, 2048), device=dev)
+    res.append(run("cfg4 PointNet++ SSG part-seg B=16 N=2048", PointNet2_partseg, (xs, xs, oh),
+                   lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps))
+    res.append(run("cfg5 PointConv cls B=32 N=1024", PointConvDensityClsSsg, (x.transpose(1, 2).contiguous(),), lambda o: soft_cross_entropy_loss(o, y32), a.steps))
+    if a.out:
+        json.dump({"device": torch.cuda.get_device_name(0), "note": "1 GPU, fp32, synthetic gauss_ball clouds, fwd+bwd+SGD", "results": res},
+                  open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
