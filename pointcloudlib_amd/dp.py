@@ -12,6 +12,13 @@ import torch.distributed as dist
 
 
 class FlatBucketDP:
+    """Gradient exchange for replicated parameters.
+
+    ``zero_grad()`` drops the gradients (autograd then *moves* fresh gradient tensors in instead of launching one
+    accumulate kernel per parameter); ``all_reduce()`` packs them into the flat bucket with one multi-tensor copy,
+    all-reduces the bucket once, scales it, and re-points ``param.grad`` at views of the bucket.  With a single rank
+    nothing is copied or communicated at all."""
+
     def __init__(self, module, process_group=None, broadcast=True):
         self.module = module
         self.group = process_group
@@ -20,10 +27,11 @@ class FlatBucketDP:
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.views = []
         o = 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[o:o + n].view_as(p)
+            self.views.append(self.flat[o:o + n].view_as(p))
             o += n
         if broadcast and self.world > 1:
             for t in list(module.parameters()) + list(module.buffers()):
@@ -34,13 +42,26 @@ class FlatBucketDP:
         return self.flat.numel() * 4
 
     def zero_grad(self):
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
 
     def all_reduce(self):
-        """Average the flat gradient bucket over ranks (sum then scale by 1/world)."""
-        if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.mul_(1.0 / self.world)
+        """Average the gradients over ranks through ONE flat all-reduce (sum, then scale by 1/world)."""
+        if self.world == 1:
+            return
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.mul_(1.0 / self.world)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
 
 def shard_batch(tensors, rank, world):
