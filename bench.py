@@ -182,7 +182,9 @@ def main():
         summ = _lib.PROFILER.summary()
         _lib.PROFILER = None
         target = max(summ.items(), key=lambda kv: kv[1]["total_ms"])[0] if summ else None
-    elif target != "none":
+    elif target == "none":
+        target = None
+    else:
         target = (target, None)
     timer = None
     if target:

@@ -182,6 +182,39 @@ int pcl_linear_bwd_dw_f32(const float* dU, const float* Y, const float* a, const
                           const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
                           int Cin, float* dW, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- duplicate-compacted ("ragged") groups --------------------------------------------------------------
+ * query_ball_point pads each group with copies of its first hit (misc/ops.py:321-324).  Identical rows stay
+ * identical through conv/BN/ReLU, so the MLP can run on the DISTINCT rows only, carrying a multiplicity per row:
+ * BatchNorm sums weight each row by it, the max over the group is unchanged, and in backward the dense BatchNorm
+ * term of a row counts `multiplicity` times.  Results equal the padded computation up to fp32 summation order.
+ *   pcl_group_compact_f32: rows [cap = B*m*ns, D] (first group_off[B*m] rows valid, (group, slot) order),
+ *     row_meta [cap,2] int32 = {group id, slot | multiplicity << 16}, row_src [cap] = b*N + point index,
+ *     group_off [B*m+1] (group_off[B*m] = number of valid rows, stays on the device: no host sync).
+ *   The *_rows_f32 GEMM entry points are the pcl_linear_* ones with that metadata (row_meta, n_rows_dev =
+ *   &group_off[B*m]); P is the capacity; with both NULL they are identical to the plain entry points.
+ *   pcl_bn_act_max_rows_f32: max over each group's valid rows (arg = slot in the compacted group).
+ *   pcl_scatter_rows_add_f32: gfeat[row_src[r], c] += grows[r, off+c]  (zero-fills gfeat [n_dst_rows, C]). */
+int pcl_group_compact_f32(const float* xyz, const float* new_xyz, const float* feat, const int32_t* idx,
+                          const int32_t* cnt, int B, int N, int m, int ns, int C, int use_xyz, float* rows,
+                          int32_t* row_meta, int32_t* row_src, int32_t* group_off, void* stream);
+int pcl_linear_fwd_rows_f32(const float* X, const float* W, const float* bias, const float* in_scale,
+                            const float* in_shift, float in_slope, int P, int Cin, int Cout, float* Y,
+                            double* stats_ws, const int32_t* row_meta, const int32_t* n_rows_dev, void* stream);
+int pcl_bn_act_max_rows_f32(const float* Y, const int32_t* group_off, const float* scale, const float* shift,
+                            float slope, int G, int C, float* out, int32_t* arg, float* ymax, void* stream);
+int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2,
+                               const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
+                               int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
+                               float prev_slope, float* dUprev, double* stats_ws, const int32_t* row_meta,
+                               const int32_t* n_rows_dev, void* stream);
+int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2,
+                               const int32_t* arg, const float* gz, int ns, const float* Xprev,
+                               const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
+                               int Cin, float* dW, void* workspace, size_t workspace_bytes, const int32_t* row_meta,
+                               const int32_t* n_rows_dev, void* stream);
+int pcl_scatter_rows_add_f32(const float* grows, const int32_t* row_src, const int32_t* n_rows_dev, int rows_cap,
+                             int D, int off, int C, int n_dst_rows, float* gfeat, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,14 @@ _SIGS = {
     "pcl_bn_bwd_consts_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "pcl_linear_bwd_dx_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_float,
                                       _P, _P, _P]),
+    "pcl_group_compact_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "pcl_linear_fwd_rows_f32": (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "pcl_bn_act_max_rows_f32": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P, _P]),
+    "pcl_linear_bwd_dx_rows_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_float,
+                                           _P, _P, _P, _P, _P]),
+    "pcl_linear_bwd_dw_rows_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_float, c_int, c_int, c_int, _P,
+                                           _P, c_size_t, _P, _P, _P]),
+    "pcl_scatter_rows_add_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_linear_bwd_dw_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "pcl_linear_bwd_dw_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_float, c_int, c_int, c_int, _P,
                                       _P, c_size_t, _P]),
@@ -137,10 +145,15 @@ class KernelTimer:
     def summary(self):
         """{(name, tag): dict(launches, avg_ms, algo_bytes, algo_flops)} -- call after a device sync."""
         out = {}
+        def val(v):            # algorithmic bytes/flops may depend on a device-resident row count: resolved here,
+            return v() if callable(v) else v          # after the timed region, never inside it
+
         for key, recs in self.records.items():
             ms = [s.elapsed_time(e) for s, e, _, _ in recs]
+            ab = [val(r[2]) for r in recs]
+            af = [val(r[3]) for r in recs]
             out[key] = {"launches": len(recs), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms),
-                        "algo_bytes": recs[0][2], "algo_flops": recs[0][3]}
+                        "algo_bytes": sum(ab) / len(ab), "algo_flops": sum(af) / len(af)}
         return out
 
 
@@ -151,7 +164,7 @@ def call(name, *args, algo_bytes=0, algo_flops=0, tag=""):
     if prof is not None and prof.want(name):
         start = prof.begin()
         rc = fn(*args)
-        prof.end(name, tag or f"{algo_bytes}", start, algo_bytes, algo_flops)
+        prof.end(name, tag or (name if callable(algo_bytes) else f"{algo_bytes}"), start, algo_bytes, algo_flops)
     else:
         rc = fn(*args)
     check(rc, name)

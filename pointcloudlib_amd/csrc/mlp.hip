@@ -52,10 +52,21 @@ struct LinArgs {
     float* gmin;         //           attaining them (first occurrence), for the fused max-pool
     int32_t* gamax;
     int32_t* gamin;
+    const int* m_dev;    // optional device-resident row count (ragged / duplicate-compacted rows): M = *m_dev
+    const int2* rmeta;   // optional per-row {group id, pos-in-group | multiplicity << 16} of compacted rows
     float slope, eslope;
     int M, N, K, ns;
     int a_mode, e_mode;
 };
+
+// Duplicate-compacted ("ragged") rows: ball query pads a group with copies of its first hit (misc/ops.py:321-324);
+// identical input rows give identical activations, so the stack runs once per DISTINCT row and carries the
+// multiplicity w: BatchNorm sums use w*y and w*y^2, and in backward the dense BatchNorm term of a row counts w
+// times (the sparse max-pool gradient goes to the first occurrence only).  Results equal the padded computation
+// up to fp32 summation order.
+__device__ __forceinline__ void row_meta(const int2 m, int& g, int& srow, float& w) {
+    g = m.x; srow = m.y & 0xffff; w = (float)(m.y >> 16);
+}
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
 
@@ -71,6 +82,8 @@ struct Stage {
     int4 vi[VEC ? NI : 1];
     float s[VEC ? 1 : NI], s2[VEC ? 1 : NI], sg[VEC ? 1 : NI];
     int si[VEC ? 1 : NI];
+    float rw[NI];                  // row multiplicity (ragged rows), 1 otherwise
+    int rs[NI];                    // row-in-group (sparse max gradient)
     float4 c_sc, c_sh, c_k2;       // per-k constants of this step (vector path)
     float f_sc, f_sh, f_k2;        // (scalar path)
     int m0;                        // first row of the staged tile (for the sparse row-in-group test)
@@ -79,7 +92,7 @@ struct Stage {
 // All staging loads are UNCONDITIONAL with clamped (always valid) addresses: a load under a divergent branch
 // makes hipcc drain vmcnt(0) at the branch join, which would serialise the prefetch against the MFMAs.
 // Out-of-range elements are zeroed later, in the transform/store stage.
-template <int AM, bool VEC, int ROWS>
+template <int AM, bool VEC, int ROWS, bool RAG>
 __device__ __forceinline__ void load_a(const LinArgs& p, int m0, int k0, int tid, Stage<VEC, ROWS>& st) {
     st.m0 = m0;
     if constexpr (VEC) {
@@ -93,13 +106,20 @@ __device__ __forceinline__ void load_a(const LinArgs& p, int m0, int k0, int tid
         for (int i = 0; i < ROWS / 32; ++i) {
             const int r = min(m0 + (tid >> 3) + 32 * i, p.M - 1);
             const size_t off = (size_t)r * p.K + k;
+            int g = 0, srow = 0;
+            float w = 1.f;
+            if constexpr (AM >= A_DY) {
+                if constexpr (RAG) row_meta(p.rmeta[r], g, srow, w);
+                else if constexpr (AM == A_DY_SPARSE) { g = r / p.ns; srow = r - g * p.ns; }
+                st.rw[i] = w; st.rs[i] = srow;
+            }
             if constexpr (AM == A_PLAIN || AM == A_BNACT) {
                 st.v[i] = *reinterpret_cast<const float4*>(p.A + off);
             } else if constexpr (AM == A_DY) {
                 st.v[i] = *reinterpret_cast<const float4*>(p.A + off);
                 st.v2[i] = *reinterpret_cast<const float4*>(p.A2 + off);
             } else {
-                const size_t go = (size_t)(r / p.ns) * p.K + k;
+                const size_t go = (size_t)g * p.K + k;
                 st.vi[i] = *reinterpret_cast<const int4*>(p.arg + go);
                 st.vg[i] = *reinterpret_cast<const float4*>(p.gz + go);
                 st.v2[i] = *reinterpret_cast<const float4*>(p.A2 + off);
@@ -115,13 +135,20 @@ __device__ __forceinline__ void load_a(const LinArgs& p, int m0, int k0, int tid
         for (int i = 0; i < ROWS / 8; ++i) {
             const int r = min(m0 + (tid >> 5) + 8 * i, p.M - 1);
             const size_t off = (size_t)r * p.K + k;
+            int g = 0, srow = 0;
+            float w = 1.f;
+            if constexpr (AM >= A_DY) {
+                if constexpr (RAG) row_meta(p.rmeta[r], g, srow, w);
+                else if constexpr (AM == A_DY_SPARSE) { g = r / p.ns; srow = r - g * p.ns; }
+                st.rw[i] = w; st.rs[i] = srow;
+            }
             if constexpr (AM == A_PLAIN || AM == A_BNACT) {
                 st.s[i] = p.A[off];
             } else if constexpr (AM == A_DY) {
                 st.s[i] = p.A[off];
                 st.s2[i] = p.A2[off];
             } else {
-                const size_t go = (size_t)(r / p.ns) * p.K + k;
+                const size_t go = (size_t)g * p.K + k;
                 st.si[i] = p.arg[go];
                 st.sg[i] = p.gz[go];
                 st.s2[i] = p.A2[off];
@@ -154,15 +181,16 @@ __device__ __forceinline__ void store_a(const LinArgs& p, float* sX, int k0, int
                     float4 du;
                     if constexpr (AM == A_DY) du = st.v[i];
                     else {
-                        const int srow = r % p.ns;
+                        const int srow = st.rs[i];
                         const int4 ar = st.vi[i];
                         const float4 gz = st.vg[i];
                         du.x = ar.x == srow ? gz.x : 0.f; du.y = ar.y == srow ? gz.y : 0.f;
                         du.z = ar.z == srow ? gz.z : 0.f; du.w = ar.w == srow ? gz.w : 0.f;
                     }
                     const float4 y = st.v2[i];
-                    a.x = fmaf(sc.x, du.x, -sh.x) - k2.x * y.x; a.y = fmaf(sc.y, du.y, -sh.y) - k2.y * y.y;
-                    a.z = fmaf(sc.z, du.z, -sh.z) - k2.z * y.z; a.w = fmaf(sc.w, du.w, -sh.w) - k2.w * y.w;
+                    const float w = st.rw[i];            // dense BatchNorm term counts once per duplicate
+                    a.x = fmaf(sc.x, du.x, -w * fmaf(k2.x, y.x, sh.x)); a.y = fmaf(sc.y, du.y, -w * fmaf(k2.y, y.y, sh.y));
+                    a.z = fmaf(sc.z, du.z, -w * fmaf(k2.z, y.z, sh.z)); a.w = fmaf(sc.w, du.w, -w * fmaf(k2.w, y.w, sh.w));
                 }
             }
             *reinterpret_cast<float4*>(&sX[rl * LDS_LD + (tid & 7) * 4]) = a;
@@ -181,8 +209,8 @@ __device__ __forceinline__ void store_a(const LinArgs& p, float* sX, int k0, int
                 else {
                     float du;
                     if constexpr (AM == A_DY) du = st.s[i];
-                    else du = st.si[i] == (r % p.ns) ? st.sg[i] : 0.f;
-                    a = fmaf(sc, du, -sh) - k2 * st.s2[i];
+                    else du = st.si[i] == st.rs[i] ? st.sg[i] : 0.f;
+                    a = fmaf(sc, du, -st.rw[i] * fmaf(k2, st.s2[i], sh));
                 }
             }
             sX[rl * LDS_LD + (tid & 31)] = a;
@@ -234,8 +262,10 @@ __device__ __forceinline__ void store_b(const LinArgs& p, float* sX, int n0, int
 // GM (E_STORE_STATS only): 0 = off; 32 / 64 = also emit per-group (ns = GM rows) max/min/argmax/argmin of the
 // raw outputs -- BatchNorm's scale is not known yet, so both extremes are kept and the tiny finalize kernel
 // picks max for scale >= 0 and min for scale < 0 (the activation is monotone).
-template <int AM, int EM, bool VEC, int TN, int GM>
-__global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p) {
+template <int AM, int EM, bool VEC, int TN, int GM, bool RAG>
+__global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in) {
+    LinArgs p = p_in;
+    if (p.m_dev) p.M = *p.m_dev;                       // compacted rows: the row count lives on the device
     constexpr int TBM = 128, TBN = 64 * TN;
     __shared__ __attribute__((aligned(16))) float sA[TBM * LDS_LD];
     __shared__ __attribute__((aligned(16))) float sB[TBN * LDS_LD];
@@ -262,7 +292,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p) {
     int mt = blockIdx.x;
     int staged_k0 = 0;
     if (mt < m_tiles) {
-        load_a<AM, VEC, TBM>(p, mt * TBM, 0, tid, ra);
+        load_a<AM, VEC, TBM, RAG>(p, mt * TBM, 0, tid, ra);
         load_b<VEC, TBN>(p, n0, 0, tid, rb);
     }
     for (; mt < m_tiles; mt += gridDim.x) {
@@ -286,7 +316,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p) {
                 if (nk >= p.K) { nk = 0; nmt = mt + gridDim.x; }
                 staged_k0 = nk;
                 if (nmt < m_tiles) {
-                    load_a<AM, VEC, TBM>(p, nmt * TBM, nk, tid, ra);
+                    load_a<AM, VEC, TBM, RAG>(p, nmt * TBM, nk, tid, ra);
                     load_b<VEC, TBN>(p, n0, nk, tid, rb);
                 }
             }
@@ -347,7 +377,8 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p) {
                             c = fmaf(esc, y, esh) > 0.f ? c : c * p.eslope;
                             ts += c; tq = fmaf(c, y, tq);
                         } else if constexpr (EM == E_STORE_STATS) {
-                            ts += c; tq = fmaf(c, c, tq);
+                            if constexpr (RAG) { const float w = (float)(p.rmeta[row].y >> 16); ts = fmaf(w, c, ts); tq = fmaf(w * c, c, tq); }
+                            else { ts += c; tq = fmaf(c, c, tq); }
                         }
                         p.C[(size_t)row * p.N + col] = c;
                     }
@@ -365,7 +396,8 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p) {
                                 c = fmaf(esc, y, esh) > 0.f ? c : c * p.eslope;
                                 ts += c; tq = fmaf(c, y, tq);
                             } else if constexpr (EM == E_STORE_STATS) {
-                                ts += c; tq = fmaf(c, c, tq);
+                                if constexpr (RAG) { const float w = (float)(p.rmeta[row].y >> 16); ts = fmaf(w, c, ts); tq = fmaf(w * c, c, tq); }
+                                else { ts += c; tq = fmaf(c, c, tq); }
                             }
                             p.C[off] = c;
                         }
@@ -438,6 +470,8 @@ struct DwArgs {
     const float* Bsrc; const float* bsc; const float* bsh;  // Y_prev (or X) [P,J], folded BN of the layer below
     float bslope;
     float* part;                                // [gridDim.x][I][J] partial sums
+    const int* p_dev;                           // optional device-resident row count (compacted rows)
+    const int2* rmeta;                          // optional per-row meta of compacted rows (see row_meta)
     int P, I, J;
     int a_mode, b_mode;                         // a: A_DY / A_DY_SPARSE ; b: A_PLAIN / A_BNACT
 };
@@ -455,10 +489,12 @@ struct DwStage {
     int4 vi[VEC ? NI : 1];
     float s[VEC ? 1 : NI], s2[VEC ? 1 : NI], sg[VEC ? 1 : NI];
     int si[VEC ? 1 : NI];
+    float rw[NI];
+    int rs[NI];
     int p0;
 };
 
-template <int AM, bool VEC, int W>
+template <int AM, bool VEC, int W, bool RAG>
 __device__ __forceinline__ void dw_load_a(const DwArgs& p, int p0, int c0, int tid, DwStage<VEC, W>& st) {
     using S = DwStage<VEC, W>;
     st.p0 = p0;
@@ -467,11 +503,16 @@ __device__ __forceinline__ void dw_load_a(const DwArgs& p, int p0, int c0, int t
     for (int i = 0; i < S::NI; ++i) {
         const int r = min(p0 + tid / S::CPR + S::RP * i, p.P - 1);
         const size_t off = (size_t)r * p.I + c;
+        int g = 0, srow = 0;
+        float w = 1.f;
+        if constexpr (RAG) row_meta(p.rmeta[r], g, srow, w);
+        else if constexpr (AM == A_DY_SPARSE) { g = r / p.ns; srow = r - g * p.ns; }
+        st.rw[i] = w; st.rs[i] = srow;
         if constexpr (VEC) {
             st.v2[i] = *reinterpret_cast<const float4*>(p.A2 + off);
             if constexpr (AM == A_DY) st.v[i] = *reinterpret_cast<const float4*>(p.A + off);
             else {
-                const size_t go = (size_t)(r / p.ns) * p.I + c;
+                const size_t go = (size_t)g * p.I + c;
                 st.vi[i] = *reinterpret_cast<const int4*>(p.arg + go);
                 st.vg[i] = *reinterpret_cast<const float4*>(p.gz + go);
             }
@@ -479,7 +520,7 @@ __device__ __forceinline__ void dw_load_a(const DwArgs& p, int p0, int c0, int t
             st.s2[i] = p.A2[off];
             if constexpr (AM == A_DY) st.s[i] = p.A[off];
             else {
-                const size_t go = (size_t)(r / p.ns) * p.I + c;
+                const size_t go = (size_t)g * p.I + c;
                 st.si[i] = p.arg[go];
                 st.sg[i] = p.gz[go];
             }
@@ -504,15 +545,16 @@ __device__ __forceinline__ void dw_store_a(const DwArgs& p, float* sX, int c0, i
                 float4 du;
                 if constexpr (AM == A_DY) du = st.v[i];
                 else {
-                    const int srow = r % p.ns;
+                    const int srow = st.rs[i];
                     const int4 ar = st.vi[i];
                     const float4 gz = st.vg[i];
                     du.x = ar.x == srow ? gz.x : 0.f; du.y = ar.y == srow ? gz.y : 0.f;
                     du.z = ar.z == srow ? gz.z : 0.f; du.w = ar.w == srow ? gz.w : 0.f;
                 }
                 const float4 y = st.v2[i];
-                a.x = fmaf(sc.x, du.x, -sh.x) - k2.x * y.x; a.y = fmaf(sc.y, du.y, -sh.y) - k2.y * y.y;
-                a.z = fmaf(sc.z, du.z, -sh.z) - k2.z * y.z; a.w = fmaf(sc.w, du.w, -sh.w) - k2.w * y.w;
+                const float w = st.rw[i];
+                a.x = fmaf(sc.x, du.x, -w * fmaf(k2.x, y.x, sh.x)); a.y = fmaf(sc.y, du.y, -w * fmaf(k2.y, y.y, sh.y));
+                a.z = fmaf(sc.z, du.z, -w * fmaf(k2.z, y.z, sh.z)); a.w = fmaf(sc.w, du.w, -w * fmaf(k2.w, y.w, sh.w));
             }
             *reinterpret_cast<float4*>(&sX[rl * (W + 4) + cl]) = a;
         } else {
@@ -520,8 +562,8 @@ __device__ __forceinline__ void dw_store_a(const DwArgs& p, float* sX, int c0, i
             if (in) {
                 float du;
                 if constexpr (AM == A_DY) du = st.s[i];
-                else du = st.si[i] == (r % p.ns) ? st.sg[i] : 0.f;
-                a = fmaf(sc.x, du, -sh.x) - k2.x * st.s2[i];
+                else du = st.si[i] == st.rs[i] ? st.sg[i] : 0.f;
+                a = fmaf(sc.x, du, -st.rw[i] * fmaf(k2.x, st.s2[i], sh.x));
             }
             sX[rl * (W + 4) + cl] = a;
         }
@@ -573,8 +615,10 @@ __device__ __forceinline__ void dw_store_b(const DwArgs& p, float* sX, int c0, i
 
 // dW tile (64*TM) x (64*TN) per workgroup (2 x 2 waves, wave tile (32*TM) x (32*TN)); persistent over
 // 32-row chunks of P with register prefetch of the next chunk; partial tiles go to `part`.
-template <int AM, bool VEC, int TM, int TN>
-__global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p) {
+template <int AM, bool VEC, int TM, int TN, bool RAG>
+__global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p_in) {
+    DwArgs p = p_in;
+    if (p.p_dev) p.P = *p.p_dev;
     constexpr int WI = 64 * TM, WJ = 64 * TN;
     __shared__ __attribute__((aligned(16))) float sA[DW_BP * (WI + 4)];   // [p][i]
     __shared__ __attribute__((aligned(16))) float sB[DW_BP * (WJ + 4)];   // [p][j]
@@ -610,14 +654,14 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p) {
     DwStage<VEC, WI> ra;
     DwStage<VEC, WJ> rb;
     int ch = blockIdx.x;
-    if (ch < chunks) { dw_load_a<AM, VEC, WI>(p, ch * DW_BP, i0, tid, ra); dw_load_b<VEC, WJ>(p, ch * DW_BP, j0, tid, rb); }
+    if (ch < chunks) { dw_load_a<AM, VEC, WI, RAG>(p, ch * DW_BP, i0, tid, ra); dw_load_b<VEC, WJ>(p, ch * DW_BP, j0, tid, rb); }
     for (; ch < chunks; ch += gridDim.x) {
         __syncthreads();
         dw_store_a<AM, VEC, WI>(p, sA, i0, tid, ra, asc, ash, ak2);
         dw_store_b<VEC, WJ>(p, sB, j0, tid, rb, bsc, bsh);
         __syncthreads();
         const int nch = ch + gridDim.x;
-        if (nch < chunks) { dw_load_a<AM, VEC, WI>(p, nch * DW_BP, i0, tid, ra); dw_load_b<VEC, WJ>(p, nch * DW_BP, j0, tid, rb); }
+        if (nch < chunks) { dw_load_a<AM, VEC, WI, RAG>(p, nch * DW_BP, i0, tid, ra); dw_load_b<VEC, WJ>(p, nch * DW_BP, j0, tid, rb); }
 #pragma unroll 4
         for (int ks = 0; ks < DW_BP / 2; ++ks) {
             const int pr = ks * 2 + lh;                 // lanes 0-31: row 2ks, lanes 32-63: row 2ks+1
@@ -656,12 +700,17 @@ static void dw_grid(int P, int I, int J, int& gx, int& ti, int& tj, int& tm, int
     if (gx < 1) gx = 1;
 }
 
+template <int AM, bool VEC, bool RAG>
+static void launch_dw_t2(const DwArgs& d, dim3 grid, int tm, int tn, hipStream_t st) {
+    if (tm == 1 && tn == 1) hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 1, 1, RAG>), grid, dim3(MLP_T), 0, st, d);
+    else if (tm == 2 && tn == 1) hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 2, 1, RAG>), grid, dim3(MLP_T), 0, st, d);
+    else if (tm == 1 && tn == 2) hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 1, 2, RAG>), grid, dim3(MLP_T), 0, st, d);
+    else hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 2, 2, RAG>), grid, dim3(MLP_T), 0, st, d);
+}
 template <int AM, bool VEC>
 static void launch_dw_t(const DwArgs& d, dim3 grid, int tm, int tn, hipStream_t st) {
-    if (tm == 1 && tn == 1) hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 1, 1>), grid, dim3(MLP_T), 0, st, d);
-    else if (tm == 2 && tn == 1) hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 2, 1>), grid, dim3(MLP_T), 0, st, d);
-    else if (tm == 1 && tn == 2) hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 1, 2>), grid, dim3(MLP_T), 0, st, d);
-    else hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 2, 2>), grid, dim3(MLP_T), 0, st, d);
+    if (d.rmeta) launch_dw_t2<AM, VEC, true>(d, grid, tm, tn, st);
+    else launch_dw_t2<AM, VEC, false>(d, grid, tm, tn, st);
 }
 
 // out[e] = sum_r part[r][e]: 32 outputs x 8 row-lanes per 256-thread block (partials are L2-resident).
@@ -851,7 +900,7 @@ static void linear_grid(int M, int N, int& gx, int& n_tiles, bool& narrow) {
     if (gx > want) gx = want;
 }
 
-template <int AM, int EM, int GM = 0>
+template <int AM, int EM, int GM = 0, bool RAG = false>
 static int launch_linear_t(const LinArgs& a, hipStream_t st) {
     const bool vec = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0) && (!a.A2 || (reinterpret_cast<uintptr_t>(a.A2) & 15) == 0);
@@ -859,11 +908,11 @@ static int launch_linear_t(const LinArgs& a, hipStream_t st) {
     linear_grid(a.M, a.N, gx, n_tiles, narrow);
     dim3 grid(gx, n_tiles);
     if (narrow) {
-        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, GM>), grid, dim3(MLP_T), 0, st, a);
-        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1, GM>), grid, dim3(MLP_T), 0, st, a);
+        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
+        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
     } else {
-        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 2, GM>), grid, dim3(MLP_T), 0, st, a);
-        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 2, GM>), grid, dim3(MLP_T), 0, st, a);
+        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 2, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
+        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 2, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
     }
     return check_launch("pcl_linear");
 }
@@ -876,6 +925,15 @@ static int linear_stat_rows(int M, int N) {
 }
 
 static int launch_linear(const LinArgs& a, hipStream_t st) {
+    if (a.rmeta) {                                     // duplicate-compacted rows
+        if (a.a_mode == A_PLAIN && a.e_mode == E_STORE_STATS) return launch_linear_t<A_PLAIN, E_STORE_STATS, 0, true>(a, st);
+        if (a.a_mode == A_BNACT && a.e_mode == E_STORE_STATS) return launch_linear_t<A_BNACT, E_STORE_STATS, 0, true>(a, st);
+        if (a.a_mode == A_DY && a.e_mode == E_MASK_STORE_STATS) return launch_linear_t<A_DY, E_MASK_STORE_STATS, 0, true>(a, st);
+        if (a.a_mode == A_DY && a.e_mode == E_STORE) return launch_linear_t<A_DY, E_STORE, 0, true>(a, st);
+        if (a.a_mode == A_DY_SPARSE && a.e_mode == E_MASK_STORE_STATS) return launch_linear_t<A_DY_SPARSE, E_MASK_STORE_STATS, 0, true>(a, st);
+        if (a.a_mode == A_DY_SPARSE && a.e_mode == E_STORE) return launch_linear_t<A_DY_SPARSE, E_STORE, 0, true>(a, st);
+        return fail(PCL_EINVAL, "pcl_linear: unsupported ragged mode combination %d/%d", a.a_mode, a.e_mode);
+    }
     if (a.e_mode == E_STORE_STATS && a.gmax) {
         if (a.a_mode == A_PLAIN && a.ns == 64) return launch_linear_t<A_PLAIN, E_STORE_STATS, 64>(a, st);
         if (a.a_mode == A_BNACT && a.ns == 64) return launch_linear_t<A_BNACT, E_STORE_STATS, 64>(a, st);
@@ -900,17 +958,25 @@ extern "C" int pcl_mlp_stat_rows(int P, int C) {
     return linear_stat_rows(P, C);
 }
 
-extern "C" int pcl_linear_fwd_f32(const float* X, const float* W, const float* bias, const float* in_scale,
-                                  const float* in_shift, float in_slope, int P, int Cin, int Cout, float* Y,
-                                  double* stats_ws, void* stream) {
+extern "C" int pcl_linear_fwd_rows_f32(const float* X, const float* W, const float* bias, const float* in_scale,
+                                       const float* in_shift, float in_slope, int P, int Cin, int Cout, float* Y,
+                                       double* stats_ws, const int32_t* row_meta, const int32_t* n_rows_dev, void* stream) {
     PCL_REQUIRE(X && W && Y && stats_ws, "pcl_linear_fwd_f32: null pointer");
     PCL_REQUIRE(P >= 1 && Cin >= 1 && Cout >= 1, "pcl_linear_fwd_f32: bad sizes P=%d Cin=%d Cout=%d", P, Cin, Cout);
     PCL_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "pcl_linear_fwd_f32: in_scale/in_shift must come together");
+    PCL_REQUIRE((row_meta == nullptr) == (n_rows_dev == nullptr), "pcl_linear_fwd_rows_f32: row_meta and n_rows_dev come together");
     LinArgs a = {};
     a.A = X; a.B = W; a.bias = bias; a.sc = in_scale; a.sh = in_shift; a.slope = in_slope;
     a.C = Y; a.stats = stats_ws; a.M = P; a.N = Cout; a.K = Cin;
+    a.rmeta = reinterpret_cast<const int2*>(row_meta); a.m_dev = n_rows_dev;
     a.a_mode = in_scale ? A_BNACT : A_PLAIN; a.e_mode = E_STORE_STATS;
     return launch_linear(a, as_stream(stream));
+}
+
+extern "C" int pcl_linear_fwd_f32(const float* X, const float* W, const float* bias, const float* in_scale,
+                                  const float* in_shift, float in_slope, int P, int Cin, int Cout, float* Y,
+                                  double* stats_ws, void* stream) {
+    return pcl_linear_fwd_rows_f32(X, W, bias, in_scale, in_shift, in_slope, P, Cin, Cout, Y, stats_ws, nullptr, nullptr, stream);
 }
 
 extern "C" int pcl_linear_fwd_gmax_f32(const float* X, const float* W, const float* bias, const float* in_scale,
@@ -942,10 +1008,25 @@ extern "C" int pcl_group_minmax_finalize_f32(const float* gmax, const float* gmi
     return check_launch("pcl_group_minmax_finalize_f32");
 }
 
+extern "C" int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,
+                                          const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
+                                          int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
+                                          float prev_slope, float* dUprev, double* stats_ws, const int32_t* row_meta,
+                                          const int32_t* n_rows_dev, void* stream);
+
 extern "C" int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,
                                      const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
                                      int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                                      float prev_slope, float* dUprev, double* stats_ws, void* stream) {
+    return pcl_linear_bwd_dx_rows_f32(dU, Y, a_, k1, k2, arg, gz, ns, Wt, P, Cout, Cin, Yprev, prev_scale, prev_shift, prev_slope,
+                                      dUprev, stats_ws, nullptr, nullptr, stream);
+}
+
+extern "C" int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,
+                                          const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
+                                          int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
+                                          float prev_slope, float* dUprev, double* stats_ws, const int32_t* row_meta,
+                                          const int32_t* n_rows_dev, void* stream) {
     PCL_REQUIRE(Y && a_ && k1 && k2 && Wt && dUprev, "pcl_linear_bwd_dx_f32: null pointer");
     PCL_REQUIRE((dU != nullptr) != (arg != nullptr && gz != nullptr), "pcl_linear_bwd_dx_f32: pass dU or (arg,gz)");
     PCL_REQUIRE(P >= 1 && Cin >= 1 && Cout >= 1 && (dU || ns >= 1), "pcl_linear_bwd_dx_f32: bad sizes");
@@ -954,6 +1035,7 @@ extern "C" int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const floa
     a.A = dU; a.A2 = Y; a.B = Wt; a.sc = a_; a.sh = k1; a.k2 = k2; a.arg = arg; a.gz = gz; a.ns = ns;
     a.C = dUprev; a.stats = stats_ws; a.Yprev = Yprev; a.esc = prev_scale; a.esh = prev_shift; a.eslope = prev_slope;
     a.M = P; a.N = Cin; a.K = Cout;
+    a.rmeta = reinterpret_cast<const int2*>(row_meta); a.m_dev = n_rows_dev;
     a.a_mode = dU ? A_DY : A_DY_SPARSE; a.e_mode = Yprev ? E_MASK_STORE_STATS : E_STORE;
     return launch_linear(a, as_stream(stream));
 }
@@ -965,10 +1047,25 @@ extern "C" size_t pcl_linear_bwd_dw_workspace_bytes(int P, int Cout, int Cin) {
     return sizeof(float) * (size_t)gx * Cout * Cin;
 }
 
+extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,
+                                          const int32_t* arg, const float* gz, int ns, const float* Xprev,
+                                          const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
+                                          int Cin, float* dW, void* workspace, size_t workspace_bytes, const int32_t* row_meta,
+                                          const int32_t* n_rows_dev, void* stream);
+
 extern "C" int pcl_linear_bwd_dw_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,
                                      const int32_t* arg, const float* gz, int ns, const float* Xprev,
                                      const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
                                      int Cin, float* dW, void* workspace, size_t workspace_bytes, void* stream) {
+    return pcl_linear_bwd_dw_rows_f32(dU, Y, a_, k1, k2, arg, gz, ns, Xprev, prev_scale, prev_shift, prev_slope, P, Cout, Cin, dW,
+                                      workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+
+extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,
+                                          const int32_t* arg, const float* gz, int ns, const float* Xprev,
+                                          const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
+                                          int Cin, float* dW, void* workspace, size_t workspace_bytes, const int32_t* row_meta,
+                                          const int32_t* n_rows_dev, void* stream) {
     PCL_REQUIRE(Y && a_ && k1 && k2 && Xprev && dW, "pcl_linear_bwd_dw_f32: null pointer");
     PCL_REQUIRE((dU != nullptr) != (arg != nullptr && gz != nullptr), "pcl_linear_bwd_dw_f32: pass dU or (arg,gz)");
     PCL_REQUIRE((prev_scale == nullptr) == (prev_shift == nullptr), "pcl_linear_bwd_dw_f32: scale/shift together");
@@ -982,6 +1079,7 @@ extern "C" int pcl_linear_bwd_dw_f32(const float* dU, const float* Y, const floa
     d.A = dU; d.A2 = Y; d.sc = a_; d.sh = k1; d.k2 = k2; d.arg = arg; d.gz = gz; d.ns = ns;
     d.Bsrc = Xprev; d.bsc = prev_scale; d.bsh = prev_shift; d.bslope = prev_slope;
     d.part = static_cast<float*>(workspace); d.P = P; d.I = Cout; d.J = Cin;
+    d.rmeta = reinterpret_cast<const int2*>(row_meta); d.p_dev = n_rows_dev;
     d.a_mode = dU ? A_DY : A_DY_SPARSE; d.b_mode = prev_scale ? A_BNACT : A_PLAIN;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const bool vec = (Cout % 4 == 0) && (Cin % 4 == 0) && al16(Y) && al16(Xprev) && (!dU || al16(dU)) && (!gz || (al16(gz) && al16(arg)));

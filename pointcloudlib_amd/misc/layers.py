@@ -92,16 +92,22 @@ class PointwiseMLP(nn.Module):
                 y = self._act(y)
         return y.reshape(*lead, y.shape[-1])
 
-    def forward(self, x, group_max=None):
+    def resolved_backend(self, x):
+        if self.backend == "auto":
+            return "hip" if x.is_cuda else "torch"
+        return self.backend
+
+    def forward(self, x, group_max=None, rowset=None):
         """x [..., C0] -> [..., CL]; with ``group_max=ns`` the rows are groups of ns consecutive rows and
-        the result is max-reduced over each group ([B,m,ns,C] -> [B,m,C])."""
-        backend = self.backend
-        if backend == "auto":
-            backend = "hip" if x.is_cuda else "torch"
+        the result is max-reduced over each group ([B,m,ns,C] -> [B,m,C]).  ``rowset``: duplicate-compacted
+        ball-query groups (ops.group_points_compact), HIP backend only."""
+        backend = self.resolved_backend(x)
+        if rowset is not None and backend != "hip":
+            raise RuntimeError("duplicate-compacted rows are a HIP-backend feature")
         if backend == "hip":
             from . import mlp_hip
             if mlp_hip.available():
-                return mlp_hip.pointwise_mlp(self, x, group_max)
+                return mlp_hip.pointwise_mlp(self, x, group_max, rowset)
         y = self.forward_torch(x)
         if group_max is not None:
             assert x.shape[-2] == group_max

@@ -22,8 +22,46 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _rows_cost(nrows_dev, P, per_row, const):
+    """Algorithmic bytes/flops of a row-streaming kernel: per_row * rows + const.  With duplicate-compacted rows the
+    row count lives on the device; return a thunk the profiler resolves after the timed region."""
+    if nrows_dev is None:
+        return per_row * P + const
+    return lambda: per_row * int(nrows_dev.item()) + const
+
+
 def _empty(shape, dev, dtype=torch.float32):
     return torch.empty(shape, dtype=dtype, device=dev)
+
+
+class _Pack:
+    """Flatten named tensors / lists of tensors (None allowed) for ctx.save_for_backward and rebuild them."""
+
+    def __init__(self):
+        self.tensors, self.layout = [], []
+
+    def add(self, name, t):
+        self.layout.append((name, None if t is None else len(self.tensors), False))
+        if t is not None:
+            self.tensors.append(t)
+
+    def add_list(self, name, ts):
+        idx = []
+        for t in ts:
+            idx.append(None if t is None else len(self.tensors))
+            if t is not None:
+                self.tensors.append(t)
+        self.layout.append((name, idx, True))
+
+    @staticmethod
+    def unpack(layout, saved):
+        out = {}
+        for name, idx, is_list in layout:
+            if is_list:
+                out[name] = [None if i is None else saved[i] for i in idx]
+            else:
+                out[name] = None if idx is None else saved[idx]
+        return out
 
 
 class _FusedMLP(torch.autograd.Function):
@@ -32,11 +70,16 @@ class _FusedMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cfg, *params):
-        ns, slope, eps, momentum, training, bn, last_act = cfg
+        ns, slope, eps, momentum, training, bn, last_act, rowset = cfg
         L = len(params) // 6
         dev = x.device
         x = x.contiguous()
-        P, C0 = x.shape
+        P, C0 = x.shape                      # P = row capacity; with a RowSet only the first *n_rows_dev rows are valid
+        Pbn = P                              # rows BatchNorm averages over (padded duplicates count, see RowSet)
+        rmeta = nrows = None
+        if rowset is not None:
+            assert ns == rowset.ns and P == rowset.capacity
+            rmeta, nrows = rowset.row_meta, rowset.n_rows_dev
         st = _stream()
         Ys, scales, shifts, means, invstds = [], [], [], [], []
         cur, in_scale, in_shift = x, None, None
@@ -47,7 +90,7 @@ class _FusedMLP(torch.autograd.Function):
             Y = _empty((P, cout), dev)
             rows = _lib.lib().pcl_mlp_stat_rows(P, cout)
             stats = _empty((rows, 2, cout), dev, torch.float64)
-            fused_max = (l == L - 1) and ns in (32, 64)
+            fused_max = (l == L - 1) and ns in (32, 64) and rowset is None
             if fused_max:      # last layer of a max-pooled stack: per-group min/max come out of the GEMM epilogue
                 G = P // ns
                 gmax, gmin = _empty((G, cout), dev), _empty((G, cout), dev)
@@ -57,12 +100,13 @@ class _FusedMLP(torch.autograd.Function):
                           algo_bytes=4 * P * (cin + cout) + 4 * cin * cout, algo_flops=2 * P * cin * cout,
                           tag=f"fwd{cin}x{cout}")
             else:
-                _lib.call("pcl_linear_fwd_f32", _P(cur), _P(W), _P(bias), _P(in_scale), _P(in_shift), slope, P, cin, cout,
-                          _P(Y), _P(stats), st, algo_bytes=4 * P * (cin + cout) + 4 * cin * cout,
-                          algo_flops=2 * P * cin * cout, tag=f"fwd{cin}x{cout}")
+                _lib.call("pcl_linear_fwd_rows_f32", _P(cur), _P(W), _P(bias), _P(in_scale), _P(in_shift), slope, P, cin, cout,
+                          _P(Y), _P(stats), _P(rmeta), _P(nrows), st,
+                          algo_bytes=_rows_cost(nrows, P, 4 * (cin + cout), 4 * cin * cout),
+                          algo_flops=_rows_cost(nrows, P, 2 * cin * cout, 0), tag=f"fwd{cin}x{cout}")
             if bn and training:
                 scale, shift, mean, invstd = (_empty((cout,), dev) for _ in range(4))
-                _lib.call("pcl_bn_finalize_f32", _P(stats), rows, _P(gamma), _P(beta), P, cout, eps, momentum, _P(scale),
+                _lib.call("pcl_bn_finalize_f32", _P(stats), rows, _P(gamma), _P(beta), Pbn, cout, eps, momentum, _P(scale),
                           _P(shift), _P(mean), _P(invstd), _P(rmean), _P(rvar), st)
             elif bn:
                 invstd = torch.rsqrt(rvar + eps)
@@ -83,6 +127,9 @@ class _FusedMLP(torch.autograd.Function):
             if fused_max:
                 _lib.call("pcl_group_minmax_finalize_f32", _P(gmax), _P(gmin), _P(gamax), _P(gamin), _P(in_scale),
                           _P(in_shift), out_slope, G, cin, _P(out), _P(arg), _P(ymax), st)
+            elif rowset is not None:
+                _lib.call("pcl_bn_act_max_rows_f32", _P(cur), _P(rowset.group_off), _P(in_scale), _P(in_shift), out_slope, G,
+                          cin, _P(out), _P(arg), _P(ymax), st)
             else:
                 _lib.call("pcl_bn_act_max_f32", _P(cur), _P(in_scale), _P(in_shift), out_slope, G, ns, cin, _P(out), _P(arg),
                           _P(ymax), st, algo_bytes=4 * P * cin + 12 * G * cin, tag=f"max{cin}")
@@ -91,15 +138,33 @@ class _FusedMLP(torch.autograd.Function):
             arg = ymax = None
             _lib.call("pcl_bn_act_f32", _P(cur), _P(in_scale), _P(in_shift), out_slope, P, cin, _P(out), st)
         ctx.cfg = (ns, slope, out_slope, training, bn, L, P, C0)
-        ctx.params = params
-        ctx.saved = (x, Ys, scales, shifts, means, invstds, out, arg, ymax)
+        # Everything goes through save_for_backward (never as plain ctx attributes): `out` is an OUTPUT of this node,
+        # and an attribute reference to it would form a node <-> tensor cycle that only the cyclic GC frees -- with
+        # ~2 GB of activations per step that is a leak of the whole working set every iteration.
+        pack = _Pack()
+        pack.add("x", x); pack.add_list("Ys", Ys); pack.add_list("scales", scales); pack.add_list("shifts", shifts)
+        pack.add_list("means", means); pack.add_list("invstds", invstds); pack.add("out", out); pack.add("arg", arg)
+        pack.add("ymax", ymax); pack.add_list("params", list(params))
+        if rowset is not None:
+            pack.add("row_meta", rowset.row_meta); pack.add("group_off", rowset.group_off)
+            ctx.rowdims = (rowset.B, rowset.m, rowset.ns)
+        else:
+            ctx.rowdims = None
+        ctx.layout = pack.layout
+        ctx.save_for_backward(*pack.tensors)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         ns, slope, out_slope, training, bn, L, P, C0 = ctx.cfg
-        params = ctx.params
-        x, Ys, scales, shifts, means, invstds, out, arg, ymax = ctx.saved
+        sv = _Pack.unpack(ctx.layout, ctx.saved_tensors)
+        rmeta = nrows = None
+        if ctx.rowdims is not None:
+            rmeta = sv["row_meta"]
+            nrows = sv["group_off"][ctx.rowdims[0] * ctx.rowdims[1]:]
+        params = sv["params"]
+        x, Ys, scales, shifts, means, invstds = sv["x"], sv["Ys"], sv["scales"], sv["shifts"], sv["means"], sv["invstds"]
+        out, arg, ymax = sv["out"], sv["arg"], sv["ymax"]
         dev = x.device
         st = _stream()
         lib = _lib.lib()
@@ -146,10 +211,11 @@ class _FusedMLP(torch.autograd.Function):
             nbytes = lib.pcl_linear_bwd_dw_workspace_bytes(P, cout, cin)
             ws = _empty(((nbytes + 3) // 4,), dev)
             dW = _empty((cout, cin), dev)
-            _lib.call("pcl_linear_bwd_dw_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(arg) if sparse else None,
+            _lib.call("pcl_linear_bwd_dw_rows_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(arg) if sparse else None,
                       _P(gz) if sparse else None, ns or 1, _P(Xprev), _P(psc), _P(psh), slope, P, cout, cin, _P(dW), _P(ws),
-                      nbytes, st, algo_bytes=4 * P * (cin + (cout if sparse else 2 * cout)) + 4 * cin * cout,
-                      algo_flops=2 * P * cin * cout, tag=f"dw{cout}x{cin}")
+                      nbytes, _P(rmeta), _P(nrows), st,
+                      algo_bytes=_rows_cost(nrows, P, 4 * (cin + (cout if sparse else 2 * cout)), 4 * cin * cout),
+                      algo_flops=_rows_cost(nrows, P, 2 * cin * cout, 0), tag=f"dw{cout}x{cin}")
             grads[6 * l] = dW
             if l > 0 or need_x:
                 Wt = W.t().contiguous()
@@ -159,19 +225,20 @@ class _FusedMLP(torch.autograd.Function):
                     stats_n = _empty((rows_n, 2, cin), dev, torch.float64)
                 else:
                     rows_n, stats_n = rows, None
-                _lib.call("pcl_linear_bwd_dx_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(arg) if sparse else None,
+                _lib.call("pcl_linear_bwd_dx_rows_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(arg) if sparse else None,
                           _P(gz) if sparse else None, ns or 1, _P(Wt), P, cout, cin, _P(Xprev) if l > 0 else None, _P(psc),
-                          _P(psh), slope, _P(dUp), _P(stats_n), st,
-                          algo_bytes=4 * P * (cin * (2 if l > 0 else 1) + (cout if sparse else 2 * cout)) + 4 * cin * cout,
-                          algo_flops=2 * P * cin * cout, tag=f"dx{cout}x{cin}")
+                          _P(psh), slope, _P(dUp), _P(stats_n), _P(rmeta), _P(nrows), st,
+                          algo_bytes=_rows_cost(nrows, P, 4 * (cin * (2 if l > 0 else 1) + (cout if sparse else 2 * cout)), 4 * cin * cout),
+                          algo_flops=_rows_cost(nrows, P, 2 * cin * cout, 0), tag=f"dx{cout}x{cin}")
                 dU, sparse, stats, rows = dUp, False, stats_n, rows_n
                 if l == 0:
                     gx = dUp
         return (gx, None) + tuple(grads)
 
 
-def pointwise_mlp(module, x, group_max=None):
-    """Run ``PointwiseMLP`` ``module`` on channel-last ``x`` [..., C0] through the fused HIP path."""
+def pointwise_mlp(module, x, group_max=None, rowset=None):
+    """Run ``PointwiseMLP`` ``module`` on channel-last ``x`` [..., C0] through the fused HIP path.  With a ``RowSet``
+    (duplicate-compacted ball-query groups) ``x`` is the [capacity, C0] row table and the result is [B, m, CL]."""
     if not x.is_cuda:
         raise RuntimeError("fused HIP MLP needs GPU tensors (no CPU fallback)")
     if x.dtype != torch.float32:
@@ -179,7 +246,9 @@ def pointwise_mlp(module, x, group_max=None):
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
     ns = 0
-    if group_max is not None:
+    if rowset is not None:
+        ns = rowset.ns
+    elif group_max is not None:
         assert x.shape[-2] == group_max, f"group_max={group_max} but group axis is {x.shape[-2]}"
         ns = int(group_max)
     params = []
@@ -188,8 +257,10 @@ def pointwise_mlp(module, x, group_max=None):
                    module.gammas[i] if module.bn else None, module.betas[i] if module.bn else None,
                    getattr(module, f"running_mean_{i}") if module.bn else None,
                    getattr(module, f"running_var_{i}") if module.bn else None]
-    cfg = (ns, module.slope, module.eps, module.momentum, module.training, module.bn, module.last_act)
+    cfg = (ns, module.slope, module.eps, module.momentum, module.training, module.bn, module.last_act, rowset)
     out = _FusedMLP.apply(x2, cfg, *params)
+    if rowset is not None:
+        return out.reshape(rowset.B, rowset.m, out.shape[-1])
     if ns:
         return out.reshape(*lead[:-1], out.shape[-1])
     return out.reshape(*lead, out.shape[-1])

@@ -15,7 +15,8 @@ from torch import nn
 from .. import _lib
 
 __all__ = [
-    "optimal_block", "furthest_point_sample", "ball_query", "group_points", "group_all", "index_points",
+    "optimal_block", "furthest_point_sample", "ball_query", "group_points", "group_points_compact", "RowSet", "group_all",
+    "index_points",
     "knn_indices", "edge_features", "three_nn", "three_interpolate", "FurthestPointSampler", "BallQueryGrouper", "GroupAll",
     "KNN", "PointNetFeaturePropagation",
 ]
@@ -176,6 +177,66 @@ class _GroupAll(torch.autograd.Function):
             gfeat = torch.empty((B, N, C), dtype=torch.float32, device=gout.device)
             _lib.call("pcl_group_all_bwd_f32", _p(gout), B, N, C, use_xyz, _p(gfeat), _stream())
         return None, gfeat, None
+
+
+class RowSet:
+    """Metadata of duplicate-compacted grouped rows (see include/pcl_hip.h, 'ragged groups')."""
+
+    def __init__(self, B, m, ns, row_meta, row_src, group_off):
+        self.B, self.m, self.ns = B, m, ns
+        self.G = B * m
+        self.row_meta, self.row_src, self.group_off = row_meta, row_src, group_off
+        self.n_rows_dev = group_off[self.G:]            # 1-element view: the valid-row count stays on the device
+
+    @property
+    def capacity(self):
+        return self.G * self.ns
+
+
+class _GroupCompact(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feat, idx, cnt, use_xyz):
+        idx = _dev(idx, "idx", torch.int32)
+        cnt = _dev(cnt, "cnt", torch.int32)
+        B, m, ns = idx.shape
+        xyz = _dev(xyz, "xyz")
+        new_xyz = _dev(new_xyz, "new_xyz")
+        feat = _dev(feat, "feature")
+        N = xyz.shape[1]
+        C = 0 if feat is None else feat.shape[2]
+        D = (3 if use_xyz else 0) + C
+        cap = B * m * ns
+        dev = idx.device
+        rows = torch.empty((cap, D), dtype=torch.float32, device=dev)
+        row_meta = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        row_src = torch.empty((cap,), dtype=torch.int32, device=dev)
+        group_off = torch.empty((B * m + 1,), dtype=torch.int32, device=dev)
+        _lib.call("pcl_group_compact_f32", _p(xyz), _p(new_xyz), _p(feat), _p(idx), _p(cnt), B, N, m, ns, C, int(use_xyz),
+                  _p(rows), _p(row_meta), _p(row_src), _p(group_off), _stream())
+        ctx.dims = (B, N, C, D, int(use_xyz), m, ns)
+        ctx.mark_non_differentiable(row_meta, row_src, group_off)
+        ctx.save_for_backward(row_src, group_off)        # outputs: saved properly, never as ctx attributes (no cycles)
+        return rows, row_meta, row_src, group_off
+
+    @staticmethod
+    def backward(ctx, grows, *_):
+        B, N, C, D, use_xyz, m, ns = ctx.dims
+        gfeat = None
+        if C > 0 and ctx.needs_input_grad[2]:
+            row_src, group_off = ctx.saved_tensors
+            grows = _dev(grows, "grad")
+            gfeat = torch.empty((B, N, C), dtype=torch.float32, device=grows.device)
+            _lib.call("pcl_scatter_rows_add_f32", _p(grows), _p(row_src), _p(group_off[B * m:]), B * m * ns, D,
+                      3 if use_xyz else 0, C, B * N, _p(gfeat), _stream())
+        return None, None, gfeat, None, None, None
+
+
+def group_points_compact(xyz, new_xyz, feature, idx, cnt, use_xyz=True):
+    """Duplicate-compacted grouping: (rows [B*m*ns (capacity), D], RowSet).  Only the first ``group_off[-1]`` rows are
+    valid: the DISTINCT points of every ball-query group in (group, slot) order, each with its multiplicity."""
+    rows, row_meta, row_src, group_off = _GroupCompact.apply(xyz, new_xyz, feature, idx, cnt, bool(use_xyz))
+    B, m, ns = idx.shape
+    return rows, RowSet(B, m, ns, row_meta, row_src, group_off)
 
 
 def group_all(xyz, feature, use_xyz=True):

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from ...misc.layers import PointwiseMLP
-from ...misc.ops import BallQueryGrouper, FurthestPointSampler, GroupAll, ball_query, group_points
+from ...misc.ops import BallQueryGrouper, FurthestPointSampler, GroupAll, ball_query, group_points, group_points_compact
 
 
 class PointNetModuleBase(nn.Module):
@@ -24,6 +24,7 @@ class PointNetModuleBase(nn.Module):
         self.sampler = None
         self.groupers = None
         self.mlps = None
+        self.compact_duplicates = True      # HIP path: skip the padded duplicates of ball-query groups (same results)
 
     def build_mlps(self, mlp_spec: List[int], use_xyz: bool = True, bn: bool = True) -> PointwiseMLP:
         spec = list(mlp_spec)           # upstream mutates the caller's list in place (:22-23); we copy
@@ -37,20 +38,24 @@ class PointNetModuleBase(nn.Module):
         if self.n_points is None:
             return None, [None] * len(self.groupers)
         new_xyz = self.sampler(xyz)                                             # :45
-        return new_xyz, [ball_query(new_xyz, xyz, g.radius, g.n_samples) for g in self.groupers]
+        return new_xyz, [ball_query(new_xyz, xyz, g.radius, g.n_samples, return_cnt=True) for g in self.groupers]
 
     def forward(self, xyz: torch.Tensor, feature: Optional[torch.Tensor], sampling=None):
         """xyz [B,N,3], feature [B,N,C] -> (new_xyz [B,n_points,3] | None, new_feature [B,n_points,C']).
         ``sampling`` = a precomputed result of ``sample(xyz)`` (see PointNet2_cls.precompute_sampling)."""
         new_xyz, idxs = sampling if sampling is not None else self.sample(xyz)
         new_feature_list = []
-        for grouper, mlp, idx in zip(self.groupers, self.mlps, idxs):
-            if idx is None:
+        for grouper, mlp, ic in zip(self.groupers, self.mlps, idxs):
+            if ic is None:
                 grouped = grouper(new_xyz, xyz, feature)                        # GroupAll
+                new_feature_list.append(mlp(grouped, group_max=grouped.shape[2]))
+            elif self.compact_duplicates and mlp.resolved_backend(xyz) == "hip":
+                # ball-query padding repeats the first hit: run the MLP on the distinct rows only (see ops.RowSet)
+                rows, rowset = group_points_compact(xyz, new_xyz, feature, ic[0], ic[1], grouper.use_xyz)
+                new_feature_list.append(mlp(rows, rowset=rowset))
             else:
-                grouped = group_points(xyz, new_xyz, feature, idx, grouper.use_xyz)   # [B, m, ns, C]   :51
-            ns = grouped.shape[2]
-            new_feature_list.append(mlp(grouped, group_max=ns))                 # conv/bn/relu x3 + max  :54-57
+                grouped = group_points(xyz, new_xyz, feature, ic[0], grouper.use_xyz)     # [B, m, ns, C]   :51
+                new_feature_list.append(mlp(grouped, group_max=grouped.shape[2]))       # conv/bn/relu x3 + max :54-57
         new_feature = new_feature_list[0] if len(new_feature_list) == 1 else torch.cat(new_feature_list, dim=-1)
         return new_xyz, new_feature
 
@@ -134,7 +139,7 @@ class PointNet2_cls(nn.Module):
             if sampling["stream"] is not cur:
                 cur.wait_event(sampling["event"])
                 for new_xyz, idxs in sampling["levels"]:              # allocator safety across streams
-                    for t in [new_xyz] + list(idxs):
+                    for t in [new_xyz] + [u for ic in idxs if ic is not None for u in ic]:
                         if t is not None:
                             t.record_stream(cur)
         for i, module in enumerate(self.pointnet_modules):

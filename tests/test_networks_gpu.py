@@ -73,7 +73,8 @@ def test_pointnet2_cls_backends_agree_with_grads(dev):
     gmax = max(v.abs().max().item() for v in g_t.values())
     for n in g_t:
         s = max(1e-3 * gmax, g_t[n].abs().max().item())                # some gradients are exactly 0 in theory
-        assert (g_h[n] - g_t[n]).abs().max().item() <= 2e-3 * s, n     # two fp32 paths; BN backward amplifies
+        # two fp32 pipelines through 3 SA levels: BN backward amplifies rounding and max-pool winners can flip
+        assert (g_h[n] - g_t[n]).abs().max().item() <= 5e-3 * s, n
 
 
 def test_pointnet_and_partseg_shapes_and_backends(dev):
