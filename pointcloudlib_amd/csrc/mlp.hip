@@ -356,24 +356,22 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
             const float bias = ep_bias[tn], esc = ep_sc[tn], esh = ep_sh[tn];
             float ts = 0.f, tq = 0.f;
             if (full) {
-                float yv[2][16];
-                if constexpr (EM == E_MASK_STORE_STATS) {
 #pragma unroll
-                    for (int tm = 0; tm < 2; ++tm)
+                for (int tm = 0; tm < 2; ++tm) {
+                    float yv[16];                          // one 32-row MFMA tile at a time: 16 loads in flight, 16 VGPRs
+                    if constexpr (EM == E_MASK_STORE_STATS) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                            yv[tm][r] = p.Yprev[(size_t)row * p.N + col];
+                            yv[r] = p.Yprev[(size_t)row * p.N + col];
                         }
-                }
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                         float c = acc[tm][tn][r] + bias;
                         if constexpr (EM == E_MASK_STORE_STATS) {
-                            const float y = yv[tm][r];
+                            const float y = yv[r];
                             c = fmaf(esc, y, esh) > 0.f ? c : c * p.eslope;
                             ts += c; tq = fmaf(c, y, tq);
                         } else if constexpr (EM == E_STORE_STATS) {
@@ -382,6 +380,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                         }
                         p.C[(size_t)row * p.N + col] = c;
                     }
+                }
             } else {
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm)
@@ -890,10 +889,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
     stats[(size_t)blockIdx.y * 2 * C + C + c] = s2;
 }
 
-static void linear_grid(int M, int N, int& gx, int& n_tiles, bool& narrow) {
-    narrow = N <= 64;                                  // 128x64 block tile instead of 128x128
-    const int tbn = narrow ? 64 : 128;
+static void linear_grid(int M, int N, bool bwd, int& gx, int& n_tiles, bool& narrow) {
+    // 128x64 block tile instead of 128x128 for narrow outputs -- and for the backward (dy-forming) loaders, whose
+    // three operand streams + 128x128 accumulators do not fit 256 VGPRs at 2 waves/SIMD (47-97 spilled VGPRs
+    // measured); re-reading the A operand from L2 for the second column tile is cheaper than the spills.
     const int m_tiles = (M + 127) / 128;
+    narrow = N <= 64 || bwd || m_tiles * ((N + 127) / 128) < 384;   // also: too few 128x128 tiles to fill 256 CUs
+    const int tbn = narrow ? 64 : 128;
     n_tiles = (N + tbn - 1) / tbn;
     gx = m_tiles < STAT_ROWS ? m_tiles : STAT_ROWS;
     const int want = (1024 + n_tiles - 1) / n_tiles;   // ~4 workgroups per CU in total
@@ -905,7 +907,7 @@ static int launch_linear_t(const LinArgs& a, hipStream_t st) {
     const bool vec = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0) && (!a.A2 || (reinterpret_cast<uintptr_t>(a.A2) & 15) == 0);
     int gx, n_tiles; bool narrow;
-    linear_grid(a.M, a.N, gx, n_tiles, narrow);
+    linear_grid(a.M, a.N, AM >= A_DY, gx, n_tiles, narrow);
     dim3 grid(gx, n_tiles);
     if (narrow) {
         if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
@@ -918,9 +920,9 @@ static int launch_linear_t(const LinArgs& a, hipStream_t st) {
 }
 
 // number of stats rows a launch_linear_t call with M rows and N columns writes
-static int linear_stat_rows(int M, int N) {
+static int linear_stat_rows(int M, int N, bool bwd) {
     int gx, n_tiles; bool narrow;
-    linear_grid(M, N, gx, n_tiles, narrow);
+    linear_grid(M, N, bwd, gx, n_tiles, narrow);
     return gx;
 }
 
@@ -953,9 +955,9 @@ static int launch_linear(const LinArgs& a, hipStream_t st) {
 }  // namespace pcl
 using namespace pcl;
 
-extern "C" int pcl_mlp_stat_rows(int P, int C) {
+extern "C" int pcl_mlp_stat_rows(int P, int C, int backward) {
     if (P < 1 || C < 1) return 1;
-    return linear_stat_rows(P, C);
+    return linear_stat_rows(P, C, backward != 0);
 }
 
 extern "C" int pcl_linear_fwd_rows_f32(const float* X, const float* W, const float* bias, const float* in_scale,

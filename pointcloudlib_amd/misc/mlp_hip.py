@@ -88,7 +88,7 @@ class _FusedMLP(torch.autograd.Function):
             W, bias, gamma, beta, rmean, rvar = params[6 * l:6 * l + 6]
             cout = W.shape[0]
             Y = _empty((P, cout), dev)
-            rows = _lib.lib().pcl_mlp_stat_rows(P, cout)
+            rows = _lib.lib().pcl_mlp_stat_rows(P, cout, 0)
             stats = _empty((rows, 2, cout), dev, torch.float64)
             fused_max = (l == L - 1) and ns in (32, 64) and rowset is None
             if fused_max:      # last layer of a max-pooled stack: per-group min/max come out of the GEMM epilogue
@@ -221,7 +221,7 @@ class _FusedMLP(torch.autograd.Function):
                 Wt = W.t().contiguous()
                 dUp = _empty((P, cin), dev)
                 if l > 0:
-                    rows_n = lib.pcl_mlp_stat_rows(P, cin)
+                    rows_n = lib.pcl_mlp_stat_rows(P, cin, 1)
                     stats_n = _empty((rows_n, 2, cin), dev, torch.float64)
                 else:
                     rows_n, stats_n = rows, None
