@@ -149,3 +149,39 @@ def test_duplicate_compacted_rows_match_padded_groups(oracle, dev):
         assert (g0[n] - g1[n]).abs().max().item() <= 1e-4 * max(1e-6, g0[n].abs().max().item()), n
     for n in b0:
         assert (b0[n] - b1[n]).abs().max().item() <= 1e-5 * max(1.0, b0[n].abs().max().item()), n
+
+
+@pytest.mark.parametrize("radius,ns", [(1e-4, 16), (10.0, 8), (0.3, 1), (0.25, 64)])
+def test_compacted_rows_edge_cases(dev, radius, ns):
+    """Groups with a single hit (all padding), saturated groups (no padding), ns = 1, and queries without any hit
+    (defined as ns copies of point 0): the compacted path equals the padded path."""
+    from pointcloudlib_amd import synth
+    from pointcloudlib_amd.misc import ops
+    torch.manual_seed(5)
+    B, N, m, C = 3, 256, 40, 5
+    x = torch.from_numpy(synth.gauss_ball(B, N, 41)).to(dev)
+    feat0 = torch.randn(B, N, C, device=dev)
+    _, new_xyz = ops.furthest_point_sample(x, m)
+    new_xyz = new_xyz.clone()
+    new_xyz[:, -3:] += 50.0                                      # three queries per cloud hit nothing
+    idx, cnt = ops.ball_query(new_xyz, x, radius, ns, return_cnt=True)
+    assert (cnt[:, -3:] == 0).all()
+    mlp = PointwiseMLP([3 + C, 16, 24]).to(dev).train()
+    gout = torch.randn(B, m, 24, device=dev)
+    outs = []
+    for compact in (False, True):
+        mm = copy.deepcopy(mlp)
+        f = feat0.clone().requires_grad_(True)
+        if compact:
+            rows, rs = ops.group_points_compact(x, new_xyz, f, idx, cnt, True)
+            assert int(rs.n_rows_dev.item()) == int(cnt.clamp(min=1).sum().item())
+            out = mm(rows, rowset=rs)
+        else:
+            out = mm(ops.group_points(x, new_xyz, f, idx, True), group_max=ns)
+        out.backward(gout)
+        outs.append((out.detach(), f.grad.detach(), [p.grad.detach() for p in mm.parameters()]))
+    (o0, f0, g0), (o1, f1, g1) = outs
+    assert (o0 - o1).abs().max().item() <= 1e-5 * max(1.0, o0.abs().max().item())
+    assert (f0 - f1).abs().max().item() <= 1e-4 * max(1e-6, f0.abs().max().item())
+    for a, b in zip(g0, g1):
+        assert (a - b).abs().max().item() <= 1e-4 * max(1e-6, a.abs().max().item())
