@@ -206,7 +206,8 @@ int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const float* a, 
                                const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
                                int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                                float prev_slope, float* dUprev, double* stats_ws, const int32_t* row_meta,
-                               const int32_t* n_rows_dev, void* stream);
+                               const int32_t* n_rows_dev, int first_col /* input gradient only: columns below it
+                               (the xyz part of a grouped tensor) are skipped and left unwritten */, void* stream);
 int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2,
                                const int32_t* arg, const float* gz, int ns, const float* Xprev,
                                const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,

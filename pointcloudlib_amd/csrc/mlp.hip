@@ -56,6 +56,8 @@ struct LinArgs {
     const int2* rmeta;   // optional per-row {group id, pos-in-group | multiplicity << 16} of compacted rows
     float slope, eslope;
     int M, N, K, ns;
+    int n_begin;         // first output column computed (columns below it are never written): input-gradient
+                         // GEMMs skip the xyz columns of a grouped tensor, which have no consumer
     int a_mode, e_mode;
 };
 
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
     __shared__ __attribute__((aligned(16))) float sB[TBN * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int n0 = blockIdx.y * TBN;
+    const int n0 = p.n_begin + blockIdx.y * TBN;
     const int m_tiles = (p.M + TBM - 1) / TBM;
     const int lr = lane & 31, lh = lane >> 5;
 
@@ -907,7 +909,7 @@ static int launch_linear_t(const LinArgs& a, hipStream_t st) {
     const bool vec = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0) && (!a.A2 || (reinterpret_cast<uintptr_t>(a.A2) & 15) == 0);
     int gx, n_tiles; bool narrow;
-    linear_grid(a.M, a.N, AM >= A_DY, gx, n_tiles, narrow);
+    linear_grid(a.M, a.N - a.n_begin, AM >= A_DY, gx, n_tiles, narrow);
     dim3 grid(gx, n_tiles);
     if (narrow) {
         if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
@@ -1014,21 +1016,21 @@ extern "C" int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const
                                           const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
                                           int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                                           float prev_slope, float* dUprev, double* stats_ws, const int32_t* row_meta,
-                                          const int32_t* n_rows_dev, void* stream);
+                                          const int32_t* n_rows_dev, int first_col, void* stream);
 
 extern "C" int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,
                                      const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
                                      int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                                      float prev_slope, float* dUprev, double* stats_ws, void* stream) {
     return pcl_linear_bwd_dx_rows_f32(dU, Y, a_, k1, k2, arg, gz, ns, Wt, P, Cout, Cin, Yprev, prev_scale, prev_shift, prev_slope,
-                                      dUprev, stats_ws, nullptr, nullptr, stream);
+                                      dUprev, stats_ws, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,
                                           const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
                                           int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                                           float prev_slope, float* dUprev, double* stats_ws, const int32_t* row_meta,
-                                          const int32_t* n_rows_dev, void* stream) {
+                                          const int32_t* n_rows_dev, int first_col, void* stream) {
     PCL_REQUIRE(Y && a_ && k1 && k2 && Wt && dUprev, "pcl_linear_bwd_dx_f32: null pointer");
     PCL_REQUIRE((dU != nullptr) != (arg != nullptr && gz != nullptr), "pcl_linear_bwd_dx_f32: pass dU or (arg,gz)");
     PCL_REQUIRE(P >= 1 && Cin >= 1 && Cout >= 1 && (dU || ns >= 1), "pcl_linear_bwd_dx_f32: bad sizes");
@@ -1036,7 +1038,8 @@ extern "C" int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const
     LinArgs a = {};
     a.A = dU; a.A2 = Y; a.B = Wt; a.sc = a_; a.sh = k1; a.k2 = k2; a.arg = arg; a.gz = gz; a.ns = ns;
     a.C = dUprev; a.stats = stats_ws; a.Yprev = Yprev; a.esc = prev_scale; a.esh = prev_shift; a.eslope = prev_slope;
-    a.M = P; a.N = Cin; a.K = Cout;
+    PCL_REQUIRE(first_col >= 0 && first_col < Cin && (first_col == 0 || !Yprev), "pcl_linear_bwd_dx_rows_f32: first_col=%d only for the input gradient", first_col);
+    a.M = P; a.N = Cin; a.K = Cout; a.n_begin = first_col;
     a.rmeta = reinterpret_cast<const int2*>(row_meta); a.m_dev = n_rows_dev;
     a.a_mode = dU ? A_DY : A_DY_SPARSE; a.e_mode = Yprev ? E_MASK_STORE_STATS : E_STORE;
     return launch_linear(a, as_stream(stream));

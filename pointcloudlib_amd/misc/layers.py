@@ -97,7 +97,7 @@ class PointwiseMLP(nn.Module):
             return "hip" if x.is_cuda else "torch"
         return self.backend
 
-    def forward(self, x, group_max=None, rowset=None):
+    def forward(self, x, group_max=None, rowset=None, x_grad_from=0):
         """x [..., C0] -> [..., CL]; with ``group_max=ns`` the rows are groups of ns consecutive rows and
         the result is max-reduced over each group ([B,m,ns,C] -> [B,m,C]).  ``rowset``: duplicate-compacted
         ball-query groups (ops.group_points_compact), HIP backend only."""
@@ -107,7 +107,7 @@ class PointwiseMLP(nn.Module):
         if backend == "hip":
             from . import mlp_hip
             if mlp_hip.available():
-                return mlp_hip.pointwise_mlp(self, x, group_max, rowset)
+                return mlp_hip.pointwise_mlp(self, x, group_max, rowset, x_grad_from)
         y = self.forward_torch(x)
         if group_max is not None:
             assert x.shape[-2] == group_max

@@ -70,7 +70,7 @@ class _FusedMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cfg, *params):
-        ns, slope, eps, momentum, training, bn, last_act, rowset = cfg
+        ns, slope, eps, momentum, training, bn, last_act, rowset, x_grad_from = cfg
         L = len(params) // 6
         dev = x.device
         x = x.contiguous()
@@ -137,6 +137,7 @@ class _FusedMLP(torch.autograd.Function):
             out = _empty((P, cin), dev)
             arg = ymax = None
             _lib.call("pcl_bn_act_f32", _P(cur), _P(in_scale), _P(in_shift), out_slope, P, cin, _P(out), st)
+        ctx.x_grad_from = x_grad_from
         ctx.cfg = (ns, slope, out_slope, training, bn, L, P, C0)
         # Everything goes through save_for_backward (never as plain ctx attributes): `out` is an OUTPUT of this node,
         # and an attribute reference to it would form a node <-> tensor cycle that only the cyclic GC frees -- with
@@ -157,6 +158,7 @@ class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         ns, slope, out_slope, training, bn, L, P, C0 = ctx.cfg
+        x_grad_from = ctx.x_grad_from
         sv = _Pack.unpack(ctx.layout, ctx.saved_tensors)
         rmeta = nrows = None
         if ctx.rowdims is not None:
@@ -227,7 +229,7 @@ class _FusedMLP(torch.autograd.Function):
                     rows_n, stats_n = rows, None
                 _lib.call("pcl_linear_bwd_dx_rows_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(arg) if sparse else None,
                           _P(gz) if sparse else None, ns or 1, _P(Wt), P, cout, cin, _P(Xprev) if l > 0 else None, _P(psc),
-                          _P(psh), slope, _P(dUp), _P(stats_n), _P(rmeta), _P(nrows), st,
+                          _P(psh), slope, _P(dUp), _P(stats_n), _P(rmeta), _P(nrows), x_grad_from if l == 0 else 0, st,
                           algo_bytes=_rows_cost(nrows, P, 4 * (cin * (2 if l > 0 else 1) + (cout if sparse else 2 * cout)), 4 * cin * cout),
                           algo_flops=_rows_cost(nrows, P, 2 * cin * cout, 0), tag=f"dx{cout}x{cin}")
                 dU, sparse, stats, rows = dUp, False, stats_n, rows_n
@@ -236,7 +238,7 @@ class _FusedMLP(torch.autograd.Function):
         return (gx, None) + tuple(grads)
 
 
-def pointwise_mlp(module, x, group_max=None, rowset=None):
+def pointwise_mlp(module, x, group_max=None, rowset=None, x_grad_from=0):
     """Run ``PointwiseMLP`` ``module`` on channel-last ``x`` [..., C0] through the fused HIP path.  With a ``RowSet``
     (duplicate-compacted ball-query groups) ``x`` is the [capacity, C0] row table and the result is [B, m, CL]."""
     if not x.is_cuda:
@@ -257,7 +259,10 @@ def pointwise_mlp(module, x, group_max=None, rowset=None):
                    module.gammas[i] if module.bn else None, module.betas[i] if module.bn else None,
                    getattr(module, f"running_mean_{i}") if module.bn else None,
                    getattr(module, f"running_var_{i}") if module.bn else None]
-    cfg = (ns, module.slope, module.eps, module.momentum, module.training, module.bn, module.last_act, rowset)
+    # x_grad_from: the first input column whose gradient anybody consumes (3 for a grouped [xyz | features] tensor:
+    # xyz never needs a gradient); lower columns of the returned input gradient are left unwritten.
+    cfg = (ns, module.slope, module.eps, module.momentum, module.training, module.bn, module.last_act, rowset,
+           int(x_grad_from))
     out = _FusedMLP.apply(x2, cfg, *params)
     if rowset is not None:
         return out.reshape(rowset.B, rowset.m, out.shape[-1])

@@ -52,7 +52,7 @@ class PointNetModuleBase(nn.Module):
             elif self.compact_duplicates and mlp.resolved_backend(xyz) == "hip":
                 # ball-query padding repeats the first hit: run the MLP on the distinct rows only (see ops.RowSet)
                 rows, rowset = group_points_compact(xyz, new_xyz, feature, ic[0], ic[1], grouper.use_xyz)
-                new_feature_list.append(mlp(rows, rowset=rowset))
+                new_feature_list.append(mlp(rows, rowset=rowset, x_grad_from=3 if grouper.use_xyz else 0))
             else:
                 grouped = group_points(xyz, new_xyz, feature, ic[0], grouper.use_xyz)     # [B, m, ns, C]   :51
                 new_feature_list.append(mlp(grouped, group_max=grouped.shape[2]))       # conv/bn/relu x3 + max :54-57
