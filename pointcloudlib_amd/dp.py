@@ -16,13 +16,14 @@ class FlatBucketDP:
 
     ``zero_grad()`` drops the gradients (autograd then *moves* fresh gradient tensors in instead of launching one
     accumulate kernel per parameter); ``all_reduce()`` packs them into the flat bucket with one multi-tensor copy,
-    all-reduces the bucket once, scales it, and re-points ``param.grad`` at views of the bucket.  With a single rank
-    nothing is copied or communicated at all."""
+    all-reduces the bucket once, scales it, and re-points ``param.grad`` at views of the bucket.  Without an initialised
+    process group nothing is copied or communicated at all."""
 
     def __init__(self, module, process_group=None, broadcast=True):
         self.module = module
         self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.active = dist.is_available() and dist.is_initialized()        # a 1-rank group still runs the collective
+        self.world = dist.get_world_size(process_group) if self.active else 1
         self.params = [p for p in module.parameters() if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
@@ -33,7 +34,7 @@ class FlatBucketDP:
             n = p.numel()
             self.views.append(self.flat[o:o + n].view_as(p))
             o += n
-        if broadcast and self.world > 1:
+        if broadcast and self.active:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=0, group=self.group)
 
@@ -47,7 +48,7 @@ class FlatBucketDP:
 
     def all_reduce(self):
         """Average the gradients over ranks through ONE flat all-reduce (sum, then scale by 1/world)."""
-        if self.world == 1:
+        if not self.active:
             return
         src, dst = [], []
         for p, v in zip(self.params, self.views):
@@ -59,7 +60,8 @@ class FlatBucketDP:
         if src:
             torch._foreach_copy_(dst, src)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.mul_(1.0 / self.world)
+        if self.world > 1:
+            self.flat.mul_(1.0 / self.world)
         for p, v in zip(self.params, self.views):
             p.grad = v
 
