@@ -11,8 +11,8 @@ variance ``max(E[x^2]-E[x]^2, 0)``, eps 1e-5, running stats ``r += (batch - r) *
 momentum 0.1 and the biased variance; affine gamma=1, beta=0 at init.
 
 Two backends with identical parameters:
-  * ``hip``   -- fused gfx950 kernels of libpcl_hip.so (default whenever the input is on the GPU);
-  * ``torch`` -- plain PyTorch fp32 ops; the numerics reference for the tests, never a fallback.
+  * ``hip`` (= ``auto``, the default) -- fused gfx950 kernels of libpcl_hip.so; CPU tensors raise;
+  * ``torch`` -- plain PyTorch fp32 ops, only when requested by name: the numerics reference of the tests.
 """
 import math
 
@@ -93,9 +93,9 @@ class PointwiseMLP(nn.Module):
         return y.reshape(*lead, y.shape[-1])
 
     def resolved_backend(self, x):
-        if self.backend == "auto":
-            return "hip" if x.is_cuda else "torch"
-        return self.backend
+        # "auto" IS the HIP path: a CPU tensor is an error there (no silent fallback).  The PyTorch implementation
+        # runs only when a test asks for it by name (backend="torch").
+        return "hip" if self.backend == "auto" else self.backend
 
     def forward(self, x, group_max=None, rowset=None, x_grad_from=0):
         """x [..., C0] -> [..., CL]; with ``group_max=ns`` the rows are groups of ns consecutive rows and
@@ -106,8 +106,9 @@ class PointwiseMLP(nn.Module):
             raise RuntimeError("duplicate-compacted rows are a HIP-backend feature")
         if backend == "hip":
             from . import mlp_hip
-            if mlp_hip.available():
-                return mlp_hip.pointwise_mlp(self, x, group_max, rowset, x_grad_from)
+            return mlp_hip.pointwise_mlp(self, x, group_max, rowset, x_grad_from)
+        if backend != "torch":
+            raise ValueError(f"unknown backend {backend!r}")
         y = self.forward_torch(x)
         if group_max is not None:
             assert x.shape[-2] == group_max

@@ -14,10 +14,6 @@ from .. import _lib
 _P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
 
 
-def available():
-    return True
-
-
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 

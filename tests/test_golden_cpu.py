@@ -87,3 +87,20 @@ def test_ops_reject_cpu_tensors():
             assert "GPU" in str(e)
         else:
             raise AssertionError("CPU tensor accepted: the HIP path must fail loudly")
+
+
+def test_mlp_has_no_silent_cpu_path():
+    """PointwiseMLP's default backend is the HIP path and must refuse CPU tensors; the PyTorch implementation runs
+    only when a test names it (backend="torch")."""
+    import torch
+    from pointcloudlib_amd.misc.layers import PointwiseMLP
+    m = PointwiseMLP([4, 8])
+    x = torch.randn(2, 5, 4)
+    try:
+        m(x)
+    except RuntimeError as e:
+        assert "GPU" in str(e)
+    else:
+        raise AssertionError("CPU tensor accepted by the default (HIP) backend")
+    m.backend = "torch"
+    assert m(x).shape == (2, 5, 8)
