@@ -70,18 +70,18 @@ _SIGS = {
     "pcl_bn_act_bwd_f32": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, ctypes.POINTER(c_int), _P]),
     "pcl_maxgrad_prep_f32": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P, ctypes.POINTER(c_int), _P]),
     "pcl_bn_bwd_consts_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
-    "pcl_linear_bwd_dx_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_float,
+    "pcl_linear_bwd_dx_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_float,
                                       _P, _P, _P]),
     "pcl_group_compact_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "pcl_linear_fwd_rows_f32": (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "pcl_bn_act_max_rows_f32": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P, _P]),
-    "pcl_linear_bwd_dx_rows_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_float,
+    "pcl_linear_bwd_dx_rows_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_float,
                                            _P, _P, _P, _P, c_int, _P]),
-    "pcl_linear_bwd_dw_rows_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_float, c_int, c_int, c_int, _P,
+    "pcl_linear_bwd_dw_rows_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_float, c_int, c_int, c_int, _P,
                                            _P, c_size_t, _P, _P, _P]),
     "pcl_scatter_rows_add_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_linear_bwd_dw_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "pcl_linear_bwd_dw_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_float, c_int, c_int, c_int, _P,
+    "pcl_linear_bwd_dw_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_float, c_int, c_int, c_int, _P,
                                       _P, c_size_t, _P]),
 }
 

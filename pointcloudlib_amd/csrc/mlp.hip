@@ -41,6 +41,7 @@ struct LinArgs {
     const float* sc;     // [K] A_BNACT: scale; A_DY*: a = gamma*invstd
     const float* sh;     // [K] A_BNACT: shift; A_DY*: k1
     const float* k2;     // [K] A_DY*
+    const float* mu;     // [K] A_DY*: batch mean of Y (the k2 term is applied to y - mu)
     const int32_t* arg;  // [M/ns, K] A_DY_SPARSE: row-in-group of the max
     const float* gz;     // [M/ns, K] A_DY_SPARSE: gradient at the max (already masked by the activation)
     float* C;            // [M,N]
@@ -86,8 +87,8 @@ struct Stage {
     int si[VEC ? 1 : NI];
     float rw[NI];                  // row multiplicity (ragged rows), 1 otherwise
     int rs[NI];                    // row-in-group (sparse max gradient)
-    float4 c_sc, c_sh, c_k2;       // per-k constants of this step (vector path)
-    float f_sc, f_sh, f_k2;        // (scalar path)
+    float4 c_sc, c_sh, c_k2, c_mu; // per-k constants of this step (vector path)
+    float f_sc, f_sh, f_k2, f_mu;  // (scalar path)
     int m0;                        // first row of the staged tile (for the sparse row-in-group test)
 };
 
@@ -102,7 +103,7 @@ __device__ __forceinline__ void load_a(const LinArgs& p, int m0, int k0, int tid
         if constexpr (AM != A_PLAIN) {
             st.c_sc = *reinterpret_cast<const float4*>(p.sc + k);
             st.c_sh = *reinterpret_cast<const float4*>(p.sh + k);
-            if constexpr (AM >= A_DY) st.c_k2 = *reinterpret_cast<const float4*>(p.k2 + k);
+            if constexpr (AM >= A_DY) { st.c_k2 = *reinterpret_cast<const float4*>(p.k2 + k); st.c_mu = *reinterpret_cast<const float4*>(p.mu + k); }
         }
 #pragma unroll
         for (int i = 0; i < ROWS / 32; ++i) {
@@ -131,7 +132,7 @@ __device__ __forceinline__ void load_a(const LinArgs& p, int m0, int k0, int tid
         const int k = min(k0 + (tid & 31), p.K - 1);
         if constexpr (AM != A_PLAIN) {
             st.f_sc = p.sc[k]; st.f_sh = p.sh[k];
-            if constexpr (AM >= A_DY) st.f_k2 = p.k2[k];
+            if constexpr (AM >= A_DY) { st.f_k2 = p.k2[k]; st.f_mu = p.mu[k]; }
         }
 #pragma unroll
         for (int i = 0; i < ROWS / 8; ++i) {
@@ -166,7 +167,7 @@ template <int AM, bool VEC, int ROWS>
 __device__ __forceinline__ void store_a(const LinArgs& p, float* sX, int k0, int tid, const Stage<VEC, ROWS>& st) {
     if constexpr (VEC) {
         const bool kin = k0 + (tid & 7) * 4 < p.K;
-        const float4 sc = st.c_sc, sh = st.c_sh, k2 = st.c_k2;
+        const float4 sc = st.c_sc, sh = st.c_sh, k2 = st.c_k2, mu = st.c_mu;
 #pragma unroll
         for (int i = 0; i < ROWS / 32; ++i) {
             const int rl = (tid >> 3) + 32 * i;
@@ -191,15 +192,15 @@ __device__ __forceinline__ void store_a(const LinArgs& p, float* sX, int k0, int
                     }
                     const float4 y = st.v2[i];
                     const float w = st.rw[i];            // dense BatchNorm term counts once per duplicate
-                    a.x = fmaf(sc.x, du.x, -w * fmaf(k2.x, y.x, sh.x)); a.y = fmaf(sc.y, du.y, -w * fmaf(k2.y, y.y, sh.y));
-                    a.z = fmaf(sc.z, du.z, -w * fmaf(k2.z, y.z, sh.z)); a.w = fmaf(sc.w, du.w, -w * fmaf(k2.w, y.w, sh.w));
+                    a.x = fmaf(sc.x, du.x, -w * fmaf(k2.x, y.x - mu.x, sh.x)); a.y = fmaf(sc.y, du.y, -w * fmaf(k2.y, y.y - mu.y, sh.y));
+                    a.z = fmaf(sc.z, du.z, -w * fmaf(k2.z, y.z - mu.z, sh.z)); a.w = fmaf(sc.w, du.w, -w * fmaf(k2.w, y.w - mu.w, sh.w));
                 }
             }
             *reinterpret_cast<float4*>(&sX[rl * LDS_LD + (tid & 7) * 4]) = a;
         }
     } else {
         const bool kin = k0 + (tid & 31) < p.K;
-        const float sc = st.f_sc, sh = st.f_sh, k2 = st.f_k2;
+        const float sc = st.f_sc, sh = st.f_sh, k2 = st.f_k2, mu = st.f_mu;
 #pragma unroll
         for (int i = 0; i < ROWS / 8; ++i) {
             const int rl = (tid >> 5) + 8 * i;
@@ -212,7 +213,7 @@ __device__ __forceinline__ void store_a(const LinArgs& p, float* sX, int k0, int
                     float du;
                     if constexpr (AM == A_DY) du = st.s[i];
                     else du = st.si[i] == st.rs[i] ? st.sg[i] : 0.f;
-                    a = fmaf(sc, du, -st.rw[i] * fmaf(k2, st.s2[i], sh));
+                    a = fmaf(sc, du, -st.rw[i] * fmaf(k2, st.s2[i] - mu, sh));
                 }
             }
             sX[rl * LDS_LD + (tid & 31)] = a;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
             const int col = n0 + wc * 32 * TN + tn * 32 + lr;
             const bool cin = col < p.N;
             const float bias = ep_bias[tn], esc = ep_sc[tn], esh = ep_sh[tn];
-            float ts = 0.f, tq = 0.f;
+            float ts = 0.f, tq = 0.f, tw = 0.f, piv = 0.f;
             if (full) {
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm) {
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                             yv[r] = p.Yprev[(size_t)row * p.N + col];
                         }
                     }
+                    if (tm == 0) piv = EM == E_MASK_STORE_STATS ? yv[0] : acc[0][tn][0] + bias;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -375,13 +377,22 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                         if constexpr (EM == E_MASK_STORE_STATS) {
                             const float y = yv[r];
                             c = fmaf(esc, y, esh) > 0.f ? c : c * p.eslope;
-                            ts += c; tq = fmaf(c, y, tq);
+                            ts += c; tq = fmaf(c, y - piv, tq);
                         } else if constexpr (EM == E_STORE_STATS) {
-                            if constexpr (RAG) { const float w = (float)(p.rmeta[row].y >> 16); ts = fmaf(w, c, ts); tq = fmaf(w * c, c, tq); }
-                            else { ts += c; tq = fmaf(c, c, tq); }
+                            const float d = c - piv;
+                            if constexpr (RAG) { const float w = (float)(p.rmeta[row].y >> 16); tw += w; ts = fmaf(w, d, ts); tq = fmaf(w * d, d, tq); }
+                            else { ts += d; tq = fmaf(d, d, tq); }
                         }
                         p.C[(size_t)row * p.N + col] = c;
                     }
+                }
+                // Sums were taken about a pivot (this lane's first value of the column) so that fp32 accumulation
+                // loses nothing when |mean| >> std; undo the shift in fp64.
+                if constexpr (EM == E_MASK_STORE_STATS) {
+                    st_s[tn] += (double)ts; st_q[tn] += (double)tq + (double)piv * (double)ts;
+                } else if constexpr (EM == E_STORE_STATS) {
+                    const double n = RAG ? (double)tw : 32.0, pv = piv;
+                    st_s[tn] += (double)ts + n * pv; st_q[tn] += (double)tq + 2.0 * pv * (double)ts + n * pv * pv;
                 }
             } else {
 #pragma unroll
@@ -395,16 +406,15 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                             if constexpr (EM == E_MASK_STORE_STATS) {
                                 const float y = p.Yprev[off];
                                 c = fmaf(esc, y, esh) > 0.f ? c : c * p.eslope;
-                                ts += c; tq = fmaf(c, y, tq);
+                                st_s[tn] += (double)c; st_q[tn] += (double)c * (double)y;
                             } else if constexpr (EM == E_STORE_STATS) {
-                                if constexpr (RAG) { const float w = (float)(p.rmeta[row].y >> 16); ts = fmaf(w, c, ts); tq = fmaf(w * c, c, tq); }
-                                else { ts += c; tq = fmaf(c, c, tq); }
+                                const double w = RAG ? (double)(p.rmeta[row].y >> 16) : 1.0;
+                                st_s[tn] += w * (double)c; st_q[tn] += w * (double)c * (double)c;
                             }
                             p.C[off] = c;
                         }
                     }
             }
-            st_s[tn] += (double)ts; st_q[tn] += (double)tq;
             if constexpr (GM != 0) {
                 // rows of this lane, ascending: s = tm*32 + (r&3) + 8*(r>>2) + 4*lh; a group is GM consecutive rows
                 constexpr int NG = 64 / GM;                      // groups per 64-row wave slab (1 or 2)
@@ -466,7 +476,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
 // ---- weight gradient: dW[I,J] = sum_p A'[p,I] * B'[p,J]  (A' = dy of this layer, B' = activation below) ----
 struct DwArgs {
     const float* A; const float* A2;           // dU / Y of this layer            [P,I]
-    const float* sc; const float* sh; const float* k2;     // a, k1, k2           [I]
+    const float* sc; const float* sh; const float* k2; const float* mu;     // a, k1, k2, mean   [I]
     const int32_t* arg; const float* gz; int ns;            // sparse max-pool gradient [P/ns, I]
     const float* Bsrc; const float* bsc; const float* bsh;  // Y_prev (or X) [P,J], folded BN of the layer below
     float bslope;
@@ -531,7 +541,7 @@ __device__ __forceinline__ void dw_load_a(const DwArgs& p, int p0, int c0, int t
 
 template <int AM, bool VEC, int W>
 __device__ __forceinline__ void dw_store_a(const DwArgs& p, float* sX, int c0, int tid, const DwStage<VEC, W>& st,
-                                           float4 sc, float4 sh, float4 k2) {
+                                           float4 sc, float4 sh, float4 k2, float4 mu) {
     using S = DwStage<VEC, W>;
     const int cl = (tid % S::CPR) * (VEC ? 4 : 1);
     const bool cin = c0 + cl < p.I;
@@ -554,8 +564,8 @@ __device__ __forceinline__ void dw_store_a(const DwArgs& p, float* sX, int c0, i
                 }
                 const float4 y = st.v2[i];
                 const float w = st.rw[i];
-                a.x = fmaf(sc.x, du.x, -w * fmaf(k2.x, y.x, sh.x)); a.y = fmaf(sc.y, du.y, -w * fmaf(k2.y, y.y, sh.y));
-                a.z = fmaf(sc.z, du.z, -w * fmaf(k2.z, y.z, sh.z)); a.w = fmaf(sc.w, du.w, -w * fmaf(k2.w, y.w, sh.w));
+                a.x = fmaf(sc.x, du.x, -w * fmaf(k2.x, y.x - mu.x, sh.x)); a.y = fmaf(sc.y, du.y, -w * fmaf(k2.y, y.y - mu.y, sh.y));
+                a.z = fmaf(sc.z, du.z, -w * fmaf(k2.z, y.z - mu.z, sh.z)); a.w = fmaf(sc.w, du.w, -w * fmaf(k2.w, y.w - mu.w, sh.w));
             }
             *reinterpret_cast<float4*>(&sX[rl * (W + 4) + cl]) = a;
         } else {
@@ -564,7 +574,7 @@ __device__ __forceinline__ void dw_store_a(const DwArgs& p, float* sX, int c0, i
                 float du;
                 if constexpr (AM == A_DY) du = st.s[i];
                 else du = st.si[i] == st.rs[i] ? st.sg[i] : 0.f;
-                a = fmaf(sc.x, du, -st.rw[i] * fmaf(k2.x, st.s2[i], sh.x));
+                a = fmaf(sc.x, du, -st.rw[i] * fmaf(k2.x, st.s2[i] - mu.x, sh.x));
             }
             sX[rl * (W + 4) + cl] = a;
         }
@@ -636,7 +646,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p_in) 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // per-thread channel constants (the thread's channels are the same for every chunk)
-    float4 asc = make_float4(0, 0, 0, 0), ash = asc, ak2 = asc, bsc = make_float4(1, 1, 1, 1), bsh = asc;
+    float4 asc = make_float4(0, 0, 0, 0), ash = asc, ak2 = asc, amu = asc, bsc = make_float4(1, 1, 1, 1), bsh = asc;
     {
         using SA = DwStage<VEC, WI>;
         using SB = DwStage<VEC, WJ>;
@@ -644,10 +654,10 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p_in) 
         const int cac = min(ca, p.I - (VEC ? 4 : 1)), cbc = min(cb, p.J - (VEC ? 4 : 1));
         if constexpr (VEC) {
             asc = *reinterpret_cast<const float4*>(p.sc + cac); ash = *reinterpret_cast<const float4*>(p.sh + cac);
-            ak2 = *reinterpret_cast<const float4*>(p.k2 + cac);
+            ak2 = *reinterpret_cast<const float4*>(p.k2 + cac); amu = *reinterpret_cast<const float4*>(p.mu + cac);
             if (p.b_mode == A_BNACT) { bsc = *reinterpret_cast<const float4*>(p.bsc + cbc); bsh = *reinterpret_cast<const float4*>(p.bsh + cbc); }
         } else {
-            asc.x = p.sc[cac]; ash.x = p.sh[cac]; ak2.x = p.k2[cac];
+            asc.x = p.sc[cac]; ash.x = p.sh[cac]; ak2.x = p.k2[cac]; amu.x = p.mu[cac];
             if (p.b_mode == A_BNACT) { bsc.x = p.bsc[cbc]; bsh.x = p.bsh[cbc]; }
         }
     }
@@ -658,7 +668,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p_in) 
     if (ch < chunks) { dw_load_a<AM, VEC, WI, RAG>(p, ch * DW_BP, i0, tid, ra); dw_load_b<VEC, WJ>(p, ch * DW_BP, j0, tid, rb); }
     for (; ch < chunks; ch += gridDim.x) {
         __syncthreads();
-        dw_store_a<AM, VEC, WI>(p, sA, i0, tid, ra, asc, ash, ak2);
+        dw_store_a<AM, VEC, WI>(p, sA, i0, tid, ra, asc, ash, ak2, amu);
         dw_store_b<VEC, WJ>(p, sB, j0, tid, rb, bsc, bsh);
         __syncthreads();
         const int nch = ch + gridDim.x;
@@ -778,8 +788,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
 }
 
 // BatchNorm backward constants from sum(du) and sum(du*y):
-//   dbeta = S1, dgamma = (S2 - mean*S1)*invstd,  dy = a*du - k1 - k2*y with a = gamma*invstd,
-//   k2 = a*dgamma*invstd/P, k1 = a*dbeta/P - k2*mean.
+//   dbeta = S1, dgamma = (S2 - mean*S1)*invstd,  dy = a*du - k1 - k2*(y - mean) with a = gamma*invstd,
+//   k2 = a*dgamma*invstd/P, k1 = a*dbeta/P   (y is centred where it is used: |mean| >> std must not cost digits).
 __global__ __launch_bounds__(256) void bn_bwd_consts_kernel(const double* __restrict__ stats, int rows, const float* __restrict__ gamma,
                                      const float* __restrict__ mean, const float* __restrict__ invstd, int P, int C,
                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ a_out,
@@ -798,7 +808,7 @@ __global__ __launch_bounds__(256) void bn_bwd_consts_kernel(const double* __rest
     if (dbeta) dbeta[c] = (float)s1;
     a_out[c] = (float)a;
     k2[c] = (float)kk2;
-    k1[c] = (float)(a * s1 / P - kk2 * mu);
+    k1[c] = (float)(a * s1 / P);
 }
 
 // out[g,c] = max_s lrelu(scale*y+shift); arg = first s attaining it; ymax = y at arg.  One thread per (g,c),
@@ -1012,31 +1022,31 @@ extern "C" int pcl_group_minmax_finalize_f32(const float* gmax, const float* gmi
     return check_launch("pcl_group_minmax_finalize_f32");
 }
 
-extern "C" int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,
+extern "C" int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2, const float* mu,
                                           const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
                                           int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                                           float prev_slope, float* dUprev, double* stats_ws, const int32_t* row_meta,
                                           const int32_t* n_rows_dev, int first_col, void* stream);
 
-extern "C" int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,
+extern "C" int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2, const float* mu,
                                      const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
                                      int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                                      float prev_slope, float* dUprev, double* stats_ws, void* stream) {
-    return pcl_linear_bwd_dx_rows_f32(dU, Y, a_, k1, k2, arg, gz, ns, Wt, P, Cout, Cin, Yprev, prev_scale, prev_shift, prev_slope,
+    return pcl_linear_bwd_dx_rows_f32(dU, Y, a_, k1, k2, mu, arg, gz, ns, Wt, P, Cout, Cin, Yprev, prev_scale, prev_shift, prev_slope,
                                       dUprev, stats_ws, nullptr, nullptr, 0, stream);
 }
 
-extern "C" int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,
+extern "C" int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2, const float* mu,
                                           const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
                                           int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                                           float prev_slope, float* dUprev, double* stats_ws, const int32_t* row_meta,
                                           const int32_t* n_rows_dev, int first_col, void* stream) {
-    PCL_REQUIRE(Y && a_ && k1 && k2 && Wt && dUprev, "pcl_linear_bwd_dx_f32: null pointer");
+    PCL_REQUIRE(Y && a_ && k1 && k2 && mu && Wt && dUprev, "pcl_linear_bwd_dx_f32: null pointer");
     PCL_REQUIRE((dU != nullptr) != (arg != nullptr && gz != nullptr), "pcl_linear_bwd_dx_f32: pass dU or (arg,gz)");
     PCL_REQUIRE(P >= 1 && Cin >= 1 && Cout >= 1 && (dU || ns >= 1), "pcl_linear_bwd_dx_f32: bad sizes");
     PCL_REQUIRE(!Yprev || (prev_scale && prev_shift && stats_ws), "pcl_linear_bwd_dx_f32: masked mode needs scale/shift/stats");
     LinArgs a = {};
-    a.A = dU; a.A2 = Y; a.B = Wt; a.sc = a_; a.sh = k1; a.k2 = k2; a.arg = arg; a.gz = gz; a.ns = ns;
+    a.A = dU; a.A2 = Y; a.B = Wt; a.sc = a_; a.sh = k1; a.k2 = k2; a.mu = mu; a.arg = arg; a.gz = gz; a.ns = ns;
     a.C = dUprev; a.stats = stats_ws; a.Yprev = Yprev; a.esc = prev_scale; a.esh = prev_shift; a.eslope = prev_slope;
     PCL_REQUIRE(first_col >= 0 && first_col < Cin && (first_col == 0 || !Yprev), "pcl_linear_bwd_dx_rows_f32: first_col=%d only for the input gradient", first_col);
     a.M = P; a.N = Cin; a.K = Cout; a.n_begin = first_col;
@@ -1052,26 +1062,26 @@ extern "C" size_t pcl_linear_bwd_dw_workspace_bytes(int P, int Cout, int Cin) {
     return sizeof(float) * (size_t)gx * Cout * Cin;
 }
 
-extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,
+extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2, const float* mu,
                                           const int32_t* arg, const float* gz, int ns, const float* Xprev,
                                           const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
                                           int Cin, float* dW, void* workspace, size_t workspace_bytes, const int32_t* row_meta,
                                           const int32_t* n_rows_dev, void* stream);
 
-extern "C" int pcl_linear_bwd_dw_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,
+extern "C" int pcl_linear_bwd_dw_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2, const float* mu,
                                      const int32_t* arg, const float* gz, int ns, const float* Xprev,
                                      const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
                                      int Cin, float* dW, void* workspace, size_t workspace_bytes, void* stream) {
-    return pcl_linear_bwd_dw_rows_f32(dU, Y, a_, k1, k2, arg, gz, ns, Xprev, prev_scale, prev_shift, prev_slope, P, Cout, Cin, dW,
+    return pcl_linear_bwd_dw_rows_f32(dU, Y, a_, k1, k2, mu, arg, gz, ns, Xprev, prev_scale, prev_shift, prev_slope, P, Cout, Cin, dW,
                                       workspace, workspace_bytes, nullptr, nullptr, stream);
 }
 
-extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2,
+extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2, const float* mu,
                                           const int32_t* arg, const float* gz, int ns, const float* Xprev,
                                           const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
                                           int Cin, float* dW, void* workspace, size_t workspace_bytes, const int32_t* row_meta,
                                           const int32_t* n_rows_dev, void* stream) {
-    PCL_REQUIRE(Y && a_ && k1 && k2 && Xprev && dW, "pcl_linear_bwd_dw_f32: null pointer");
+    PCL_REQUIRE(Y && a_ && k1 && k2 && mu && Xprev && dW, "pcl_linear_bwd_dw_f32: null pointer");
     PCL_REQUIRE((dU != nullptr) != (arg != nullptr && gz != nullptr), "pcl_linear_bwd_dw_f32: pass dU or (arg,gz)");
     PCL_REQUIRE((prev_scale == nullptr) == (prev_shift == nullptr), "pcl_linear_bwd_dw_f32: scale/shift together");
     PCL_REQUIRE(P >= 1 && Cin >= 1 && Cout >= 1 && (dU || ns >= 1), "pcl_linear_bwd_dw_f32: bad sizes");
@@ -1081,7 +1091,7 @@ extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const
     int gx, ti, tj, tm, tn;
     dw_grid(P, Cout, Cin, gx, ti, tj, tm, tn);
     DwArgs d = {};
-    d.A = dU; d.A2 = Y; d.sc = a_; d.sh = k1; d.k2 = k2; d.arg = arg; d.gz = gz; d.ns = ns;
+    d.A = dU; d.A2 = Y; d.sc = a_; d.sh = k1; d.k2 = k2; d.mu = mu; d.arg = arg; d.gz = gz; d.ns = ns;
     d.Bsrc = Xprev; d.bsc = prev_scale; d.bsh = prev_shift; d.bslope = prev_slope;
     d.part = static_cast<float*>(workspace); d.P = P; d.I = Cout; d.J = Cin;
     d.rmeta = reinterpret_cast<const int2*>(row_meta); d.p_dev = n_rows_dev;

@@ -209,7 +209,7 @@ class _FusedMLP(torch.autograd.Function):
             nbytes = lib.pcl_linear_bwd_dw_workspace_bytes(P, cout, cin)
             ws = _empty(((nbytes + 3) // 4,), dev)
             dW = _empty((cout, cin), dev)
-            _lib.call("pcl_linear_bwd_dw_rows_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(arg) if sparse else None,
+            _lib.call("pcl_linear_bwd_dw_rows_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(means[l]), _P(arg) if sparse else None,
                       _P(gz) if sparse else None, ns or 1, _P(Xprev), _P(psc), _P(psh), slope, P, cout, cin, _P(dW), _P(ws),
                       nbytes, _P(rmeta), _P(nrows), st,
                       algo_bytes=_rows_cost(nrows, P, 4 * (cin + (cout if sparse else 2 * cout)), 4 * cin * cout),
@@ -223,7 +223,7 @@ class _FusedMLP(torch.autograd.Function):
                     stats_n = _empty((rows_n, 2, cin), dev, torch.float64)
                 else:
                     rows_n, stats_n = rows, None
-                _lib.call("pcl_linear_bwd_dx_rows_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(arg) if sparse else None,
+                _lib.call("pcl_linear_bwd_dx_rows_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(means[l]), _P(arg) if sparse else None,
                           _P(gz) if sparse else None, ns or 1, _P(Wt), P, cout, cin, _P(Xprev) if l > 0 else None, _P(psc),
                           _P(psh), slope, _P(dUp), _P(stats_n), _P(rmeta), _P(nrows), x_grad_from if l == 0 else 0, st,
                           algo_bytes=_rows_cost(nrows, P, 4 * (cin * (2 if l > 0 else 1) + (cout if sparse else 2 * cout)), 4 * cin * cout),

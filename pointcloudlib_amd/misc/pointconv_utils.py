@@ -2,7 +2,7 @@
 
 Same function/class names and argument meaning: ``farthest_point_sample`` :74, ``knn_point`` :120,
 ``sample_and_group`` :133, ``compute_density`` :174, ``DensityNet`` :186, ``WeightNet`` :220,
-``PointConvDensitySetAbstraction`` :340.  All tensors channel-last ([B,N,C]); the reference's permutes to
+``PointConvDensitySetInterpolation`` :252, ``PointConvDensitySetAbstraction`` :340.  All tensors channel-last ([B,N,C]); the reference's permutes to
 [B,C,ns,npoint] around its Conv2d(k=1) stacks disappear (1x1 conv == row-wise linear map).
 
 What runs where: FPS (no origin skip, caller-supplied start index -- the reference draws it with
@@ -21,7 +21,7 @@ from torch import nn
 
 from .. import _lib
 from .layers import PointwiseMLP
-from .ops import _dev, _p, _stream, furthest_point_sample, index_points, knn_indices
+from .ops import _dev, _p, _stream, furthest_point_sample, index_points, knn_indices, three_interpolate, three_nn
 
 
 def farthest_point_sample(xyz, npoint, start_idx=None):
@@ -131,6 +131,45 @@ class PointConvDensitySetAbstraction(nn.Module):
         new_points = torch.matmul(new_points.transpose(2, 3), weights).reshape(B, S, -1)   # [B,S,C*16]   :394
         new_points = self.linear(new_points)                                              # :395-397
         return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
+
+    def execute(self, *a, **k):
+        return self(*a, **k)
+
+
+class PointConvDensitySetInterpolation(nn.Module):
+    """(:252-330).  ``forward(xyz1 [B,3,N], xyz2 [B,3,S], points1 [B,D,N], points2 [B,D2,S]) -> [B,D',N]``.
+
+    3-NN inverse-distance interpolation of ``points2`` onto ``xyz1`` (HIP three_nn + three_interpolate; the
+    reference sorts a dense [B,N,S] matrix, :293-301), then a PointConv over ``xyz1`` itself.  Kept as written
+    upstream: ``points1`` is accepted and ignored (:286,:305), and the grouping step is
+    ``sample_and_group(N, nsample, ...)`` -- i.e. FPS asked for all N points (:305), so the output rows follow the
+    FPS visiting order (random start) rather than the order of ``xyz1``."""
+
+    def __init__(self, nsample, in_channel, mlp, bandwidth):
+        super().__init__()
+        self.bandwidth = bandwidth
+        self.nsample = nsample
+        self.in_channel = in_channel
+        self.mlp = PointwiseMLP([in_channel] + list(mlp), bias=True)
+        self.weightnet = WeightNet(3, 16)
+        self.densitynet = DensityNet()
+        self.linear = PointwiseMLP([16 * mlp[-1], mlp[-1]], bias=True)
+
+    def forward(self, xyz1, xyz2, points1, points2, start_idx=None):
+        xyz1 = xyz1.permute(0, 2, 1).contiguous()
+        xyz2 = xyz2.permute(0, 2, 1).contiguous()
+        points2 = points2.permute(0, 2, 1).contiguous()
+        B, N, _ = xyz1.shape
+        idx3, w3 = three_nn(xyz1, xyz2)                                                   # :293-299
+        interpolated = three_interpolate(points2, idx3, w3)                               # :300
+        density_scale = self.densitynet(compute_density(xyz1, self.bandwidth))            # :304-305
+        _, new_points, grouped_xyz_norm, _, grouped_density = sample_and_group(
+            N, self.nsample, xyz1, interpolated, density_scale, start_idx)                # :307
+        new_points = self.mlp(new_points.contiguous())                                    # :311-315
+        weights = self.weightnet(grouped_xyz_norm.contiguous())                           # :317-318
+        new_points = new_points * grouped_density                                         # :319
+        new_points = torch.matmul(new_points.transpose(2, 3), weights).reshape(B, N, -1)  # :320
+        return self.linear(new_points).permute(0, 2, 1)                                   # :321-323
 
     def execute(self, *a, **k):
         return self(*a, **k)
