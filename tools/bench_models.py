@@ -57,6 +57,18 @@ def main():
     res.append(run("cfg4 PointNet++ SSG part-seg B=16 N=2048", PointNet2_partseg, (xs, xs, oh),
                    lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps))
     res.append(run("cfg5 PointConv cls B=32 N=1024", PointConvDensityClsSsg, (x.transpose(1, 2).contiguous(),), lambda o: soft_cross_entropy_loss(o, y32), a.steps))
+    from pointcloudlib_amd.networks.cls.pointcnn import PointCNNcls
+    from pointcloudlib_amd.networks.seg.pointcnn_partseg import PointCNN_partseg
+    from pointcloudlib_amd.networks.seg.pointnet_partseg import PointNet_partseg
+    from pointcloudlib_amd.networks.seg.dgcnn_partseg import DGCNN_partseg
+    from pointcloudlib_amd.networks.seg.pointconv_partseg import PointConvDensity_partseg
+    ce = torch.nn.functional.cross_entropy
+    xst = xs.transpose(1, 2).contiguous()
+    res.append(run("PointCNN cls B=32 N=1024", PointCNNcls, (x,), lambda o: soft_cross_entropy_loss(o, y32), a.steps))
+    res.append(run("PointNet part-seg B=16 N=2048", PointNet_partseg, (xst, oh), lambda o: ce(o, seg), a.steps))
+    res.append(run("DGCNN part-seg B=16 N=2048 k=40", lambda: DGCNN_partseg(50), (xst, oh), lambda o: ce(o, seg), a.steps))
+    res.append(run("PointCNN part-seg B=16 N=2048", PointCNN_partseg, (xs,), lambda o: ce(o, seg), a.steps))
+    res.append(run("PointConv part-seg B=16 N=2048", PointConvDensity_partseg, (xs, oh), lambda o: ce(o.permute(0, 2, 1), seg), a.steps))
     if a.out:
         json.dump({"device": torch.cuda.get_device_name(0), "note": "1 GPU, fp32, synthetic gauss_ball clouds, fwd+bwd+SGD", "results": res},
                   open(a.out, "w"), indent=1)
