@@ -198,7 +198,9 @@ def main():
         target = (target, None)
     timer = None
     if target:
-        timer = _lib.KernelTimer([target[0]])
+        # HIP events around the dominant kernel's dominant launch shape only, at most 64 launches of the timed region
+        # (every timing event is a marker packet on the stream; bracketing everything would perturb `value`)
+        timer = _lib.KernelTimer([target[0]], tags=None if target[1] is None else [target[1]], max_records=64)
         _lib.PROFILER = timer
 
     fence()

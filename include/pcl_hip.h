@@ -192,11 +192,14 @@ int pcl_linear_bwd_dw_f32(const float* dU, const float* Y, const float* a, const
  *     group_off [B*m+1] (group_off[B*m] = number of valid rows, stays on the device: no host sync).
  *   The *_rows_f32 GEMM entry points are the pcl_linear_* ones with that metadata (row_meta, n_rows_dev =
  *   &group_off[B*m]); P is the capacity; with both NULL they are identical to the plain entry points.
+ *   group_off depends on the ball-query counts only (pcl_group_offsets_i32), so it can be produced with the indices.
  *   pcl_bn_act_max_rows_f32: max over each group's valid rows (arg = slot in the compacted group).
  *   pcl_scatter_rows_add_f32: gfeat[row_src[r], c] += grows[r, off+c]  (zero-fills gfeat [n_dst_rows, C]). */
+int pcl_group_offsets_i32(const int32_t* cnt, int G, int32_t* group_off, void* stream);   /* exclusive scan of max(cnt,1) */
 int pcl_group_compact_f32(const float* xyz, const float* new_xyz, const float* feat, const int32_t* idx,
-                          const int32_t* cnt, int B, int N, int m, int ns, int C, int use_xyz, float* rows,
-                          int32_t* row_meta, int32_t* row_src, int32_t* group_off, void* stream);
+                          const int32_t* cnt, const int32_t* group_off, int B, int N, int m, int ns, int C, int use_xyz,
+                          int row_stride /* >= 3*use_xyz + C; extra columns are written as zeros */, float* rows,
+                          int32_t* row_meta, int32_t* row_src, void* stream);
 int pcl_linear_fwd_rows_f32(const float* X, const float* W, const float* bias, const float* in_scale,
                             const float* in_shift, float in_slope, int P, int Cin, int Cout, float* Y,
                             double* stats_ws, const int32_t* row_meta, const int32_t* n_rows_dev, void* stream);
@@ -207,7 +210,8 @@ int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const float* a, 
                                int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                                float prev_slope, float* dUprev, double* stats_ws, const int32_t* row_meta,
                                const int32_t* n_rows_dev, int first_col /* input gradient only: columns below it
-                               (the xyz part of a grouped tensor) are skipped and left unwritten */, void* stream);
+                               (the xyz part of a grouped tensor) are skipped and left unwritten */,
+                               int out_stride /* row stride of dUprev in floats, 0 = Cin (zero-padded input rows) */, void* stream);
 int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2, const float* mu,
                                const int32_t* arg, const float* gz, int ns, const float* Xprev,
                                const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,

@@ -72,11 +72,12 @@ _SIGS = {
     "pcl_bn_bwd_consts_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "pcl_linear_bwd_dx_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_float,
                                       _P, _P, _P]),
-    "pcl_group_compact_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "pcl_group_offsets_i32": (c_int, [_P, c_int, _P, _P]),
+    "pcl_group_compact_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "pcl_linear_fwd_rows_f32": (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "pcl_bn_act_max_rows_f32": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P, _P]),
     "pcl_linear_bwd_dx_rows_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_float,
-                                           _P, _P, _P, _P, c_int, _P]),
+                                           _P, _P, _P, _P, c_int, c_int, _P]),
     "pcl_linear_bwd_dw_rows_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_float, c_int, c_int, c_int, _P,
                                            _P, c_size_t, _P, _P, _P]),
     "pcl_scatter_rows_add_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
@@ -123,12 +124,20 @@ class KernelTimer:
     """Brackets selected C-ABI calls with HIP events on the stream they are launched on (torch's current
     stream) and accumulates per-entry-point time plus the algorithmic bytes/flops the caller states."""
 
-    def __init__(self, names=None):
+    def __init__(self, names=None, tags=None, max_records=None):
         self.names = None if names is None else set(names)
-        self.records = {}
+        self.tags = None if tags is None else set(tags)          # restrict to these launch shapes
+        self.max_records = max_records                           # per (name, tag): timing events perturb the stream
+        self.records = {}                                        # (each record is a marker packet), so bound them
 
-    def want(self, name):
-        return self.names is None or name in self.names
+    def want(self, name, tag=None):
+        if self.names is not None and name not in self.names:
+            return False
+        if self.tags is not None and tag is not None and tag not in self.tags:
+            return False
+        if self.max_records is not None and tag is not None:
+            return len(self.records.get((name, tag), ())) < self.max_records
+        return True
 
     def begin(self):
         import torch
@@ -161,10 +170,12 @@ def call(name, *args, algo_bytes=0, algo_flops=0, tag=""):
     """Invoke one C-ABI entry point; raises on a non-zero return code."""
     fn = getattr(lib(), name)
     prof = PROFILER
-    if prof is not None and prof.want(name):
+    if prof is not None:
+        tag = tag or (name if callable(algo_bytes) else f"{algo_bytes}")
+    if prof is not None and prof.want(name, tag):
         start = prof.begin()
         rc = fn(*args)
-        prof.end(name, tag or (name if callable(algo_bytes) else f"{algo_bytes}"), start, algo_bytes, algo_flops)
+        prof.end(name, tag, start, algo_bytes, algo_flops)
     else:
         rc = fn(*args)
     check(rc, name)

@@ -33,99 +33,180 @@ __global__ __launch_bounds__(1024) void group_offsets_kernel(const int32_t* __re
     if (t == 1023) goff[G] = part[1023];
 }
 
-// one wave per group: rows off..off+c-1 = concat(xyz[idx]-new_xyz, feat[idx]) for the c distinct slots
+// One workgroup per group, wave w takes the slots [w*chunk, (w+1)*chunk) of the group's c distinct ones.
+// rows off..off+c-1 = concat(xyz[idx]-new_xyz, feat[idx]).  Wide rows (C >= 32): a slot's feature row is copied by the
+// whole wave (coalesced 256 B pieces), four slots in flight; narrow rows: one lane per slot.
 __global__ __launch_bounds__(256) void group_compact_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                             const float* __restrict__ feat, const int32_t* __restrict__ idx,
                                                             const int32_t* __restrict__ cnt, const int32_t* __restrict__ goff,
-                                                            int G, int N, int m, int ns, int C, int use_xyz,
+                                                            int G, int N, int m, int ns, int C, int use_xyz, int S,
                                                             float* __restrict__ rows, int2* __restrict__ rmeta,
                                                             int32_t* __restrict__ rsrc) {
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (g >= G) return;
+    const int g = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int D = (use_xyz ? 3 : 0) + C, off3 = use_xyz ? 3 : 0;
     const int c = max(cnt[g], 1), base = goff[g];
     const int b = g / m;
     const int32_t* I = idx + (size_t)g * ns;
-    // lanes run over the flattened (slot, channel) pairs so narrow rows (D = 6 at SA1) still fill the wave
-    float* o = rows + (size_t)base * D;
-    for (int e = lane; e < c * D; e += 64) {
-        const int s = e / D, d = e - s * D;
-        const int k = I[s];
-        float v;
-        if (d < off3) v = __fsub_rn(xyz[((size_t)b * N + k) * 3 + d], new_xyz[(size_t)g * 3 + d]);
-        else v = feat[((size_t)b * N + k) * C + (d - off3)];
-        o[e] = v;
+    const int chunk = (ns + 3) >> 2;
+    const int s_lo = wave * chunk, s_hi = min(s_lo + chunk, c);
+    if (s_lo >= s_hi) return;
+    float* o = rows + (size_t)base * S;               // row stride S >= D; columns D..S-1 are zero
+    const float* fb = feat ? feat + (size_t)b * N * C : nullptr;
+    if (C >= 32) {
+        float q[3] = {0.f, 0.f, 0.f};
+        if (use_xyz && lane < 3) q[0] = new_xyz[(size_t)g * 3 + lane];
+        for (int s = s_lo; s < s_hi; s += 4) {
+            int k[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) k[j] = I[min(s + j, s_hi - 1)];
+            for (int c0 = 0; c0 < C; c0 += 128) {
+                float v[4][2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int ch = min(c0 + h * 64 + lane, C - 1);
+                        v[j][h] = fb[(size_t)k[j] * C + ch];
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int ch = c0 + h * 64 + lane;
+                        if (s + j < s_hi && ch < C) o[(size_t)(s + j) * S + off3 + ch] = v[j][h];
+                    }
+            }
+            if (use_xyz && lane < 3) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (s + j < s_hi) o[(size_t)(s + j) * S + lane] = __fsub_rn(xyz[((size_t)b * N + k[j]) * 3 + lane], q[0]);
+            }
+            if (lane < S - D) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (s + j < s_hi) o[(size_t)(s + j) * S + D + lane] = 0.f;
+            }
+        }
+    } else {
+        for (int s = s_lo + lane; s < s_hi; s += 64) {
+            const int k = I[s];
+            float* oo = o + (size_t)s * S;
+            if (use_xyz) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) oo[d] = __fsub_rn(xyz[((size_t)b * N + k) * 3 + d], new_xyz[(size_t)g * 3 + d]);
+            }
+            for (int d = 0; d < C; ++d) oo[off3 + d] = fb[(size_t)k * C + d];
+            for (int d = D; d < S; ++d) oo[d] = 0.f;
+        }
     }
-    for (int s = lane; s < c; s += 64) {
+    for (int s = s_lo + lane; s < s_hi; s += 64) {
         const int mult = s == 0 ? ns - c + 1 : 1;
         rmeta[base + s] = make_int2(g, s | (mult << 16));
         rsrc[base + s] = b * N + I[s];
     }
 }
 
-// out[g,c] = max over the group's rows of lrelu(scale*y+shift); arg = compact row-in-group; ymax = y there
+// out[g,c] = max over the group's rows of lrelu(scale*y+shift); arg = compact row-in-group; ymax = y there.
+// A lane owns V consecutive channels of one group; four rows are in flight per lane.
+template <int V>
 __global__ __launch_bounds__(256) void bn_act_max_rows_kernel(const float* __restrict__ Y, const int32_t* __restrict__ goff,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               float slope, int G, int C, float* __restrict__ out,
                                                               int32_t* __restrict__ arg, float* __restrict__ ymax) {
-    const size_t total = (size_t)G * C;
+    const int CV = C / V;
+    const size_t total = (size_t)G * CV;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const size_t g = e / C;
-        const int c = (int)(e - g * C);
-        const float a = scale[c], bsh = shift[c];
+        const size_t g = e / CV;
+        const int c = (int)(e - g * CV) * V;
+        float a[V], bsh[V], best[V], by[V];
+        int bi[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) { a[v] = scale[c + v]; bsh[v] = shift[c + v]; best[v] = -INFINITY; by[v] = 0.f; bi[v] = 0; }
         const int r0 = goff[g], r1 = goff[g + 1];
-        float best = -INFINITY, by = 0.f;
-        int bi = 0;
-        for (int r = r0; r < r1; ++r) {
-            const float yy = Y[(size_t)r * C + c];
-            const float u = fmaf(a, yy, bsh);
-            const float z = u > 0.f ? u : u * slope;
-            if (z > best) { best = z; bi = r - r0; by = yy; }
+        for (int r = r0; r < r1; r += 4) {
+            float yy[4][V];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* src = Y + (size_t)min(r + j, r1 - 1) * C + c;
+                if constexpr (V == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(src);
+                    yy[j][0] = t.x; yy[j][1] = t.y; yy[j][2] = t.z; yy[j][3] = t.w;
+                } else {
+                    yy[j][0] = *src;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (r + j < r1) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        const float u = fmaf(a[v], yy[j][v], bsh[v]);
+                        const float z = u > 0.f ? u : u * slope;
+                        if (z > best[v]) { best[v] = z; bi[v] = r + j - r0; by[v] = yy[j][v]; }
+                    }
+                }
+            }
         }
-        out[e] = best; arg[e] = bi; ymax[e] = by;
+#pragma unroll
+        for (int v = 0; v < V; ++v) { out[g * C + c + v] = best[v]; arg[g * C + c + v] = bi[v]; ymax[g * C + c + v] = by[v]; }
     }
 }
 
-// gfeat[rsrc[r], c] += grows[r, off+c] for r < *n_rows
+// gfeat[rsrc[r], c] += grows[r, off+c] for r < *n_rows.  One wave per row (two rows in flight), lanes over channels.
 __global__ __launch_bounds__(256) void scatter_rows_add_kernel(const float* __restrict__ grows, const int32_t* __restrict__ rsrc,
                                                                const int32_t* __restrict__ n_rows, int D, int off, int C,
                                                                float* __restrict__ gfeat) {
-    const size_t total = (size_t)(*n_rows) * C;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const size_t r = e / C;
-        const int c = (int)(e - r * C);
-        unsafeAtomicAdd(&gfeat[(size_t)rsrc[r] * C + c], grows[r * D + off + c]);
+    const int n = *n_rows, lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    for (int r = wv * 2; r < n; r += nw * 2) {
+        const int r2 = min(r + 1, n - 1);
+        const size_t d0 = (size_t)rsrc[r] * C, d1 = (size_t)rsrc[r2] * C;
+        for (int c = lane; c < C; c += 64) {
+            const float v0 = grows[(size_t)r * D + off + c], v1 = grows[(size_t)r2 * D + off + c];
+            unsafeAtomicAdd(&gfeat[d0 + c], v0);
+            if (r + 1 < n) unsafeAtomicAdd(&gfeat[d1 + c], v1);
+        }
     }
 }
 
 }  // namespace pcl
 using namespace pcl;
 
+extern "C" int pcl_group_offsets_i32(const int32_t* cnt, int G, int32_t* group_off, void* stream) {
+    PCL_REQUIRE(cnt && group_off && G >= 1, "pcl_group_offsets_i32: bad arguments");
+    hipLaunchKernelGGL(group_offsets_kernel, dim3(1), dim3(1024), 0, as_stream(stream), cnt, G, group_off);
+    return check_launch("pcl_group_offsets_i32");
+}
+
 extern "C" int pcl_group_compact_f32(const float* xyz, const float* new_xyz, const float* feat, const int32_t* idx,
-                                     const int32_t* cnt, int B, int N, int m, int ns, int C, int use_xyz, float* rows,
-                                     int32_t* row_meta, int32_t* row_src, int32_t* group_off, void* stream) {
+                                     const int32_t* cnt, const int32_t* group_off, int B, int N, int m, int ns, int C,
+                                     int use_xyz, int row_stride, float* rows, int32_t* row_meta, int32_t* row_src,
+                                     void* stream) {
     PCL_REQUIRE(idx && cnt && rows && row_meta && row_src && group_off, "pcl_group_compact_f32: null pointer");
     PCL_REQUIRE(!use_xyz || (xyz && new_xyz), "pcl_group_compact_f32: use_xyz needs xyz and new_xyz");
     PCL_REQUIRE(C == 0 || feat, "pcl_group_compact_f32: C=%d needs feat", C);
     PCL_REQUIRE(B >= 1 && N >= 1 && m >= 1 && ns >= 1 && ns < 32768 && C >= 0 && (use_xyz || C > 0), "pcl_group_compact_f32: bad sizes");
-    hipStream_t st = as_stream(stream);
+    const int D = (use_xyz ? 3 : 0) + C;
+    PCL_REQUIRE(row_stride >= D && row_stride < D + 64, "pcl_group_compact_f32: row_stride=%d for %d columns", row_stride, D);
     const int G = B * m;
-    hipLaunchKernelGGL(group_offsets_kernel, dim3(1), dim3(1024), 0, st, cnt, G, group_off);
-    int rc = check_launch("pcl_group_compact_f32(offsets)");
-    if (rc) return rc;
-    hipLaunchKernelGGL(group_compact_kernel, dim3((G + 3) / 4), dim3(256), 0, st, xyz, new_xyz, feat, idx, cnt, group_off, G, N, m, ns,
-                       C, use_xyz, rows, reinterpret_cast<int2*>(row_meta), row_src);
+    hipLaunchKernelGGL(group_compact_kernel, dim3(G), dim3(256), 0, as_stream(stream), xyz, new_xyz, feat, idx, cnt, group_off, G, N, m,
+                       ns, C, use_xyz, row_stride, rows, reinterpret_cast<int2*>(row_meta), row_src);
     return check_launch("pcl_group_compact_f32");
 }
 
 extern "C" int pcl_bn_act_max_rows_f32(const float* Y, const int32_t* group_off, const float* scale, const float* shift,
                                        float slope, int G, int C, float* out, int32_t* arg, float* ymax, void* stream) {
     PCL_REQUIRE(Y && group_off && scale && shift && out && arg && ymax && G >= 1 && C >= 1, "pcl_bn_act_max_rows_f32: bad arguments");
-    const size_t total = (size_t)G * C;
+    const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
+    const size_t total = (size_t)G * (vec ? C / 4 : C);
     int blocks = (int)((total + 255) / 256);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bn_act_max_rows_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), Y, group_off, scale, shift, slope, G, C,
-                       out, arg, ymax);
+    if (blocks > 16384) blocks = 16384;
+    if (vec)
+        hipLaunchKernelGGL(bn_act_max_rows_kernel<4>, dim3(blocks), dim3(256), 0, as_stream(stream), Y, group_off, scale, shift, slope,
+                           G, C, out, arg, ymax);
+    else
+        hipLaunchKernelGGL(bn_act_max_rows_kernel<1>, dim3(blocks), dim3(256), 0, as_stream(stream), Y, group_off, scale, shift, slope,
+                           G, C, out, arg, ymax);
     return check_launch("pcl_bn_act_max_rows_f32");
 }
 
@@ -136,8 +217,8 @@ extern "C" int pcl_scatter_rows_add_f32(const float* grows, const int32_t* row_s
     hipStream_t st = as_stream(stream);
     hipError_t e = hipMemsetAsync(gfeat, 0, sizeof(float) * (size_t)n_dst_rows * C, st);
     if (e != hipSuccess) return fail(PCL_EHIP, "pcl_scatter_rows_add_f32: memset: %s", hipGetErrorString(e));
-    size_t blocks = ((size_t)rows_cap * C + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    size_t blocks = ((size_t)rows_cap + 7) / 8;
+    if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(scatter_rows_add_kernel, dim3((int)blocks), dim3(256), 0, st, grows, row_src, n_rows_dev, D, off, C, gfeat);
     return check_launch("pcl_scatter_rows_add_f32");
 }

@@ -44,7 +44,8 @@ struct LinArgs {
     const float* mu;     // [K] A_DY*: batch mean of Y (the k2 term is applied to y - mu)
     const int32_t* arg;  // [M/ns, K] A_DY_SPARSE: row-in-group of the max
     const float* gz;     // [M/ns, K] A_DY_SPARSE: gradient at the max (already masked by the activation)
-    float* C;            // [M,N]
+    float* C;            // [M,N], row stride ldc (>= N)
+    int ldc;
     double* stats;       // [STAT_ROWS][2][N] partials (E_STORE_STATS, E_MASK_STORE_STATS)
     const float* Yprev;  // [M,N] E_MASK_STORE_STATS: pre-BN output of the layer below
     const float* esc;    // [N]   its folded BN scale
@@ -265,6 +266,21 @@ __device__ __forceinline__ void store_b(const LinArgs& p, float* sX, int n0, int
 // GM (E_STORE_STATS only): 0 = off; 32 / 64 = also emit per-group (ns = GM rows) max/min/argmax/argmin of the
 // raw outputs -- BatchNorm's scale is not known yet, so both extremes are kept and the tiny finalize kernel
 // picks max for scale >= 0 and min for scale < 0 (the activation is monotone).
+
+// In-place 4x4 transpose across the four lanes of a quad: afterwards register j of lane i holds what register i of
+// lane j held.  The MFMA C/D layout gives a lane ONE column and four consecutive rows per register group; transposed,
+// a lane holds four consecutive columns of ONE row, i.e. a 16-byte piece of a C row -> global_store_dwordx4 on whole
+// 128-byte lines instead of four dword stores (the epilogue is store-issue bound otherwise).
+__device__ __forceinline__ float quad_xchg1(float x) { return __uint_as_float(dpp_u32<0xB1>(__float_as_uint(x), __float_as_uint(x))); }
+__device__ __forceinline__ float quad_xchg2(float x) { return __uint_as_float(dpp_u32<0x4E>(__float_as_uint(x), __float_as_uint(x))); }
+__device__ __forceinline__ void quad_transpose4(float& v0, float& v1, float& v2, float& v3, bool b0, bool b1) {
+    float y;
+    y = quad_xchg1(b0 ? v0 : v1); v0 = b0 ? y : v0; v1 = b0 ? v1 : y;
+    y = quad_xchg1(b0 ? v2 : v3); v2 = b0 ? y : v2; v3 = b0 ? v3 : y;
+    y = quad_xchg2(b1 ? v0 : v2); v0 = b1 ? y : v0; v2 = b1 ? v2 : y;
+    y = quad_xchg2(b1 ? v1 : v3); v1 = b1 ? y : v1; v3 = b1 ? v3 : y;
+}
+
 template <int AM, int EM, bool VEC, int TN, int GM, bool RAG>
 __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in) {
     LinArgs p = p_in;
@@ -272,11 +288,19 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
     constexpr int TBM = 128, TBN = 64 * TN;
     __shared__ __attribute__((aligned(16))) float sA[TBM * LDS_LD];
     __shared__ __attribute__((aligned(16))) float sB[TBN * LDS_LD];
+    // multiplicities of the tile's rows for the BatchNorm sums of compacted rows: prefetched with the operands and kept
+    // in LDS (a global load in the epilogue would sit behind the tile's own stores in the in-order vmcnt queue)
+    constexpr bool NEEDW = RAG && EM == E_STORE_STATS;
+    __shared__ __attribute__((aligned(16))) float sW[NEEDW ? TBM : 4];
+    int wmeta = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int n0 = p.n_begin + blockIdx.y * TBN;
     const int m_tiles = (p.M + TBM - 1) / TBM;
     const int lr = lane & 31, lh = lane >> 5;
+    // rows of C (and Yprev) can be moved as 16-byte pieces
+    // (not for the masked epilogue: moving Yprev the same way costs two transposes per register group and measured slower)
+    const bool vec_c = EM != E_MASK_STORE_STATS && (p.ldc % 4 == 0) && (p.n_begin % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
 
     double st_s[TN], st_q[TN];
 #pragma unroll
@@ -297,6 +321,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
     if (mt < m_tiles) {
         load_a<AM, VEC, TBM, RAG>(p, mt * TBM, 0, tid, ra);
         load_b<VEC, TBN>(p, n0, 0, tid, rb);
+        if constexpr (NEEDW) wmeta = p.rmeta[min(mt * TBM + (tid & (TBM - 1)), p.M - 1)].y;
     }
     for (; mt < m_tiles; mt += gridDim.x) {
         const int m0 = mt * TBM;
@@ -312,6 +337,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
             __syncthreads();                       // previous step's fragment reads are done
             store_a<AM, VEC, TBM>(p, sA, staged_k0, tid, ra);
             store_b<VEC, TBN>(p, sB, n0, staged_k0, tid, rb);
+            if constexpr (NEEDW) { if (tid < TBM) sW[tid] = (float)(wmeta >> 16); }
             __syncthreads();
             // request the next step's operands (next k block, or the first k block of this workgroup's next tile)
             {
@@ -321,6 +347,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                 if (nmt < m_tiles) {
                     load_a<AM, VEC, TBM, RAG>(p, nmt * TBM, nk, tid, ra);
                     load_b<VEC, TBN>(p, n0, nk, tid, rb);
+                    if constexpr (NEEDW) wmeta = p.rmeta[min(nmt * TBM + (tid & (TBM - 1)), p.M - 1)].y;
                 }
             }
             const int kc = min(BK, p.K - k0);
@@ -359,20 +386,41 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
             const float bias = ep_bias[tn], esc = ep_sc[tn], esh = ep_sh[tn];
             float ts = 0.f, tq = 0.f, tw = 0.f, piv = 0.f;
             if (full) {
+                const bool b0 = lane & 1, b1 = lane & 2;
+                const int qcol = n0 + wc * 32 * TN + tn * 32 + (lr & ~3);      // first of this lane's 4 columns after the transpose
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm) {
-                    float yv[16];                          // one 32-row MFMA tile at a time: 16 loads in flight, 16 VGPRs
+                    const int rbase = m0 + wr * 64 + tm * 32 + 4 * lh + (lane & 3);   // + 8*(r>>2): this lane's row after the transpose
+                    float yv[16];                          // one 32-row MFMA tile at a time: 16 VGPRs
                     if constexpr (EM == E_MASK_STORE_STATS) {
+                        if (vec_c) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                            yv[r] = p.Yprev[(size_t)row * p.N + col];
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 t = *reinterpret_cast<const float4*>(p.Yprev + (size_t)(rbase + 8 * q) * p.N + qcol);
+                                yv[4 * q] = t.x; yv[4 * q + 1] = t.y; yv[4 * q + 2] = t.z; yv[4 * q + 3] = t.w;
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) quad_transpose4(yv[4 * q], yv[4 * q + 1], yv[4 * q + 2], yv[4 * q + 3], b0, b1);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                                yv[r] = p.Yprev[(size_t)row * p.N + col];
+                            }
                         }
                     }
                     if (tm == 0) piv = EM == E_MASK_STORE_STATS ? yv[0] : acc[0][tn][0] + bias;
+                    float cv[16];
+                    float wv[16];
+                    if constexpr (NEEDW) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 t = *reinterpret_cast<const float4*>(&sW[wr * 64 + tm * 32 + 8 * q + 4 * lh]);
+                            wv[4 * q] = t.x; wv[4 * q + 1] = t.y; wv[4 * q + 2] = t.z; wv[4 * q + 3] = t.w;
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                         float c = acc[tm][tn][r] + bias;
                         if constexpr (EM == E_MASK_STORE_STATS) {
                             const float y = yv[r];
@@ -380,10 +428,24 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                             ts += c; tq = fmaf(c, y - piv, tq);
                         } else if constexpr (EM == E_STORE_STATS) {
                             const float d = c - piv;
-                            if constexpr (RAG) { const float w = (float)(p.rmeta[row].y >> 16); tw += w; ts = fmaf(w, d, ts); tq = fmaf(w * d, d, tq); }
+                            if constexpr (RAG) { const float w = wv[r]; tw += w; ts = fmaf(w, d, ts); tq = fmaf(w * d, d, tq); }
                             else { ts += d; tq = fmaf(d, d, tq); }
                         }
-                        p.C[(size_t)row * p.N + col] = c;
+                        cv[r] = c;
+                    }
+                    if (vec_c) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            quad_transpose4(cv[4 * q], cv[4 * q + 1], cv[4 * q + 2], cv[4 * q + 3], b0, b1);
+                            *reinterpret_cast<float4*>(p.C + (size_t)(rbase + 8 * q) * p.ldc + qcol) =
+                                make_float4(cv[4 * q], cv[4 * q + 1], cv[4 * q + 2], cv[4 * q + 3]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            p.C[(size_t)row * p.ldc + col] = cv[r];
+                        }
                     }
                 }
                 // Sums were taken about a pivot (this lane's first value of the column) so that fp32 accumulation
@@ -411,7 +473,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                                 const double w = RAG ? (double)(p.rmeta[row].y >> 16) : 1.0;
                                 st_s[tn] += w * (double)c; st_q[tn] += w * (double)c * (double)c;
                             }
-                            p.C[off] = c;
+                            p.C[(size_t)row * p.ldc + col] = c;
                         }
                     }
             }
@@ -981,7 +1043,7 @@ extern "C" int pcl_linear_fwd_rows_f32(const float* X, const float* W, const flo
     PCL_REQUIRE((row_meta == nullptr) == (n_rows_dev == nullptr), "pcl_linear_fwd_rows_f32: row_meta and n_rows_dev come together");
     LinArgs a = {};
     a.A = X; a.B = W; a.bias = bias; a.sc = in_scale; a.sh = in_shift; a.slope = in_slope;
-    a.C = Y; a.stats = stats_ws; a.M = P; a.N = Cout; a.K = Cin;
+    a.C = Y; a.stats = stats_ws; a.M = P; a.N = Cout; a.K = Cin; a.ldc = Cout;
     a.rmeta = reinterpret_cast<const int2*>(row_meta); a.m_dev = n_rows_dev;
     a.a_mode = in_scale ? A_BNACT : A_PLAIN; a.e_mode = E_STORE_STATS;
     return launch_linear(a, as_stream(stream));
@@ -1003,7 +1065,7 @@ extern "C" int pcl_linear_fwd_gmax_f32(const float* X, const float* W, const flo
     PCL_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "pcl_linear_fwd_gmax_f32: in_scale/in_shift must come together");
     LinArgs a = {};
     a.A = X; a.B = W; a.bias = bias; a.sc = in_scale; a.sh = in_shift; a.slope = in_slope;
-    a.C = Y; a.stats = stats_ws; a.M = P; a.N = Cout; a.K = Cin; a.ns = ns;
+    a.C = Y; a.stats = stats_ws; a.M = P; a.N = Cout; a.K = Cin; a.ldc = Cout; a.ns = ns;
     a.gmax = gmax; a.gmin = gmin; a.gamax = gamax; a.gamin = gamin;
     a.a_mode = in_scale ? A_BNACT : A_PLAIN; a.e_mode = E_STORE_STATS;
     return launch_linear(a, as_stream(stream));
@@ -1026,21 +1088,21 @@ extern "C" int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const
                                           const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
                                           int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                                           float prev_slope, float* dUprev, double* stats_ws, const int32_t* row_meta,
-                                          const int32_t* n_rows_dev, int first_col, void* stream);
+                                          const int32_t* n_rows_dev, int first_col, int out_stride, void* stream);
 
 extern "C" int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2, const float* mu,
                                      const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
                                      int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                                      float prev_slope, float* dUprev, double* stats_ws, void* stream) {
     return pcl_linear_bwd_dx_rows_f32(dU, Y, a_, k1, k2, mu, arg, gz, ns, Wt, P, Cout, Cin, Yprev, prev_scale, prev_shift, prev_slope,
-                                      dUprev, stats_ws, nullptr, nullptr, 0, stream);
+                                      dUprev, stats_ws, nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2, const float* mu,
                                           const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
                                           int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                                           float prev_slope, float* dUprev, double* stats_ws, const int32_t* row_meta,
-                                          const int32_t* n_rows_dev, int first_col, void* stream) {
+                                          const int32_t* n_rows_dev, int first_col, int out_stride, void* stream) {
     PCL_REQUIRE(Y && a_ && k1 && k2 && mu && Wt && dUprev, "pcl_linear_bwd_dx_f32: null pointer");
     PCL_REQUIRE((dU != nullptr) != (arg != nullptr && gz != nullptr), "pcl_linear_bwd_dx_f32: pass dU or (arg,gz)");
     PCL_REQUIRE(P >= 1 && Cin >= 1 && Cout >= 1 && (dU || ns >= 1), "pcl_linear_bwd_dx_f32: bad sizes");
@@ -1049,7 +1111,8 @@ extern "C" int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const
     a.A = dU; a.A2 = Y; a.B = Wt; a.sc = a_; a.sh = k1; a.k2 = k2; a.mu = mu; a.arg = arg; a.gz = gz; a.ns = ns;
     a.C = dUprev; a.stats = stats_ws; a.Yprev = Yprev; a.esc = prev_scale; a.esh = prev_shift; a.eslope = prev_slope;
     PCL_REQUIRE(first_col >= 0 && first_col < Cin && (first_col == 0 || !Yprev), "pcl_linear_bwd_dx_rows_f32: first_col=%d only for the input gradient", first_col);
-    a.M = P; a.N = Cin; a.K = Cout; a.n_begin = first_col;
+    a.M = P; a.N = Cin; a.K = Cout; a.n_begin = first_col; a.ldc = out_stride > 0 ? out_stride : Cin;
+    PCL_REQUIRE(a.ldc >= Cin && (a.ldc == Cin || !Yprev), "pcl_linear_bwd_dx_rows_f32: out_stride=%d", out_stride);
     a.rmeta = reinterpret_cast<const int2*>(row_meta); a.m_dev = n_rows_dev;
     a.a_mode = dU ? A_DY : A_DY_SPARSE; a.e_mode = Yprev ? E_MASK_STORE_STATS : E_STORE;
     return launch_linear(a, as_stream(stream));

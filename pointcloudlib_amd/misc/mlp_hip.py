@@ -80,9 +80,15 @@ class _FusedMLP(torch.autograd.Function):
         Ys, scales, shifts, means, invstds = [], [], [], [], []
         cur, in_scale, in_shift = x, None, None
         cin = C0
+        W0p = None
         for l in range(L):
             W, bias, gamma, beta, rmean, rvar = params[6 * l:6 * l + 6]
             cout = W.shape[0]
+            if l == 0 and W.shape[1] != cin:
+                # the input rows carry zero columns beyond the layer's fan-in (ops.group_points_compact pads rows to a
+                # multiple of 4 floats so that every kernel moves 16-byte pieces): pad W with zero columns to match
+                assert W.shape[1] < cin, f"input has {cin} columns, first layer expects {W.shape[1]}"
+                W = W0p = torch.nn.functional.pad(W.detach(), (0, cin - W.shape[1]))
             Y = _empty((P, cout), dev)
             rows = _lib.lib().pcl_mlp_stat_rows(P, cout, 0)
             stats = _empty((rows, 2, cout), dev, torch.float64)
@@ -141,7 +147,7 @@ class _FusedMLP(torch.autograd.Function):
         pack = _Pack()
         pack.add("x", x); pack.add_list("Ys", Ys); pack.add_list("scales", scales); pack.add_list("shifts", shifts)
         pack.add_list("means", means); pack.add_list("invstds", invstds); pack.add("out", out); pack.add("arg", arg)
-        pack.add("ymax", ymax); pack.add_list("params", list(params))
+        pack.add("ymax", ymax); pack.add_list("params", list(params)); pack.add("W0p", W0p)
         if rowset is not None:
             pack.add("row_meta", rowset.row_meta); pack.add("group_off", rowset.group_off)
             ctx.rowdims = (rowset.B, rowset.m, rowset.ns)
@@ -187,6 +193,9 @@ class _FusedMLP(torch.autograd.Function):
         gx = None
         for l in range(L - 1, -1, -1):
             W, bias, gamma, beta, _, _ = params[6 * l:6 * l + 6]
+            fan_in = W.shape[1]
+            if l == 0 and sv["W0p"] is not None:
+                W = sv["W0p"]
             cout, cin = W.shape
             a, k1, k2 = (_empty((cout,), dev) for _ in range(3))
             if bn and training:
@@ -214,7 +223,7 @@ class _FusedMLP(torch.autograd.Function):
                       nbytes, _P(rmeta), _P(nrows), st,
                       algo_bytes=_rows_cost(nrows, P, 4 * (cin + (cout if sparse else 2 * cout)), 4 * cin * cout),
                       algo_flops=_rows_cost(nrows, P, 2 * cin * cout, 0), tag=f"dw{cout}x{cin}")
-            grads[6 * l] = dW
+            grads[6 * l] = dW if cin == fan_in else dW[:, :fan_in].contiguous()
             if l > 0 or need_x:
                 Wt = W.t().contiguous()
                 dUp = _empty((P, cin), dev)
@@ -223,9 +232,12 @@ class _FusedMLP(torch.autograd.Function):
                     stats_n = _empty((rows_n, 2, cin), dev, torch.float64)
                 else:
                     rows_n, stats_n = rows, None
+                # zero-padded input rows (cin > fan_in): only the fan_in real columns are computed, the output keeps the
+                # padded row stride (the pad columns are never read: the scatter takes columns [x_grad_from, fan_in))
                 _lib.call("pcl_linear_bwd_dx_rows_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(means[l]), _P(arg) if sparse else None,
-                          _P(gz) if sparse else None, ns or 1, _P(Wt), P, cout, cin, _P(Xprev) if l > 0 else None, _P(psc),
-                          _P(psh), slope, _P(dUp), _P(stats_n), _P(rmeta), _P(nrows), x_grad_from if l == 0 else 0, st,
+                          _P(gz) if sparse else None, ns or 1, _P(Wt), P, cout, fan_in, _P(Xprev) if l > 0 else None, _P(psc),
+                          _P(psh), slope, _P(dUp), _P(stats_n), _P(rmeta), _P(nrows), x_grad_from if l == 0 else 0,
+                          cin if cin != fan_in else 0, st,
                           algo_bytes=_rows_cost(nrows, P, 4 * (cin * (2 if l > 0 else 1) + (cout if sparse else 2 * cout)), 4 * cin * cout),
                           algo_flops=_rows_cost(nrows, P, 2 * cin * cout, 0), tag=f"dx{cout}x{cin}")
                 dU, sparse, stats, rows = dUp, False, stats_n, rows_n

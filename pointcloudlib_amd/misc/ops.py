@@ -193,11 +193,22 @@ class RowSet:
         return self.G * self.ns
 
 
+def group_offsets(cnt):
+    """cnt int32 [B,m] (ball-query hit counts) -> group_off int32 [B*m+1]: exclusive scan of max(cnt,1); the last entry
+    is the number of distinct rows.  Depends on the indices only, so it can be produced with them (side stream)."""
+    cnt = _dev(cnt, "cnt", torch.int32)
+    G = cnt.numel()
+    group_off = torch.empty((G + 1,), dtype=torch.int32, device=cnt.device)
+    _lib.call("pcl_group_offsets_i32", _p(cnt), G, _p(group_off), _stream())
+    return group_off
+
+
 class _GroupCompact(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, new_xyz, feat, idx, cnt, use_xyz):
+    def forward(ctx, xyz, new_xyz, feat, idx, cnt, group_off, use_xyz, pad_to):
         idx = _dev(idx, "idx", torch.int32)
         cnt = _dev(cnt, "cnt", torch.int32)
+        group_off = _dev(group_off, "group_off", torch.int32)
         B, m, ns = idx.shape
         xyz = _dev(xyz, "xyz")
         new_xyz = _dev(new_xyz, "new_xyz")
@@ -205,36 +216,40 @@ class _GroupCompact(torch.autograd.Function):
         N = xyz.shape[1]
         C = 0 if feat is None else feat.shape[2]
         D = (3 if use_xyz else 0) + C
+        S = (D + pad_to - 1) // pad_to * pad_to            # row stride: zero columns up to a multiple of pad_to
         cap = B * m * ns
         dev = idx.device
-        rows = torch.empty((cap, D), dtype=torch.float32, device=dev)
+        rows = torch.empty((cap, S), dtype=torch.float32, device=dev)
         row_meta = torch.empty((cap, 2), dtype=torch.int32, device=dev)
         row_src = torch.empty((cap,), dtype=torch.int32, device=dev)
-        group_off = torch.empty((B * m + 1,), dtype=torch.int32, device=dev)
-        _lib.call("pcl_group_compact_f32", _p(xyz), _p(new_xyz), _p(feat), _p(idx), _p(cnt), B, N, m, ns, C, int(use_xyz),
-                  _p(rows), _p(row_meta), _p(row_src), _p(group_off), _stream())
-        ctx.dims = (B, N, C, D, int(use_xyz), m, ns)
-        ctx.mark_non_differentiable(row_meta, row_src, group_off)
-        ctx.save_for_backward(row_src, group_off)        # outputs: saved properly, never as ctx attributes (no cycles)
-        return rows, row_meta, row_src, group_off
+        _lib.call("pcl_group_compact_f32", _p(xyz), _p(new_xyz), _p(feat), _p(idx), _p(cnt), _p(group_off), B, N, m, ns, C,
+                  int(use_xyz), S, _p(rows), _p(row_meta), _p(row_src), _stream())
+        ctx.dims = (B, N, C, S, int(use_xyz), m, ns)
+        ctx.mark_non_differentiable(row_meta, row_src)
+        ctx.save_for_backward(row_src, group_off)        # saved properly, never as ctx attributes (no cycles)
+        return rows, row_meta, row_src
 
     @staticmethod
     def backward(ctx, grows, *_):
-        B, N, C, D, use_xyz, m, ns = ctx.dims
+        B, N, C, S, use_xyz, m, ns = ctx.dims
         gfeat = None
         if C > 0 and ctx.needs_input_grad[2]:
             row_src, group_off = ctx.saved_tensors
             grows = _dev(grows, "grad")
             gfeat = torch.empty((B, N, C), dtype=torch.float32, device=grows.device)
-            _lib.call("pcl_scatter_rows_add_f32", _p(grows), _p(row_src), _p(group_off[B * m:]), B * m * ns, D,
+            _lib.call("pcl_scatter_rows_add_f32", _p(grows), _p(row_src), _p(group_off[B * m:]), B * m * ns, S,
                       3 if use_xyz else 0, C, B * N, _p(gfeat), _stream())
-        return None, None, gfeat, None, None, None
+        return None, None, gfeat, None, None, None, None, None
 
 
-def group_points_compact(xyz, new_xyz, feature, idx, cnt, use_xyz=True):
-    """Duplicate-compacted grouping: (rows [B*m*ns (capacity), D], RowSet).  Only the first ``group_off[-1]`` rows are
-    valid: the DISTINCT points of every ball-query group in (group, slot) order, each with its multiplicity."""
-    rows, row_meta, row_src, group_off = _GroupCompact.apply(xyz, new_xyz, feature, idx, cnt, bool(use_xyz))
+def group_points_compact(xyz, new_xyz, feature, idx, cnt, use_xyz=True, group_off=None, pad_to=4):
+    """Duplicate-compacted grouping: (rows [B*m*ns (capacity), S], RowSet).  Only the first ``group_off[-1]`` rows are
+    valid: the DISTINCT points of every ball-query group in (group, slot) order, each with its multiplicity.  Rows are
+    ``[xyz - centre | features]`` padded with zero columns to a multiple of ``pad_to`` (S >= 3+C) so that every consumer
+    moves them as 16-byte pieces; ``PointwiseMLP`` pads its first weight matrix to match."""
+    if group_off is None:
+        group_off = group_offsets(cnt)
+    rows, row_meta, row_src = _GroupCompact.apply(xyz, new_xyz, feature, idx, cnt, group_off, bool(use_xyz), int(pad_to))
     B, m, ns = idx.shape
     return rows, RowSet(B, m, ns, row_meta, row_src, group_off)
 

@@ -14,7 +14,8 @@ import torch
 from torch import nn
 
 from ...misc.layers import PointwiseMLP
-from ...misc.ops import BallQueryGrouper, FurthestPointSampler, GroupAll, ball_query, group_points, group_points_compact
+from ...misc.ops import (BallQueryGrouper, FurthestPointSampler, GroupAll, ball_query, group_offsets, group_points,
+                         group_points_compact)
 
 
 class PointNetModuleBase(nn.Module):
@@ -38,7 +39,11 @@ class PointNetModuleBase(nn.Module):
         if self.n_points is None:
             return None, [None] * len(self.groupers)
         new_xyz = self.sampler(xyz)                                             # :45
-        return new_xyz, [ball_query(new_xyz, xyz, g.radius, g.n_samples, return_cnt=True) for g in self.groupers]
+        out = []
+        for g in self.groupers:
+            idx, cnt = ball_query(new_xyz, xyz, g.radius, g.n_samples, return_cnt=True)
+            out.append((idx, cnt, group_offsets(cnt) if self.compact_duplicates else None))
+        return new_xyz, out
 
     def forward(self, xyz: torch.Tensor, feature: Optional[torch.Tensor], sampling=None):
         """xyz [B,N,3], feature [B,N,C] -> (new_xyz [B,n_points,3] | None, new_feature [B,n_points,C']).
@@ -51,7 +56,7 @@ class PointNetModuleBase(nn.Module):
                 new_feature_list.append(mlp(grouped, group_max=grouped.shape[2]))
             elif self.compact_duplicates and mlp.resolved_backend(xyz) == "hip":
                 # ball-query padding repeats the first hit: run the MLP on the distinct rows only (see ops.RowSet)
-                rows, rowset = group_points_compact(xyz, new_xyz, feature, ic[0], ic[1], grouper.use_xyz)
+                rows, rowset = group_points_compact(xyz, new_xyz, feature, ic[0], ic[1], grouper.use_xyz, group_off=ic[2])
                 new_feature_list.append(mlp(rows, rowset=rowset, x_grad_from=3 if grouper.use_xyz else 0))
             else:
                 grouped = group_points(xyz, new_xyz, feature, ic[0], grouper.use_xyz)     # [B, m, ns, C]   :51
@@ -120,7 +125,7 @@ class PointNet2_cls(nn.Module):
         cur = torch.cuda.current_stream()
         if stream is None:
             stream = cur
-        if stream is not cur:
+        if stream != cur:
             stream.wait_stream(cur)                       # xyz may have just been produced on the current stream
         out = []
         with torch.cuda.stream(stream), torch.no_grad():
@@ -136,7 +141,7 @@ class PointNet2_cls(nn.Module):
     def forward(self, xyz, feature, sampling=None):
         if sampling is not None:
             cur = torch.cuda.current_stream()
-            if sampling["stream"] is not cur:
+            if sampling["stream"] != cur:
                 cur.wait_event(sampling["event"])
                 for new_xyz, idxs in sampling["levels"]:              # allocator safety across streams
                     for t in [new_xyz] + [u for ic in idxs if ic is not None for u in ic]:
