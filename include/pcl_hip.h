@@ -167,12 +167,12 @@ int pcl_maxgrad_prep_f32(const float* gout, const float* out, const float* ymax,
 int pcl_bn_bwd_consts_f32(const double* stats_ws, int stat_rows, const float* gamma, const float* mean,
                           const float* invstd, int P, int C, float* dgamma, float* dbeta, float* a_out,
                           float* k1, float* k2, void* stream);
-/* dUprev[P,Cin] = act'_prev(.) * (dy[P,Cout] Wt[Cin,Cout]^T), dy = a*du - k1 - k2*(Y - mu) formed on the fly from
+/* dUprev[P,Cin] = act'_prev(.) * (dy[P,Cout] W[Cout,Cin]), dy = a*du - k1 - k2*(Y - mu) formed on the fly from
  * dU (dense) or from (arg, gz, ns) (sparse max gradient; pass dU = NULL).  With Yprev: masked by the layer
  * below's activation and stats_ws gets (sum dUprev, sum dUprev*Yprev); Yprev NULL: plain store (input grad).
- * Wt is W transposed, [Cin,Cout] row-major. */
+ * W is the layer's weight as stored, [Cout,Cin] row-major (no transposed copy is needed). */
 int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2, const float* mu,
-                          const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
+                          const int32_t* arg, const float* gz, int ns, const float* W, int P, int Cout,
                           int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                           float prev_slope, float* dUprev, double* stats_ws, void* stream);
 /* dW[Cout,Cin] = dy^T act_prev(Xprev);  workspace of pcl_linear_bwd_dw_workspace_bytes() bytes. */
@@ -206,12 +206,13 @@ int pcl_linear_fwd_rows_f32(const float* X, const float* W, const float* bias, c
 int pcl_bn_act_max_rows_f32(const float* Y, const int32_t* group_off, const float* scale, const float* shift,
                             float slope, int G, int C, float* out, int32_t* arg, float* ymax, void* stream);
 int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2, const float* mu,
-                               const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
+                               const int32_t* arg, const float* gz, int ns, const float* W, int P, int Cout,
                                int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                                float prev_slope, float* dUprev, double* stats_ws, const int32_t* row_meta,
                                const int32_t* n_rows_dev, int first_col /* input gradient only: columns below it
                                (the xyz part of a grouped tensor) are skipped and left unwritten */,
-                               int out_stride /* row stride of dUprev in floats, 0 = Cin (zero-padded input rows) */, void* stream);
+                               int cin_stride /* row stride, in floats, of W and of dUprev when the layer's input rows are zero-padded
+                               beyond Cin (0 = Cin) */, void* stream);
 int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2, const float* mu,
                                const int32_t* arg, const float* gz, int ns, const float* Xprev,
                                const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,

@@ -36,7 +36,8 @@ enum EMode { E_STORE_STATS = 0, E_MASK_STORE_STATS = 1, E_STORE = 2 };
 struct LinArgs {
     const float* A;      // [M,K] primary rows (X / Y_prev / dU)
     const float* A2;     // [M,K] pre-BN output y of THIS layer (A_DY, A_DY_SPARSE)
-    const float* B;      // [N,K] weights (forward: W[Cout,Cin]; dX: W^T[Cin,Cout])
+    int ldb;             // BT only: row stride of B
+    const float* B;      // forward: W[N=Cout][K=Cin]; dX (BT): the same W[K=Cout][ldb >= N=Cin], consumed K-major
     const float* bias;   // [N] or null
     const float* sc;     // [K] A_BNACT: scale; A_DY*: a = gamma*invstd
     const float* sh;     // [K] A_BNACT: shift; A_DY*: k1
@@ -222,9 +223,26 @@ __device__ __forceinline__ void store_a(const LinArgs& p, float* sX, int k0, int
     }
 }
 
-template <bool VEC, int ROWS>
+// BT: the B operand is given K-major, B[k][n] with row stride ldb (the dX GEMMs consume the layer's weight W[Cout][Cin]
+// as it is stored instead of a transposed copy); a lane then reads 4 consecutive n for one k and the tile is transposed
+// on its way into LDS (lanes run over k, so the four scalar LDS writes are conflict-free).
+template <bool VEC, int ROWS, bool BT>
 __device__ __forceinline__ void load_b(const LinArgs& p, int n0, int k0, int tid, Stage<VEC, ROWS>& st) {
-    if constexpr (VEC) {
+    if constexpr (BT && VEC) {
+        const int k = min(k0 + (tid & 31), p.K - 1);
+#pragma unroll
+        for (int i = 0; i < ROWS / 32; ++i) {
+            const int n = min(n0 + (tid >> 5) * 4 + 32 * i, p.ldb - 4);
+            st.v[i] = *reinterpret_cast<const float4*>(p.B + (size_t)k * p.ldb + n);
+        }
+    } else if constexpr (BT) {
+        const int k = min(k0 + (tid & 31), p.K - 1);
+#pragma unroll
+        for (int i = 0; i < ROWS / 8; ++i) {
+            const int n = min(n0 + (tid >> 5) + 8 * i, p.N - 1);
+            st.s[i] = p.B[(size_t)k * p.ldb + n];
+        }
+    } else if constexpr (VEC) {
         const int k = min(k0 + (tid & 7) * 4, p.K - 4);
 #pragma unroll
         for (int i = 0; i < ROWS / 32; ++i) {
@@ -241,9 +259,20 @@ __device__ __forceinline__ void load_b(const LinArgs& p, int n0, int k0, int tid
     }
 }
 
-template <bool VEC, int ROWS>
+template <bool VEC, int ROWS, bool BT>
 __device__ __forceinline__ void store_b(const LinArgs& p, float* sX, int n0, int k0, int tid, const Stage<VEC, ROWS>& st) {
-    if constexpr (VEC) {
+    if constexpr (BT && VEC) {
+        const bool kin = k0 + (tid & 31) < p.K;
+#pragma unroll
+        for (int i = 0; i < ROWS / 32; ++i) {
+            const int rl = (tid >> 5) * 4 + 32 * i;
+            const float4 v = st.v[i];
+            sX[(rl + 0) * LDS_LD + (tid & 31)] = (kin && n0 + rl + 0 < p.N) ? v.x : 0.f;
+            sX[(rl + 1) * LDS_LD + (tid & 31)] = (kin && n0 + rl + 1 < p.N) ? v.y : 0.f;
+            sX[(rl + 2) * LDS_LD + (tid & 31)] = (kin && n0 + rl + 2 < p.N) ? v.z : 0.f;
+            sX[(rl + 3) * LDS_LD + (tid & 31)] = (kin && n0 + rl + 3 < p.N) ? v.w : 0.f;
+        }
+    } else if constexpr (VEC) {
         const bool kin = k0 + (tid & 7) * 4 < p.K;
 #pragma unroll
         for (int i = 0; i < ROWS / 32; ++i) {
@@ -286,6 +315,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
     LinArgs p = p_in;
     if (p.m_dev) p.M = *p.m_dev;                       // compacted rows: the row count lives on the device
     constexpr int TBM = 128, TBN = 64 * TN;
+    constexpr bool BT = AM >= A_DY;              // backward: B is the weight matrix as stored, [K][N]
     __shared__ __attribute__((aligned(16))) float sA[TBM * LDS_LD];
     __shared__ __attribute__((aligned(16))) float sB[TBN * LDS_LD];
     // multiplicities of the tile's rows for the BatchNorm sums of compacted rows: prefetched with the operands and kept
@@ -320,7 +350,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
     int staged_k0 = 0;
     if (mt < m_tiles) {
         load_a<AM, VEC, TBM, RAG>(p, mt * TBM, 0, tid, ra);
-        load_b<VEC, TBN>(p, n0, 0, tid, rb);
+        load_b<VEC, TBN, BT>(p, n0, 0, tid, rb);
         if constexpr (NEEDW) wmeta = p.rmeta[min(mt * TBM + (tid & (TBM - 1)), p.M - 1)].y;
     }
     for (; mt < m_tiles; mt += gridDim.x) {
@@ -336,7 +366,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
         for (int k0 = 0; k0 < p.K; k0 += BK) {
             __syncthreads();                       // previous step's fragment reads are done
             store_a<AM, VEC, TBM>(p, sA, staged_k0, tid, ra);
-            store_b<VEC, TBN>(p, sB, n0, staged_k0, tid, rb);
+            store_b<VEC, TBN, BT>(p, sB, n0, staged_k0, tid, rb);
             if constexpr (NEEDW) { if (tid < TBM) sW[tid] = (float)(wmeta >> 16); }
             __syncthreads();
             // request the next step's operands (next k block, or the first k block of this workgroup's next tile)
@@ -346,7 +376,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                 staged_k0 = nk;
                 if (nmt < m_tiles) {
                     load_a<AM, VEC, TBM, RAG>(p, nmt * TBM, nk, tid, ra);
-                    load_b<VEC, TBN>(p, n0, nk, tid, rb);
+                    load_b<VEC, TBN, BT>(p, n0, nk, tid, rb);
                     if constexpr (NEEDW) wmeta = p.rmeta[min(nmt * TBM + (tid & (TBM - 1)), p.M - 1)].y;
                 }
             }
@@ -811,18 +841,29 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 // mean/var from the fp64 partials; folded scale/shift; Jittor-style running statistics (biased variance).
 // column sums of a [rows][2][C] fp64 partial workspace: 4 channels x 64 row-lanes per 256-thread block
 __device__ __forceinline__ void stat_colsum(const double* __restrict__ stats, int rows, int C, int c, int ry, double& s,
-                                            double& q, double* red /*[2][64][4]*/) {
-    s = 0.0; q = 0.0;
-    if (c < C)
-        for (int r = ry; r < rows; r += 64) { s += stats[(size_t)r * 2 * C + c]; q += stats[(size_t)r * 2 * C + C + c]; }
-    const int cl = threadIdx.x & 3;
-    red[(0 * 64 + ry) * 4 + cl] = s; red[(1 * 64 + ry) * 4 + cl] = q;
-    __syncthreads();
-    for (int h = 32; h >= 1; h >>= 1) {
-        if (ry < h) { red[(0 * 64 + ry) * 4 + cl] += red[(0 * 64 + ry + h) * 4 + cl]; red[(1 * 64 + ry) * 4 + cl] += red[(1 * 64 + ry + h) * 4 + cl]; }
-        __syncthreads();
+                                            double& q, double* red /*[2][4][4]*/) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    if (c < C) {
+        const double* b = stats + c;
+        const size_t st = (size_t)2 * C;
+        int r = ry;
+        for (; r + 192 < rows; r += 256) {          // four independent row streams in flight per lane
+            s0 += b[(size_t)r * st]; q0 += b[(size_t)r * st + C];
+            s1 += b[(size_t)(r + 64) * st]; q1 += b[(size_t)(r + 64) * st + C];
+            s2 += b[(size_t)(r + 128) * st]; q2 += b[(size_t)(r + 128) * st + C];
+            s3 += b[(size_t)(r + 192) * st]; q3 += b[(size_t)(r + 192) * st + C];
+        }
+        for (; r < rows; r += 64) { s0 += b[(size_t)r * st]; q0 += b[(size_t)r * st + C]; }
     }
-    s = red[cl]; q = red[64 * 4 + cl];
+    s = (s0 + s1) + (s2 + s3); q = (q0 + q1) + (q2 + q3);
+    // thread = ry*4 + channel-in-block: a wave holds 16 row-lanes of each of the 4 channels (lane bits 2..5)
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
+    const int cl = threadIdx.x & 3, wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < 4) { red[wave * 4 + cl] = s; red[16 + wave * 4 + cl] = q; }
+    __syncthreads();
+    s = (red[cl] + red[4 + cl]) + (red[8 + cl] + red[12 + cl]);
+    q = (red[16 + cl] + red[20 + cl]) + (red[24 + cl] + red[28 + cl]);
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ stats, int rows, const float* __restrict__ gamma,
@@ -979,7 +1020,8 @@ static void linear_grid(int M, int N, bool bwd, int& gx, int& n_tiles, bool& nar
 template <int AM, int EM, int GM = 0, bool RAG = false>
 static int launch_linear_t(const LinArgs& a, hipStream_t st) {
     const bool vec = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0) && (!a.A2 || (reinterpret_cast<uintptr_t>(a.A2) & 15) == 0);
+                     ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0) && (!a.A2 || (reinterpret_cast<uintptr_t>(a.A2) & 15) == 0) &&
+                     (AM < A_DY || a.ldb % 4 == 0);
     int gx, n_tiles; bool narrow;
     linear_grid(a.M, a.N - a.n_begin, AM >= A_DY, gx, n_tiles, narrow);
     dim3 grid(gx, n_tiles);
@@ -1085,34 +1127,34 @@ extern "C" int pcl_group_minmax_finalize_f32(const float* gmax, const float* gmi
 }
 
 extern "C" int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2, const float* mu,
-                                          const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
+                                          const int32_t* arg, const float* gz, int ns, const float* W, int P, int Cout,
                                           int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                                           float prev_slope, float* dUprev, double* stats_ws, const int32_t* row_meta,
-                                          const int32_t* n_rows_dev, int first_col, int out_stride, void* stream);
+                                          const int32_t* n_rows_dev, int first_col, int cin_stride, void* stream);
 
 extern "C" int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2, const float* mu,
-                                     const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
+                                     const int32_t* arg, const float* gz, int ns, const float* W, int P, int Cout,
                                      int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                                      float prev_slope, float* dUprev, double* stats_ws, void* stream) {
-    return pcl_linear_bwd_dx_rows_f32(dU, Y, a_, k1, k2, mu, arg, gz, ns, Wt, P, Cout, Cin, Yprev, prev_scale, prev_shift, prev_slope,
+    return pcl_linear_bwd_dx_rows_f32(dU, Y, a_, k1, k2, mu, arg, gz, ns, W, P, Cout, Cin, Yprev, prev_scale, prev_shift, prev_slope,
                                       dUprev, stats_ws, nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2, const float* mu,
-                                          const int32_t* arg, const float* gz, int ns, const float* Wt, int P, int Cout,
+                                          const int32_t* arg, const float* gz, int ns, const float* W, int P, int Cout,
                                           int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                                           float prev_slope, float* dUprev, double* stats_ws, const int32_t* row_meta,
-                                          const int32_t* n_rows_dev, int first_col, int out_stride, void* stream) {
-    PCL_REQUIRE(Y && a_ && k1 && k2 && mu && Wt && dUprev, "pcl_linear_bwd_dx_f32: null pointer");
+                                          const int32_t* n_rows_dev, int first_col, int cin_stride, void* stream) {
+    PCL_REQUIRE(Y && a_ && k1 && k2 && mu && W && dUprev, "pcl_linear_bwd_dx_f32: null pointer");
     PCL_REQUIRE((dU != nullptr) != (arg != nullptr && gz != nullptr), "pcl_linear_bwd_dx_f32: pass dU or (arg,gz)");
     PCL_REQUIRE(P >= 1 && Cin >= 1 && Cout >= 1 && (dU || ns >= 1), "pcl_linear_bwd_dx_f32: bad sizes");
     PCL_REQUIRE(!Yprev || (prev_scale && prev_shift && stats_ws), "pcl_linear_bwd_dx_f32: masked mode needs scale/shift/stats");
     LinArgs a = {};
-    a.A = dU; a.A2 = Y; a.B = Wt; a.sc = a_; a.sh = k1; a.k2 = k2; a.mu = mu; a.arg = arg; a.gz = gz; a.ns = ns;
+    a.A = dU; a.A2 = Y; a.B = W; a.sc = a_; a.sh = k1; a.k2 = k2; a.mu = mu; a.arg = arg; a.gz = gz; a.ns = ns;
     a.C = dUprev; a.stats = stats_ws; a.Yprev = Yprev; a.esc = prev_scale; a.esh = prev_shift; a.eslope = prev_slope;
     PCL_REQUIRE(first_col >= 0 && first_col < Cin && (first_col == 0 || !Yprev), "pcl_linear_bwd_dx_rows_f32: first_col=%d only for the input gradient", first_col);
-    a.M = P; a.N = Cin; a.K = Cout; a.n_begin = first_col; a.ldc = out_stride > 0 ? out_stride : Cin;
-    PCL_REQUIRE(a.ldc >= Cin && (a.ldc == Cin || !Yprev), "pcl_linear_bwd_dx_rows_f32: out_stride=%d", out_stride);
+    a.M = P; a.N = Cin; a.K = Cout; a.n_begin = first_col; a.ldc = a.ldb = cin_stride > 0 ? cin_stride : Cin;
+    PCL_REQUIRE(a.ldc >= Cin && (a.ldc == Cin || !Yprev), "pcl_linear_bwd_dx_rows_f32: cin_stride=%d", cin_stride);
     a.rmeta = reinterpret_cast<const int2*>(row_meta); a.m_dev = n_rows_dev;
     a.a_mode = dU ? A_DY : A_DY_SPARSE; a.e_mode = Yprev ? E_MASK_STORE_STATS : E_STORE;
     return launch_linear(a, as_stream(stream));

@@ -225,7 +225,6 @@ class _FusedMLP(torch.autograd.Function):
                       algo_flops=_rows_cost(nrows, P, 2 * cin * cout, 0), tag=f"dw{cout}x{cin}")
             grads[6 * l] = dW if cin == fan_in else dW[:, :fan_in].contiguous()
             if l > 0 or need_x:
-                Wt = W.t().contiguous()
                 dUp = _empty((P, cin), dev)
                 if l > 0:
                     rows_n = lib.pcl_mlp_stat_rows(P, cin, 1)
@@ -235,7 +234,7 @@ class _FusedMLP(torch.autograd.Function):
                 # zero-padded input rows (cin > fan_in): only the fan_in real columns are computed, the output keeps the
                 # padded row stride (the pad columns are never read: the scatter takes columns [x_grad_from, fan_in))
                 _lib.call("pcl_linear_bwd_dx_rows_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(means[l]), _P(arg) if sparse else None,
-                          _P(gz) if sparse else None, ns or 1, _P(Wt), P, cout, fan_in, _P(Xprev) if l > 0 else None, _P(psc),
+                          _P(gz) if sparse else None, ns or 1, _P(W), P, cout, fan_in, _P(Xprev) if l > 0 else None, _P(psc),
                           _P(psh), slope, _P(dUp), _P(stats_n), _P(rmeta), _P(nrows), x_grad_from if l == 0 else 0,
                           cin if cin != fan_in else 0, st,
                           algo_bytes=_rows_cost(nrows, P, 4 * (cin * (2 if l > 0 else 1) + (cout if sparse else 2 * cout)), 4 * cin * cout),
