@@ -22,4 +22,7 @@ def soft_cross_entropy_loss(output, target, smoothing=True):
 
 
 def make_sgd(params, lr=0.02, momentum=0.9, weight_decay=0.0):
-    return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay)
+    params = list(params)
+    # one multi-tensor kernel for the whole update on the GPU (same arithmetic as the default three-kernel foreach path)
+    fused = bool(params) and all(p.is_cuda for p in params)
+    return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay, fused=fused)
