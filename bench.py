@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--no-prefetch-sampling", dest="prefetch_sampling", action="store_false",
                     help="run FPS/ball query inline at the head of each forward instead of one step ahead on a side stream")
     ap.add_argument("--profile-all", action="store_true", help="print a per-entry-point event-timed table to stderr")
+    ap.add_argument("--no-settle", dest="settle", action="store_false", help="skip the untimed clock-settling windows (profiler passes)")
+    ap.add_argument("--dump-launch-order", default=None, help="write the (entry point, shape) sequence of one step as JSON")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -162,7 +164,7 @@ def main():
     # clocks, allocator pools and the sampling pipeline settle over the first ~50 ms; short runs (W=5, K=30) otherwise
     # swing by 10 % from run to run.  Untimed, like the W steps above.
     prev = None
-    for _ in range(12):                      # 10-step windows until two consecutive ones agree within 2 % (<= 120 steps)
+    for _ in range(12 if args.settle else 0):                      # 10-step windows until two consecutive ones agree within 2 % (<= 120 steps)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10):
             step(it); it += 1
@@ -184,6 +186,12 @@ def main():
             tf = v["algo_flops"] / (v["avg_ms"] * 1e-3) / 1e12 if v["algo_flops"] else 0
             print(f"{name:28s} {tag:14s} n/step={v['launches'] / 3:4.1f} avg={v['avg_ms']:8.4f} ms  {gbs:8.1f} GB/s {tf:7.2f} TF",
                   file=sys.stderr)
+    if args.dump_launch_order and rank == 0:
+        _lib.PROFILER = _lib.KernelTimer()
+        step(it); it += 1
+        torch.cuda.synchronize()
+        json.dump({"step_launch_order": _lib.PROFILER.order}, open(args.dump_launch_order, "w"))
+        _lib.PROFILER = None
     # pick the dominant own kernel (untimed 2-step pre-pass with every entry point bracketed by events)
     target = args.roofline_kernel
     if target == "auto":

@@ -129,6 +129,7 @@ class KernelTimer:
         self.tags = None if tags is None else set(tags)          # restrict to these launch shapes
         self.max_records = max_records                           # per (name, tag): timing events perturb the stream
         self.records = {}                                        # (each record is a marker packet), so bound them
+        self.order = []                                          # (name, tag) in launch order
 
     def want(self, name, tag=None):
         if self.names is not None and name not in self.names:
@@ -150,6 +151,7 @@ class KernelTimer:
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         self.records.setdefault((name, tag), []).append((start, ev, algo_bytes, algo_flops))
+        self.order.append((name, tag))
 
     def summary(self):
         """{(name, tag): dict(launches, avg_ms, algo_bytes, algo_flops)} -- call after a device sync."""
