@@ -169,7 +169,12 @@ def main():
         for _ in range(10):
             step(it); it += 1
         torch.cuda.synchronize(); cur = time.perf_counter() - t0
-        if prev is not None and abs(cur - prev) <= 0.02 * cur:
+        stop = prev is not None and abs(cur - prev) <= 0.02 * cur
+        if distributed:                      # every step holds a collective: all ranks must leave together
+            flag = torch.tensor([1.0 if stop else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            stop = bool(flag.item() > 0.5)
+        if stop:
             break
         prev = cur
     if args.profile_all and rank == 0:
