@@ -177,7 +177,7 @@ def main():
         if stop:
             break
         prev = cur
-    if args.profile_all and rank == 0:
+    if args.profile_all:                                # every rank steps (collectives); rank 0 prints
         _lib.PROFILER = _lib.KernelTimer()
         for _ in range(3):
             step(it); it += 1
@@ -185,17 +185,19 @@ def main():
         summ = _lib.PROFILER.summary()
         _lib.PROFILER = None
         tot = sum(v["total_ms"] for v in summ.values()) / 3
-        print(f"--- own C-ABI calls, per step total {tot:.3f} ms", file=sys.stderr)
-        for (name, tag), v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
-            gbs = v["algo_bytes"] / (v["avg_ms"] * 1e-3) / 1e9 if v["algo_bytes"] else 0
-            tf = v["algo_flops"] / (v["avg_ms"] * 1e-3) / 1e12 if v["algo_flops"] else 0
-            print(f"{name:28s} {tag:14s} n/step={v['launches'] / 3:4.1f} avg={v['avg_ms']:8.4f} ms  {gbs:8.1f} GB/s {tf:7.2f} TF",
-                  file=sys.stderr)
-    if args.dump_launch_order and rank == 0:
+        if rank == 0:
+            print(f"--- own C-ABI calls, per step total {tot:.3f} ms", file=sys.stderr)
+            for (name, tag), v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
+                gbs = v["algo_bytes"] / (v["avg_ms"] * 1e-3) / 1e9 if v["algo_bytes"] else 0
+                tf = v["algo_flops"] / (v["avg_ms"] * 1e-3) / 1e12 if v["algo_flops"] else 0
+                print(f"{name:28s} {tag:14s} n/step={v['launches'] / 3:4.1f} avg={v['avg_ms']:8.4f} ms  {gbs:8.1f} GB/s {tf:7.2f} TF",
+                      file=sys.stderr)
+    if args.dump_launch_order:
         _lib.PROFILER = _lib.KernelTimer()
         step(it); it += 1
         torch.cuda.synchronize()
-        json.dump({"step_launch_order": _lib.PROFILER.order}, open(args.dump_launch_order, "w"))
+        if rank == 0:
+            json.dump({"step_launch_order": _lib.PROFILER.order}, open(args.dump_launch_order, "w"))
         _lib.PROFILER = None
     # pick the dominant own kernel (untimed 2-step pre-pass with every entry point bracketed by events)
     target = args.roofline_kernel
