@@ -248,3 +248,25 @@ def test_full_size_digests(dev):
     pts = synth.gauss_ball(c["B"], c["N"], c["seed"])
     x = T(np.ascontiguousarray(pts.transpose(0, 2, 1)), dev)
     assert sha(ops.knn_indices(x, x, c["k"]).cpu().numpy()) == c["knn_sha"]
+
+
+def test_degenerate_sizes(oracle, dev):
+    """Smallest legal shapes of every index op: one point, one sample, one neighbour, one cloud."""
+    one = np.array([[[0.5, -0.25, 0.125]]], np.float32)                       # B=1, N=1
+    idx, new_xyz = ops.furthest_point_sample(T(one, dev), 1)
+    assert idx.cpu().numpy().tolist() == [[0]] and np.array_equal(new_xyz.cpu().numpy(), one)
+    bq, cnt = ops.ball_query(T(one, dev), T(one, dev), 0.1, 1, return_cnt=True)
+    assert bq.cpu().numpy().tolist() == [[[0]]] and cnt.cpu().numpy().tolist() == [[1]]
+    assert ops.knn_indices(T(one.transpose(0, 2, 1), dev), T(one.transpose(0, 2, 1), dev), 1).cpu().numpy().tolist() == [[[0]]]
+    g = ops.group_points(T(one, dev), T(one, dev), T(one, dev), bq, True).cpu().numpy()
+    assert g.shape == (1, 1, 1, 6) and np.array_equal(g[0, 0, 0], np.concatenate([np.zeros(3, np.float32), one[0, 0]]))
+    pts = synth.gauss_ball(1, 3, 5)                                            # m == N == 3: a permutation of the cloud
+    for S in (1, 2):
+        want = oracle.fps(pts, 3, block_size=S)
+        assert np.array_equal(ops.furthest_point_sample(T(pts, dev), 3, tie_stride=S)[0].cpu().numpy(), want)
+    idx = ops.ball_query(T(pts, dev), T(pts, dev), 10.0, 5).cpu().numpy()     # ns > N: every row = 0,1,2 padded with 0
+    assert np.array_equal(idx, oracle.ball_query(pts, pts, 10.0, 5))
+    kk = ops.knn_indices(T(pts.transpose(0, 2, 1), dev), T(pts.transpose(0, 2, 1), dev), 3).cpu().numpy()
+    assert np.array_equal(kk, oracle.knn(np.ascontiguousarray(pts.transpose(0, 2, 1)), np.ascontiguousarray(pts.transpose(0, 2, 1)), 3))
+    with pytest.raises((ValueError, RuntimeError)):
+        ops.furthest_point_sample(T(pts, dev), 4)                              # n_samples > N  (misc/ops.py:269)
