@@ -119,6 +119,15 @@ int pcl_three_interp_bwd_f32(const float* gout, const int32_t* idx3, const float
  *   density[b,i] = mean_j exp(-|x_i-x_j|^2 / (2 bw^2)) / (2.5 bw), without the [B,N,N] matrix (direct-form d2). */
 int pcl_density_f32(const float* xyz, int B, int N, float bandwidth, float* density_out, void* stream);
 
+/* PointConv's density-weighted contraction (misc/pointconv_utils.py:393-394, :319-320):
+ *   out[g,c,m] = sum_s feat[g,s,c] * density[g,s] * weights[g,s,m]      feat [G,ns,C], density [G,ns], weights [G,ns,M],
+ * out [G,C,M] (= the reference's `matmul((new_points*density)^T, weights).reshape(B,S,-1)` rows).  M must be 16
+ * (WeightNet(3,16)).  The backward entry point returns all three input gradients. */
+int pcl_pointconv_contract_f32(const float* feat, const float* density, const float* weights, int G, int ns, int C, int M,
+                               float* out, void* stream);
+int pcl_pointconv_contract_bwd_f32(const float* dout, const float* feat, const float* density, const float* weights, int G,
+                                   int ns, int C, int M, float* dfeat, float* dweights, float* ddensity, void* stream);
+
 /* ---- per-group pointwise MLP: 1x1 conv + BatchNorm(train) + (Leaky)ReLU [+ max over the group] ---------
  * Replaces the nn.Conv(k=1)+nn.BatchNorm+nn.ReLU stacks of build_mlps (networks/cls/pointnet2.py:18-31;
  * DGCNN conv1-4 networks/cls/dgcnn.py:72-83; FP stacks misc/ops.py:54-64) and the max over the group

@@ -8,8 +8,8 @@ Same function/class names and argument meaning: ``farthest_point_sample`` :74, `
 What runs where: FPS (no origin skip, caller-supplied start index -- the reference draws it with
 np.random.randint, :88), k-NN grouping (HIP KNN kernel, direct-form distances, ties -> lower index; the reference
 uses matmul-form distances + a full argsort, :120-131 -- parity unpinned, documented), gathers, Gaussian KDE
-(pcl_density_f32, no [B,N,N] matrix) and every Conv+BN+ReLU stack (fused MFMA MLP) are HIP; the per-point
-(C x ns)(ns x 16) contraction and the density multiply are small PyTorch ops (rocBLAS batched GEMM).
+(pcl_density_f32, no [B,N,N] matrix), every Conv+BN+ReLU stack (fused MFMA MLP) and the density-weighted per-point
+(C x ns)(ns x 16) contraction (pcl_pointconv_contract_f32, one streaming pass instead of multiply + transpose + bmm) are HIP.
 
 Upstream bugs handled: ``sample_and_group_all`` is called at :380 but defined nowhere --
 implemented here with the original PointConv semantics (one group of all N points, xyz relative to the cloud
@@ -75,6 +75,39 @@ def sample_and_group_all(xyz, points, density_scale=None):
     return new_xyz, new_points, grouped_xyz, density_scale.view(B, 1, N, 1)
 
 
+class _PointConvContract(torch.autograd.Function):
+    """out[B,S,C*16] = sum_s feat[B,S,ns,C] * density[B,S,ns,1] * weights[B,S,ns,16]   (:393-394)."""
+
+    @staticmethod
+    def forward(ctx, feat, density, weights):
+        feat, density, weights = _dev(feat, "feat"), _dev(density, "density"), _dev(weights, "weights")
+        B, S, ns, C = feat.shape
+        M = weights.shape[-1]
+        out = torch.empty((B, S, C * M), dtype=torch.float32, device=feat.device)
+        _lib.call("pcl_pointconv_contract_f32", _p(feat), _p(density), _p(weights), B * S, ns, C, M, _p(out), _stream(),
+                  algo_bytes=4 * B * S * (ns * (C + 1 + M) + C * M), algo_flops=2 * B * S * ns * C * M)
+        ctx.save_for_backward(feat, density, weights)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        feat, density, weights = ctx.saved_tensors
+        B, S, ns, C = feat.shape
+        M = weights.shape[-1]
+        gout = _dev(gout, "grad")
+        dfeat, dw, dd = torch.empty_like(feat), torch.empty_like(weights), torch.empty_like(density)
+        _lib.call("pcl_pointconv_contract_bwd_f32", _p(gout), _p(feat), _p(density), _p(weights), B * S, ns, C, M, _p(dfeat),
+                  _p(dw), _p(dd), _stream())
+        return dfeat, dd, dw
+
+
+def pointconv_contract(new_points, grouped_density, weights):
+    """The density multiply + per-point (C x ns)(ns x 16) contraction of PointConv as one HIP kernel:
+    new_points [B,S,ns,C], grouped_density [B,S,ns,1], weights [B,S,ns,16] -> [B,S,C*16]."""
+    B, S, ns, _ = new_points.shape
+    return _PointConvContract.apply(new_points, grouped_density.reshape(B, S, ns), weights)
+
+
 class DensityNet(nn.Module):
     """Conv1d 1->8->8->1, each + BatchNorm1d + ReLU (:186-218; the sigmoid branch never fires upstream)."""
 
@@ -126,9 +159,7 @@ class PointConvDensitySetAbstraction(nn.Module):
                 self.npoint, self.nsample, xyz, points, density_scale, start_idx)
         new_points = self.mlp(new_points.contiguous())                                   # [B,S,ns,C]   :384-389
         weights = self.weightnet(grouped_xyz_norm.contiguous())                          # [B,S,ns,16]  :391-392
-        new_points = new_points * grouped_density                                         # :393
-        S = new_points.shape[1]
-        new_points = torch.matmul(new_points.transpose(2, 3), weights).reshape(B, S, -1)   # [B,S,C*16]   :394
+        new_points = pointconv_contract(new_points, grouped_density, weights)            # [B,S,C*16]   :393-394
         new_points = self.linear(new_points)                                              # :395-397
         return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
 
@@ -167,8 +198,7 @@ class PointConvDensitySetInterpolation(nn.Module):
             N, self.nsample, xyz1, interpolated, density_scale, start_idx)                # :307
         new_points = self.mlp(new_points.contiguous())                                    # :311-315
         weights = self.weightnet(grouped_xyz_norm.contiguous())                           # :317-318
-        new_points = new_points * grouped_density                                         # :319
-        new_points = torch.matmul(new_points.transpose(2, 3), weights).reshape(B, N, -1)  # :320
+        new_points = pointconv_contract(new_points, grouped_density, weights)            # :319-320
         return self.linear(new_points).permute(0, 2, 1)                                   # :321-323
 
     def execute(self, *a, **k):

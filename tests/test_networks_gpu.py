@@ -201,3 +201,24 @@ def test_stn_identity_at_zero_weights(dev):
     torch.nn.init.zeros_(stn.fc3.weight); torch.nn.init.zeros_(stn.fc3.bias)
     assert torch.equal(stn(x), torch.eye(3, device=dev).expand(3, 3, 3))      # fc3 == 0 -> exactly the identity (:50-56)
     assert STNkd(16).to(dev)(torch.randn(2, 64, 16, device=dev)).shape == (2, 16, 16)
+
+
+@pytest.mark.parametrize("B,S,ns,C", [(2, 5, 32, 128), (1, 3, 7, 20), (2, 1, 200, 64), (1, 4, 64, 300)])
+def test_pointconv_contraction_kernel(dev, B, S, ns, C):
+    """pcl_pointconv_contract_f32 (+bwd) against the reference formula (misc/pointconv_utils.py:393-394) in PyTorch."""
+    from pointcloudlib_amd.misc.pointconv_utils import pointconv_contract
+    torch.manual_seed(ns + C)
+    f = torch.randn(B, S, ns, C, device=dev, requires_grad=True)
+    d = torch.rand(B, S, ns, 1, device=dev, requires_grad=True)
+    w = torch.randn(B, S, ns, 16, device=dev, requires_grad=True)
+    g = torch.randn(B, S, C * 16, device=dev)
+    out = pointconv_contract(f, d, w)
+    out.backward(g)
+    got = [out.detach(), f.grad.clone(), d.grad.clone(), w.grad.clone()]
+    f2, d2, w2 = (t.detach().double().requires_grad_(True) for t in (f, d, w))
+    ref = torch.matmul((f2 * d2).transpose(2, 3), w2).reshape(B, S, -1)
+    ref.backward(g.double())
+    want = [ref.detach(), f2.grad, d2.grad, w2.grad]
+    for a, b, name in zip(got, want, ("out", "dfeat", "ddens", "dw")):
+        assert a.shape == b.shape, name
+        assert (a.double() - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item()), name
