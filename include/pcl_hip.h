@@ -119,6 +119,20 @@ int pcl_three_interp_bwd_f32(const float* gout, const int32_t* idx3, const float
  *   density[b,i] = mean_j exp(-|x_i-x_j|^2 / (2 bw^2)) / (2.5 bw), without the [B,N,N] matrix (direct-form d2). */
 int pcl_density_f32(const float* xyz, int B, int N, float bandwidth, float* density_out, void* stream);
 
+/* DGCNN EdgeConv without the edge tensor (networks/cls/dgcnn.py:29-50,:72-83,:100-111).  With the 1x1 conv weight split
+ * W = [Wa | Wb], y[i,j] = U[nbr(i,j)] + V[i] where UV [B*N, 2C] = x [Wa ; Wb-Wa]^T is ONE plain GEMM over the points.
+ *   pcl_edgeconv_gather_f32: per point and channel max/min of y over the k neighbours and their positions (the sign of
+ *     the BatchNorm scale is not known yet; pcl_group_minmax_finalize_f32 picks), plus the BatchNorm batch sums of y over
+ *     all B*N*k edges as pcl_edgeconv_stat_rows(B,N) fp64 partial rows [rows][2][C] (pcl_bn_finalize_f32 consumes them).
+ *   pcl_edgeconv_scatter_f32: dy = [j == arg] a*gz - k1 - k2*(y - mu) for every edge, summed into dUV (U half: over the
+ *     edges pointing at a point; V half: over a point's own edges).  idx [B*N,k] int32 neighbour index within the cloud. */
+int pcl_edgeconv_stat_rows(int B, int N);
+int pcl_edgeconv_gather_f32(const float* UV, const int32_t* idx, int B, int N, int k, int C, float* ymax, float* ymin,
+                            int32_t* jmax, int32_t* jmin, double* stats_ws, void* stream);
+int pcl_edgeconv_scatter_f32(const float* UV, const int32_t* idx, const float* gz, const int32_t* arg, const float* a,
+                             const float* k1, const float* k2, const float* mu, int B, int N, int k, int C, float* dUV,
+                             void* stream);
+
 /* PointConv's density-weighted contraction (misc/pointconv_utils.py:393-394, :319-320):
  *   out[g,c,m] = sum_s feat[g,s,c] * density[g,s] * weights[g,s,m]      feat [G,ns,C], density [G,ns], weights [G,ns,M],
  * out [G,C,M] (= the reference's `matmul((new_points*density)^T, weights).reshape(B,S,-1)` rows).  M must be 16

@@ -1,0 +1,97 @@
+"""DGCNN's EdgeConv stage (kNN graph -> edge features -> Conv2d 1x1 + BatchNorm + LeakyReLU -> max over the neighbours;
+/root/reference/networks/cls/dgcnn.py:29-50, :72-83, :100-111) without the [B,N,k,2C] edge tensor.
+
+The conv is linear: with W = [Wa | Wb], ``W [x_nbr - x_i, x_i] = Wa x_nbr + (Wb - Wa) x_i = U[nbr] + V[i]`` where
+``[U | V] = x [Wa ; Wb - Wa]^T`` is one plain GEMM over the N points (k = 20 times fewer flops than the conv over the
+edges).  The rest -- BatchNorm batch statistics over all B*N*k edges, LeakyReLU, the max over the neighbours and their
+backward -- runs in two streaming HIP kernels (csrc/edgeconv.hip).  Parameters live in a one-layer ``PointwiseMLP``
+(weight [Cout, 2C], gamma, beta, running statistics), so the module tree and state dict are those of the dense path.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+from .ops import _dev, _p, _stream, edge_features
+
+
+class _EdgeConvPool(torch.autograd.Function):
+    """UV [B,N,2C] (U | V), idx [B,N,k] -> max_j lrelu(BN(U[idx[.,j]] + V)) [B,N,C]."""
+
+    @staticmethod
+    def forward(ctx, UV, idx, gamma, beta, rmean, rvar, cfg):
+        slope, eps, momentum, training = cfg
+        UV = _dev(UV, "UV")
+        idx = _dev(idx, "idx", torch.int32)
+        B, N, C2 = UV.shape
+        C, k = C2 // 2, idx.shape[2]
+        dev = UV.device
+        G = B * N
+        st = _stream()
+        rows = _lib.lib().pcl_edgeconv_stat_rows(B, N)
+        stats = torch.empty((rows, 2, C), dtype=torch.float64, device=dev)
+        ymax, ymin = torch.empty((G, C), device=dev), torch.empty((G, C), device=dev)
+        jmax, jmin = torch.empty((G, C), dtype=torch.int32, device=dev), torch.empty((G, C), dtype=torch.int32, device=dev)
+        _lib.call("pcl_edgeconv_gather_f32", _p(UV), _p(idx), B, N, k, C, _p(ymax), _p(ymin), _p(jmax), _p(jmin), _p(stats), st,
+                  algo_bytes=4 * G * (2 * C + k + 4 * C), tag=f"edge{C}")
+        if training:
+            scale, shift, mean, invstd = (torch.empty((C,), device=dev) for _ in range(4))
+            _lib.call("pcl_bn_finalize_f32", _p(stats), rows, _p(gamma), _p(beta), G * k, C, eps, momentum, _p(scale), _p(shift),
+                      _p(mean), _p(invstd), _p(rmean), _p(rvar), st)
+        else:
+            invstd = torch.rsqrt(rvar + eps)
+            mean = rmean
+            scale = gamma * invstd
+            shift = beta - scale * rmean
+        out = torch.empty((G, C), device=dev)
+        arg = torch.empty((G, C), dtype=torch.int32, device=dev)
+        ysel = torch.empty((G, C), device=dev)
+        _lib.call("pcl_group_minmax_finalize_f32", _p(ymax), _p(ymin), _p(jmax), _p(jmin), _p(scale), _p(shift), slope, G, C,
+                  _p(out), _p(arg), _p(ysel), st)
+        ctx.cfg = (slope, training, B, N, k, C)
+        ctx.save_for_backward(UV, idx, out, arg, ysel, gamma, mean, invstd, scale)
+        return out.view(B, N, C)
+
+    @staticmethod
+    def backward(ctx, gout):
+        slope, training, B, N, k, C = ctx.cfg
+        UV, idx, out, arg, ysel, gamma, mean, invstd, scale = ctx.saved_tensors
+        dev = UV.device
+        G = B * N
+        st = _stream()
+        gout = _dev(gout, "grad").reshape(G, C)
+        gz = torch.empty((G, C), device=dev)
+        stats = torch.empty((1024, 2, C), dtype=torch.float64, device=dev)
+        rows_c = ctypes.c_int(0)
+        _lib.call("pcl_maxgrad_prep_f32", _p(gout), _p(out), _p(ysel), slope, G, C, _p(gz), _p(stats), ctypes.byref(rows_c), st)
+        rows = rows_c.value
+        a, k1, k2 = (torch.empty((C,), device=dev) for _ in range(3))
+        if training:
+            dgamma, dbeta = torch.empty((C,), device=dev), torch.empty((C,), device=dev)
+            _lib.call("pcl_bn_bwd_consts_f32", _p(stats), rows, _p(gamma), _p(mean), _p(invstd), G * k, C, _p(dgamma), _p(dbeta),
+                      _p(a), _p(k1), _p(k2), st)
+        else:
+            s = stats[:rows].sum(0)
+            a.copy_(scale); k1.zero_(); k2.zero_()
+            dbeta = s[0].float()
+            dgamma = ((s[1] - mean.double() * s[0]) * invstd.double()).float()
+        dUV = torch.empty_like(UV)
+        _lib.call("pcl_edgeconv_scatter_f32", _p(UV), _p(idx), _p(gz), _p(arg), _p(a), _p(k1), _p(k2), _p(mean), B, N, k, C,
+                  _p(dUV), st)
+        return dUV, None, dgamma, dbeta, None, None, None
+
+
+def edge_conv(mlp, x, idx):
+    """One EdgeConv stage on channel-last ``x`` [B,N,C] with neighbour lists ``idx`` [B,N,k] (int32) -> [B,N,Cout].
+    ``mlp``: the stage's one-layer ``PointwiseMLP([2C, Cout], slope=0.2)``.  The HIP backend takes the factorised path;
+    the plain-PyTorch backend (tests) and anything that is not a single bias-free conv+BN layer build the edge tensor."""
+    k = idx.shape[2]
+    if mlp.resolved_backend(x) == "hip" and mlp.n_layers == 1 and mlp.bn and mlp.biases is None and mlp.last_act:
+        C = x.shape[-1]
+        W = mlp.weights[0]
+        Wcat = torch.cat([W[:, :C], W[:, C:] - W[:, :C]], dim=0)              # [2*Cout, C]
+        UV = F.linear(x, Wcat)                                                # plain GEMM over the points
+        cfg = (mlp.slope, mlp.eps, mlp.momentum, mlp.training)
+        return _EdgeConvPool.apply(UV, idx, mlp.gammas[0], mlp.betas[0], mlp.running_mean_0, mlp.running_var_0, cfg)
+    return mlp(edge_features(x, idx), group_max=k)

@@ -6,15 +6,23 @@ concat(nbr - ctr, ctr) -> Conv2d 1x1 (bias=False) + BN + LeakyReLU(0.2) -> max o
 concat(x1..x4) -> Conv1d 512->1024 + BN1d + LeakyReLU :84-86,:113; global max || global mean :114-116; FC head
 :87-93,:117-121.  Input is [B,3,N] like the reference; internally activations are channel-last [B,N,C].
 
-kNN runs in the HIP KNN kernel (index-exact vs the oracle), the gather/concat in pcl_edge_feature_f32 (no k-fold
-`repeat` of the centres), the conv+BN+LeakyReLU+max in the fused MFMA MLP path.
+kNN runs in the HIP KNN kernel (index-exact vs the oracle).  The EdgeConv stages use the factorised form of
+misc/edgeconv.py (one GEMM over the points + two streaming kernels, no edge tensor); ``get_graph_feature`` -- the
+reference's edge tensor, via pcl_edge_feature_f32 -- stays available and is what the plain-PyTorch backend uses.
 """
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from ...misc.layers import PointwiseMLP
+from ...misc.edgeconv import edge_conv
 from ...misc.ops import KNN, edge_features
+
+
+def knn_graph(x, knn):
+    """x [B,N,C] channel-last -> neighbour lists int32 [B,N,k] in the CURRENT feature space (dgcnn.py:34-35)."""
+    xt = x.transpose(1, 2).contiguous()               # [B,C,N] as KNN expects (misc/ops.py:651)
+    return knn(xt, xt).permute(0, 2, 1).contiguous()
 
 
 def get_graph_feature(x, knn=None, k=None, idx=None):
@@ -46,10 +54,10 @@ class DGCNN(nn.Module):
     def forward(self, x):
         """x [B,3,N] -> logits [B,n_classes]."""
         x = x.transpose(1, 2).contiguous()                                 # channel-last
-        x1 = self.conv1(get_graph_feature(x, self.knn), group_max=self.k)   # :100-102
-        x2 = self.conv2(get_graph_feature(x1, self.knn), group_max=self.k)  # :103-105
-        x3 = self.conv3(get_graph_feature(x2, self.knn), group_max=self.k)  # :106-108
-        x4 = self.conv4(get_graph_feature(x3, self.knn), group_max=self.k)  # :109-111
+        x1 = edge_conv(self.conv1, x, knn_graph(x, self.knn))       # :100-102
+        x2 = edge_conv(self.conv2, x1, knn_graph(x1, self.knn))     # :103-105
+        x3 = edge_conv(self.conv3, x2, knn_graph(x2, self.knn))     # :106-108
+        x4 = edge_conv(self.conv4, x3, knn_graph(x3, self.knn))     # :109-111
         x = torch.cat((x1, x2, x3, x4), dim=2)                              # [B,N,512]   :112
         x = self.conv5(x)                                                   # [B,N,1024]  :113
         x = torch.cat((x.max(dim=1)[0], x.mean(dim=1)), dim=1)              # :114-116

@@ -9,7 +9,8 @@ from torch import nn
 
 from ...misc.layers import PointwiseMLP
 from ...misc.ops import KNN
-from ..cls.dgcnn import get_graph_feature
+from ...misc.edgeconv import edge_conv
+from ..cls.dgcnn import get_graph_feature, knn_graph
 
 
 class DGCNN_partseg(nn.Module):
@@ -35,7 +36,7 @@ class DGCNN_partseg(nn.Module):
         x = x.transpose(1, 2).contiguous()                                         # channel-last [B,N,3]
         x1 = self.conv12(get_graph_feature(x, self.knn), group_max=self.k)         # :95-98
         x2 = self.conv34(get_graph_feature(x1, self.knn), group_max=self.k)        # :100-103
-        x3 = self.conv5(get_graph_feature(x2, self.knn), group_max=self.k)         # :105-107
+        x3 = edge_conv(self.conv5, x2, knn_graph(x2, self.knn))                    # :105-107 (single conv: factorised)
         x123 = torch.cat((x1, x2, x3), dim=2)                                      # [B,N,192]  :109
         g = self.conv6(x123[:, None].contiguous(), group_max=N).reshape(B, 1024)   # conv6 + max over N  :111-112
         lf = self.conv7(l.reshape(B, 16))                                          # :114-115

@@ -222,3 +222,37 @@ def test_pointconv_contraction_kernel(dev, B, S, ns, C):
     for a, b, name in zip(got, want, ("out", "dfeat", "ddens", "dw")):
         assert a.shape == b.shape, name
         assert (a.double() - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item()), name
+
+
+@pytest.mark.parametrize("B,N,C,Cout,k", [(2, 64, 3, 64, 8), (3, 200, 64, 128, 20), (1, 33, 5, 20, 33)])
+def test_edgeconv_factorised_matches_edge_tensor(oracle, dev, B, N, C, Cout, k):
+    """misc/edgeconv.py (U[nbr] + V, no edge tensor) against the reference formulation (edge tensor -> conv -> BN ->
+    LeakyReLU -> max, networks/cls/dgcnn.py:29-50,:100-102) in fp64 PyTorch, forward and every gradient."""
+    from pointcloudlib_amd.misc.edgeconv import edge_conv
+    from pointcloudlib_amd.misc.layers import PointwiseMLP
+    torch.manual_seed(N + C)
+    mlp = PointwiseMLP([2 * C, Cout], slope=0.2).to(dev).train()
+    mlp.gammas[0].data.uniform_(-1.0, 1.5)                 # both signs: exercises the max/min choice
+    mlp.betas[0].data.uniform_(-0.5, 0.5)
+    x = torch.randn(B, N, C, device=dev)
+    xn = x.cpu().numpy().transpose(0, 2, 1).copy()
+    idx_np = oracle.knn(xn, xn, k).transpose(0, 2, 1).copy()
+    idx = torch.from_numpy(idx_np).to(dev)
+    g = torch.randn(B, N, Cout, device=dev)
+    ref = copy.deepcopy(mlp).double(); ref.backend = "torch"          # before the first forward touches the running stats
+    xa = x.clone().requires_grad_(True)
+    out = edge_conv(mlp, xa, idx)
+    out.backward(g)
+    got = {"out": out.detach(), "dx": xa.grad.clone(), **{n: p.grad.clone() for n, p in mlp.named_parameters()}}
+    # fp64 reference with the edge tensor
+    xb = x.double().clone().requires_grad_(True)
+    nb = xb[torch.arange(B, device=dev)[:, None, None], idx.long()]
+    e = torch.cat([nb - xb[:, :, None, :], xb[:, :, None, :].expand_as(nb)], -1)
+    want = ref(e, group_max=k)
+    want.backward(g.double())
+    exp = {"out": want.detach(), "dx": xb.grad, **{n: p.grad for n, p in ref.named_parameters()}}
+    for n in exp:
+        s = max(1.0, exp[n].abs().max().item())
+        assert (got[n].double() - exp[n]).abs().max().item() <= 2e-5 * s, n
+    for b in ("running_mean_0", "running_var_0"):
+        assert torch.allclose(getattr(mlp, b).double(), getattr(ref, b), rtol=1e-5, atol=1e-6), b

@@ -30,7 +30,7 @@ def run(name, make, inputs, loss_fn, steps, warmup=3):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     from pointcloudlib_amd.networks.cls.pointnet import PointNet
