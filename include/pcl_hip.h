@@ -119,6 +119,26 @@ int pcl_three_interp_bwd_f32(const float* gout, const int32_t* idx3, const float
  *   density[b,i] = mean_j exp(-|x_i-x_j|^2 / (2 bw^2)) / (2.5 bw), without the [B,N,N] matrix (direct-form d2). */
 int pcl_density_f32(const float* xyz, int B, int N, float bandwidth, float* density_out, void* stream);
 
+/* First MLP layer folded into the grouping.  The first 1x1 conv of a set-abstraction MLP is linear in the grouped row
+ * [xyz_nbr - centre | feat_nbr] (networks/cls/pointnet2.py:18-57, misc/ops.py:383-403):
+ *     y[g,s] = Wx (xyz[nbr] - centre[g]) + Uf[nbr],   Uf [B*N, C1] = feat Wf^T  (one GEMM over the points, not the rows)
+ * pcl_group_linear_f32 writes that pre-BatchNorm output for the DISTINCT rows of every ball-query group (same row order
+ * and metadata as pcl_group_compact_f32) and the multiplicity-weighted BatchNorm sums as pcl_group_linear_stat_rows(B,m)
+ * fp64 partial rows [rows][2][C1].  Wx [C1,3] or NULL (use_xyz = 0), Uf or NULL; C1 <= 256.  Narrow point features
+ * (CF <= 4 columns, e.g. the normals of the first level) are folded inline instead: feat_small [B*N,CF], Wf_small [C1,CF].
+ * pcl_group_linear_bwd_f32: dy = a*du - w*(k1 + k2*(y - mu)) per row (du: gradient w.r.t. the BatchNorm output as the dX
+ * GEMM of the next layer leaves it), accumulated into dUf [B*N, C1] (zero-filled here) and into dWx_part
+ * [pcl_group_linear_stat_rows][C1][3] / dWf_part [..][C1][CF] partial sums (sum over the first axis = dWx, dWf_small). */
+int pcl_group_linear_stat_rows(int B, int m);
+int pcl_group_linear_f32(const float* xyz, const float* new_xyz, const float* Uf, const float* Wx, const float* feat_small,
+                         const float* Wf_small, int CF, const int32_t* idx, const int32_t* cnt, const int32_t* group_off,
+                         int B, int N, int m, int ns, int C1, float* Y, int32_t* row_meta, int32_t* row_src,
+                         double* stats_ws, void* stream);
+int pcl_group_linear_bwd_f32(const float* xyz, const float* new_xyz, const float* feat_small, int CF, const float* dU,
+                             const float* Y, const float* a, const float* k1, const float* k2, const float* mu,
+                             const int32_t* row_meta, const int32_t* row_src, const int32_t* n_rows_dev /* &group_off[B*m] */,
+                             int B, int N, int C1, float* dUf, float* dWx_part, float* dWf_part, void* stream);
+
 /* DGCNN EdgeConv without the edge tensor (networks/cls/dgcnn.py:29-50,:72-83,:100-111).  With the 1x1 conv weight split
  * W = [Wa | Wb], y[i,j] = U[nbr(i,j)] + V[i] where UV [B*N, 2C] = x [Wa ; Wb-Wa]^T is ONE plain GEMM over the points.
  *   pcl_edgeconv_gather_f32: per point and channel max/min of y over the k neighbours and their positions (the sign of

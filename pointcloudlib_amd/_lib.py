@@ -60,6 +60,9 @@ _SIGS = {
     "pcl_three_interp_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_three_interp_bwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_density_f32": (c_int, [_P, c_int, c_int, c_float, _P, _P]),
+    "pcl_group_linear_stat_rows": (c_int, [c_int, c_int]),
+    "pcl_group_linear_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "pcl_group_linear_bwd_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "pcl_edgeconv_stat_rows": (c_int, [c_int, c_int]),
     "pcl_edgeconv_gather_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "pcl_edgeconv_scatter_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),

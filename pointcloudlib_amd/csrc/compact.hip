@@ -169,6 +169,206 @@ __global__ __launch_bounds__(256) void scatter_rows_add_kernel(const float* __re
     }
 }
 
+// ---- first MLP layer folded into the grouping ------------------------------------------------------------------
+// The first 1x1 conv of a set-abstraction MLP is linear in the grouped row [xyz_nbr - centre | feat_nbr]:
+//     y[g,s] = Wx (xyz[nbr] - centre[g]) + Wf feat[nbr] = Wx (xyz[nbr] - centre[g]) + Uf[nbr],   Uf = feat Wf^T,
+// and Uf is one GEMM over the N points of a cloud instead of over its m*ns grouped rows (16x fewer rows at SA2).  The
+// xyz part (3 FMAs per output) is evaluated here on the exact local coordinates, as the reference forms them.
+// This kernel writes the layer's pre-BatchNorm output for the DISTINCT rows of every group (see the header of this
+// file), the row metadata, and the multiplicity-weighted BatchNorm batch sums as fp64 partial rows [gridDim.x][2][C1].
+// Persistent: workgroup b walks groups b, b+gridDim.x, ...; wave w takes the slots [w*chunk, (w+1)*chunk) of a group.
+constexpr int GL_MAXH = 4;       // channels per lane: C1 <= 256
+constexpr int GL_RPI = 4;        // rows in flight per wave
+constexpr int GL_CF = 4;         // features folded inline (e.g. the 3 normals of the first level), wider ones come as Uf
+
+// metadata of the distinct rows: one wave per group
+__global__ __launch_bounds__(256) void group_rows_meta_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ cnt,
+                                                              const int32_t* __restrict__ goff, int G, int N, int m, int ns,
+                                                              int2* __restrict__ rmeta, int32_t* __restrict__ rsrc) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= G) return;
+    const int c = max(cnt[g], 1), base = goff[g], b = g / m;
+    const int32_t* I = idx + (size_t)g * ns;
+    for (int s = lane; s < c; s += 64) {
+        const int mult = s == 0 ? ns - c + 1 : 1;
+        rmeta[base + s] = make_int2(g, s | (mult << 16));
+        rsrc[base + s] = b * N + I[s];
+    }
+}
+
+// Row-parallel: wave w walks rows 4w.., 4w + 4*nwaves.., four rows in flight, lanes over the C1 channels; the next
+// iteration's row metadata is requested before the current rows are processed (two dependent gathers per row otherwise).
+__global__ __launch_bounds__(256) void group_linear_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                           const float* __restrict__ Uf, const float* __restrict__ Wx,
+                                                           const float* __restrict__ fs, const float* __restrict__ Wfs, int CF,
+                                                           const int2* __restrict__ rmeta, const int32_t* __restrict__ rsrc,
+                                                           const int32_t* __restrict__ n_rows, int C1, float* __restrict__ Y,
+                                                           double* __restrict__ stats) {
+    __shared__ double red[2][4][64 * GL_MAXH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nh = (C1 + 63) >> 6;
+    const int R = *n_rows;
+    float wx[GL_MAXH][3], wf[GL_MAXH][GL_CF];          // coordinate weights and the weights of up to GL_CF inline features
+    double ss[GL_MAXH], qq[GL_MAXH];
+#pragma unroll
+    for (int h = 0; h < GL_MAXH; ++h) {
+        const int ch = lane + 64 * h;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) wx[h][d] = (Wx && ch < C1) ? Wx[ch * 3 + d] : 0.f;
+#pragma unroll
+        for (int f = 0; f < GL_CF; ++f) wf[h][f] = (f < CF && ch < C1) ? Wfs[ch * CF + f] : 0.f;
+        ss[h] = 0.0; qq[h] = 0.0;
+    }
+    const int stride = gridDim.x * 4 * GL_RPI;
+    int r0 = (blockIdx.x * 4 + wave) * GL_RPI;
+    int2 me[GL_RPI]; int sr[GL_RPI];
+#pragma unroll
+    for (int j = 0; j < GL_RPI; ++j) { const int r = min(r0 + j, R - 1); me[j] = rmeta[r]; sr[j] = rsrc[r]; }
+    for (; r0 < R; r0 += stride) {
+        int2 cm[GL_RPI]; int cs[GL_RPI];
+#pragma unroll
+        for (int j = 0; j < GL_RPI; ++j) { cm[j] = me[j]; cs[j] = sr[j]; }
+        {
+            const int rn = r0 + stride;
+#pragma unroll
+            for (int j = 0; j < GL_RPI; ++j) { const int r = min(rn + j, R - 1); me[j] = rmeta[r]; sr[j] = rsrc[r]; }
+        }
+        float dx[GL_RPI][3];
+#pragma unroll
+        for (int j = 0; j < GL_RPI; ++j) {
+            if (Wx) {
+                const float* pk = xyz + (size_t)cs[j] * 3;
+                const float* qc = new_xyz + (size_t)cm[j].x * 3;
+                dx[j][0] = __fsub_rn(pk[0], qc[0]); dx[j][1] = __fsub_rn(pk[1], qc[1]); dx[j][2] = __fsub_rn(pk[2], qc[2]);
+            } else { dx[j][0] = dx[j][1] = dx[j][2] = 0.f; }
+        }
+        float fi[GL_RPI][GL_CF];
+#pragma unroll
+        for (int j = 0; j < GL_RPI; ++j)
+#pragma unroll
+            for (int f = 0; f < GL_CF; ++f) fi[j][f] = f < CF ? fs[(size_t)cs[j] * CF + f] : 0.f;
+#pragma unroll
+        for (int h = 0; h < GL_MAXH; ++h) {
+            if (h >= nh) break;
+            const int ch = min(lane + 64 * h, C1 - 1);
+            float u[GL_RPI];
+#pragma unroll
+            for (int j = 0; j < GL_RPI; ++j) u[j] = Uf ? Uf[(size_t)cs[j] * C1 + ch] : 0.f;
+#pragma unroll
+            for (int j = 0; j < GL_RPI; ++j) {
+                if (r0 + j < R && lane + 64 * h < C1) {
+                    float y = fmaf(wx[h][2], dx[j][2], fmaf(wx[h][1], dx[j][1], fmaf(wx[h][0], dx[j][0], u[j])));
+#pragma unroll
+                    for (int f = 0; f < GL_CF; ++f) y = fmaf(wf[h][f], fi[j][f], y);
+                    Y[(size_t)(r0 + j) * C1 + ch] = y;
+                    const double w = (double)(cm[j].y >> 16);
+                    ss[h] += w * (double)y; qq[h] += w * (double)y * (double)y;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < GL_MAXH; ++h) { red[0][wave][lane + 64 * h] = ss[h]; red[1][wave][lane + 64 * h] = qq[h]; }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C1; ch += 256) {
+        double* dst = stats + (size_t)blockIdx.x * 2 * C1;
+        dst[ch] = (red[0][0][ch] + red[0][1][ch]) + (red[0][2][ch] + red[0][3][ch]);
+        dst[C1 + ch] = (red[1][0][ch] + red[1][1][ch]) + (red[1][2][ch] + red[1][3][ch]);
+    }
+}
+
+// backward: dy = a*du - w*(k1 + k2*(y - mu)) per distinct row; dUf[point] += dy (atomics), dWx partial sums per workgroup.
+__global__ __launch_bounds__(256) void group_linear_bwd_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                               const float* __restrict__ fs, int CF,
+                                                               const float* __restrict__ dU, const float* __restrict__ Y,
+                                                               const float* __restrict__ a_, const float* __restrict__ k1_,
+                                                               const float* __restrict__ k2_, const float* __restrict__ mu_,
+                                                               const int2* __restrict__ rmeta, const int32_t* __restrict__ rsrc,
+                                                               const int32_t* __restrict__ n_rows, int C1, float* __restrict__ dUf,
+                                                               float* __restrict__ dWx_part, float* __restrict__ dWf_part) {
+    __shared__ float red[3 + GL_CF][4][64 * GL_MAXH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nh = (C1 + 63) >> 6;
+    const int R = *n_rows;
+    float a[GL_MAXH], k1[GL_MAXH], k2[GL_MAXH], mu[GL_MAXH], gw[GL_MAXH][3 + GL_CF];
+#pragma unroll
+    for (int h = 0; h < GL_MAXH; ++h) {
+        const int ch = min(lane + 64 * h, C1 - 1);
+        a[h] = a_[ch]; k1[h] = k1_[ch]; k2[h] = k2_[ch]; mu[h] = mu_[ch];
+#pragma unroll
+        for (int d = 0; d < 3 + GL_CF; ++d) gw[h][d] = 0.f;
+    }
+    const int stride = gridDim.x * 4 * GL_RPI;
+    int r0 = (blockIdx.x * 4 + wave) * GL_RPI;
+    int2 me[GL_RPI]; int sr[GL_RPI];
+#pragma unroll
+    for (int j = 0; j < GL_RPI; ++j) { const int r = min(r0 + j, R - 1); me[j] = rmeta[r]; sr[j] = rsrc[r]; }
+    for (; r0 < R; r0 += stride) {
+        int2 cm[GL_RPI]; int cs[GL_RPI];
+#pragma unroll
+        for (int j = 0; j < GL_RPI; ++j) { cm[j] = me[j]; cs[j] = sr[j]; }
+        {
+            const int rn = r0 + stride;
+#pragma unroll
+            for (int j = 0; j < GL_RPI; ++j) { const int r = min(rn + j, R - 1); me[j] = rmeta[r]; sr[j] = rsrc[r]; }
+        }
+        float dx[GL_RPI][3];
+#pragma unroll
+        for (int j = 0; j < GL_RPI; ++j) {
+            if (dWx_part) {
+                const float* pk = xyz + (size_t)cs[j] * 3;
+                const float* qc = new_xyz + (size_t)cm[j].x * 3;
+                dx[j][0] = __fsub_rn(pk[0], qc[0]); dx[j][1] = __fsub_rn(pk[1], qc[1]); dx[j][2] = __fsub_rn(pk[2], qc[2]);
+            } else { dx[j][0] = dx[j][1] = dx[j][2] = 0.f; }
+        }
+        float fi[GL_RPI][GL_CF];
+#pragma unroll
+        for (int j = 0; j < GL_RPI; ++j)
+#pragma unroll
+            for (int f = 0; f < GL_CF; ++f) fi[j][f] = (dWf_part && f < CF) ? fs[(size_t)cs[j] * CF + f] : 0.f;
+#pragma unroll
+        for (int h = 0; h < GL_MAXH; ++h) {
+            if (h >= nh) break;
+            const int ch = min(lane + 64 * h, C1 - 1);
+            float du[GL_RPI], y[GL_RPI];
+#pragma unroll
+            for (int j = 0; j < GL_RPI; ++j) {
+                const size_t o = (size_t)min(r0 + j, R - 1) * C1 + ch;
+                du[j] = dU[o]; y[j] = Y[o];
+            }
+#pragma unroll
+            for (int j = 0; j < GL_RPI; ++j) {
+                if (r0 + j < R && lane + 64 * h < C1) {
+                    const float w = (float)(cm[j].y >> 16);
+                    const float dy = fmaf(a[h], du[j], -w * fmaf(k2[h], y[j] - mu[h], k1[h]));
+                    if (dUf) unsafeAtomicAdd(&dUf[(size_t)cs[j] * C1 + ch], dy);
+                    gw[h][0] = fmaf(dy, dx[j][0], gw[h][0]); gw[h][1] = fmaf(dy, dx[j][1], gw[h][1]);
+                    gw[h][2] = fmaf(dy, dx[j][2], gw[h][2]);
+#pragma unroll
+                    for (int f = 0; f < GL_CF; ++f) gw[h][3 + f] = fmaf(dy, fi[j][f], gw[h][3 + f]);
+                }
+            }
+        }
+    }
+    if (dWx_part || dWf_part) {
+#pragma unroll
+        for (int h = 0; h < GL_MAXH; ++h)
+#pragma unroll
+            for (int d = 0; d < 3 + GL_CF; ++d) red[d][wave][lane + 64 * h] = gw[h][d];
+        __syncthreads();
+        if (dWx_part)
+            for (int e = threadIdx.x; e < C1 * 3; e += 256) {
+                const int ch = e / 3, d = e - ch * 3;
+                dWx_part[(size_t)blockIdx.x * C1 * 3 + e] = (red[d][0][ch] + red[d][1][ch]) + (red[d][2][ch] + red[d][3][ch]);
+            }
+        if (dWf_part)
+            for (int e = threadIdx.x; e < C1 * CF; e += 256) {
+                const int ch = e / CF, d = 3 + (e - ch * CF);
+                dWf_part[(size_t)blockIdx.x * C1 * CF + e] = (red[d][0][ch] + red[d][1][ch]) + (red[d][2][ch] + red[d][3][ch]);
+            }
+    }
+}
+
 }  // namespace pcl
 using namespace pcl;
 
@@ -221,4 +421,48 @@ extern "C" int pcl_scatter_rows_add_f32(const float* grows, const int32_t* row_s
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(scatter_rows_add_kernel, dim3((int)blocks), dim3(256), 0, st, grows, row_src, n_rows_dev, D, off, C, gfeat);
     return check_launch("pcl_scatter_rows_add_f32");
+}
+
+constexpr int GL_BLOCKS = 2048;      // 8 workgroups of 4 waves per CU; also the number of BatchNorm / dWx partial rows
+
+extern "C" int pcl_group_linear_stat_rows(int B, int m) { return (B < 1 || m < 1) ? 0 : GL_BLOCKS; }
+
+extern "C" int pcl_group_linear_f32(const float* xyz, const float* new_xyz, const float* Uf, const float* Wx, const float* feat_small,
+                                    const float* Wf_small, int CF, const int32_t* idx, const int32_t* cnt,
+                                    const int32_t* group_off, int B, int N, int m, int ns, int C1, float* Y, int32_t* row_meta,
+                                    int32_t* row_src, double* stats_ws, void* stream) {
+    PCL_REQUIRE(idx && cnt && group_off && Y && row_meta && row_src && stats_ws, "pcl_group_linear_f32: null pointer");
+    PCL_REQUIRE(Uf || Wx || CF > 0, "pcl_group_linear_f32: need features (Uf or feat_small) and/or coordinates (Wx)");
+    PCL_REQUIRE(CF >= 0 && CF <= GL_CF && (CF == 0 || (feat_small && Wf_small)), "pcl_group_linear_f32: CF=%d inline features (<= %d)", CF, GL_CF);
+    PCL_REQUIRE(!Wx || (xyz && new_xyz), "pcl_group_linear_f32: Wx needs xyz and new_xyz");
+    PCL_REQUIRE(B >= 1 && N >= 1 && m >= 1 && ns >= 1 && ns < 32768 && C1 >= 1 && C1 <= 64 * GL_MAXH,
+                "pcl_group_linear_f32: bad sizes B=%d N=%d m=%d ns=%d C1=%d (C1 <= %d)", B, N, m, ns, C1, 64 * GL_MAXH);
+    const int G = B * m;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(group_rows_meta_kernel, dim3((G + 3) / 4), dim3(256), 0, st, idx, cnt, group_off, G, N, m, ns,
+                       reinterpret_cast<int2*>(row_meta), row_src);
+    int rc = check_launch("pcl_group_linear_f32(meta)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(group_linear_kernel, dim3(GL_BLOCKS), dim3(256), 0, st, xyz, new_xyz, Uf, Wx, feat_small, Wf_small, CF,
+                       reinterpret_cast<const int2*>(row_meta), row_src, group_off + G, C1, Y, stats_ws);
+    return check_launch("pcl_group_linear_f32");
+}
+
+extern "C" int pcl_group_linear_bwd_f32(const float* xyz, const float* new_xyz, const float* feat_small, int CF, const float* dU,
+                                        const float* Y, const float* a, const float* k1, const float* k2, const float* mu,
+                                        const int32_t* row_meta, const int32_t* row_src, const int32_t* n_rows_dev, int B, int N,
+                                        int C1, float* dUf, float* dWx_part, float* dWf_part, void* stream) {
+    PCL_REQUIRE(dU && Y && a && k1 && k2 && mu && row_meta && row_src && n_rows_dev, "pcl_group_linear_bwd_f32: null pointer");
+    PCL_REQUIRE(dUf || dWx_part || dWf_part, "pcl_group_linear_bwd_f32: nothing to compute");
+    PCL_REQUIRE(!dWf_part || (feat_small && CF >= 1 && CF <= GL_CF), "pcl_group_linear_bwd_f32: dWf needs feat_small, CF=%d", CF);
+    PCL_REQUIRE(!dWx_part || (xyz && new_xyz), "pcl_group_linear_bwd_f32: dWx needs xyz and new_xyz");
+    PCL_REQUIRE(B >= 1 && N >= 1 && C1 >= 1 && C1 <= 64 * GL_MAXH, "pcl_group_linear_bwd_f32: bad sizes");
+    hipStream_t st = as_stream(stream);
+    if (dUf) {
+        hipError_t e = hipMemsetAsync(dUf, 0, sizeof(float) * (size_t)B * N * C1, st);
+        if (e != hipSuccess) return fail(PCL_EHIP, "pcl_group_linear_bwd_f32: memset: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(group_linear_bwd_kernel, dim3(GL_BLOCKS), dim3(256), 0, st, xyz, new_xyz, feat_small, CF, dU, Y, a, k1, k2, mu,
+                       reinterpret_cast<const int2*>(row_meta), row_src, n_rows_dev, C1, dUf, dWx_part, dWf_part);
+    return check_launch("pcl_group_linear_bwd_f32");
 }

@@ -97,6 +97,17 @@ class PointwiseMLP(nn.Module):
         # runs only when a test asks for it by name (backend="torch").
         return "hip" if self.backend == "auto" else self.backend
 
+    def forward_grouped(self, xyz, new_xyz, feature, idx, cnt, group_off, use_xyz=True):
+        """Ball-query grouping + this MLP + max over each group -> [B, m, C_last] (HIP backend): duplicate-compacted rows,
+        and the first conv folded into the grouping where possible (mlp_hip.grouped_mlp); otherwise the rows are built
+        by ``ops.group_points_compact`` and run through ``forward``."""
+        from . import mlp_hip
+        from .ops import group_points_compact
+        if mlp_hip.can_fold_first_layer(self, use_xyz, feature):
+            return mlp_hip.grouped_mlp(self, xyz, new_xyz, feature, idx, cnt, group_off, use_xyz)
+        rows, rowset = group_points_compact(xyz, new_xyz, feature, idx, cnt, use_xyz, group_off=group_off)
+        return self.forward(rows, rowset=rowset, x_grad_from=3 if use_xyz else 0)
+
     def forward(self, x, group_max=None, rowset=None, x_grad_from=0):
         """x [..., C0] -> [..., CL]; with ``group_max=ns`` the rows are groups of ns consecutive rows and
         the result is max-reduced over each group ([B,m,ns,C] -> [B,m,C]).  ``rowset``: duplicate-compacted

@@ -66,7 +66,7 @@ class _FusedMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cfg, *params):
-        ns, slope, eps, momentum, training, bn, last_act, rowset, x_grad_from = cfg
+        ns, slope, eps, momentum, training, bn, last_act, rowset, x_grad_from, link = cfg
         L = len(params) // 6
         dev = x.device
         x = x.contiguous()
@@ -84,16 +84,23 @@ class _FusedMLP(torch.autograd.Function):
         for l in range(L):
             W, bias, gamma, beta, rmean, rvar = params[6 * l:6 * l + 6]
             cout = W.shape[0]
-            if l == 0 and W.shape[1] != cin:
+            if l == 0 and link is None and W.shape[1] != cin:
                 # the input rows carry zero columns beyond the layer's fan-in (ops.group_points_compact pads rows to a
                 # multiple of 4 floats so that every kernel moves 16-byte pieces): pad W with zero columns to match
                 assert W.shape[1] < cin, f"input has {cin} columns, first layer expects {W.shape[1]}"
                 W = W0p = torch.nn.functional.pad(W.detach(), (0, cin - W.shape[1]))
-            Y = _empty((P, cout), dev)
-            rows = _lib.lib().pcl_mlp_stat_rows(P, cout, 0)
-            stats = _empty((rows, 2, cout), dev, torch.float64)
             fused_max = (l == L - 1) and ns in (32, 64) and rowset is None
-            if fused_max:      # last layer of a max-pooled stack: per-group min/max come out of the GEMM epilogue
+            if l == 0 and link is not None:
+                # the first layer was folded into the grouping (_GroupLinear): x IS its pre-BatchNorm output
+                assert cout == cin and L >= 2, "folded first layer: x must be the layer's own output"
+                Y, stats, rows = x, link.stats, link.rows
+            else:
+                Y = _empty((P, cout), dev)
+                rows = _lib.lib().pcl_mlp_stat_rows(P, cout, 0)
+                stats = _empty((rows, 2, cout), dev, torch.float64)
+            if l == 0 and link is not None:
+                pass
+            elif fused_max:      # last layer of a max-pooled stack: per-group min/max come out of the GEMM epilogue
                 G = P // ns
                 gmax, gmin = _empty((G, cout), dev), _empty((G, cout), dev)
                 gamax, gamin = _empty((G, cout), dev, torch.int32), _empty((G, cout), dev, torch.int32)
@@ -140,6 +147,7 @@ class _FusedMLP(torch.autograd.Function):
             arg = ymax = None
             _lib.call("pcl_bn_act_f32", _P(cur), _P(in_scale), _P(in_shift), out_slope, P, cin, _P(out), st)
         ctx.x_grad_from = x_grad_from
+        ctx.link = link
         ctx.cfg = (ns, slope, out_slope, training, bn, L, P, C0)
         # Everything goes through save_for_backward (never as plain ctx attributes): `out` is an OUTPUT of this node,
         # and an attribute reference to it would form a node <-> tensor cycle that only the cyclic GC frees -- with
@@ -194,6 +202,8 @@ class _FusedMLP(torch.autograd.Function):
         for l in range(L - 1, -1, -1):
             W, bias, gamma, beta, _, _ = params[6 * l:6 * l + 6]
             fan_in = W.shape[1]
+            if l == 0 and ctx.link is not None:
+                W = W[:, :0].new_empty((W.shape[0], W.shape[0]))      # folded layer: only the shape (cout) is used below
             if l == 0 and sv["W0p"] is not None:
                 W = sv["W0p"]
             cout, cin = W.shape
@@ -212,6 +222,13 @@ class _FusedMLP(torch.autograd.Function):
             if bias is not None:
                 # bias feeds BatchNorm -> its gradient is exactly zero; without BatchNorm it is sum(du)
                 grads[6 * l + 1] = torch.zeros_like(bias) if (bn and training) else stats[:rows, 0].sum(0).float() * a
+            if l == 0 and ctx.link is not None:
+                # hand the BatchNorm-backward constants of the folded first layer to _GroupLinear.backward, which forms
+                # dy = a*du - w*(k1 + k2*(y - mean)) itself; what flows back as "the gradient of x" is du (protocol
+                # between the two private autograd nodes, see grouped_mlp)
+                ctx.link.consts = (a, k1, k2, means[0])
+                gx = dU
+                break
             Xprev = Ys[l - 1] if l > 0 else x
             psc = scales[l - 1] if l > 0 else None
             psh = shifts[l - 1] if l > 0 else None
@@ -269,10 +286,148 @@ def pointwise_mlp(module, x, group_max=None, rowset=None, x_grad_from=0):
     # x_grad_from: the first input column whose gradient anybody consumes (3 for a grouped [xyz | features] tensor:
     # xyz never needs a gradient); lower columns of the returned input gradient are left unwritten.
     cfg = (ns, module.slope, module.eps, module.momentum, module.training, module.bn, module.last_act, rowset,
-           int(x_grad_from))
+           int(x_grad_from), None)
     out = _FusedMLP.apply(x2, cfg, *params)
     if rowset is not None:
         return out.reshape(rowset.B, rowset.m, out.shape[-1])
     if ns:
         return out.reshape(*lead[:-1], out.shape[-1])
     return out.reshape(*lead, out.shape[-1])
+
+
+class _Link:
+    """Side channel between _GroupLinear and _FusedMLP (both private): forward hands over the BatchNorm partial sums of the
+    folded first layer, backward hands back its BatchNorm-backward constants."""
+    __slots__ = ("stats", "rows", "consts")
+
+    def __init__(self):
+        self.stats = self.rows = self.consts = None
+
+
+_CONST = {}
+
+
+def _const_vec(dev, n, value):
+    """cached per-device constant vectors (ones / zeros) for the plain-GEMM use of the BatchNorm-backward entry points"""
+    key = (dev, n, value)
+    if key not in _CONST:
+        _CONST[key] = torch.full((n,), float(value), dtype=torch.float32, device=dev)
+    return _CONST[key]
+
+
+class _GroupLinear(torch.autograd.Function):
+    """Pre-BatchNorm output of the first MLP layer for the distinct rows of every ball-query group
+    (csrc/compact.hip, group_linear_kernel): ``y = W0[:, :3] (xyz_nbr - centre) + W0[:, 3:] feat_nbr``.  Features of up to 4
+    columns (the normals of the first level) are folded inline; wider ones go through the per-point product
+    ``Uf = feat W0[:, 3:]^T`` -- one GEMM over the N points of a cloud instead of its m*ns grouped rows -- on the library's
+    own GEMM kernels, forward and backward."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feature, W0, idx, cnt, group_off, link, use_xyz):
+        B, m, ns = idx.shape
+        N = xyz.shape[1]
+        C1 = W0.shape[0]
+        off = 3 if use_xyz else 0
+        C = 0 if feature is None else feature.shape[-1]
+        dev = idx.device
+        cap = B * m * ns
+        st = _stream()
+        Wx = W0[:, :3].contiguous() if use_xyz else None
+        Wf = W0[:, off:].contiguous() if C else None
+        inline = 0 < C <= 4 and not feature.requires_grad
+        feat2 = feature.reshape(B * N, C).contiguous() if C else None
+        Uf = None
+        if C and not inline:
+            Uf = _empty((B * N, C1), dev)
+            rows_u = _lib.lib().pcl_mlp_stat_rows(B * N, C1, 0)
+            _lib.call("pcl_linear_fwd_rows_f32", _P(feat2), _P(Wf), None, None, None, 0.0, B * N, C, C1, _P(Uf),
+                      _P(_empty((rows_u, 2, C1), dev, torch.float64)), None, None, st, tag=f"pt{C}x{C1}")
+        Y = _empty((cap, C1), dev)
+        row_meta = _empty((cap, 2), dev, torch.int32)
+        row_src = _empty((cap,), dev, torch.int32)
+        rows = _lib.lib().pcl_group_linear_stat_rows(B, m)
+        stats = _empty((rows, 2, C1), dev, torch.float64)
+        _lib.call("pcl_group_linear_f32", _P(xyz), _P(new_xyz), _P(Uf), _P(Wx), _P(feat2) if inline else None,
+                  _P(Wf) if inline else None, C if inline else 0, _P(idx), _P(cnt), _P(group_off), B, N, m, ns, C1, _P(Y),
+                  _P(row_meta), _P(row_src), _P(stats), st)
+        link.stats, link.rows = stats, rows
+        ctx.link = link
+        ctx.dims = (B, N, m, ns, C1, C, off, inline, rows)
+        ctx.mark_non_differentiable(row_meta, row_src)
+        ctx.save_for_backward(xyz, new_xyz, group_off, Y, row_meta, row_src, feat2, Wf)
+        return Y, row_meta, row_src
+
+    @staticmethod
+    def backward(ctx, du, *_):
+        B, N, m, ns, C1, C, off, inline, rows = ctx.dims
+        xyz, new_xyz, group_off, Y, row_meta, row_src, feat2, Wf = ctx.saved_tensors
+        a, k1, k2, mu = ctx.link.consts
+        ctx.link.consts = None
+        dev = Y.device
+        st = _stream()
+        lib = _lib.lib()
+        need_w = ctx.needs_input_grad[3]
+        wide = C > 0 and not inline
+        dUf = _empty((B * N, C1), dev) if wide else None
+        dWxp = _empty((rows, C1, 3), dev) if (off and need_w) else None
+        dWfp = _empty((rows, C1, C), dev) if (inline and need_w) else None
+        if dUf is not None or dWxp is not None or dWfp is not None:
+            _lib.call("pcl_group_linear_bwd_f32", _P(xyz), _P(new_xyz), _P(feat2) if inline else None, C if inline else 0,
+                      _P(du.contiguous()), _P(Y), _P(a), _P(k1), _P(k2), _P(mu), _P(row_meta), _P(row_src), _P(group_off[B * m:]),
+                      B, N, C1, _P(dUf), _P(dWxp), _P(dWfp), st)
+        dfeat = dW0 = None
+        parts = []
+        if need_w and off:
+            parts.append(dWxp.sum(0))
+        if wide:
+            # plain GEMMs through the BatchNorm-backward entry points with a = 1, k1 = k2 = 0 (dy == dUf)
+            one, zero = _const_vec(dev, C1, 1.0), _const_vec(dev, C1, 0.0)
+            P = B * N
+            if need_w:
+                nbytes = lib.pcl_linear_bwd_dw_workspace_bytes(P, C1, C)
+                ws = _empty(((nbytes + 3) // 4,), dev)
+                dWf = _empty((C1, C), dev)
+                _lib.call("pcl_linear_bwd_dw_rows_f32", _P(dUf), _P(dUf), _P(one), _P(zero), _P(zero), _P(zero), None, None, 1,
+                          _P(feat2), None, None, 0.0, P, C1, C, _P(dWf), _P(ws), nbytes, None, None, st, tag=f"ptdw{C1}x{C}")
+                parts.append(dWf)
+            if ctx.needs_input_grad[2]:
+                dfeat = _empty((P, C), dev)
+                _lib.call("pcl_linear_bwd_dx_rows_f32", _P(dUf), _P(dUf), _P(one), _P(zero), _P(zero), _P(zero), None, None, 1,
+                          _P(Wf), P, C1, C, None, None, None, 0.0, _P(dfeat), None, None, None, 0, 0, st, tag=f"ptdx{C1}x{C}")
+                dfeat = dfeat.view(B, N, C)
+        elif inline and need_w:
+            parts.append(dWfp.sum(0))
+        if need_w:
+            dW0 = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+        return None, None, dfeat, dW0, None, None, None, None, None
+
+
+def can_fold_first_layer(module, use_xyz, feature):
+    """The folded path needs >= 2 layers (the first layer's gradient arrives dense from the second), no conv bias and at
+    most 256 first-layer outputs."""
+    return (module.n_layers >= 2 and module.biases is None and module.spec[1] <= 256 and (use_xyz or feature is not None))
+
+
+def grouped_mlp(module, xyz, new_xyz, feature, idx, cnt, group_off, use_xyz):
+    """Ball-query grouping + ``PointwiseMLP`` + max over each group, with the first conv folded into the grouping:
+    ``W0 [xyz_nbr - centre | feat_nbr] = W0[:, :3] (xyz_nbr - centre) + (feat W0[:, 3:]^T)[nbr]`` -- the feature product
+    is one GEMM over the N points of a cloud (plain library GEMM) instead of over its m*ns grouped rows.  Returns
+    [B, m, C_last]."""
+    from .ops import RowSet
+    if not xyz.is_cuda:
+        raise RuntimeError("fused HIP MLP needs GPU tensors (no CPU fallback)")
+    B, m, ns = idx.shape
+    link = _Link()
+    Y0, row_meta, row_src = _GroupLinear.apply(xyz.contiguous(), new_xyz.contiguous(), feature, module.weights[0], idx, cnt,
+                                               group_off, link, bool(use_xyz))
+    rowset = RowSet(B, m, ns, row_meta, row_src, group_off)
+    params = []
+    for i in range(module.n_layers):
+        params += [module.weights[i] if i > 0 else None, None,
+                   module.gammas[i] if module.bn else None, module.betas[i] if module.bn else None,
+                   getattr(module, f"running_mean_{i}") if module.bn else None,
+                   getattr(module, f"running_var_{i}") if module.bn else None]
+    params[0] = module.weights[0].detach()          # shape carrier only: the folded layer's weight gets its gradient outside
+    cfg = (ns, module.slope, module.eps, module.momentum, module.training, module.bn, module.last_act, rowset, 0, link)
+    out = _FusedMLP.apply(Y0, cfg, *params)
+    return out.reshape(B, m, out.shape[-1])

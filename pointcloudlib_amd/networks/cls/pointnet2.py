@@ -56,8 +56,7 @@ class PointNetModuleBase(nn.Module):
                 new_feature_list.append(mlp(grouped, group_max=grouped.shape[2]))
             elif self.compact_duplicates and mlp.resolved_backend(xyz) == "hip":
                 # ball-query padding repeats the first hit: run the MLP on the distinct rows only (see ops.RowSet)
-                rows, rowset = group_points_compact(xyz, new_xyz, feature, ic[0], ic[1], grouper.use_xyz, group_off=ic[2])
-                new_feature_list.append(mlp(rows, rowset=rowset, x_grad_from=3 if grouper.use_xyz else 0))
+                new_feature_list.append(mlp.forward_grouped(xyz, new_xyz, feature, ic[0], ic[1], ic[2], grouper.use_xyz))
             else:
                 grouped = group_points(xyz, new_xyz, feature, ic[0], grouper.use_xyz)     # [B, m, ns, C]   :51
                 new_feature_list.append(mlp(grouped, group_max=grouped.shape[2]))       # conv/bn/relu x3 + max :54-57
