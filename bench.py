@@ -273,7 +273,7 @@ def main():
             cpu = cpu_baseline(state0, B, N)
         value = world * B * args.steps / dt
         line = {
-            "metric": "point-clouds/sec fwd+bwd, PointNet++ SSG B=32 N=1024", "value": round(value, 2),
+            "metric": f"point-clouds/sec fwd+bwd, PointNet++ SSG B={B} N={N}", "value": round(value, 2),
             "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
