@@ -66,6 +66,20 @@ class FlatBucketDP:
             p.grad = v
 
 
+    def all_reduce_into_grads(self):
+        """Same exchange for gradients that must stay where they are (``param.grad`` tensors written in place by a
+        captured HIP graph): pack, one all-reduce, scale, unpack."""
+        if not self.active:
+            return
+        grads = [p.grad for p in self.params if p.grad is not None]
+        views = [v for p, v in zip(self.params, self.views) if p.grad is not None]
+        torch._foreach_copy_(views, grads)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self.world > 1:
+            self.flat.mul_(1.0 / self.world)
+        torch._foreach_copy_(grads, views)
+
+
 def shard_batch(tensors, rank, world):
     """Split the leading (cloud) axis of each tensor into `world` equal contiguous shards."""
     out = []

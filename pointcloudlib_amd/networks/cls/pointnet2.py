@@ -140,7 +140,7 @@ class PointNet2_cls(nn.Module):
     def forward(self, xyz, feature, sampling=None):
         if sampling is not None:
             cur = torch.cuda.current_stream()
-            if sampling["stream"] != cur:
+            if sampling.get("event") is not None and sampling["stream"] != cur:
                 cur.wait_event(sampling["event"])
                 for new_xyz, idxs in sampling["levels"]:              # allocator safety across streams
                     for t in [new_xyz] + [u for ic in idxs if ic is not None for u in ic]:

@@ -256,3 +256,42 @@ def test_edgeconv_factorised_matches_edge_tensor(oracle, dev, B, N, C, Cout, k):
         assert (got[n].double() - exp[n]).abs().max().item() <= 2e-5 * s, n
     for b in ("running_mean_0", "running_var_0"):
         assert torch.allclose(getattr(mlp, b).double(), getattr(ref, b), rtol=1e-5, atol=1e-6), b
+
+
+def test_graphed_step_matches_eager_step(dev):
+    """graph_step.GraphedStep (main stream captured as a HIP graph, sampling of the next batch eager on a side stream)
+    trains like the plain eager loop: same losses for the first steps (later ones drift through fp32 atomics)."""
+    from pointcloudlib_amd.dp import FlatBucketDP
+    from pointcloudlib_amd.graph_step import GraphedStep
+    from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
+    from pointcloudlib_amd.train_utils import make_sgd, soft_cross_entropy_loss
+    B, N = 8, 512
+    batches = [(torch.from_numpy(synth.gauss_ball(B, N, 50 + i)).to(dev), torch.from_numpy(synth.unit_normals(B, N, 60 + i)).to(dev),
+                torch.from_numpy(synth.labels(B, 40, 70 + i)).to(dev)) for i in range(3)]
+
+    def make():
+        torch.manual_seed(0)
+        net = no_dropout(PointNet2_cls().to(dev)).train()
+        return net, make_sgd(net.parameters(), lr=0.02, momentum=0.9)
+
+    net, opt = make()
+    eager = []
+    for i in range(6):
+        x, f, y = batches[i % 3]
+        for p in net.parameters():
+            p.grad = None
+        loss = soft_cross_entropy_loss(net(x, f), y)
+        loss.backward(); opt.step()
+        eager.append(loss.item())
+    net, opt = make()
+    init = {k: v.clone() for k, v in net.state_dict().items()}
+    gs = GraphedStep(net, soft_cross_entropy_loss, opt, FlatBucketDP(net), lambda b: b[0], batches[0], torch.cuda.Stream(priority=-1))
+    gs.capture(warmup=2)                                   # warm-up steps train: restore the initial state afterwards
+    net.load_state_dict(init)
+    for st in opt.state.values():
+        st["momentum_buffer"].zero_()
+    got = []
+    for i in range(6):
+        got.append(gs.step(batches[i % 3], batches[(i + 1) % 3], eager=(i == 3)).item())
+    assert abs(got[0] - eager[0]) <= 1e-5 * abs(eager[0]) and abs(got[1] - eager[1]) <= 1e-3 * abs(eager[1]), (got, eager)
+    assert all(abs(a - b) <= 5e-2 * abs(b) for a, b in zip(got, eager)), (got, eager)
