@@ -252,6 +252,9 @@ def main():
         # (every timing event is a marker packet on the stream; bracketing everything would perturb `value`)
         timer = _lib.KernelTimer([target[0]], tags=None if target[1] is None else [target[1]], max_records=N_EAGER if gs else 64)
 
+    import gc
+    gc.collect()
+    gc.disable()                 # no collector pauses inside the timed region (a gen-2 pass over the autograd objects is ~ms)
     fence()
     t0 = time.perf_counter()
     for j in range(args.steps):
@@ -265,6 +268,7 @@ def main():
         it += 1
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     _lib.PROFILER = None
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
