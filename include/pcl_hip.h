@@ -171,9 +171,10 @@ int pcl_pointconv_contract_bwd_f32(const float* dout, const float* feat, const f
  * u = scale*y + shift (BatchNorm, scale = gamma*invstd, shift = beta - scale*mean), z = lrelu(u).
  *
  * Statistics workspaces `stats_ws` are [rows][2][C] doubles with rows <= 1024; a GEMM epilogue producing C
- * channels over P rows writes pcl_mlp_stat_rows(P, C, backward) rows (backward = 0 for pcl_linear_fwd*, 1 for
- * pcl_linear_bwd_dx*), the elementwise producers report the count through *stat_rows_out. */
-int pcl_mlp_stat_rows(int P, int C, int backward);
+ * channels over P rows writes pcl_mlp_stat_rows(P, C, flags) rows (flags: bit 0 = the producer is pcl_linear_bwd_dx*
+ * rather than pcl_linear_fwd*, bit 1 = it runs on duplicate-compacted rows, i.e. row_meta is passed), the elementwise
+ * producers report the count through *stat_rows_out. */
+int pcl_mlp_stat_rows(int P, int C, int flags);
 /* Y[P,Cout] = act_in(X[P,Cin]) W[Cout,Cin]^T (+bias);  act_in = identity (in_scale NULL) or
  * lrelu(in_scale*x+in_shift, in_slope).  stats_ws rows: (sum Y, sum Y^2) per channel. */
 int pcl_linear_fwd_f32(const float* X, const float* W, const float* bias, const float* in_scale,

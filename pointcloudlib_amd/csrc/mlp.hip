@@ -311,11 +311,12 @@ __device__ __forceinline__ void quad_transpose4(float& v0, float& v1, float& v2,
     y = quad_xchg2(b1 ? v1 : v3); v1 = b1 ? y : v1; v3 = b1 ? v3 : y;
 }
 
-template <int AM, int EM, bool VEC, int TN, int GM, bool RAG>
+template <int AM, int EM, bool VEC, int TN, int GM, bool RAG, int TM = 2>
 __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in) {
+    static_assert(GM == 0 || TM == 2, "the fused group max works on 64-row wave slabs");
     LinArgs p = p_in;
     if (p.m_dev) p.M = *p.m_dev;                       // compacted rows: the row count lives on the device
-    constexpr int TBM = 128, TBN = 64 * TN;
+    constexpr int TBM = 64 * TM, TBN = 64 * TN;        // TM = 1: 64-row tiles for small M (twice the workgroups)
     constexpr bool BT = AM >= A_DY;              // backward: B is the weight matrix as stored, [K][N]
     __shared__ __attribute__((aligned(16))) float sA[TBM * LDS_LD];
     __shared__ __attribute__((aligned(16))) float sB[TBN * LDS_LD];
@@ -356,9 +357,9 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
     }
     for (; mt < m_tiles; mt += gridDim.x) {
         const int m0 = mt * TBM;
-        f32x16 acc[2][TN];
+        f32x16 acc[TM][TN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -384,17 +385,17 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
             const int kc = min(BK, p.K - k0);
             const int nkk = (kc + 7) >> 3;
             for (int kk = 0; kk < nkk; ++kk) {
-                float4 a4[2], b4[TN];
+                float4 a4[TM], b4[TN];
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    a4[t] = *reinterpret_cast<const float4*>(&sA[(wr * 64 + t * 32 + lr) * LDS_LD + kk * 8 + lh * 4]);
+                for (int t = 0; t < TM; ++t)
+                    a4[t] = *reinterpret_cast<const float4*>(&sA[(wr * (32 * TM) + t * 32 + lr) * LDS_LD + kk * 8 + lh * 4]);
 #pragma unroll
                 for (int t = 0; t < TN; ++t)
                     b4[t] = *reinterpret_cast<const float4*>(&sB[(wc * 32 * TN + t * 32 + lr) * LDS_LD + kk * 8 + lh * 4]);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
 #pragma unroll
-                    for (int tm = 0; tm < 2; ++tm) {
+                    for (int tm = 0; tm < TM; ++tm) {
                         const float av = s == 0 ? a4[tm].x : s == 1 ? a4[tm].y : s == 2 ? a4[tm].z : a4[tm].w;
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn) {
@@ -420,8 +421,8 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                 const bool b0 = lane & 1, b1 = lane & 2;
                 const int qcol = n0 + wc * 32 * TN + tn * 32 + (lr & ~3);      // first of this lane's 4 columns after the transpose
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm) {
-                    const int rbase = m0 + wr * 64 + tm * 32 + 4 * lh + (lane & 3);   // + 8*(r>>2): this lane's row after the transpose
+                for (int tm = 0; tm < TM; ++tm) {
+                    const int rbase = m0 + wr * (32 * TM) + tm * 32 + 4 * lh + (lane & 3);   // + 8*(r>>2): this lane's row after the transpose
                     float yv[16];                          // one 32-row MFMA tile at a time: 16 VGPRs
                     if constexpr (EM == E_MASK_STORE_STATS) {
                         if (vec_c) {
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                         } else {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
-                                const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                                const int row = m0 + wr * (32 * TM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                                 yv[r] = p.Yprev[(size_t)row * p.N + col];
                             }
                         }
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                     if constexpr (NEEDW) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float4 t = *reinterpret_cast<const float4*>(&sW[wr * 64 + tm * 32 + 8 * q + 4 * lh]);
+                            const float4 t = *reinterpret_cast<const float4*>(&sW[wr * (32 * TM) + tm * 32 + 8 * q + 4 * lh]);
                             wv[4 * q] = t.x; wv[4 * q + 1] = t.y; wv[4 * q + 2] = t.z; wv[4 * q + 3] = t.w;
                         }
                     }
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                     } else {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            const int row = m0 + wr * (32 * TM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                             p.C[(size_t)row * p.ldc + col] = cv[r];
                         }
                     }
@@ -484,15 +485,15 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                 if constexpr (EM == E_MASK_STORE_STATS) {
                     st_s[tn] += (double)ts; st_q[tn] += (double)tq + (double)piv * (double)ts;
                 } else if constexpr (EM == E_STORE_STATS) {
-                    const double n = RAG ? (double)tw : 32.0, pv = piv;
+                    const double n = RAG ? (double)tw : 16.0 * TM, pv = piv;
                     st_s[tn] += (double)ts + n * pv; st_q[tn] += (double)tq + 2.0 * pv * (double)ts + n * pv * pv;
                 }
             } else {
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
+                for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int row = m0 + wr * (32 * TM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                         if (cin && row < p.M) {
                             const size_t off = (size_t)row * p.N + col;
                             float c = acc[tm][tn][r] + bias;
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                     const int oimax = __shfl_xor(imax, 32), oimin = __shfl_xor(imin, 32);
                     if (omax > vmax || (omax == vmax && oimax < imax)) { vmax = omax; imax = oimax; }
                     if (omin < vmin || (omin == vmin && oimin < imin)) { vmin = omin; imin = oimin; }
-                    const int row0 = m0 + wr * 64 + gi * GM;
+                    const int row0 = m0 + wr * (32 * TM) + gi * GM;
                     if (lh == 0 && cin && row0 < p.M) {
                         const size_t o = (size_t)(row0 / GM) * p.N + col;
                         p.gmax[o] = vmax; p.gmin[o] = vmin; p.gamax[o] = imax; p.gamin[o] = imin;
@@ -1005,14 +1006,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
     stats[(size_t)blockIdx.y * 2 * C + C + c] = s2;
 }
 
-static void linear_grid(int M, int N, bool bwd, int& gx, int& n_tiles, bool& narrow) {
+static void linear_grid(int M, int N, bool bwd, bool rag, int& gx, int& n_tiles, bool& narrow, bool& low) {
     // 128x64 block tile instead of 128x128 for narrow outputs -- and for the backward (dy-forming) loaders, whose
     // three operand streams + 128x128 accumulators do not fit 256 VGPRs at 2 waves/SIMD (47-97 spilled VGPRs
     // measured); re-reading the A operand from L2 for the second column tile is cheaper than the spills.
-    const int m_tiles = (M + 127) / 128;
+    int m_tiles = (M + 127) / 128;
     narrow = N <= 64 || bwd || m_tiles * ((N + 127) / 128) < 384;   // also: too few 128x128 tiles to fill 256 CUs
     const int tbn = narrow ? 64 : 128;
     n_tiles = (N + tbn - 1) / tbn;
+    // small M (the GroupAll level: 4096 rows): 64-row tiles double the workgroups, two per CU hide each other's latency
+    low = narrow && !rag && m_tiles * n_tiles < 768;
+    if (low) m_tiles = (M + 63) / 64;
     gx = m_tiles < STAT_ROWS ? m_tiles : STAT_ROWS;
     const int want = (1024 + n_tiles - 1) / n_tiles;   // ~4 workgroups per CU in total
     if (gx > want) gx = want;
@@ -1023,9 +1027,16 @@ static int launch_linear_t(const LinArgs& a, hipStream_t st) {
     const bool vec = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0) && (!a.A2 || (reinterpret_cast<uintptr_t>(a.A2) & 15) == 0) &&
                      (AM < A_DY || a.ldb % 4 == 0);
-    int gx, n_tiles; bool narrow;
-    linear_grid(a.M, a.N - a.n_begin, AM >= A_DY, gx, n_tiles, narrow);
+    int gx, n_tiles; bool narrow, low;
+    linear_grid(a.M, a.N - a.n_begin, AM >= A_DY, RAG, gx, n_tiles, narrow, low);
     dim3 grid(gx, n_tiles);
+    if constexpr (!RAG && GM == 0) {
+        if (low) {
+            if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, 0, false, 1>), grid, dim3(MLP_T), 0, st, a);
+            else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1, 0, false, 1>), grid, dim3(MLP_T), 0, st, a);
+            return check_launch("pcl_linear");
+        }
+    }
     if (narrow) {
         if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
         else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
@@ -1037,9 +1048,9 @@ static int launch_linear_t(const LinArgs& a, hipStream_t st) {
 }
 
 // number of stats rows a launch_linear_t call with M rows and N columns writes
-static int linear_stat_rows(int M, int N, bool bwd) {
-    int gx, n_tiles; bool narrow;
-    linear_grid(M, N, bwd, gx, n_tiles, narrow);
+static int linear_stat_rows(int M, int N, bool bwd, bool rag) {
+    int gx, n_tiles; bool narrow, low;
+    linear_grid(M, N, bwd, rag, gx, n_tiles, narrow, low);
     return gx;
 }
 
@@ -1072,9 +1083,9 @@ static int launch_linear(const LinArgs& a, hipStream_t st) {
 }  // namespace pcl
 using namespace pcl;
 
-extern "C" int pcl_mlp_stat_rows(int P, int C, int backward) {
+extern "C" int pcl_mlp_stat_rows(int P, int C, int flags) {
     if (P < 1 || C < 1) return 1;
-    return linear_stat_rows(P, C, backward != 0);
+    return linear_stat_rows(P, C, (flags & 1) != 0, (flags & 2) != 0);
 }
 
 extern "C" int pcl_linear_fwd_rows_f32(const float* X, const float* W, const float* bias, const float* in_scale,

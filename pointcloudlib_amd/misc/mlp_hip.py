@@ -96,7 +96,7 @@ class _FusedMLP(torch.autograd.Function):
                 Y, stats, rows = x, link.stats, link.rows
             else:
                 Y = _empty((P, cout), dev)
-                rows = _lib.lib().pcl_mlp_stat_rows(P, cout, 0)
+                rows = _lib.lib().pcl_mlp_stat_rows(P, cout, 2 if rowset is not None else 0)
                 stats = _empty((rows, 2, cout), dev, torch.float64)
             if l == 0 and link is not None:
                 pass
@@ -244,7 +244,7 @@ class _FusedMLP(torch.autograd.Function):
             if l > 0 or need_x:
                 dUp = _empty((P, cin), dev)
                 if l > 0:
-                    rows_n = lib.pcl_mlp_stat_rows(P, cin, 1)
+                    rows_n = lib.pcl_mlp_stat_rows(P, cin, 1 | (2 if rmeta is not None else 0))
                     stats_n = _empty((rows_n, 2, cin), dev, torch.float64)
                 else:
                     rows_n, stats_n = rows, None
