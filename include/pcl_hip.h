@@ -139,6 +139,20 @@ int pcl_group_linear_bwd_f32(const float* xyz, const float* new_xyz, const float
                              const int32_t* row_meta, const int32_t* row_src, const int32_t* n_rows_dev /* &group_off[B*m] */,
                              int B, int N, int C1, float* dUf, float* dWx_part, float* dWf_part, void* stream);
 
+/* The classification head on R <= 64 rows (one row per cloud): Linear (+bias) -> BatchNorm1d -> (Leaky)ReLU as ONE kernel
+ * per layer (networks/cls/pointnet2.py:138-147, dgcnn.py:87-93, pointnet.py:22-38).  X [R,K], W [N,K] (nn.Linear layout).
+ * bn_mode: 0 none, 1 training (batch statistics over the R rows; running_mean/var updated in place torch-style, unbiased
+ * running variance), 2 evaluation (running statistics).  slope: 1 = no activation, 0 = ReLU, 0.2 = LeakyReLU.
+ * Forward keeps Ypre (pre-BatchNorm) and mean/invstd for backward; backward returns dW, dbias/dgamma/dbeta (nullable) and,
+ * when dX != NULL, the input gradient (dY_ws: [R,N] scratch). */
+int pcl_head_layer_fwd_f32(const float* X, const float* W, const float* bias, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, int R, int K, int N, int bn_mode, float eps, float momentum,
+                           float slope, float* Ypre, float* OUT, float* mean_out, float* invstd_out, void* stream);
+int pcl_head_layer_bwd_f32(const float* X, const float* W, const float* dOUT, const float* OUT, const float* Ypre,
+                           const float* gamma, const float* mean, const float* invstd, int R, int K, int N, int bn_mode,
+                           float slope, float* dY_ws, float* dW, float* dbias, float* dgamma, float* dbeta, float* dX,
+                           void* stream);
+
 /* DGCNN EdgeConv without the edge tensor (networks/cls/dgcnn.py:29-50,:72-83,:100-111).  With the 1x1 conv weight split
  * W = [Wa | Wb], y[i,j] = U[nbr(i,j)] + V[i] where UV [B*N, 2C] = x [Wa ; Wb-Wa]^T is ONE plain GEMM over the points.
  *   pcl_edgeconv_gather_f32: per point and channel max/min of y over the k neighbours and their positions (the sign of

@@ -1,0 +1,247 @@
+// head.hip -- the classification head on a handful of rows, gfx950.
+//
+// After the last set-abstraction level a cloud is ONE row: the FC head (Linear -> BatchNorm1d -> ReLU -> ... -> Linear,
+// /root/reference/networks/cls/pointnet2.py:138-147, dgcnn.py:87-93,117-121, pointnet.py:22-38) runs on R = batch-size rows
+// (32).  As library GEMM + BatchNorm + activation launches that is ~45 tiny kernels per step, each a few microseconds of
+// latency for microseconds of work.  With R <= 64 a whole column of the output fits one wave, so a layer is one kernel:
+//   forward : wave = one output column n; lanes split K (coalesced reads of W[n,:], X staged through LDS); after the
+//             cross-lane reduction lane r holds y[r,n]; batch mean / variance over the R rows, normalise, activate, store.
+//   backward: (1) wave = column n again: du = dout * act'(out), BatchNorm backward over the column, dy[:,n] stored;
+//                 dW[n,:] = sum_r dy[r] X[r,:] written coalesced; dgamma, dbeta, dbias.
+//             (2) dX[r,k] = sum_n dy[r,n] W[n,k]: lane = k, the n range split over waves, atomics into dX.
+// BatchNorm1d follows torch (the head is torch's BatchNorm1d in the counterpart networks): biased variance for the
+// normalisation, UNBIASED variance into running_var, momentum 0.1.
+#include "common.h"
+
+namespace pcl {
+
+constexpr int HD_KC = 256;       // k per wave pass: 64 lanes x 4
+
+// One workgroup per output column n, its 4 waves split K in 256-wide chunks; X rows are read straight from global
+// memory (L2-resident, 16-byte pieces), so a lane has RMAX + 1 independent loads in flight per chunk and no barrier
+// until the four partial sums meet in LDS.
+template <int RMAX>
+__device__ __forceinline__ void head_col_dot(const float* __restrict__ X, const float* __restrict__ Wn, int R, int K, int wave,
+                                             int lane, float (&acc)[RMAX]) {
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) acc[r] = 0.f;
+    const bool vec = (K & 3) == 0;
+    for (int k0 = wave * HD_KC; k0 < K; k0 += 4 * HD_KC) {
+        const int k = k0 + 4 * lane;
+        float w[4];
+        if (vec && k + 3 < K) {
+            const float4 t = *reinterpret_cast<const float4*>(Wn + k);
+            w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = k + j < K ? Wn[k + j] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            float x[4] = {0.f, 0.f, 0.f, 0.f};
+            if (r < R) {
+                if (vec && k + 3 < K) {
+                    const float4 t = *reinterpret_cast<const float4*>(X + (size_t)r * K + k);
+                    x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[j] = k + j < K ? X[(size_t)r * K + k + j] : 0.f;
+                }
+            }
+            acc[r] = fmaf(w[3], x[3], fmaf(w[2], x[2], fmaf(w[1], x[1], fmaf(w[0], x[0], acc[r]))));
+        }
+    }
+}
+
+// Y_pre [R,N] (pre-BatchNorm, kept for backward), OUT [R,N] = act(BN(Y_pre)); mean/invstd [N] saved.
+template <int RMAX>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ rmean,
+                                                       float* __restrict__ rvar, int R, int K, int N, int bn_mode /*0 none,1 train,2 eval*/,
+                                                       float eps, float momentum, float slope, float* __restrict__ Ypre,
+                                                       float* __restrict__ OUT, float* __restrict__ mean_out,
+                                                       float* __restrict__ invstd_out) {
+    __shared__ float part[4][RMAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x;
+    float acc[RMAX];
+    head_col_dot<RMAX>(X, W + (size_t)n * K, R, K, wave, lane, acc);
+    // lane r of each wave gets that wave's partial of row r; the four partials meet in LDS
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        float v = acc[r];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == r) part[wave][r] = v;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const bool in = lane < R;
+    float y = 0.f;
+    if (lane < RMAX) y = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    y = in ? y + (bias ? bias[n] : 0.f) : 0.f;
+    float out = y;
+    if (bn_mode != 0) {
+        float mean, invstd;
+        if (bn_mode == 1) {
+            float s = y, q = 0.f;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+            mean = s / (float)R;
+            const float d = in ? y - mean : 0.f;
+            q = d * d;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+            const float var = q / (float)R;
+            invstd = 1.0f / sqrtf(var + eps);
+            if (lane == 0) {
+                if (rmean) rmean[n] += (mean - rmean[n]) * momentum;
+                if (rvar) rvar[n] += ((R > 1 ? q / (float)(R - 1) : var) - rvar[n]) * momentum;
+            }
+        } else {
+            mean = rmean[n];
+            invstd = 1.0f / sqrtf(rvar[n] + eps);
+        }
+        if (lane == 0) { mean_out[n] = mean; invstd_out[n] = invstd; }
+        out = fmaf((y - mean) * invstd, gamma ? gamma[n] : 1.f, beta ? beta[n] : 0.f);
+    }
+    out = out > 0.f ? out : out * slope;
+    if (in) { Ypre[(size_t)lane * N + n] = y; OUT[(size_t)lane * N + n] = out; }
+}
+
+// backward, column part: dy[:,n], dW[n,:], dbias[n], dgamma[n], dbeta[n].  One workgroup per column; every wave forms
+// the column's dy (R values, lane r) itself and writes its quarter of dW[n,:].
+template <int RMAX>
+__global__ __launch_bounds__(256) void head_bwd_col_kernel(const float* __restrict__ X, const float* __restrict__ dOUT,
+                                                           const float* __restrict__ OUT, const float* __restrict__ Ypre,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, int R, int K, int N, int bn_mode,
+                                                           float slope, float* __restrict__ dY, float* __restrict__ dW,
+                                                           float* __restrict__ dbias, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x;
+    const bool in = lane < R;
+    const size_t o = (size_t)min(lane, R - 1) * N + n;
+    float du = in ? dOUT[o] : 0.f;
+    const float outv = OUT[o];
+    du = outv > 0.f ? du : du * slope;                      // act'(.) from the sign of the activation's output (slope >= 0)
+    float dy = du;
+    if (bn_mode != 0) {
+        const float g = gamma ? gamma[n] : 1.f, mu = mean[n], is = invstd[n];
+        const float xh = in ? (Ypre[o] - mu) * is : 0.f;
+        float s1 = du, s2 = du * xh;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+        if (lane == 0 && wave == 0) { if (dgamma) dgamma[n] = s2; if (dbeta) dbeta[n] = s1; }
+        dy = bn_mode == 1 ? g * is * (du - s1 / (float)R - xh * s2 / (float)R) : g * is * du;
+        if (!in) dy = 0.f;
+    }
+    if (in && wave == 0) dY[o] = dy;
+    if (dbias) {
+        float s = dy;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0 && wave == 0) dbias[n] = s;
+    }
+    // dW[n, k] = sum_r dy[r] * X[r, k]: lane r holds dy[r]; broadcast it row by row
+    const bool vec = (K & 3) == 0;
+    for (int k0 = wave * HD_KC; k0 < K; k0 += 4 * HD_KC) {
+        const int k = k0 + 4 * lane;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const float d = __shfl(dy, r);
+            if (r < R) {
+                if (vec && k + 3 < K) {
+                    const float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * K + k);
+                    a[0] = fmaf(d, x.x, a[0]); a[1] = fmaf(d, x.y, a[1]); a[2] = fmaf(d, x.z, a[2]); a[3] = fmaf(d, x.w, a[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (k + j < K) a[j] = fmaf(d, X[(size_t)r * K + k + j], a[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (k + j < K) dW[(size_t)n * K + k + j] = a[j];
+    }
+}
+
+// dX[r,k] += sum_{n in this wave's range} dy[r,n] * W[n,k]; grid (ceil(K/64), N splits of HD_NS)
+constexpr int HD_NS = 8;
+template <int RMAX>
+__global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restrict__ dY, const float* __restrict__ W, int R, int K,
+                                                          int N, float* __restrict__ dX) {
+    __shared__ float sD[4][RMAX][HD_NS + 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 64 + lane;
+    const int n0 = (blockIdx.y * 4 + wave) * HD_NS;
+    for (int e = lane; e < RMAX * HD_NS; e += 64) {
+        const int r = e / HD_NS, j = e - r * HD_NS;
+        sD[wave][r][j] = (r < R && n0 + j < N) ? dY[(size_t)r * N + n0 + j] : 0.f;
+    }
+    __syncthreads();
+    float acc[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) acc[r] = 0.f;
+    const int kc = min(k, K - 1);
+    for (int j = 0; j < HD_NS; ++j) {
+        if (n0 + j >= N) break;
+        const float w = W[(size_t)(n0 + j) * K + kc];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) acc[r] = fmaf(sD[wave][r][j], w, acc[r]);
+    }
+    if (k < K && n0 < N) {
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r)
+            if (r < R) unsafeAtomicAdd(&dX[(size_t)r * K + k], acc[r]);
+    }
+}
+
+}  // namespace pcl
+using namespace pcl;
+
+extern "C" int pcl_head_layer_fwd_f32(const float* X, const float* W, const float* bias, const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, int R, int K, int N, int bn_mode, float eps,
+                                      float momentum, float slope, float* Ypre, float* OUT, float* mean_out, float* invstd_out,
+                                      void* stream) {
+    PCL_REQUIRE(X && W && Ypre && OUT, "pcl_head_layer_fwd_f32: null pointer");
+    PCL_REQUIRE(R >= 1 && R <= 64 && K >= 1 && N >= 1, "pcl_head_layer_fwd_f32: bad sizes R=%d K=%d N=%d (R <= 64)", R, K, N);
+    PCL_REQUIRE(bn_mode >= 0 && bn_mode <= 2 && (bn_mode == 0 || (mean_out && invstd_out)) && (bn_mode != 2 || (running_mean && running_var)),
+                "pcl_head_layer_fwd_f32: bn_mode=%d", bn_mode);
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(N), block(256);
+    if (R <= 32)
+        hipLaunchKernelGGL(head_fwd_kernel<32>, grid, block, 0, st, X, W, bias, gamma, beta, running_mean, running_var, R, K, N, bn_mode, eps,
+                           momentum, slope, Ypre, OUT, mean_out, invstd_out);
+    else
+        hipLaunchKernelGGL(head_fwd_kernel<64>, grid, block, 0, st, X, W, bias, gamma, beta, running_mean, running_var, R, K, N, bn_mode, eps,
+                           momentum, slope, Ypre, OUT, mean_out, invstd_out);
+    return check_launch("pcl_head_layer_fwd_f32");
+}
+
+extern "C" int pcl_head_layer_bwd_f32(const float* X, const float* W, const float* dOUT, const float* OUT, const float* Ypre,
+                                      const float* gamma, const float* mean, const float* invstd, int R, int K, int N, int bn_mode,
+                                      float slope, float* dY_ws, float* dW, float* dbias, float* dgamma, float* dbeta, float* dX,
+                                      void* stream) {
+    PCL_REQUIRE(X && W && dOUT && OUT && Ypre && dY_ws && dW, "pcl_head_layer_bwd_f32: null pointer");
+    PCL_REQUIRE(R >= 1 && R <= 64 && K >= 1 && N >= 1, "pcl_head_layer_bwd_f32: bad sizes R=%d K=%d N=%d (R <= 64)", R, K, N);
+    PCL_REQUIRE(bn_mode == 0 || (mean && invstd), "pcl_head_layer_bwd_f32: BatchNorm needs mean / invstd");
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(N), block(256);
+    if (R <= 32)
+        hipLaunchKernelGGL(head_bwd_col_kernel<32>, grid, block, 0, st, X, dOUT, OUT, Ypre, gamma, mean, invstd, R, K, N, bn_mode, slope, dY_ws,
+                           dW, dbias, dgamma, dbeta);
+    else
+        hipLaunchKernelGGL(head_bwd_col_kernel<64>, grid, block, 0, st, X, dOUT, OUT, Ypre, gamma, mean, invstd, R, K, N, bn_mode, slope, dY_ws,
+                           dW, dbias, dgamma, dbeta);
+    int rc = check_launch("pcl_head_layer_bwd_f32(col)");
+    if (rc || !dX) return rc;
+    hipError_t e = hipMemsetAsync(dX, 0, sizeof(float) * (size_t)R * K, st);
+    if (e != hipSuccess) return fail(PCL_EHIP, "pcl_head_layer_bwd_f32: memset: %s", hipGetErrorString(e));
+    const dim3 g2((K + 63) / 64, (N + 4 * HD_NS - 1) / (4 * HD_NS));
+    if (R <= 32) hipLaunchKernelGGL(head_bwd_dx_kernel<32>, g2, block, 0, st, dY_ws, W, R, K, N, dX);
+    else hipLaunchKernelGGL(head_bwd_dx_kernel<64>, g2, block, 0, st, dY_ws, W, R, K, N, dX);
+    return check_launch("pcl_head_layer_bwd_f32(dx)");
+}

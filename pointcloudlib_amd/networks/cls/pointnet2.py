@@ -13,6 +13,7 @@ from typing import List, Optional
 import torch
 from torch import nn
 
+from ...misc.head import fc_head
 from ...misc.layers import PointwiseMLP
 from ...misc.ops import (BallQueryGrouper, FurthestPointSampler, GroupAll, ball_query, group_offsets, group_points,
                          group_points_compact)
@@ -149,7 +150,7 @@ class PointNet2_cls(nn.Module):
         for i, module in enumerate(self.pointnet_modules):
             xyz, feature = module(xyz, feature, None if sampling is None else sampling["levels"][i])
         feature = feature.squeeze(dim=1)                                                         # :157
-        return self.fc_layer(feature)
+        return fc_head(self.fc_layer, feature)
 
     def execute(self, *a, **k):
         return self(*a, **k)

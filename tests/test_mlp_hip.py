@@ -207,3 +207,46 @@ def test_batchnorm_statistics_survive_large_mean(dev, offset, spread):
         s = max(1e-6, g_d[n].abs().max().item())
         eh, et = (g_h[n].double() - g_d[n]).abs().max().item(), (g_t[n].double() - g_d[n]).abs().max().item()
         assert eh <= max(4 * et, 1e-4 * s), (n, eh, et)
+
+
+@pytest.mark.parametrize("R,K,N,bn,slope,bias", [(32, 1024, 512, True, 0.0, False), (32, 256, 40, False, 1.0, True),
+                                                 (5, 300, 33, True, 0.2, True), (64, 2048, 512, True, 0.2, False),
+                                                 (1, 16, 8, False, 0.0, True), (33, 70, 130, True, 0.0, True)])
+def test_head_layer_matches_torch(dev, R, K, N, bn, slope, bias):
+    """csrc/head.hip (Linear + BatchNorm1d + activation on <= 64 rows as one kernel) against the PyTorch modules in fp64:
+    outputs, running statistics and every gradient; training and evaluation mode."""
+    from torch import nn
+    from pointcloudlib_amd.misc.head import head_layer
+    torch.manual_seed(R + K)
+    lin = nn.Linear(K, N, bias=bias).to(dev)
+    b = nn.BatchNorm1d(N).to(dev) if bn else None
+    if bn:
+        b.weight.data.uniform_(-1.0, 1.5); b.bias.data.uniform_(-0.5, 0.5)
+    act = None if slope == 1.0 else (nn.ReLU() if slope == 0.0 else nn.LeakyReLU(slope))
+    for training in ((True, False) if R > 1 else (False,)):
+        lin_d, b_d = copy.deepcopy(lin).double(), (copy.deepcopy(b).double() if bn else None)
+        for m in (b, b_d):
+            if m is not None:
+                m.train(training)
+        x = torch.randn(R, K, device=dev, requires_grad=True)
+        g = torch.randn(R, N, device=dev)
+        out = head_layer(x, lin, b, act)
+        out.backward(g)
+        xd = x.detach().double().requires_grad_(True)
+        y = lin_d(xd)
+        if bn:
+            y = b_d(y)
+        ref = y if act is None else torch.nn.functional.leaky_relu(y, slope)
+        ref.backward(g.double())
+        pairs = [("out", out.detach(), ref.detach()), ("dx", x.grad, xd.grad), ("dW", lin.weight.grad, lin_d.weight.grad)]
+        if bias:
+            pairs.append(("db", lin.bias.grad, lin_d.bias.grad))
+        if bn:
+            pairs += [("dgamma", b.weight.grad, b_d.weight.grad), ("dbeta", b.bias.grad, b_d.bias.grad),
+                      ("rmean", b.running_mean, b_d.running_mean), ("rvar", b.running_var, b_d.running_var)]
+        for name, a, r in pairs:
+            s = max(1.0, r.abs().max().item())
+            assert (a.double() - r).abs().max().item() <= 2e-5 * s, (name, training)
+        for m in (lin, b):
+            if m is not None:
+                m.zero_grad()
