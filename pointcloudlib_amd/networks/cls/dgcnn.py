@@ -16,6 +16,7 @@ from torch import nn
 
 from ...misc.layers import PointwiseMLP
 from ...misc.edgeconv import edge_conv
+from ...misc.head import head_layer
 from ...misc.ops import KNN, edge_features
 
 
@@ -61,11 +62,11 @@ class DGCNN(nn.Module):
         x = torch.cat((x1, x2, x3, x4), dim=2)                              # [B,N,512]   :112
         x = self.conv5(x)                                                   # [B,N,1024]  :113
         x = torch.cat((x.max(dim=1)[0], x.mean(dim=1)), dim=1)              # :114-116
-        x = F.leaky_relu(self.bn6(self.linear1(x)), 0.2)
+        x = head_layer(x, self.linear1, self.bn6, 0.2)           # fused head kernels (misc/head.py)
         x = self.dp1(x)
-        x = F.leaky_relu(self.bn7(self.linear2(x)), 0.2)
+        x = head_layer(x, self.linear2, self.bn7, 0.2)
         x = self.dp2(x)
-        return self.linear3(x)
+        return head_layer(x, self.linear3)
 
     def execute(self, *a, **k):
         return self(*a, **k)

@@ -2,6 +2,7 @@
 sa3 uses ``group_all=True``, which upstream cannot run (missing ``sample_and_group_all``); see pointconv_utils."""
 from torch import nn
 
+from ...misc.head import head_layer
 from ...misc.pointconv_utils import PointConvDensitySetAbstraction
 
 
@@ -27,9 +28,9 @@ class PointConvDensityClsSsg(nn.Module):
         l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, None if start_idx is None else start_idx[1])
         _, l3_points = self.sa3(l2_xyz, l2_points)
         x = l3_points.reshape(B, 1024)
-        x = self.drop1(self.relu(self.bn1(self.fc1(x))))
-        x = self.drop2(self.relu(self.bn2(self.fc2(x))))
-        return self.fc3(x)
+        x = self.drop1(head_layer(x, self.fc1, self.bn1, self.relu))       # fused head kernels (misc/head.py)
+        x = self.drop2(head_layer(x, self.fc2, self.bn2, self.relu))
+        return head_layer(x, self.fc3)
 
     def execute(self, *a, **k):
         return self(*a, **k)
