@@ -133,11 +133,12 @@ int pcl_group_linear_stat_rows(int B, int m);
 int pcl_group_linear_f32(const float* xyz, const float* new_xyz, const float* Uf, const float* Wx, const float* feat_small,
                          const float* Wf_small, int CF, const int32_t* idx, const int32_t* cnt, const int32_t* group_off,
                          int B, int N, int m, int ns, int C1, float* Y, int32_t* row_meta, int32_t* row_src,
+                         float* row_loc /* [cap,4]: xyz - centre, multiplicity */, float* row_feat /* [cap,4] or NULL */,
                          double* stats_ws, void* stream);
-int pcl_group_linear_bwd_f32(const float* xyz, const float* new_xyz, const float* feat_small, int CF, const float* dU,
-                             const float* Y, const float* a, const float* k1, const float* k2, const float* mu,
-                             const int32_t* row_meta, const int32_t* row_src, const int32_t* n_rows_dev /* &group_off[B*m] */,
-                             int B, int N, int C1, float* dUf, float* dWx_part, float* dWf_part, void* stream);
+int pcl_group_linear_bwd_f32(const float* row_loc, const float* row_feat, int CF, const float* dU, const float* Y,
+                             const float* a, const float* k1, const float* k2, const float* mu, const int32_t* row_src,
+                             const int32_t* n_rows_dev /* &group_off[B*m] */, int B, int N, int C1, float* dUf,
+                             float* dWx_part, float* dWf_part, void* stream);
 
 /* The classification head on R <= 64 rows (one row per cloud): Linear (+bias) -> BatchNorm1d -> (Leaky)ReLU as ONE kernel
  * per layer (networks/cls/pointnet2.py:138-147, dgcnn.py:87-93, pointnet.py:22-38).  X [R,K], W [N,K] (nn.Linear layout).

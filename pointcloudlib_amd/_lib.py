@@ -61,8 +61,8 @@ _SIGS = {
     "pcl_three_interp_bwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_density_f32": (c_int, [_P, c_int, c_int, c_float, _P, _P]),
     "pcl_group_linear_stat_rows": (c_int, [c_int, c_int]),
-    "pcl_group_linear_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
-    "pcl_group_linear_bwd_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "pcl_group_linear_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "pcl_group_linear_bwd_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "pcl_head_layer_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P]),
     "pcl_head_layer_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "pcl_edgeconv_stat_rows": (c_int, [c_int, c_int]),

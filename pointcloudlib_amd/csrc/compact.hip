@@ -182,26 +182,45 @@ constexpr int GL_RPI = 4;        // rows in flight per wave
 constexpr int GL_CF = 4;         // features folded inline (e.g. the 3 normals of the first level), wider ones come as Uf
 
 // metadata of the distinct rows: one wave per group
-__global__ __launch_bounds__(256) void group_rows_meta_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ cnt,
+// Also per row: rloc = (xyz[nbr] - centre, multiplicity) and rfeat = the (<= 4) inline feature columns, so that the
+// streaming kernels below read one or two 16-byte records per row instead of a dozen scalars.
+__global__ __launch_bounds__(256) void group_rows_meta_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                              const float* __restrict__ fs, int CF,
+                                                              const int32_t* __restrict__ idx, const int32_t* __restrict__ cnt,
                                                               const int32_t* __restrict__ goff, int G, int N, int m, int ns,
-                                                              int2* __restrict__ rmeta, int32_t* __restrict__ rsrc) {
+                                                              int2* __restrict__ rmeta, int32_t* __restrict__ rsrc,
+                                                              float4* __restrict__ rloc, float4* __restrict__ rfeat) {
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (g >= G) return;
     const int c = max(cnt[g], 1), base = goff[g], b = g / m;
     const int32_t* I = idx + (size_t)g * ns;
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+    if (xyz) { q0 = new_xyz[(size_t)g * 3]; q1 = new_xyz[(size_t)g * 3 + 1]; q2 = new_xyz[(size_t)g * 3 + 2]; }
     for (int s = lane; s < c; s += 64) {
         const int mult = s == 0 ? ns - c + 1 : 1;
+        const int src = b * N + I[s];
         rmeta[base + s] = make_int2(g, s | (mult << 16));
-        rsrc[base + s] = b * N + I[s];
+        rsrc[base + s] = src;
+        float4 L = make_float4(0.f, 0.f, 0.f, (float)mult);
+        if (xyz) {
+            const float* pk = xyz + (size_t)src * 3;
+            L.x = __fsub_rn(pk[0], q0); L.y = __fsub_rn(pk[1], q1); L.z = __fsub_rn(pk[2], q2);
+        }
+        rloc[base + s] = L;
+        if (rfeat) {
+            float f[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < CF; ++j) f[j] = fs[(size_t)src * CF + j];
+            rfeat[base + s] = make_float4(f[0], f[1], f[2], f[3]);
+        }
     }
 }
 
 // Row-parallel: wave w walks rows 4w.., 4w + 4*nwaves.., four rows in flight, lanes over the C1 channels; the next
 // iteration's row metadata is requested before the current rows are processed (two dependent gathers per row otherwise).
-__global__ __launch_bounds__(256) void group_linear_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
-                                                           const float* __restrict__ Uf, const float* __restrict__ Wx,
-                                                           const float* __restrict__ fs, const float* __restrict__ Wfs, int CF,
-                                                           const int2* __restrict__ rmeta, const int32_t* __restrict__ rsrc,
+__global__ __launch_bounds__(256) void group_linear_kernel(const float* __restrict__ Uf, const float* __restrict__ Wx,
+                                                           const float* __restrict__ Wfs, int CF,
+                                                           const float4* __restrict__ rloc, const float4* __restrict__ rfeat,
+                                                           const int32_t* __restrict__ rsrc,
                                                            const int32_t* __restrict__ n_rows, int C1, float* __restrict__ Y,
                                                            double* __restrict__ stats) {
     __shared__ double red[2][4][64 * GL_MAXH];
@@ -221,32 +240,24 @@ __global__ __launch_bounds__(256) void group_linear_kernel(const float* __restri
     }
     const int stride = gridDim.x * 4 * GL_RPI;
     int r0 = (blockIdx.x * 4 + wave) * GL_RPI;
-    int2 me[GL_RPI]; int sr[GL_RPI];
+    float4 nl[GL_RPI], nf[GL_RPI]; int sr[GL_RPI];
 #pragma unroll
-    for (int j = 0; j < GL_RPI; ++j) { const int r = min(r0 + j, R - 1); me[j] = rmeta[r]; sr[j] = rsrc[r]; }
+    for (int j = 0; j < GL_RPI; ++j) {
+        const int r = min(r0 + j, R - 1);
+        nl[j] = rloc[r]; sr[j] = Uf ? rsrc[r] : 0; nf[j] = CF ? rfeat[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     for (; r0 < R; r0 += stride) {
-        int2 cm[GL_RPI]; int cs[GL_RPI];
+        float4 L[GL_RPI], F[GL_RPI]; int cs[GL_RPI];
 #pragma unroll
-        for (int j = 0; j < GL_RPI; ++j) { cm[j] = me[j]; cs[j] = sr[j]; }
+        for (int j = 0; j < GL_RPI; ++j) { L[j] = nl[j]; F[j] = nf[j]; cs[j] = sr[j]; }
         {
             const int rn = r0 + stride;
 #pragma unroll
-            for (int j = 0; j < GL_RPI; ++j) { const int r = min(rn + j, R - 1); me[j] = rmeta[r]; sr[j] = rsrc[r]; }
+            for (int j = 0; j < GL_RPI; ++j) {
+                const int r = min(rn + j, R - 1);
+                nl[j] = rloc[r]; sr[j] = Uf ? rsrc[r] : 0; nf[j] = CF ? rfeat[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
-        float dx[GL_RPI][3];
-#pragma unroll
-        for (int j = 0; j < GL_RPI; ++j) {
-            if (Wx) {
-                const float* pk = xyz + (size_t)cs[j] * 3;
-                const float* qc = new_xyz + (size_t)cm[j].x * 3;
-                dx[j][0] = __fsub_rn(pk[0], qc[0]); dx[j][1] = __fsub_rn(pk[1], qc[1]); dx[j][2] = __fsub_rn(pk[2], qc[2]);
-            } else { dx[j][0] = dx[j][1] = dx[j][2] = 0.f; }
-        }
-        float fi[GL_RPI][GL_CF];
-#pragma unroll
-        for (int j = 0; j < GL_RPI; ++j)
-#pragma unroll
-            for (int f = 0; f < GL_CF; ++f) fi[j][f] = f < CF ? fs[(size_t)cs[j] * CF + f] : 0.f;
 #pragma unroll
         for (int h = 0; h < GL_MAXH; ++h) {
             if (h >= nh) break;
@@ -257,11 +268,10 @@ __global__ __launch_bounds__(256) void group_linear_kernel(const float* __restri
 #pragma unroll
             for (int j = 0; j < GL_RPI; ++j) {
                 if (r0 + j < R && lane + 64 * h < C1) {
-                    float y = fmaf(wx[h][2], dx[j][2], fmaf(wx[h][1], dx[j][1], fmaf(wx[h][0], dx[j][0], u[j])));
-#pragma unroll
-                    for (int f = 0; f < GL_CF; ++f) y = fmaf(wf[h][f], fi[j][f], y);
+                    float y = fmaf(wx[h][2], L[j].z, fmaf(wx[h][1], L[j].y, fmaf(wx[h][0], L[j].x, u[j])));
+                    y = fmaf(wf[h][3], F[j].w, fmaf(wf[h][2], F[j].z, fmaf(wf[h][1], F[j].y, fmaf(wf[h][0], F[j].x, y))));
                     Y[(size_t)(r0 + j) * C1 + ch] = y;
-                    const double w = (double)(cm[j].y >> 16);
+                    const double w = (double)L[j].w;
                     ss[h] += w * (double)y; qq[h] += w * (double)y * (double)y;
                 }
             }
@@ -278,12 +288,11 @@ __global__ __launch_bounds__(256) void group_linear_kernel(const float* __restri
 }
 
 // backward: dy = a*du - w*(k1 + k2*(y - mu)) per distinct row; dUf[point] += dy (atomics), dWx partial sums per workgroup.
-__global__ __launch_bounds__(256) void group_linear_bwd_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
-                                                               const float* __restrict__ fs, int CF,
-                                                               const float* __restrict__ dU, const float* __restrict__ Y,
+__global__ __launch_bounds__(256) void group_linear_bwd_kernel(const float4* __restrict__ rloc, const float4* __restrict__ rfeat,
+                                                               int CF, const float* __restrict__ dU, const float* __restrict__ Y,
                                                                const float* __restrict__ a_, const float* __restrict__ k1_,
                                                                const float* __restrict__ k2_, const float* __restrict__ mu_,
-                                                               const int2* __restrict__ rmeta, const int32_t* __restrict__ rsrc,
+                                                               const int32_t* __restrict__ rsrc,
                                                                const int32_t* __restrict__ n_rows, int C1, float* __restrict__ dUf,
                                                                float* __restrict__ dWx_part, float* __restrict__ dWf_part) {
     __shared__ float red[3 + GL_CF][4][64 * GL_MAXH];
@@ -300,32 +309,24 @@ __global__ __launch_bounds__(256) void group_linear_bwd_kernel(const float* __re
     }
     const int stride = gridDim.x * 4 * GL_RPI;
     int r0 = (blockIdx.x * 4 + wave) * GL_RPI;
-    int2 me[GL_RPI]; int sr[GL_RPI];
+    float4 nl[GL_RPI], nf[GL_RPI]; int sr[GL_RPI];
 #pragma unroll
-    for (int j = 0; j < GL_RPI; ++j) { const int r = min(r0 + j, R - 1); me[j] = rmeta[r]; sr[j] = rsrc[r]; }
+    for (int j = 0; j < GL_RPI; ++j) {
+        const int r = min(r0 + j, R - 1);
+        nl[j] = rloc[r]; sr[j] = dUf ? rsrc[r] : 0; nf[j] = dWf_part ? rfeat[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     for (; r0 < R; r0 += stride) {
-        int2 cm[GL_RPI]; int cs[GL_RPI];
+        float4 L[GL_RPI], F[GL_RPI]; int cs[GL_RPI];
 #pragma unroll
-        for (int j = 0; j < GL_RPI; ++j) { cm[j] = me[j]; cs[j] = sr[j]; }
+        for (int j = 0; j < GL_RPI; ++j) { L[j] = nl[j]; F[j] = nf[j]; cs[j] = sr[j]; }
         {
             const int rn = r0 + stride;
 #pragma unroll
-            for (int j = 0; j < GL_RPI; ++j) { const int r = min(rn + j, R - 1); me[j] = rmeta[r]; sr[j] = rsrc[r]; }
+            for (int j = 0; j < GL_RPI; ++j) {
+                const int r = min(rn + j, R - 1);
+                nl[j] = rloc[r]; sr[j] = dUf ? rsrc[r] : 0; nf[j] = dWf_part ? rfeat[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
-        float dx[GL_RPI][3];
-#pragma unroll
-        for (int j = 0; j < GL_RPI; ++j) {
-            if (dWx_part) {
-                const float* pk = xyz + (size_t)cs[j] * 3;
-                const float* qc = new_xyz + (size_t)cm[j].x * 3;
-                dx[j][0] = __fsub_rn(pk[0], qc[0]); dx[j][1] = __fsub_rn(pk[1], qc[1]); dx[j][2] = __fsub_rn(pk[2], qc[2]);
-            } else { dx[j][0] = dx[j][1] = dx[j][2] = 0.f; }
-        }
-        float fi[GL_RPI][GL_CF];
-#pragma unroll
-        for (int j = 0; j < GL_RPI; ++j)
-#pragma unroll
-            for (int f = 0; f < GL_CF; ++f) fi[j][f] = (dWf_part && f < CF) ? fs[(size_t)cs[j] * CF + f] : 0.f;
 #pragma unroll
         for (int h = 0; h < GL_MAXH; ++h) {
             if (h >= nh) break;
@@ -339,13 +340,12 @@ __global__ __launch_bounds__(256) void group_linear_bwd_kernel(const float* __re
 #pragma unroll
             for (int j = 0; j < GL_RPI; ++j) {
                 if (r0 + j < R && lane + 64 * h < C1) {
-                    const float w = (float)(cm[j].y >> 16);
-                    const float dy = fmaf(a[h], du[j], -w * fmaf(k2[h], y[j] - mu[h], k1[h]));
+                    const float dy = fmaf(a[h], du[j], -L[j].w * fmaf(k2[h], y[j] - mu[h], k1[h]));
                     if (dUf) unsafeAtomicAdd(&dUf[(size_t)cs[j] * C1 + ch], dy);
-                    gw[h][0] = fmaf(dy, dx[j][0], gw[h][0]); gw[h][1] = fmaf(dy, dx[j][1], gw[h][1]);
-                    gw[h][2] = fmaf(dy, dx[j][2], gw[h][2]);
-#pragma unroll
-                    for (int f = 0; f < GL_CF; ++f) gw[h][3 + f] = fmaf(dy, fi[j][f], gw[h][3 + f]);
+                    gw[h][0] = fmaf(dy, L[j].x, gw[h][0]); gw[h][1] = fmaf(dy, L[j].y, gw[h][1]);
+                    gw[h][2] = fmaf(dy, L[j].z, gw[h][2]);
+                    gw[h][3] = fmaf(dy, F[j].x, gw[h][3]); gw[h][4] = fmaf(dy, F[j].y, gw[h][4]);
+                    gw[h][5] = fmaf(dy, F[j].z, gw[h][5]); gw[h][6] = fmaf(dy, F[j].w, gw[h][6]);
                 }
             }
         }
@@ -430,8 +430,9 @@ extern "C" int pcl_group_linear_stat_rows(int B, int m) { return (B < 1 || m < 1
 extern "C" int pcl_group_linear_f32(const float* xyz, const float* new_xyz, const float* Uf, const float* Wx, const float* feat_small,
                                     const float* Wf_small, int CF, const int32_t* idx, const int32_t* cnt,
                                     const int32_t* group_off, int B, int N, int m, int ns, int C1, float* Y, int32_t* row_meta,
-                                    int32_t* row_src, double* stats_ws, void* stream) {
-    PCL_REQUIRE(idx && cnt && group_off && Y && row_meta && row_src && stats_ws, "pcl_group_linear_f32: null pointer");
+                                    int32_t* row_src, float* row_loc, float* row_feat, double* stats_ws, void* stream) {
+    PCL_REQUIRE(idx && cnt && group_off && Y && row_meta && row_src && row_loc && stats_ws, "pcl_group_linear_f32: null pointer");
+    PCL_REQUIRE(CF == 0 || row_feat, "pcl_group_linear_f32: inline features need row_feat");
     PCL_REQUIRE(Uf || Wx || CF > 0, "pcl_group_linear_f32: need features (Uf or feat_small) and/or coordinates (Wx)");
     PCL_REQUIRE(CF >= 0 && CF <= GL_CF && (CF == 0 || (feat_small && Wf_small)), "pcl_group_linear_f32: CF=%d inline features (<= %d)", CF, GL_CF);
     PCL_REQUIRE(!Wx || (xyz && new_xyz), "pcl_group_linear_f32: Wx needs xyz and new_xyz");
@@ -439,30 +440,31 @@ extern "C" int pcl_group_linear_f32(const float* xyz, const float* new_xyz, cons
                 "pcl_group_linear_f32: bad sizes B=%d N=%d m=%d ns=%d C1=%d (C1 <= %d)", B, N, m, ns, C1, 64 * GL_MAXH);
     const int G = B * m;
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(group_rows_meta_kernel, dim3((G + 3) / 4), dim3(256), 0, st, idx, cnt, group_off, G, N, m, ns,
-                       reinterpret_cast<int2*>(row_meta), row_src);
+    hipLaunchKernelGGL(group_rows_meta_kernel, dim3((G + 3) / 4), dim3(256), 0, st, Wx ? xyz : nullptr, new_xyz, feat_small, CF, idx, cnt,
+                       group_off, G, N, m, ns, reinterpret_cast<int2*>(row_meta), row_src, reinterpret_cast<float4*>(row_loc),
+                       reinterpret_cast<float4*>(CF ? row_feat : nullptr));
     int rc = check_launch("pcl_group_linear_f32(meta)");
     if (rc) return rc;
-    hipLaunchKernelGGL(group_linear_kernel, dim3(GL_BLOCKS), dim3(256), 0, st, xyz, new_xyz, Uf, Wx, feat_small, Wf_small, CF,
-                       reinterpret_cast<const int2*>(row_meta), row_src, group_off + G, C1, Y, stats_ws);
+    hipLaunchKernelGGL(group_linear_kernel, dim3(GL_BLOCKS), dim3(256), 0, st, Uf, Wx, Wf_small, CF, reinterpret_cast<const float4*>(row_loc),
+                       reinterpret_cast<const float4*>(row_feat), row_src, group_off + G, C1, Y, stats_ws);
     return check_launch("pcl_group_linear_f32");
 }
 
-extern "C" int pcl_group_linear_bwd_f32(const float* xyz, const float* new_xyz, const float* feat_small, int CF, const float* dU,
-                                        const float* Y, const float* a, const float* k1, const float* k2, const float* mu,
-                                        const int32_t* row_meta, const int32_t* row_src, const int32_t* n_rows_dev, int B, int N,
-                                        int C1, float* dUf, float* dWx_part, float* dWf_part, void* stream) {
-    PCL_REQUIRE(dU && Y && a && k1 && k2 && mu && row_meta && row_src && n_rows_dev, "pcl_group_linear_bwd_f32: null pointer");
+extern "C" int pcl_group_linear_bwd_f32(const float* row_loc, const float* row_feat, int CF, const float* dU, const float* Y,
+                                        const float* a, const float* k1, const float* k2, const float* mu, const int32_t* row_src,
+                                        const int32_t* n_rows_dev, int B, int N, int C1, float* dUf, float* dWx_part,
+                                        float* dWf_part, void* stream) {
+    PCL_REQUIRE(row_loc && dU && Y && a && k1 && k2 && mu && row_src && n_rows_dev, "pcl_group_linear_bwd_f32: null pointer");
     PCL_REQUIRE(dUf || dWx_part || dWf_part, "pcl_group_linear_bwd_f32: nothing to compute");
-    PCL_REQUIRE(!dWf_part || (feat_small && CF >= 1 && CF <= GL_CF), "pcl_group_linear_bwd_f32: dWf needs feat_small, CF=%d", CF);
-    PCL_REQUIRE(!dWx_part || (xyz && new_xyz), "pcl_group_linear_bwd_f32: dWx needs xyz and new_xyz");
+    PCL_REQUIRE(!dWf_part || (row_feat && CF >= 1 && CF <= GL_CF), "pcl_group_linear_bwd_f32: dWf needs row_feat, CF=%d", CF);
     PCL_REQUIRE(B >= 1 && N >= 1 && C1 >= 1 && C1 <= 64 * GL_MAXH, "pcl_group_linear_bwd_f32: bad sizes");
     hipStream_t st = as_stream(stream);
     if (dUf) {
         hipError_t e = hipMemsetAsync(dUf, 0, sizeof(float) * (size_t)B * N * C1, st);
         if (e != hipSuccess) return fail(PCL_EHIP, "pcl_group_linear_bwd_f32: memset: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(group_linear_bwd_kernel, dim3(GL_BLOCKS), dim3(256), 0, st, xyz, new_xyz, feat_small, CF, dU, Y, a, k1, k2, mu,
-                       reinterpret_cast<const int2*>(row_meta), row_src, n_rows_dev, C1, dUf, dWx_part, dWf_part);
+    hipLaunchKernelGGL(group_linear_bwd_kernel, dim3(GL_BLOCKS), dim3(256), 0, st, reinterpret_cast<const float4*>(row_loc),
+                       reinterpret_cast<const float4*>(row_feat), CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, C1, dUf, dWx_part,
+                       dWf_part);
     return check_launch("pcl_group_linear_bwd_f32");
 }

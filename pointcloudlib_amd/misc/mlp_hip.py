@@ -347,20 +347,22 @@ class _GroupLinear(torch.autograd.Function):
         row_src = _empty((cap,), dev, torch.int32)
         rows = _lib.lib().pcl_group_linear_stat_rows(B, m)
         stats = _empty((rows, 2, C1), dev, torch.float64)
+        row_loc = _empty((cap, 4), dev)
+        row_feat = _empty((cap, 4), dev) if inline else None
         _lib.call("pcl_group_linear_f32", _P(xyz), _P(new_xyz), _P(Uf), _P(Wx), _P(feat2) if inline else None,
                   _P(Wf) if inline else None, C if inline else 0, _P(idx), _P(cnt), _P(group_off), B, N, m, ns, C1, _P(Y),
-                  _P(row_meta), _P(row_src), _P(stats), st)
+                  _P(row_meta), _P(row_src), _P(row_loc), _P(row_feat), _P(stats), st)
         link.stats, link.rows = stats, rows
         ctx.link = link
         ctx.dims = (B, N, m, ns, C1, C, off, inline, rows)
         ctx.mark_non_differentiable(row_meta, row_src)
-        ctx.save_for_backward(xyz, new_xyz, group_off, Y, row_meta, row_src, feat2, Wf)
+        ctx.save_for_backward(group_off, Y, row_src, row_loc, row_feat, feat2, Wf)
         return Y, row_meta, row_src
 
     @staticmethod
     def backward(ctx, du, *_):
         B, N, m, ns, C1, C, off, inline, rows = ctx.dims
-        xyz, new_xyz, group_off, Y, row_meta, row_src, feat2, Wf = ctx.saved_tensors
+        group_off, Y, row_src, row_loc, row_feat, feat2, Wf = ctx.saved_tensors
         a, k1, k2, mu = ctx.link.consts
         ctx.link.consts = None
         dev = Y.device
@@ -372,9 +374,8 @@ class _GroupLinear(torch.autograd.Function):
         dWxp = _empty((rows, C1, 3), dev) if (off and need_w) else None
         dWfp = _empty((rows, C1, C), dev) if (inline and need_w) else None
         if dUf is not None or dWxp is not None or dWfp is not None:
-            _lib.call("pcl_group_linear_bwd_f32", _P(xyz), _P(new_xyz), _P(feat2) if inline else None, C if inline else 0,
-                      _P(du.contiguous()), _P(Y), _P(a), _P(k1), _P(k2), _P(mu), _P(row_meta), _P(row_src), _P(group_off[B * m:]),
-                      B, N, C1, _P(dUf), _P(dWxp), _P(dWfp), st)
+            _lib.call("pcl_group_linear_bwd_f32", _P(row_loc), _P(row_feat), C if inline else 0, _P(du.contiguous()), _P(Y),
+                      _P(a), _P(k1), _P(k2), _P(mu), _P(row_src), _P(group_off[B * m:]), B, N, C1, _P(dUf), _P(dWxp), _P(dWfp), st)
         dfeat = dW0 = None
         parts = []
         if need_w and off:
