@@ -217,20 +217,20 @@ __global__ __launch_bounds__(256) void group_rows_meta_kernel(const float* __res
 
 // Row-parallel: wave w walks rows 4w.., 4w + 4*nwaves.., four rows in flight, lanes over the C1 channels; the next
 // iteration's row metadata is requested before the current rows are processed (two dependent gathers per row otherwise).
+template <int NH>
 __global__ __launch_bounds__(256) void group_linear_kernel(const float* __restrict__ Uf, const float* __restrict__ Wx,
                                                            const float* __restrict__ Wfs, int CF,
                                                            const float4* __restrict__ rloc, const float4* __restrict__ rfeat,
                                                            const int32_t* __restrict__ rsrc,
                                                            const int32_t* __restrict__ n_rows, int C1, float* __restrict__ Y,
                                                            double* __restrict__ stats) {
-    __shared__ double red[2][4][64 * GL_MAXH];
+    __shared__ double red[2][4][64 * NH];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int nh = (C1 + 63) >> 6;
     const int R = *n_rows;
-    float wx[GL_MAXH][3], wf[GL_MAXH][GL_CF];          // coordinate weights and the weights of up to GL_CF inline features
-    double ss[GL_MAXH], qq[GL_MAXH];
+    float wx[NH][3], wf[NH][GL_CF];          // coordinate weights and the weights of up to GL_CF inline features
+    double ss[NH], qq[NH];
 #pragma unroll
-    for (int h = 0; h < GL_MAXH; ++h) {
+    for (int h = 0; h < NH; ++h) {
         const int ch = lane + 64 * h;
 #pragma unroll
         for (int d = 0; d < 3; ++d) wx[h][d] = (Wx && ch < C1) ? Wx[ch * 3 + d] : 0.f;
@@ -259,8 +259,7 @@ __global__ __launch_bounds__(256) void group_linear_kernel(const float* __restri
             }
         }
 #pragma unroll
-        for (int h = 0; h < GL_MAXH; ++h) {
-            if (h >= nh) break;
+        for (int h = 0; h < NH; ++h) {
             const int ch = min(lane + 64 * h, C1 - 1);
             float u[GL_RPI];
 #pragma unroll
@@ -278,7 +277,7 @@ __global__ __launch_bounds__(256) void group_linear_kernel(const float* __restri
         }
     }
 #pragma unroll
-    for (int h = 0; h < GL_MAXH; ++h) { red[0][wave][lane + 64 * h] = ss[h]; red[1][wave][lane + 64 * h] = qq[h]; }
+    for (int h = 0; h < NH; ++h) { red[0][wave][lane + 64 * h] = ss[h]; red[1][wave][lane + 64 * h] = qq[h]; }
     __syncthreads();
     for (int ch = threadIdx.x; ch < C1; ch += 256) {
         double* dst = stats + (size_t)blockIdx.x * 2 * C1;
@@ -288,6 +287,7 @@ __global__ __launch_bounds__(256) void group_linear_kernel(const float* __restri
 }
 
 // backward: dy = a*du - w*(k1 + k2*(y - mu)) per distinct row; dUf[point] += dy (atomics), dWx partial sums per workgroup.
+template <int NH>
 __global__ __launch_bounds__(256) void group_linear_bwd_kernel(const float4* __restrict__ rloc, const float4* __restrict__ rfeat,
                                                                int CF, const float* __restrict__ dU, const float* __restrict__ Y,
                                                                const float* __restrict__ a_, const float* __restrict__ k1_,
@@ -295,13 +295,12 @@ __global__ __launch_bounds__(256) void group_linear_bwd_kernel(const float4* __r
                                                                const int32_t* __restrict__ rsrc,
                                                                const int32_t* __restrict__ n_rows, int C1, float* __restrict__ dUf,
                                                                float* __restrict__ dWx_part, float* __restrict__ dWf_part) {
-    __shared__ float red[3 + GL_CF][4][64 * GL_MAXH];
+    __shared__ float red[3 + GL_CF][4][64 * NH];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int nh = (C1 + 63) >> 6;
     const int R = *n_rows;
-    float a[GL_MAXH], k1[GL_MAXH], k2[GL_MAXH], mu[GL_MAXH], gw[GL_MAXH][3 + GL_CF];
+    float a[NH], k1[NH], k2[NH], mu[NH], gw[NH][3 + GL_CF];
 #pragma unroll
-    for (int h = 0; h < GL_MAXH; ++h) {
+    for (int h = 0; h < NH; ++h) {
         const int ch = min(lane + 64 * h, C1 - 1);
         a[h] = a_[ch]; k1[h] = k1_[ch]; k2[h] = k2_[ch]; mu[h] = mu_[ch];
 #pragma unroll
@@ -328,8 +327,7 @@ __global__ __launch_bounds__(256) void group_linear_bwd_kernel(const float4* __r
             }
         }
 #pragma unroll
-        for (int h = 0; h < GL_MAXH; ++h) {
-            if (h >= nh) break;
+        for (int h = 0; h < NH; ++h) {
             const int ch = min(lane + 64 * h, C1 - 1);
             float du[GL_RPI], y[GL_RPI];
 #pragma unroll
@@ -352,7 +350,7 @@ __global__ __launch_bounds__(256) void group_linear_bwd_kernel(const float4* __r
     }
     if (dWx_part || dWf_part) {
 #pragma unroll
-        for (int h = 0; h < GL_MAXH; ++h)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
             for (int d = 0; d < 3 + GL_CF; ++d) red[d][wave][lane + 64 * h] = gw[h][d];
         __syncthreads();
@@ -445,8 +443,12 @@ extern "C" int pcl_group_linear_f32(const float* xyz, const float* new_xyz, cons
                        reinterpret_cast<float4*>(CF ? row_feat : nullptr));
     int rc = check_launch("pcl_group_linear_f32(meta)");
     if (rc) return rc;
-    hipLaunchKernelGGL(group_linear_kernel, dim3(GL_BLOCKS), dim3(256), 0, st, Uf, Wx, Wf_small, CF, reinterpret_cast<const float4*>(row_loc),
-                       reinterpret_cast<const float4*>(row_feat), row_src, group_off + G, C1, Y, stats_ws);
+    const float4* rl = reinterpret_cast<const float4*>(row_loc);
+    const float4* rf = reinterpret_cast<const float4*>(row_feat);
+    const dim3 grid(GL_BLOCKS), block(256);
+    if (C1 <= 64) hipLaunchKernelGGL(group_linear_kernel<1>, grid, block, 0, st, Uf, Wx, Wf_small, CF, rl, rf, row_src, group_off + G, C1, Y, stats_ws);
+    else if (C1 <= 128) hipLaunchKernelGGL(group_linear_kernel<2>, grid, block, 0, st, Uf, Wx, Wf_small, CF, rl, rf, row_src, group_off + G, C1, Y, stats_ws);
+    else hipLaunchKernelGGL(group_linear_kernel<4>, grid, block, 0, st, Uf, Wx, Wf_small, CF, rl, rf, row_src, group_off + G, C1, Y, stats_ws);
     return check_launch("pcl_group_linear_f32");
 }
 
@@ -463,8 +465,11 @@ extern "C" int pcl_group_linear_bwd_f32(const float* row_loc, const float* row_f
         hipError_t e = hipMemsetAsync(dUf, 0, sizeof(float) * (size_t)B * N * C1, st);
         if (e != hipSuccess) return fail(PCL_EHIP, "pcl_group_linear_bwd_f32: memset: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(group_linear_bwd_kernel, dim3(GL_BLOCKS), dim3(256), 0, st, reinterpret_cast<const float4*>(row_loc),
-                       reinterpret_cast<const float4*>(row_feat), CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, C1, dUf, dWx_part,
-                       dWf_part);
+    const float4* rl = reinterpret_cast<const float4*>(row_loc);
+    const float4* rf = reinterpret_cast<const float4*>(row_feat);
+    const dim3 grid(GL_BLOCKS), block(256);
+    if (C1 <= 64) hipLaunchKernelGGL(group_linear_bwd_kernel<1>, grid, block, 0, st, rl, rf, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, C1, dUf, dWx_part, dWf_part);
+    else if (C1 <= 128) hipLaunchKernelGGL(group_linear_bwd_kernel<2>, grid, block, 0, st, rl, rf, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, C1, dUf, dWx_part, dWf_part);
+    else hipLaunchKernelGGL(group_linear_bwd_kernel<4>, grid, block, 0, st, rl, rf, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, C1, dUf, dWx_part, dWf_part);
     return check_launch("pcl_group_linear_bwd_f32");
 }
