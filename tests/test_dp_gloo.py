@@ -23,7 +23,7 @@ def _make_model():
     return m
 
 
-def _worker(rank, world, port, out_q):
+def _worker(rank, world, port, out_q, in_place=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pointcloudlib_amd.dp import FlatBucketDP, shard_batch
@@ -41,19 +41,28 @@ def _worker(rank, world, port, out_q):
     for _ in range(2):
         dp.zero_grad()
         ((model(xs) - ys) ** 2).mean().backward()
-        dp.all_reduce()
+        if in_place:            # the variant for gradients that must stay where a captured HIP graph writes them
+            before = [p.grad.data_ptr() for p in model.parameters()]
+            dp.all_reduce_into_grads()
+            assert before == [p.grad.data_ptr() for p in model.parameters()]
+        else:
+            dp.all_reduce()
         opt.step()
     out_q.put((rank, [p.detach().numpy().copy() for p in model.parameters()], dp.flat.numpy().copy(), dp.nbytes))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_flat_bucket_dp_matches_single_process():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("in_place", [False, True])
+def test_flat_bucket_dp_matches_single_process(in_place):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, in_place)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
