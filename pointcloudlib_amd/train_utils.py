@@ -4,9 +4,16 @@
   one-hot with a per-sample host sync (:41-42), here it is a device-side scatter.
 * ``make_sgd`` -- ``nn.SGD(net.parameters(), lr, momentum)`` (train_cls.py:404): g += wd*p; v = mu*v + g;
   p -= lr*v, no dampening, no Nesterov == torch.optim.SGD.
+* ``calculate_shape_IoU`` -- train_partseg.py:24-63 (per-shape mean part IoU over the parts of the shape's category; an
+  empty union counts as IoU 1).
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
+
+# ShapeNet-part: number of parts per object category and their first part id (train_partseg.py:24-25)
+seg_num = [4, 2, 2, 4, 4, 3, 3, 2, 4, 2, 6, 2, 3, 3, 3, 3]
+index_start = [0, 4, 6, 8, 12, 16, 19, 22, 24, 28, 30, 36, 38, 41, 44, 47]
 
 
 def soft_cross_entropy_loss(output, target, smoothing=True):
@@ -26,3 +33,22 @@ def make_sgd(params, lr=0.02, momentum=0.9, weight_decay=0.0):
     # one multi-tensor kernel for the whole update on the GPU (same arithmetic as the default three-kernel foreach path)
     fused = bool(params) and all(p.is_cuda for p in params)
     return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay, fused=fused)
+
+
+def calculate_shape_IoU(pred_np, seg_np, label, class_choice=None):
+    """pred_np, seg_np [S,N] part ids, label [S,1] category ids -> list of per-shape IoUs (train_partseg.py:27-48)."""
+    pred_np, seg_np, label = np.asarray(pred_np), np.asarray(seg_np), np.asarray(label)
+    shape_ious = []
+    for shape_idx in range(seg_np.shape[0]):
+        if not class_choice:
+            idx = int(label[shape_idx][0])
+            parts = range(index_start[idx], index_start[idx] + seg_num[idx])
+        else:
+            parts = range(seg_num[int(label[0])])
+        part_ious = []
+        for part in parts:
+            inter = np.sum(np.logical_and(pred_np[shape_idx] == part, seg_np[shape_idx] == part))
+            union = np.sum(np.logical_or(pred_np[shape_idx] == part, seg_np[shape_idx] == part))
+            part_ious.append(1 if union == 0 else inter / float(union))
+        shape_ious.append(np.mean(part_ious))
+    return shape_ious
