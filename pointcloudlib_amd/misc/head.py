@@ -66,7 +66,9 @@ def _slope_of(act):
 def head_layer(x, linear, bn=None, act=None):
     """``act(bn(linear(x)))`` for x [R, K]; ``act``: None, ``nn.ReLU``/``nn.LeakyReLU`` instance or a negative slope."""
     slope = float(act) if isinstance(act, (int, float)) else _slope_of(act)
-    if not x.is_cuda or x.shape[0] > MAX_ROWS or x.dim() != 2 or x.dtype != torch.float32:
+    if not x.is_cuda:
+        raise RuntimeError("head_layer: expected a tensor on the GPU (libpcl_hip has no CPU path)")
+    if x.shape[0] > MAX_ROWS or x.dim() != 2 or x.dtype != torch.float32:     # large batches: plain library GEMMs
         y = linear(x)
         if bn is not None:
             y = bn(y)

@@ -104,3 +104,24 @@ def test_mlp_has_no_silent_cpu_path():
         raise AssertionError("CPU tensor accepted by the default (HIP) backend")
     m.backend = "torch"
     assert m(x).shape == (2, 5, 8)
+
+
+def test_new_paths_refuse_cpu_tensors():
+    """The fused head, EdgeConv, PointConv contraction and folded-grouping paths have no CPU route either."""
+    import pytest
+    import torch
+    from torch import nn
+    from pointcloudlib_amd.misc.head import head_layer
+    from pointcloudlib_amd.misc.edgeconv import edge_conv
+    from pointcloudlib_amd.misc.layers import PointwiseMLP
+    from pointcloudlib_amd.misc.pointconv_utils import pointconv_contract
+    with pytest.raises(RuntimeError):
+        head_layer(torch.randn(4, 8), nn.Linear(8, 3))
+    with pytest.raises(RuntimeError):
+        edge_conv(PointwiseMLP([6, 8], slope=0.2), torch.randn(1, 5, 3), torch.zeros(1, 5, 2, dtype=torch.int32))
+    with pytest.raises(RuntimeError):
+        pointconv_contract(torch.randn(1, 2, 3, 4), torch.rand(1, 2, 3, 1), torch.randn(1, 2, 3, 16))
+    with pytest.raises(RuntimeError):
+        PointwiseMLP([6, 8, 8]).forward_grouped(torch.randn(1, 9, 3), torch.randn(1, 2, 3), torch.randn(1, 9, 3),
+                                                torch.zeros(1, 2, 4, dtype=torch.int32), torch.ones(1, 2, dtype=torch.int32),
+                                                torch.zeros(3, dtype=torch.int32))
