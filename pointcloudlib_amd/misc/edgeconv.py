@@ -82,16 +82,60 @@ class _EdgeConvPool(torch.autograd.Function):
         return dUV, None, dgamma, dbeta, None, None, None
 
 
+class _PointLinear(torch.autograd.Function):
+    """UV [B,N,2*Cout] = x [B,N,C] @ [Wa ; Wb - Wa]^T for W = [Wa | Wb] [Cout, 2C], on the library's own GEMM kernels
+    (forward, dX and dW); returns the gradient of W itself."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        x = _dev(x, "x")
+        B, N, C = x.shape
+        Co = W.shape[0]
+        dev = x.device
+        Wcat = torch.cat([W[:, :C], W[:, C:] - W[:, :C]], dim=0).contiguous()       # [2*Cout, C]
+        P = B * N
+        UV = torch.empty((B, N, 2 * Co), device=dev)
+        rows = _lib.lib().pcl_mlp_stat_rows(P, 2 * Co, 0)
+        _lib.call("pcl_linear_fwd_rows_f32", _p(x), _p(Wcat), None, None, None, 0.0, P, C, 2 * Co, _p(UV),
+                  _p(torch.empty((rows, 2, 2 * Co), dtype=torch.float64, device=dev)), None, None, _stream(), tag=f"uv{C}x{2 * Co}")
+        ctx.save_for_backward(x, Wcat)
+        return UV
+
+    @staticmethod
+    def backward(ctx, dUV):
+        x, Wcat = ctx.saved_tensors
+        B, N, C = x.shape
+        C2 = Wcat.shape[0]
+        Co = C2 // 2
+        dev = x.device
+        P = B * N
+        st = _stream()
+        lib = _lib.lib()
+        dUV = _dev(dUV, "grad")
+        one = torch.ones(C2, device=dev)
+        zero = torch.zeros(C2, device=dev)
+        dx = dW = None
+        if ctx.needs_input_grad[1]:
+            nbytes = lib.pcl_linear_bwd_dw_workspace_bytes(P, C2, C)
+            ws = torch.empty(((nbytes + 3) // 4,), device=dev)
+            dWcat = torch.empty((C2, C), device=dev)
+            _lib.call("pcl_linear_bwd_dw_rows_f32", _p(dUV), _p(dUV), _p(one), _p(zero), _p(zero), _p(zero), None, None, 1, _p(x),
+                      None, None, 0.0, P, C2, C, _p(dWcat), _p(ws), nbytes, None, None, st, tag=f"uvdw{C2}x{C}")
+            dW = torch.cat([dWcat[:Co] - dWcat[Co:], dWcat[Co:]], dim=1)           # Wcat = [Wa ; Wb - Wa]
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((B, N, C), device=dev)
+            _lib.call("pcl_linear_bwd_dx_rows_f32", _p(dUV), _p(dUV), _p(one), _p(zero), _p(zero), _p(zero), None, None, 1, _p(Wcat),
+                      P, C2, C, None, None, None, 0.0, _p(dx), None, None, None, 0, 0, st, tag=f"uvdx{C2}x{C}")
+        return dx, dW
+
+
 def edge_conv(mlp, x, idx):
     """One EdgeConv stage on channel-last ``x`` [B,N,C] with neighbour lists ``idx`` [B,N,k] (int32) -> [B,N,Cout].
     ``mlp``: the stage's one-layer ``PointwiseMLP([2C, Cout], slope=0.2)``.  The HIP backend takes the factorised path;
     the plain-PyTorch backend (tests) and anything that is not a single bias-free conv+BN layer build the edge tensor."""
     k = idx.shape[2]
     if mlp.resolved_backend(x) == "hip" and mlp.n_layers == 1 and mlp.bn and mlp.biases is None and mlp.last_act:
-        C = x.shape[-1]
-        W = mlp.weights[0]
-        Wcat = torch.cat([W[:, :C], W[:, C:] - W[:, :C]], dim=0)              # [2*Cout, C]
-        UV = F.linear(x, Wcat)                                                # plain GEMM over the points
+        UV = _PointLinear.apply(x, mlp.weights[0])                            # one GEMM over the points
         cfg = (mlp.slope, mlp.eps, mlp.momentum, mlp.training)
         return _EdgeConvPool.apply(UV, idx, mlp.gammas[0], mlp.betas[0], mlp.running_mean_0, mlp.running_var_0, cfg)
     return mlp(edge_features(x, idx), group_max=k)
