@@ -11,12 +11,14 @@
 //     (never materialised);
 //   * BatchNorm batch statistics (sum, sum of squares per channel) are produced by the GEMM epilogue as
 //     per-workgroup fp64 partials (no atomics; summed by the tiny finalize kernel);
-//   * backward: dy = a*du - k1 - k2*y (BatchNorm backward, affine per channel once the two channel sums are
-//     known) is formed while staging, for the dense case and for the sparse max-pool gradient; the ReLU mask
-//     of the layer below and ITS two channel sums are produced by the dX GEMM's epilogue.
+//   * backward: dy = a*du - k1 - k2*(y - mean) (BatchNorm backward, affine per channel once the two channel sums
+//     are known) is formed while staging, for the dense case and for the sparse max-pool gradient; the ReLU mask
+//     of the layer below and ITS two channel sums are produced by the dX GEMM's epilogue; the dX GEMM reads the
+//     weight matrix as stored (K-major B tile, transposed on its way into LDS);
+//   * statistics are summed about a per-lane pivot in fp32 and shifted back in fp64 (|mean| >> std loses nothing).
 //
-// Tiling (wave64): workgroup = 4 waves, block tile 128x128, K step 32; each wave owns a 64x64 tile = 2x2
-// MFMA 32x32 accumulators (64 VGPRs).  LDS rows are padded to 36 dwords so the per-lane ds_read_b128
+// Tiling (wave64): workgroup = 4 waves, block tile 128x128 (forward, wide N), 128x64 (N <= 64 and every backward
+// GEMM) or 64x64 (small M), K step 32; each wave owns a (32*TM)x(32*TN) tile of MFMA 32x32 accumulators.  LDS rows are padded to 36 dwords so the per-lane ds_read_b128
 // fragment reads (4 consecutive k per lane; lanes 0-31 take k..k+3, lanes 32-63 take k+4..k+7 of each
 // 8-wide k block, identically for A and B) are bank-conflict-free.  Grids are persistent over row tiles so
 // statistics are reduced in registers across tiles.
