@@ -5,7 +5,7 @@ index op and every group is per-cloud.  The only exchange is the weight gradient
 live in ONE flat fp32 buffer (``param.grad`` are views into it), so a step issues a single
 ``all_reduce(sum)`` of ~5.9 MB (PointNet++ SSG) and one scale -- sized for xGMI's per-link rate (7 x ~153 GB/s
 point-to-point) instead of many small NCCL-style buckets.  BatchNorm statistics stay per-rank (weak scaling,
-per-GPU batch = the reference's batch); ``sync_bn_stats`` is available for strong-scaling parity tests.
+per-GPU batch = the reference's batch; a synchronised BatchNorm for strong-scaling parity is not built).
 """
 import torch
 import torch.distributed as dist
