@@ -18,16 +18,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_PEAK_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
-
-# which roofline bounds each C-ABI entry point
-BOUND = {"pcl_fps_f32": "hbm", "pcl_ball_query_f32": "hbm", "pcl_group_f32": "hbm", "pcl_group_bwd_f32": "hbm",
-         "pcl_group_all_f32": "hbm", "pcl_knn_f32": "hbm"}
 
 
 def make_batches(B, N, n_batches, rank, dev):

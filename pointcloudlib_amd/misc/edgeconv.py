@@ -10,7 +10,6 @@ backward -- runs in two streaming HIP kernels (csrc/edgeconv.hip).  Parameters l
 import ctypes
 
 import torch
-import torch.nn.functional as F
 
 from .. import _lib
 from .ops import _dev, _p, _stream, edge_features

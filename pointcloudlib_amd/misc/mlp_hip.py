@@ -90,7 +90,8 @@ class _FusedMLP(torch.autograd.Function):
                 assert W.shape[1] < cin, f"input has {cin} columns, first layer expects {W.shape[1]}"
                 W = W0p = torch.nn.functional.pad(W.detach(), (0, cin - W.shape[1]))
             fused_max = (l == L - 1) and ns in (32, 64) and rowset is None
-            if l == 0 and link is not None:
+            folded = l == 0 and link is not None
+            if folded:
                 # the first layer was folded into the grouping (_GroupLinear): x IS its pre-BatchNorm output
                 assert cout == cin and L >= 2, "folded first layer: x must be the layer's own output"
                 Y, stats, rows = x, link.stats, link.rows
@@ -98,8 +99,8 @@ class _FusedMLP(torch.autograd.Function):
                 Y = _empty((P, cout), dev)
                 rows = _lib.lib().pcl_mlp_stat_rows(P, cout, 2 if rowset is not None else 0)
                 stats = _empty((rows, 2, cout), dev, torch.float64)
-            if l == 0 and link is not None:
-                pass
+            if folded:
+                pass                       # nothing to launch: the grouping kernel already produced Y and its sums
             elif fused_max:      # last layer of a max-pooled stack: per-group min/max come out of the GEMM epilogue
                 G = P // ns
                 gmax, gmin = _empty((G, cout), dev), _empty((G, cout), dev)

@@ -11,7 +11,6 @@ misc/edgeconv.py (one GEMM over the points + two streaming kernels, no edge tens
 reference's edge tensor, via pcl_edge_feature_f32 -- stays available and is what the plain-PyTorch backend uses.
 """
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from ...misc.layers import PointwiseMLP

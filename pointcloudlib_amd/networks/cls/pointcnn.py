@@ -5,7 +5,6 @@
 head ``Dense_Conv1d`` 384->192->128(dropout 0.5)->n_classes, logits = mean over the remaining points (:50-52).
 Activations are channel-last ``[B,P,C]`` throughout (the reference permutes to ``[B,C,P]`` for its head, :49).
 """
-import torch
 from torch import nn
 
 from ...misc.pointcnn import Dense_Conv1d, RandPointCNN

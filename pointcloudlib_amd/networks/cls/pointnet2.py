@@ -15,8 +15,7 @@ from torch import nn
 
 from ...misc.head import fc_head
 from ...misc.layers import PointwiseMLP
-from ...misc.ops import (BallQueryGrouper, FurthestPointSampler, GroupAll, ball_query, group_offsets, group_points,
-                         group_points_compact)
+from ...misc.ops import BallQueryGrouper, FurthestPointSampler, GroupAll, ball_query, group_offsets, group_points
 
 
 class PointNetModuleBase(nn.Module):

@@ -4,7 +4,6 @@
 worse than 4x the error of PyTorch's own fp32 GPU path against the same fp64 truth."""
 import copy
 
-import numpy as np
 import pytest
 import torch
 
