@@ -56,6 +56,9 @@ def main():
     seg = torch.randint(0, 50, (16, 2048), device=dev)
     res.append(run("cfg4 PointNet++ SSG part-seg B=16 N=2048", PointNet2_partseg, (xs, xs, oh),
                    lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps))
+    from pointcloudlib_amd.networks.seg.pointnet2_partseg import PointNetMSG
+    res.append(run("cfg4' PointNet++ MSG part-seg B=16 N=2048 (FP widths corrected, see DESIGN 7)", PointNetMSG, (xs, xs, oh),
+                   lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps))
     res.append(run("cfg5 PointConv cls B=32 N=1024", PointConvDensityClsSsg, (x.transpose(1, 2).contiguous(),), lambda o: soft_cross_entropy_loss(o, y32), a.steps))
     from pointcloudlib_amd.networks.cls.pointcnn import PointCNNcls
     from pointcloudlib_amd.networks.seg.pointcnn_partseg import PointCNN_partseg
