@@ -38,7 +38,7 @@ class PointNet2_partseg(nn.Module):
         # Conv1d(128,128,1) + BatchNorm1d(128) [no activation] ; Dropout ; Conv1d(128, part_num, 1)   :151-156
         self.head1 = PointwiseMLP([128, 128], bias=True, slope=0.0, last_act=False)
         self.drop = nn.Dropout(0.5)
-        self.head2 = nn.Linear(128, self.part_num)
+        self.head2 = PointwiseMLP([128, self.part_num], bias=True, bn=False, last_act=False)   # Conv1d(128, part_num, 1)
 
     def forward(self, xyz, feature, cls_label):
         """xyz [B,N,3], feature [B,N,3], cls_label one-hot [B,16] -> [B,part_num,N]."""
