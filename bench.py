@@ -18,6 +18,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from pointcloudlib_amd.affinity import pin_to_gpu_node  # noqa: E402
+
+# before torch / HIP start their threads: the rank's host thread stays on its GPU's socket (pointcloudlib_amd/affinity.py)
+CPU_AFFINITY = pin_to_gpu_node(int(os.environ.get("LOCAL_RANK", "0")))
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -311,7 +316,7 @@ def main():
                        "global_batch": world * B, "n_points": N, "parallelism": f"dp{world}",
                        "sampling": "indices of batch t+1 on a side stream during backward of batch t" if args.prefetch_sampling
                        else "inline",
-                       "launch": launch, "grad_bucket_bytes": dp.nbytes},
+                       "launch": launch, "grad_bucket_bytes": dp.nbytes, "cpu_affinity": CPU_AFFINITY},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -367,6 +367,146 @@ __global__ __launch_bounds__(256) void group_linear_bwd_kernel(const float4* __r
     }
 }
 
+// ---- 16-byte-channel variants of the two kernels above (C1 = 64 / 128 / 256) -----------------------------------------
+// A lane owns 4 consecutive channels, LPR = C1/4 lanes cover a row, so one wave instruction moves 64/LPR consecutive
+// rows = 1 KiB of contiguous Y (or dU) instead of 256 B: a quarter of the memory instructions for the same bytes.
+template <int LPR>     // lanes per row: 16, 32 or 64
+__global__ __launch_bounds__(256) void group_linear_v4_kernel(const float* __restrict__ Uf, const float* __restrict__ Wx,
+                                                              const float* __restrict__ Wfs, int CF,
+                                                              const float4* __restrict__ rloc, const float4* __restrict__ rfeat,
+                                                              const int32_t* __restrict__ rsrc,
+                                                              const int32_t* __restrict__ n_rows, float* __restrict__ Y,
+                                                              double* __restrict__ stats) {
+    constexpr int C1 = 4 * LPR, RPW = 64 / LPR, U = 4;          // rows per wave instruction; instructions in flight
+    __shared__ double red[2][4][C1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cl = lane % LPR, rsub = lane / LPR, c4 = 4 * cl;
+    const int R = *n_rows;
+    float wx[3][4], wf[GL_CF][4];
+    double ss[4], qq[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) wx[d][v] = Wx ? Wx[(c4 + v) * 3 + d] : 0.f;
+#pragma unroll
+        for (int f = 0; f < GL_CF; ++f) wf[f][v] = f < CF ? Wfs[(c4 + v) * CF + f] : 0.f;
+        ss[v] = 0.0; qq[v] = 0.0;
+    }
+    const int stride = gridDim.x * 4 * RPW * U;
+    for (int r0 = (blockIdx.x * 4 + wave) * RPW * U; r0 < R; r0 += stride) {
+        float4 L[U], F[U], u[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int r = min(r0 + j * RPW + rsub, R - 1);
+            L[j] = rloc[r];
+            F[j] = CF ? rfeat[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+            u[j] = Uf ? *reinterpret_cast<const float4*>(Uf + (size_t)rsrc[r] * C1 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int r = r0 + j * RPW + rsub;
+            if (r < R) {
+                float y[4] = {u[j].x, u[j].y, u[j].z, u[j].w};
+                const double w = (double)L[j].w;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    float t = fmaf(wx[2][v], L[j].z, fmaf(wx[1][v], L[j].y, fmaf(wx[0][v], L[j].x, y[v])));
+                    t = fmaf(wf[3][v], F[j].w, fmaf(wf[2][v], F[j].z, fmaf(wf[1][v], F[j].y, fmaf(wf[0][v], F[j].x, t))));
+                    y[v] = t;
+                    ss[v] += w * (double)t; qq[v] += w * (double)t * (double)t;
+                }
+                *reinterpret_cast<float4*>(Y + (size_t)r * C1 + c4) = make_float4(y[0], y[1], y[2], y[3]);
+            }
+        }
+    }
+    // fold the RPW row-lanes of a wave, then the four waves
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) { ss[v] += __shfl_xor(ss[v], off); qq[v] += __shfl_xor(qq[v], off); }
+        if (rsub == 0) { red[0][wave][c4 + v] = ss[v]; red[1][wave][c4 + v] = qq[v]; }
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C1; ch += 256) {
+        double* dst = stats + (size_t)blockIdx.x * 2 * C1;
+        dst[ch] = (red[0][0][ch] + red[0][1][ch]) + (red[0][2][ch] + red[0][3][ch]);
+        dst[C1 + ch] = (red[1][0][ch] + red[1][1][ch]) + (red[1][2][ch] + red[1][3][ch]);
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void group_linear_bwd_v4_kernel(const float4* __restrict__ rloc, const float4* __restrict__ rfeat,
+                                                                  int CF, const float* __restrict__ dU, const float* __restrict__ Y,
+                                                                  const float* __restrict__ a_, const float* __restrict__ k1_,
+                                                                  const float* __restrict__ k2_, const float* __restrict__ mu_,
+                                                                  const int32_t* __restrict__ rsrc,
+                                                                  const int32_t* __restrict__ n_rows, float* __restrict__ dUf,
+                                                                  float* __restrict__ dWx_part, float* __restrict__ dWf_part) {
+    constexpr int C1 = 4 * LPR, RPW = 64 / LPR, U = 4;
+    __shared__ float red[3 + GL_CF][4][C1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cl = lane % LPR, rsub = lane / LPR, c4 = 4 * cl;
+    const int R = *n_rows;
+    float a[4], k1[4], k2[4], mu[4], gw[3 + GL_CF][4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        a[v] = a_[c4 + v]; k1[v] = k1_[c4 + v]; k2[v] = k2_[c4 + v]; mu[v] = mu_[c4 + v];
+#pragma unroll
+        for (int d = 0; d < 3 + GL_CF; ++d) gw[d][v] = 0.f;
+    }
+    const int stride = gridDim.x * 4 * RPW * U;
+    for (int r0 = (blockIdx.x * 4 + wave) * RPW * U; r0 < R; r0 += stride) {
+        float4 L[U], F[U], du[U], yv[U];
+        int src[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int r = min(r0 + j * RPW + rsub, R - 1);
+            L[j] = rloc[r];
+            F[j] = dWf_part ? rfeat[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+            src[j] = dUf ? rsrc[r] : 0;
+            du[j] = *reinterpret_cast<const float4*>(dU + (size_t)r * C1 + c4);
+            yv[j] = *reinterpret_cast<const float4*>(Y + (size_t)r * C1 + c4);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int r = r0 + j * RPW + rsub;
+            if (r < R) {
+                const float dd[4] = {du[j].x, du[j].y, du[j].z, du[j].w}, yy[4] = {yv[j].x, yv[j].y, yv[j].z, yv[j].w};
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float dy = fmaf(a[v], dd[v], -L[j].w * fmaf(k2[v], yy[v] - mu[v], k1[v]));
+                    if (dUf) unsafeAtomicAdd(&dUf[(size_t)src[j] * C1 + c4 + v], dy);
+                    gw[0][v] = fmaf(dy, L[j].x, gw[0][v]); gw[1][v] = fmaf(dy, L[j].y, gw[1][v]); gw[2][v] = fmaf(dy, L[j].z, gw[2][v]);
+                    gw[3][v] = fmaf(dy, F[j].x, gw[3][v]); gw[4][v] = fmaf(dy, F[j].y, gw[4][v]);
+                    gw[5][v] = fmaf(dy, F[j].z, gw[5][v]); gw[6][v] = fmaf(dy, F[j].w, gw[6][v]);
+                }
+            }
+        }
+    }
+    if (dWx_part || dWf_part) {
+#pragma unroll
+        for (int d = 0; d < 3 + GL_CF; ++d)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float t = gw[d][v];
+#pragma unroll
+                for (int off = LPR; off < 64; off <<= 1) t += __shfl_xor(t, off);
+                if (rsub == 0) red[d][wave][c4 + v] = t;
+            }
+        __syncthreads();
+        if (dWx_part)
+            for (int e = threadIdx.x; e < C1 * 3; e += 256) {
+                const int ch = e / 3, d = e - ch * 3;
+                dWx_part[(size_t)blockIdx.x * C1 * 3 + e] = (red[d][0][ch] + red[d][1][ch]) + (red[d][2][ch] + red[d][3][ch]);
+            }
+        if (dWf_part)
+            for (int e = threadIdx.x; e < C1 * CF; e += 256) {
+                const int ch = e / CF, d = 3 + (e - ch * CF);
+                dWf_part[(size_t)blockIdx.x * C1 * CF + e] = (red[d][0][ch] + red[d][1][ch]) + (red[d][2][ch] + red[d][3][ch]);
+            }
+    }
+}
+
 }  // namespace pcl
 using namespace pcl;
 
@@ -446,6 +586,13 @@ extern "C" int pcl_group_linear_f32(const float* xyz, const float* new_xyz, cons
     const float4* rl = reinterpret_cast<const float4*>(row_loc);
     const float4* rf = reinterpret_cast<const float4*>(row_feat);
     const dim3 grid(GL_BLOCKS), block(256);
+    const bool al16 = ((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(Uf)) & 15) == 0;
+    if (al16 && (C1 == 64 || C1 == 128 || C1 == 256)) {
+        if (C1 == 64) hipLaunchKernelGGL(group_linear_v4_kernel<16>, grid, block, 0, st, Uf, Wx, Wf_small, CF, rl, rf, row_src, group_off + G, Y, stats_ws);
+        else if (C1 == 128) hipLaunchKernelGGL(group_linear_v4_kernel<32>, grid, block, 0, st, Uf, Wx, Wf_small, CF, rl, rf, row_src, group_off + G, Y, stats_ws);
+        else hipLaunchKernelGGL(group_linear_v4_kernel<64>, grid, block, 0, st, Uf, Wx, Wf_small, CF, rl, rf, row_src, group_off + G, Y, stats_ws);
+        return check_launch("pcl_group_linear_f32");
+    }
     if (C1 <= 64) hipLaunchKernelGGL(group_linear_kernel<1>, grid, block, 0, st, Uf, Wx, Wf_small, CF, rl, rf, row_src, group_off + G, C1, Y, stats_ws);
     else if (C1 <= 128) hipLaunchKernelGGL(group_linear_kernel<2>, grid, block, 0, st, Uf, Wx, Wf_small, CF, rl, rf, row_src, group_off + G, C1, Y, stats_ws);
     else hipLaunchKernelGGL(group_linear_kernel<4>, grid, block, 0, st, Uf, Wx, Wf_small, CF, rl, rf, row_src, group_off + G, C1, Y, stats_ws);
@@ -468,6 +615,15 @@ extern "C" int pcl_group_linear_bwd_f32(const float* row_loc, const float* row_f
     const float4* rl = reinterpret_cast<const float4*>(row_loc);
     const float4* rf = reinterpret_cast<const float4*>(row_feat);
     const dim3 grid(GL_BLOCKS), block(256);
+    // with dUf the scatter is one atomic per element either way, and a lane owning 4 consecutive channels spreads every
+    // atomic instruction over 4x the cache lines (measured 187 vs 77 us on SA2): the 16-byte layout only when there is none
+    const bool al16 = !dUf && ((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(dU)) & 15) == 0;
+    if (al16 && (C1 == 64 || C1 == 128 || C1 == 256)) {
+        if (C1 == 64) hipLaunchKernelGGL(group_linear_bwd_v4_kernel<16>, grid, block, 0, st, rl, rf, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, dUf, dWx_part, dWf_part);
+        else if (C1 == 128) hipLaunchKernelGGL(group_linear_bwd_v4_kernel<32>, grid, block, 0, st, rl, rf, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, dUf, dWx_part, dWf_part);
+        else hipLaunchKernelGGL(group_linear_bwd_v4_kernel<64>, grid, block, 0, st, rl, rf, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, dUf, dWx_part, dWf_part);
+        return check_launch("pcl_group_linear_bwd_f32");
+    }
     if (C1 <= 64) hipLaunchKernelGGL(group_linear_bwd_kernel<1>, grid, block, 0, st, rl, rf, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, C1, dUf, dWx_part, dWf_part);
     else if (C1 <= 128) hipLaunchKernelGGL(group_linear_bwd_kernel<2>, grid, block, 0, st, rl, rf, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, C1, dUf, dWx_part, dWf_part);
     else hipLaunchKernelGGL(group_linear_bwd_kernel<4>, grid, block, 0, st, rl, rf, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, C1, dUf, dWx_part, dWf_part);

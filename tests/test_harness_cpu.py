@@ -34,3 +34,33 @@ def test_shape_iou():
     assert abs(ious[0] - np.mean([1 / 2, 2 / 3, 1 / 2, 0.0])) < 1e-12 and ious[1] == 1.0
     assert calculate_shape_IoU(np.zeros((1, 4)), np.zeros((1, 4)), np.array([[2]]), None) == [1.0]   # empty unions count as 1
     assert len(seg_num) == len(index_start) == 16 and index_start[-1] + seg_num[-1] == 50
+
+
+def test_affinity_helper_parses_topology(tmp_path, monkeypatch):
+    """pin_to_gpu_node(): KFD topology -> NUMA node -> cpulist, on a fake sysfs; never raises on a host without one."""
+    from pointcloudlib_amd import affinity
+    assert affinity._cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    kfd = tmp_path / "kfd"
+    for n, (simd, minor) in enumerate([(0, 0), (1024, 128), (1024, 129)]):
+        (kfd / str(n)).mkdir(parents=True)
+        (kfd / str(n) / "properties").write_text(f"cpu_cores_count 0\nsimd_count {simd}\ndrm_render_minor {minor}\n")
+    monkeypatch.setattr(affinity, "_KFD", str(kfd))
+    real_open = open
+
+    def fake_open(path, *a, **k):
+        if str(path).startswith("/sys/class/drm/renderD"):
+            import io
+            return io.StringIO("0\n" if "renderD128" in str(path) else "1\n")
+        return real_open(path, *a, **k)
+    monkeypatch.setattr("builtins.open", fake_open)
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert affinity.gpu_numa_nodes() == [0, 1]
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")
+    assert affinity.gpu_numa_nodes() == [1]
+    monkeypatch.undo()
+    import os
+    before = os.sched_getaffinity(0)
+    r = affinity.pin_to_gpu_node(5)              # no such GPU here: pins to the current node or does nothing
+    assert r is None or "numa node" in r
+    os.sched_setaffinity(0, before)

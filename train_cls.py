@@ -11,9 +11,14 @@ synthetic clouds (throughput and plumbing only -- accuracy on random labels mean
 ``--lr_decay`` enables the evident intent (x0.7 every 20 epochs) and is off by default to match.
 """
 import argparse
+import os
 import time
 
-import torch
+from pointcloudlib_amd.affinity import pin_to_gpu_node
+
+pin_to_gpu_node(int(os.environ.get("LOCAL_RANK", "0")))      # before torch / HIP start threads (pointcloudlib_amd/affinity.py)
+
+import torch  # noqa: E402
 
 from pointcloudlib_amd.data_utils.modelnet40_loader import ModelNet40, SyntheticModelNet40
 from pointcloudlib_amd.train_utils import make_sgd, soft_cross_entropy_loss
