@@ -1,0 +1,128 @@
+"""Part-segmentation training driver -- counterpart of /root/reference/train_partseg.py on the HIP path.
+
+Same recipe: ShapeNet-Part 'trainval' / 'test' at 2048 points, batch 16 (:67-69), SGD lr 0.01 momentum 0.9 weight decay
+1e-4 (:75-76), cross entropy over the 50 part classes on every point (:114-118), per-epoch point accuracy, balanced
+accuracy and mean shape IoU (:139-158, `calculate_shape_IoU` :28-63).  Input conventions per model follow :108-113:
+PointNet and DGCNN take ``[B,3,N]``, PointNet++ takes ``(xyz, xyz, one_hot)`` (the "normals" are the coordinates again),
+the others ``(xyz, one_hot)``; every network returns per-point scores which are brought to ``[B,N,50]`` here (the
+counterparts in ``pointcloudlib_amd/networks/seg`` return ``[B,50,N]`` like the reference except PointConv's ``[B,N,50]``).
+The reference's LRScheduler never changes the rate (see train_cls.py) and is not reproduced.  Without the dataset the
+run falls back to synthetic shapes (throughput only).
+"""
+import argparse
+import os
+import time
+
+from pointcloudlib_amd.affinity import pin_to_gpu_node
+
+pin_to_gpu_node(int(os.environ.get("LOCAL_RANK", "0")))      # before torch / HIP start threads
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from pointcloudlib_amd.data_utils.shapenet_loader import ShapeNetPart, SyntheticShapeNetPart  # noqa: E402
+from pointcloudlib_amd.train_utils import calculate_shape_IoU, make_sgd  # noqa: E402
+
+
+def build_model(name, part_num=50):
+    if name == "pointnet":
+        from pointcloudlib_amd.networks.seg.pointnet_partseg import PointNet_partseg as M
+    elif name == "pointnet2":
+        from pointcloudlib_amd.networks.seg.pointnet2_partseg import PointNet2_partseg as M
+    elif name == "pointnet2_msg":
+        from pointcloudlib_amd.networks.seg.pointnet2_partseg import PointNetMSG as M
+    elif name == "pointcnn":
+        from pointcloudlib_amd.networks.seg.pointcnn_partseg import PointCNN_partseg as M
+    elif name == "dgcnn":
+        from pointcloudlib_amd.networks.seg.dgcnn_partseg import DGCNN_partseg as M
+    elif name == "pointconv":
+        from pointcloudlib_amd.networks.seg.pointconv_partseg import PointConvDensity_partseg as M
+    else:
+        raise SystemExit(f"unknown --model {name} (pointnet | pointnet2 | pointnet2_msg | pointcnn | dgcnn | pointconv)")
+    return M(part_num=part_num)
+
+
+def forward(net, name, data, one_hot):
+    """-> per-point scores [B, N, part_num]"""
+    if name in ("pointnet", "dgcnn"):
+        out = net(data.transpose(1, 2).contiguous(), one_hot)                    # train_partseg.py:108-109
+    elif name.startswith("pointnet2"):
+        out = net(data, data, one_hot)                                           # :111-112
+    else:
+        out = net(data, one_hot)
+    # :115 permutes every model's output; PointConv's head already ends point-major (pointconv_partseg.py:59-61), where
+    # that permute followed by view(-1, 50) would interleave points and classes -- kept point-major here instead
+    return out if name == "pointconv" else out.permute(0, 2, 1)
+
+
+def balanced_accuracy(true, pred, n_classes):
+    """Mean per-class recall over the classes present in `true` (what sklearn's balanced_accuracy_score computes)."""
+    hit = np.bincount(true[true == pred], minlength=n_classes).astype(np.float64)
+    tot = np.bincount(true, minlength=n_classes).astype(np.float64)
+    return float((hit[tot > 0] / tot[tot > 0]).mean())
+
+
+def run_epoch(net, name, loader, dev, seg_num_all, optimizer=None):
+    train = optimizer is not None
+    net.train(train)
+    loss_sum, count = 0.0, 0
+    true_seg, pred_seg, labels = [], [], []
+    t0 = time.perf_counter()
+    for data, label, seg in loader:
+        data, seg = data.to(dev), (seg - loader.seg_start_index).to(dev)
+        one_hot = torch.zeros(label.shape[0], 16, device=dev)
+        one_hot[torch.arange(label.shape[0], device=dev), label[:, 0].to(dev)] = 1                  # :103-107
+        with torch.set_grad_enabled(train):
+            scores = forward(net, name, data, one_hot)
+            loss = torch.nn.functional.cross_entropy(scores.reshape(-1, seg_num_all), seg.reshape(-1))
+            if train:
+                optimizer.zero_grad(set_to_none=True)
+                loss.backward()
+                optimizer.step()
+        loss_sum += float(loss) * data.shape[0]
+        count += data.shape[0]
+        true_seg.append(seg.cpu().numpy())
+        pred_seg.append(scores.argmax(2).cpu().numpy())
+        labels.append(label.numpy().reshape(-1, 1))
+    torch.cuda.synchronize()
+    rate = count / (time.perf_counter() - t0)
+    true_seg, pred_seg, labels = np.concatenate(true_seg), np.concatenate(pred_seg), np.concatenate(labels)
+    acc = float((true_seg == pred_seg).mean())
+    bacc = balanced_accuracy(true_seg.reshape(-1), pred_seg.reshape(-1), seg_num_all)
+    iou = float(np.mean(calculate_shape_IoU(pred_seg, true_seg, labels, None)))
+    return loss_sum / max(count, 1), acc, bacc, iou, rate
+
+
+def main():
+    ap = argparse.ArgumentParser(description="Point cloud part segmentation")
+    ap.add_argument("--model", default="pointnet2")
+    ap.add_argument("--batch_size", type=int, default=16)               # the reference hard-codes 16 (:67)
+    ap.add_argument("--lr", type=float, default=0.01)                   # ... and 0.01 (:75)
+    ap.add_argument("--momentum", type=float, default=0.9)
+    ap.add_argument("--num_points", type=int, default=2048)
+    ap.add_argument("--epochs", type=int, default=200)
+    ap.add_argument("--data_root", default=None)
+    ap.add_argument("--synthetic_items", type=int, default=128)
+    a = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("train_partseg.py needs a GPU (the HIP path has no CPU fallback)")
+    dev = torch.device("cuda")
+    try:
+        train_set = ShapeNetPart(a.num_points, "trainval", None, a.batch_size, shuffle=True, root=a.data_root)
+        test_set = ShapeNetPart(a.num_points, "test", None, a.batch_size, shuffle=False, root=a.data_root)
+    except (FileNotFoundError, ImportError) as e:
+        print(f"[train_partseg] {e}\n[train_partseg] -> synthetic shapes")
+        train_set = SyntheticShapeNetPart(a.num_points, "trainval", None, a.batch_size, shuffle=True, n_items=a.synthetic_items)
+        test_set = SyntheticShapeNetPart(a.num_points, "test", None, a.batch_size, n_items=max(a.batch_size, a.synthetic_items // 4), seed=1)
+    torch.manual_seed(0)
+    net = build_model(a.model).to(dev)
+    opt = make_sgd(net.parameters(), lr=a.lr, momentum=a.momentum, weight_decay=1e-4)
+    for epoch in range(a.epochs):
+        loss, acc, bacc, iou, rate = run_epoch(net, a.model, train_set, dev, train_set.seg_num_all, opt)
+        print(f"Train {epoch}, loss: {loss:.6f}, train acc: {acc:.6f}, train avg acc: {bacc:.6f}, train iou: {iou:.6f} ({rate:.0f} shapes/s)", flush=True)
+        loss, acc, bacc, iou, rate = run_epoch(net, a.model, test_set, dev, test_set.seg_num_all)
+        print(f"Test {epoch}, loss: {loss:.6f}, test acc: {acc:.6f}, test avg acc: {bacc:.6f}, test iou: {iou:.6f} ({rate:.0f} shapes/s)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
