@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the main stream's part of a step as ONE captured HIP graph instead of enqueueing it from Python "
                          "(measured: 2.90 vs 2.86 ms/step eager on ROCm 7.2 -- the replay is not faster, so it is opt-in)")
+    ap.add_argument("--dp-bucket-bytes", type=int, default=0, help="cut the gradient exchange (N>1) into buckets of this size; 0 = one all-reduce")
+    ap.add_argument("--dp-overlap", action="store_true",
+                    help="send gradient buckets from autograd hooks during backward (measured slower, see pointcloudlib_amd/dp.py)")
     ap.add_argument("--no-settle", dest="settle", action="store_false", help="skip the untimed clock-settling windows (profiler passes)")
     ap.add_argument("--dump-launch-order", default=None, help="write the (entry point, shape) sequence of one step as JSON")
     args = ap.parse_args()
@@ -132,7 +135,7 @@ def main():
     torch.manual_seed(0)
     net = PointNet2_cls().to(dev).train()
     state0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
-    dp = FlatBucketDP(net)
+    dp = FlatBucketDP(net, bucket_bytes=args.dp_bucket_bytes, overlap=args.dp_overlap)
     opt = make_sgd(net.parameters(), lr=0.02, momentum=0.9)   # train_cls.py:374-377,404
     batches = make_batches(B, N, 4, rank, dev)
 
@@ -316,7 +319,7 @@ def main():
                        "global_batch": world * B, "n_points": N, "parallelism": f"dp{world}",
                        "sampling": "indices of batch t+1 on a side stream during backward of batch t" if args.prefetch_sampling
                        else "inline",
-                       "launch": launch, "grad_bucket_bytes": dp.nbytes, "cpu_affinity": CPU_AFFINITY},
+                       "launch": launch, "grad_bucket_bytes": dp.bucket_nbytes, "grad_overlap": bool(dp.overlap and dp.active), "cpu_affinity": CPU_AFFINITY},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

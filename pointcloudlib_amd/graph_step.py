@@ -23,6 +23,7 @@ def _flat(sampling):
 class GraphedStep:
     def __init__(self, net, loss_fn, optimizer, dp, sample_xyz, example_batch, side_stream, capture_optimizer=True):
         self.net, self.loss_fn, self.opt, self.dp = net, loss_fn, optimizer, dp
+        dp.overlap = False                                    # no collectives from autograd hooks inside a capture
         self.side = side_stream
         self.capture_optimizer = capture_optimizer
         self.inputs = [torch.empty_like(t) for t in example_batch]

@@ -19,11 +19,11 @@ def _free_port():
 def _make_model():
     from pointcloudlib_amd.misc.layers import PointwiseMLP
     torch.manual_seed(7)
-    m = PointwiseMLP([5, 16, 8], bias=True, bn=False, backend="torch")     # no BatchNorm: grads are batch-additive
+    m = PointwiseMLP([5, 16, 12, 8], bias=True, bn=False, backend="torch")     # no BatchNorm: grads are batch-additive
     return m
 
 
-def _worker(rank, world, port, out_q, in_place=False):
+def _worker(rank, world, port, out_q, in_place=False, bucket_bytes=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pointcloudlib_amd.dp import FlatBucketDP, shard_batch
@@ -32,7 +32,12 @@ def _worker(rank, world, port, out_q, in_place=False):
         with torch.no_grad():
             for p in model.parameters():
                 p.add_(1.0)
-    dp = FlatBucketDP(model)
+    dp = FlatBucketDP(model, bucket_bytes=bucket_bytes, overlap=bool(bucket_bytes))
+    if bucket_bytes:                         # several buckets, sent from the autograd hooks during backward
+        assert len(dp.buckets) >= 3 and sum(dp.bucket_nbytes) == dp.nbytes
+        sent = []
+        orig = dp._send
+        dp._send = lambda b: (sent.append((dp._armed, dp.buckets.index(b))), orig(b))
     torch.manual_seed(0)
     x = torch.randn(8, 12, 5)
     y = torch.randn(8, 12, 8)
@@ -46,7 +51,13 @@ def _worker(rank, world, port, out_q, in_place=False):
             dp.all_reduce_into_grads()
             assert before == [p.grad.data_ptr() for p in model.parameters()]
         else:
+            if bucket_bytes:
+                n_early = sum(1 for armed, _ in sent if armed)
+                assert n_early >= len(dp.buckets) - 1, sent          # all but (at most) the tail went out during backward
+                assert [b for _, b in sent] == sorted(b for _, b in sent)     # in gradient-ready order
+                sent.clear()
             dp.all_reduce()
+            assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(dp.params, dp.views))
         opt.step()
     out_q.put((rank, [p.detach().numpy().copy() for p in model.parameters()], dp.flat.numpy().copy(), dp.nbytes))
     dist.barrier()
@@ -56,13 +67,13 @@ def _worker(rank, world, port, out_q, in_place=False):
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("in_place", [False, True])
-def test_flat_bucket_dp_matches_single_process(in_place):
+@pytest.mark.parametrize("in_place,bucket_bytes", [(False, None), (True, None), (False, 256)])
+def test_flat_bucket_dp_matches_single_process(in_place, bucket_bytes):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, in_place)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, in_place, bucket_bytes)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
