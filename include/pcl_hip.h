@@ -35,6 +35,7 @@ extern "C" {
 #define PCL_EWS (-4)      /* workspace too small                                  */
 
 int pcl_version(void);
+/* reference: no reference counterpart: the reference has no error channel (CUDA errors surface at the next Jittor sync, misc/ops.py:269-271 are Python asserts) */
 const char* pcl_last_error(void);
 
 /* misc/ops.py:110-111  optimal_block(): 2 ** int(ln(batch_size)).  The reference launches FPS and
@@ -73,23 +74,27 @@ int pcl_ball_query_f32(const float* new_xyz, const float* xyz, int B, int m, int
  * gradient of reindex); it zero-fills gfeat [B,N,C] itself. */
 int pcl_group_f32(const float* xyz, const float* new_xyz, const float* feat, const int32_t* idx,
                   int B, int N, int m, int ns, int C, int use_xyz, float* out, void* stream);
+/* reference: gradient of the Var.reindex gathers of misc/ops.py:384-396 (Jittor derives it as reindex_reduce add) */
 int pcl_group_bwd_f32(const float* gout, const int32_t* idx, int B, int N, int m, int ns, int C,
                       int use_xyz, float* gfeat, void* stream);
 /* GroupAll.execute, misc/ops.py:415-419: out [B,1,N,D] = concat(xyz, feat), xyz not re-centred. */
 int pcl_group_all_f32(const float* xyz, const float* feat, int B, int N, int C, int use_xyz,
                       float* out, void* stream);
+/* reference: gradient of GroupAll's concat, misc/ops.py:415-419 */
 int pcl_group_all_bwd_f32(const float* gout, int B, int N, int C, int use_xyz, float* gfeat,
                           void* stream);
 /* Plain row gather out[b,i,:] = src[b,idx[b,i],:]  (index_points, misc/ops.py:12-27) and its
  * scatter-add gradient (zero-fills gsrc). */
 int pcl_gather_rows_f32(const float* src, const int32_t* idx, int B, int N, int M, int C, float* out,
                         void* stream);
+/* reference: gradient of index_points, misc/ops.py:12-27 */
 int pcl_gather_rows_bwd_f32(const float* gout, const int32_t* idx, int B, int N, int M, int C,
                             float* gsrc, void* stream);
 
 /* DGCNN edge features, get_graph_feature (networks/cls/dgcnn.py:29-50):
  *   x [B,N,C] channel-last, idx [B,N,k] -> out [B,N,k,2C] = concat(x[idx]-x[n], x[n]);  bwd defines all of gx. */
 int pcl_edge_feature_f32(const float* x, const int32_t* idx, int B, int N, int k, int C, float* out, void* stream);
+/* reference: gradient of get_graph_feature, networks/cls/dgcnn.py:29-50 */
 int pcl_edge_feature_bwd_f32(const float* gout, const int32_t* idx, int B, int N, int k, int C, float* gx,
                              void* stream);
 
@@ -101,6 +106,7 @@ int pcl_edge_feature_bwd_f32(const float* gout, const int32_t* idx, int B, int N
  * The reference takes an uninitialised [B,Nr,Nq] scratch as a third input (misc/ops.py:655); here
  * the caller provides `workspace` of at least pcl_knn_workspace_bytes(...) bytes. */
 size_t pcl_knn_workspace_bytes(int B, int C, int Nr, int Nq, int k);
+/* reference: replaces compute_distances + modified_insertion_sort + the host glue, misc/ops.py:429-552, :562-663 */
 int pcl_knn_f32(const float* ref, const float* qry, int B, int C, int Nr, int Nq, int k,
                 int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -110,8 +116,10 @@ int pcl_knn_f32(const float* ref, const float* qry, int B, int C, int Nr, int Nq
  *   interp fwd: out[b,n,:] = sum_j w3[b,n,j] * points2[b,idx3[b,n,j],:];  bwd zero-fills gpoints2. */
 int pcl_three_nn_f32(const float* xyz1, const float* xyz2, int B, int N, int S, int32_t* idx3,
                      float* w3, void* stream);
+/* reference: replaces the weighted index_points sum of PointNetFeaturePropagation, misc/ops.py:90-93 */
 int pcl_three_interp_f32(const float* points2, const int32_t* idx3, const float* w3, int B, int N,
                          int S, int D, float* out, void* stream);
+/* reference: gradient of misc/ops.py:90-93 w.r.t. points2 */
 int pcl_three_interp_bwd_f32(const float* gout, const int32_t* idx3, const float* w3, int B, int N,
                              int S, int D, float* gpoints2, void* stream);
 
@@ -130,11 +138,13 @@ int pcl_density_f32(const float* xyz, int B, int N, float bandwidth, float* dens
  * GEMM of the next layer leaves it), accumulated into dUf [B*N, C1] (zero-filled here) and into dWx_part
  * [pcl_group_linear_stat_rows][C1][3] / dWf_part [..][C1][CF] partial sums (sum over the first axis = dWx, dWf_small). */
 int pcl_group_linear_stat_rows(int B, int m);
+/* reference: replaces BallQueryGrouper's gathers (misc/ops.py:383-407) + the first Conv2d 1x1 of build_mlps (networks/cls/pointnet2.py:25-26, execute :51-54) */
 int pcl_group_linear_f32(const float* xyz, const float* new_xyz, const float* Uf, const float* Wx, const float* feat_small,
                          const float* Wf_small, int CF, const int32_t* idx, const int32_t* cnt, const int32_t* group_off,
                          int B, int N, int m, int ns, int C1, float* Y, int32_t* row_meta, int32_t* row_src,
                          float* row_loc /* [cap,4]: xyz - centre, multiplicity */, float* row_feat /* [cap,4] or NULL */,
                          double* stats_ws, void* stream);
+/* reference: gradient of the same pair (misc/ops.py:383-407 + networks/cls/pointnet2.py:25-26) */
 int pcl_group_linear_bwd_f32(const float* row_loc, const float* row_feat, int CF, const float* dU, const float* Y,
                              const float* a, const float* k1, const float* k2, const float* mu, const int32_t* row_src,
                              const int32_t* n_rows_dev /* &group_off[B*m] */, int B, int N, int C1, float* dUf,
@@ -149,6 +159,7 @@ int pcl_group_linear_bwd_f32(const float* row_loc, const float* row_feat, int CF
 int pcl_head_layer_fwd_f32(const float* X, const float* W, const float* bias, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, int R, int K, int N, int bn_mode, float eps, float momentum,
                            float slope, float* Ypre, float* OUT, float* mean_out, float* invstd_out, void* stream);
+/* reference: gradient of Linear + BatchNorm1d + ReLU of the heads, networks/cls/pointnet2.py:138-147, :155-158 */
 int pcl_head_layer_bwd_f32(const float* X, const float* W, const float* dOUT, const float* OUT, const float* Ypre,
                            const float* gamma, const float* mean, const float* invstd, int R, int K, int N, int bn_mode,
                            float slope, float* dY_ws, float* dW, float* dbias, float* dgamma, float* dbeta, float* dX,
@@ -162,8 +173,10 @@ int pcl_head_layer_bwd_f32(const float* X, const float* W, const float* dOUT, co
  *   pcl_edgeconv_scatter_f32: dy = [j == arg] a*gz - k1 - k2*(y - mu) for every edge, summed into dUV (U half: over the
  *     edges pointing at a point; V half: over a point's own edges).  idx [B*N,k] int32 neighbour index within the cloud. */
 int pcl_edgeconv_stat_rows(int B, int N);
+/* reference: replaces get_graph_feature + conv + max over k, networks/cls/dgcnn.py:29-50, :72-83, :100-111 */
 int pcl_edgeconv_gather_f32(const float* UV, const int32_t* idx, int B, int N, int k, int C, float* ymax, float* ymin,
                             int32_t* jmax, int32_t* jmin, double* stats_ws, void* stream);
+/* reference: gradient of the same composition (networks/cls/dgcnn.py:100-111) */
 int pcl_edgeconv_scatter_f32(const float* UV, const int32_t* idx, const float* gz, const int32_t* arg, const float* a,
                              const float* k1, const float* k2, const float* mu, int B, int N, int k, int C, float* dUV,
                              void* stream);
@@ -174,6 +187,7 @@ int pcl_edgeconv_scatter_f32(const float* UV, const int32_t* idx, const float* g
  * (WeightNet(3,16)).  The backward entry point returns all three input gradients. */
 int pcl_pointconv_contract_f32(const float* feat, const float* density, const float* weights, int G, int ns, int C, int M,
                                float* out, void* stream);
+/* reference: gradient of misc/pointconv_utils.py:393-394 */
 int pcl_pointconv_contract_bwd_f32(const float* dout, const float* feat, const float* density, const float* weights, int G,
                                    int ns, int C, int M, float* dfeat, float* dweights, float* ddensity, void* stream);
 
@@ -192,6 +206,7 @@ int pcl_pointconv_contract_bwd_f32(const float* dout, const float* feat, const f
 int pcl_mlp_stat_rows(int P, int C, int flags);
 /* Y[P,Cout] = act_in(X[P,Cin]) W[Cout,Cin]^T (+bias);  act_in = identity (in_scale NULL) or
  * lrelu(in_scale*x+in_shift, in_slope).  stats_ws rows: (sum Y, sum Y^2) per channel. */
+/* reference: replaces nn.Conv 1x1 (+ the BatchNorm/ReLU of the layer below), networks/cls/pointnet2.py:25-29, execute :53-54 */
 int pcl_linear_fwd_f32(const float* X, const float* W, const float* bias, const float* in_scale,
                        const float* in_shift, float in_slope, int P, int Cin, int Cout, float* Y,
                        double* stats_ws, void* stream);
@@ -199,30 +214,38 @@ int pcl_linear_fwd_f32(const float* X, const float* W, const float* bias, const 
  * epilogue also emits per-group max / min of Y and the row-in-group attaining them (first occurrence);
  * pcl_group_minmax_finalize_f32 then yields out = max_s lrelu(scale*y+shift) (max for scale >= 0, min otherwise),
  * arg and ymax without re-reading Y. */
+/* reference: replaces the last nn.Conv 1x1 + argmax over nsample, networks/cls/pointnet2.py:25-29 and :57 */
 int pcl_linear_fwd_gmax_f32(const float* X, const float* W, const float* bias, const float* in_scale,
                             const float* in_shift, float in_slope, int P, int Cin, int Cout, int ns, float* Y,
                             double* stats_ws, float* gmax, float* gmin, int32_t* gamax, int32_t* gamin, void* stream);
+/* reference: replaces new_feature.argmax(dim=2)[1], networks/cls/pointnet2.py:57 (dgcnn.py:102-111: x.max(dim=-1)) */
 int pcl_group_minmax_finalize_f32(const float* gmax, const float* gmin, const int32_t* gamax, const int32_t* gamin,
                                   const float* scale, const float* shift, float slope, int G, int C, float* out,
                                   int32_t* arg, float* ymax, void* stream);
 /* mean/var (biased, max(E[y^2]-E[y]^2,0)) from the partials -> scale, shift, mean, invstd; running stats
  * r += (batch - r)*momentum with the biased variance (nullable). */
+/* reference: replaces nn.BatchNorm (training mode) statistics, networks/cls/pointnet2.py:28 (dgcnn.py:66-70) */
 int pcl_bn_finalize_f32(const double* stats_ws, int stat_rows, const float* gamma, const float* beta, int P,
                         int C, float eps, float momentum, float* scale, float* shift, float* mean_out,
                         float* invstd_out, float* running_mean, float* running_var, void* stream);
 /* out[g,c] = max_s lrelu(scale*Y[g*ns+s,c]+shift); arg = first s attaining it; ymax = Y there (nullable). */
+/* reference: replaces BatchNorm + ReLU + argmax over nsample, networks/cls/pointnet2.py:28-29, :57 */
 int pcl_bn_act_max_f32(const float* Y, const float* scale, const float* shift, float slope, int G, int ns,
                        int C, float* out, int32_t* arg, float* ymax, void* stream);
 /* out = lrelu(scale*Y+shift) on [P,C];  bwd: du = gz*act'(u) plus partial (sum du, sum du*y). */
+/* reference: replaces BatchNorm + ReLU of the last layer when nothing is pooled (PointNetFeaturePropagation's mlp, misc/ops.py:100-105) */
 int pcl_bn_act_f32(const float* Y, const float* scale, const float* shift, float slope, int P, int C,
                    float* out, void* stream);
+/* reference: gradient of that BatchNorm + ReLU (misc/ops.py:100-105) */
 int pcl_bn_act_bwd_f32(const float* gz, const float* Y, const float* scale, const float* shift, float slope,
                        int P, int C, float* du, double* stats_ws, int* stat_rows_out, void* stream);
 /* backward of the max: gz[g,c] = gout*act'(out) plus partial (sum gz, sum gz*ymax). */
+/* reference: gradient of the max over nsample, networks/cls/pointnet2.py:57 */
 int pcl_maxgrad_prep_f32(const float* gout, const float* out, const float* ymax, float slope, int G, int C,
                          float* gz, double* stats_ws, int* stat_rows_out, void* stream);
 /* BatchNorm backward constants from (sum du, sum du*y): dgamma, dbeta (nullable) and a, k1, k2 with
  * dy = a*du - k1 - k2*(y - mean)   (k1 = a*dbeta/P, k2 = a*dgamma*invstd/P; y is centred where it is used). */
+/* reference: gradient of training-mode nn.BatchNorm, networks/cls/pointnet2.py:28 */
 int pcl_bn_bwd_consts_f32(const double* stats_ws, int stat_rows, const float* gamma, const float* mean,
                           const float* invstd, int P, int C, float* dgamma, float* dbeta, float* a_out,
                           float* k1, float* k2, void* stream);
@@ -230,12 +253,15 @@ int pcl_bn_bwd_consts_f32(const double* stats_ws, int stat_rows, const float* ga
  * dU (dense) or from (arg, gz, ns) (sparse max gradient; pass dU = NULL).  With Yprev: masked by the layer
  * below's activation and stats_ws gets (sum dUprev, sum dUprev*Yprev); Yprev NULL: plain store (input grad).
  * W is the layer's weight as stored, [Cout,Cin] row-major (no transposed copy is needed). */
+/* reference: gradient of nn.Conv 1x1 w.r.t. its input fused with BatchNorm/ReLU backward, networks/cls/pointnet2.py:25-29 */
 int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2, const float* mu,
                           const int32_t* arg, const float* gz, int ns, const float* W, int P, int Cout,
                           int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                           float prev_slope, float* dUprev, double* stats_ws, void* stream);
 /* dW[Cout,Cin] = dy^T act_prev(Xprev);  workspace of pcl_linear_bwd_dw_workspace_bytes() bytes. */
+/* reference: workspace of pcl_linear_bwd_dw_f32 (the reference lets Jittor allocate, networks/cls/pointnet2.py:25-29) */
 size_t pcl_linear_bwd_dw_workspace_bytes(int P, int Cout, int Cin);
+/* reference: gradient of nn.Conv 1x1 w.r.t. its weight, networks/cls/pointnet2.py:25-26 */
 int pcl_linear_bwd_dw_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2, const float* mu,
                           const int32_t* arg, const float* gz, int ns, const float* Xprev,
                           const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
@@ -255,15 +281,19 @@ int pcl_linear_bwd_dw_f32(const float* dU, const float* Y, const float* a, const
  *   pcl_bn_act_max_rows_f32: max over each group's valid rows (arg = slot in the compacted group).
  *   pcl_scatter_rows_add_f32: gfeat[row_src[r], c] += grows[r, off+c]  (zero-fills gfeat [n_dst_rows, C]). */
 int pcl_group_offsets_i32(const int32_t* cnt, int G, int32_t* group_off, void* stream);   /* exclusive scan of max(cnt,1) */
+/* reference: replaces BallQueryGrouper.execute's gathers + concat, misc/ops.py:383-407, on rows without the padding duplicates of misc/ops.py:321-324 */
 int pcl_group_compact_f32(const float* xyz, const float* new_xyz, const float* feat, const int32_t* idx,
                           const int32_t* cnt, const int32_t* group_off, int B, int N, int m, int ns, int C, int use_xyz,
                           int row_stride /* >= 3*use_xyz + C; extra columns are written as zeros */, float* rows,
                           int32_t* row_meta, int32_t* row_src, void* stream);
+/* reference: as pcl_linear_fwd_f32 (networks/cls/pointnet2.py:25-29) on duplicate-compacted rows */
 int pcl_linear_fwd_rows_f32(const float* X, const float* W, const float* bias, const float* in_scale,
                             const float* in_shift, float in_slope, int P, int Cin, int Cout, float* Y,
                             double* stats_ws, const int32_t* row_meta, const int32_t* n_rows_dev, void* stream);
+/* reference: as pcl_bn_act_max_f32 (networks/cls/pointnet2.py:28-29, :57) on duplicate-compacted rows */
 int pcl_bn_act_max_rows_f32(const float* Y, const int32_t* group_off, const float* scale, const float* shift,
                             float slope, int G, int C, float* out, int32_t* arg, float* ymax, void* stream);
+/* reference: as pcl_linear_bwd_dx_f32 (networks/cls/pointnet2.py:25-29) on duplicate-compacted rows */
 int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2, const float* mu,
                                const int32_t* arg, const float* gz, int ns, const float* W, int P, int Cout,
                                int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
@@ -272,11 +302,13 @@ int pcl_linear_bwd_dx_rows_f32(const float* dU, const float* Y, const float* a, 
                                (the xyz part of a grouped tensor) are skipped and left unwritten */,
                                int cin_stride /* row stride, in floats, of W and of dUprev when the layer's input rows are zero-padded
                                beyond Cin (0 = Cin) */, void* stream);
+/* reference: as pcl_linear_bwd_dw_f32 (networks/cls/pointnet2.py:25-26) on duplicate-compacted rows */
 int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2, const float* mu,
                                const int32_t* arg, const float* gz, int ns, const float* Xprev,
                                const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
                                int Cin, float* dW, void* workspace, size_t workspace_bytes, const int32_t* row_meta,
                                const int32_t* n_rows_dev, void* stream);
+/* reference: gradient of the gathers of misc/ops.py:384-396 on duplicate-compacted rows */
 int pcl_scatter_rows_add_f32(const float* grows, const int32_t* row_src, const int32_t* n_rows_dev, int rows_cap,
                              int D, int off, int C, int n_dst_rows, float* gfeat, void* stream);
 
