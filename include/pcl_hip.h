@@ -140,7 +140,7 @@ int pcl_density_f32(const float* xyz, int B, int N, float bandwidth, float* dens
 int pcl_group_linear_stat_rows(int B, int m);
 /* reference: replaces BallQueryGrouper's gathers (misc/ops.py:383-407) + the first Conv2d 1x1 of build_mlps (networks/cls/pointnet2.py:25-26, execute :51-54) */
 int pcl_group_linear_f32(const float* xyz, const float* new_xyz, const float* Uf, const float* Wx, const float* feat_small,
-                         const float* Wf_small, int CF, const int32_t* idx, const int32_t* cnt, const int32_t* group_off,
+                         const float* Wf_small, int CF, int ldw, const int32_t* idx, const int32_t* cnt, const int32_t* group_off,
                          int B, int N, int m, int ns, int C1, float* Y, int32_t* row_meta, int32_t* row_src,
                          float* row_loc /* [cap,4]: xyz - centre, multiplicity */, float* row_feat /* [cap,4] or NULL */,
                          double* stats_ws, void* stream);
@@ -148,7 +148,7 @@ int pcl_group_linear_f32(const float* xyz, const float* new_xyz, const float* Uf
 int pcl_group_linear_bwd_f32(const float* row_loc, const float* row_feat, int CF, const float* dU, const float* Y,
                              const float* a, const float* k1, const float* k2, const float* mu, const int32_t* row_src,
                              const int32_t* n_rows_dev /* &group_off[B*m] */, int B, int N, int C1, float* dUf,
-                             float* dWx_part, float* dWf_part, void* stream);
+                             float* dWx_part, float* dWf_part, float* dW0, int ldw, int off, void* stream);
 
 /* The classification head on R <= 64 rows (one row per cloud): Linear (+bias) -> BatchNorm1d -> (Leaky)ReLU as ONE kernel
  * per layer (networks/cls/pointnet2.py:138-147, dgcnn.py:87-93, pointnet.py:22-38).  X [R,K], W [N,K] (nn.Linear layout).
@@ -164,6 +164,12 @@ int pcl_head_layer_bwd_f32(const float* X, const float* W, const float* dOUT, co
                            const float* gamma, const float* mean, const float* invstd, int R, int K, int N, int bn_mode,
                            float slope, float* dY_ws, float* dW, float* dbias, float* dgamma, float* dbeta, float* dX,
                            void* stream);
+
+/* Label-smoothed cross entropy of the classification drivers, soft_cross_entropy_loss of train_cls.py:31-51:
+ *   w = one_hot*(1-eps) + (1-one_hot)*eps/(C-1);  *loss = -mean_r sum_c w[r,c] log_softmax(logits)[r,c]
+ * logits [R,C], target [R] int64 class ids; dlogits [R,C] (nullable) = d loss / d logits = (softmax - w)/R.  One launch
+ * (one workgroup; R <= 65536) instead of the ~12 elementwise launches of the composite. */
+int pcl_soft_ce_f32(const float* logits, const int64_t* target, float eps, int R, int C, float* loss, float* dlogits, void* stream);
 
 /* DGCNN EdgeConv without the edge tensor (networks/cls/dgcnn.py:29-50,:72-83,:100-111).  With the 1x1 conv weight split
  * W = [Wa | Wb], y[i,j] = U[nbr(i,j)] + V[i] where UV [B*N, 2C] = x [Wa ; Wb-Wa]^T is ONE plain GEMM over the points.
@@ -307,7 +313,7 @@ int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const float* a, 
                                const int32_t* arg, const float* gz, int ns, const float* Xprev,
                                const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
                                int Cin, float* dW, void* workspace, size_t workspace_bytes, const int32_t* row_meta,
-                               const int32_t* n_rows_dev, void* stream);
+                               const int32_t* n_rows_dev, int dw_ld, void* stream);
 /* reference: gradient of the gathers of misc/ops.py:384-396 on duplicate-compacted rows */
 int pcl_scatter_rows_add_f32(const float* grows, const int32_t* row_src, const int32_t* n_rows_dev, int rows_cap,
                              int D, int off, int C, int n_dst_rows, float* gfeat, void* stream);

@@ -61,10 +61,11 @@ _SIGS = {
     "pcl_three_interp_bwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_density_f32": (c_int, [_P, c_int, c_int, c_float, _P, _P]),
     "pcl_group_linear_stat_rows": (c_int, [c_int, c_int]),
-    "pcl_group_linear_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
-    "pcl_group_linear_bwd_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "pcl_group_linear_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "pcl_group_linear_bwd_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P]),
     "pcl_head_layer_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P]),
     "pcl_head_layer_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "pcl_soft_ce_f32": (c_int, [_P, _P, c_float, c_int, c_int, _P, _P, _P]),
     "pcl_edgeconv_stat_rows": (c_int, [c_int, c_int]),
     "pcl_edgeconv_gather_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "pcl_edgeconv_scatter_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
@@ -89,7 +90,7 @@ _SIGS = {
     "pcl_linear_bwd_dx_rows_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_float,
                                            _P, _P, _P, _P, c_int, c_int, _P]),
     "pcl_linear_bwd_dw_rows_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_float, c_int, c_int, c_int, _P,
-                                           _P, c_size_t, _P, _P, _P]),
+                                           _P, c_size_t, _P, _P, c_int, _P]),
     "pcl_scatter_rows_add_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_linear_bwd_dw_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "pcl_linear_bwd_dw_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_float, c_int, c_int, c_int, _P,

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void group_rows_meta_kernel(const float* __res
 // iteration's row metadata is requested before the current rows are processed (two dependent gathers per row otherwise).
 template <int NH>
 __global__ __launch_bounds__(256) void group_linear_kernel(const float* __restrict__ Uf, const float* __restrict__ Wx,
-                                                           const float* __restrict__ Wfs, int CF,
+                                                           const float* __restrict__ Wfs, int CF, int ldw,
                                                            const float4* __restrict__ rloc, const float4* __restrict__ rfeat,
                                                            const int32_t* __restrict__ rsrc,
                                                            const int32_t* __restrict__ n_rows, int C1, float* __restrict__ Y,
@@ -233,9 +233,9 @@ __global__ __launch_bounds__(256) void group_linear_kernel(const float* __restri
     for (int h = 0; h < NH; ++h) {
         const int ch = lane + 64 * h;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) wx[h][d] = (Wx && ch < C1) ? Wx[ch * 3 + d] : 0.f;
+        for (int d = 0; d < 3; ++d) wx[h][d] = (Wx && ch < C1) ? Wx[(size_t)ch * ldw + d] : 0.f;
 #pragma unroll
-        for (int f = 0; f < GL_CF; ++f) wf[h][f] = (f < CF && ch < C1) ? Wfs[ch * CF + f] : 0.f;
+        for (int f = 0; f < GL_CF; ++f) wf[h][f] = (f < CF && ch < C1) ? Wfs[(size_t)ch * ldw + f] : 0.f;
         ss[h] = 0.0; qq[h] = 0.0;
     }
     const int stride = gridDim.x * 4 * GL_RPI;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void group_linear_bwd_kernel(const float4* __r
 // rows = 1 KiB of contiguous Y (or dU) instead of 256 B: a quarter of the memory instructions for the same bytes.
 template <int LPR>     // lanes per row: 16, 32 or 64
 __global__ __launch_bounds__(256) void group_linear_v4_kernel(const float* __restrict__ Uf, const float* __restrict__ Wx,
-                                                              const float* __restrict__ Wfs, int CF,
+                                                              const float* __restrict__ Wfs, int CF, int ldw,
                                                               const float4* __restrict__ rloc, const float4* __restrict__ rfeat,
                                                               const int32_t* __restrict__ rsrc,
                                                               const int32_t* __restrict__ n_rows, float* __restrict__ Y,
@@ -387,9 +387,9 @@ __global__ __launch_bounds__(256) void group_linear_v4_kernel(const float* __res
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) wx[d][v] = Wx ? Wx[(c4 + v) * 3 + d] : 0.f;
+        for (int d = 0; d < 3; ++d) wx[d][v] = Wx ? Wx[(size_t)(c4 + v) * ldw + d] : 0.f;
 #pragma unroll
-        for (int f = 0; f < GL_CF; ++f) wf[f][v] = f < CF ? Wfs[(c4 + v) * CF + f] : 0.f;
+        for (int f = 0; f < GL_CF; ++f) wf[f][v] = f < CF ? Wfs[(size_t)(c4 + v) * ldw + f] : 0.f;
         ss[v] = 0.0; qq[v] = 0.0;
     }
     const int stride = gridDim.x * 4 * RPW * U;
@@ -507,6 +507,26 @@ __global__ __launch_bounds__(256) void group_linear_bwd_v4_kernel(const float4* 
     }
 }
 
+// dW0[c, 0..2] = sum_r dWx_part[r][c][0..2];  dW0[c, off + f] = sum_r dWf_part[r][c][f]  (dW0 has leading dimension ld):
+// one wave per output element group -- 64 row-lanes per element, partials are L2-resident.
+__global__ __launch_bounds__(256) void group_linear_dw_kernel(const float* __restrict__ px, const float* __restrict__ pf, int rows,
+                                                              int C1, int CF, int off, int ld, float* __restrict__ dW0) {
+    const int nx = px ? C1 * 3 : 0, nf = pf ? C1 * CF : 0;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= nx + nf) return;
+    const bool isx = e < nx;
+    const float* src = isx ? px + e : pf + (e - nx);
+    const int n = isx ? nx : nf;
+    float s = 0.f;
+    for (int r = lane; r < rows; r += 64) s += src[(size_t)r * n];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        if (isx) dW0[(size_t)(e / 3) * ld + e % 3] = s;
+        else dW0[(size_t)((e - nx) / CF) * ld + off + (e - nx) % CF] = s;
+    }
+}
+
 }  // namespace pcl
 using namespace pcl;
 
@@ -566,7 +586,7 @@ constexpr int GL_BLOCKS = 2048;      // 8 workgroups of 4 waves per CU; also the
 extern "C" int pcl_group_linear_stat_rows(int B, int m) { return (B < 1 || m < 1) ? 0 : GL_BLOCKS; }
 
 extern "C" int pcl_group_linear_f32(const float* xyz, const float* new_xyz, const float* Uf, const float* Wx, const float* feat_small,
-                                    const float* Wf_small, int CF, const int32_t* idx, const int32_t* cnt,
+                                    const float* Wf_small, int CF, int ldw, const int32_t* idx, const int32_t* cnt,
                                     const int32_t* group_off, int B, int N, int m, int ns, int C1, float* Y, int32_t* row_meta,
                                     int32_t* row_src, float* row_loc, float* row_feat, double* stats_ws, void* stream) {
     PCL_REQUIRE(idx && cnt && group_off && Y && row_meta && row_src && row_loc && stats_ws, "pcl_group_linear_f32: null pointer");
@@ -574,6 +594,7 @@ extern "C" int pcl_group_linear_f32(const float* xyz, const float* new_xyz, cons
     PCL_REQUIRE(Uf || Wx || CF > 0, "pcl_group_linear_f32: need features (Uf or feat_small) and/or coordinates (Wx)");
     PCL_REQUIRE(CF >= 0 && CF <= GL_CF && (CF == 0 || (feat_small && Wf_small)), "pcl_group_linear_f32: CF=%d inline features (<= %d)", CF, GL_CF);
     PCL_REQUIRE(!Wx || (xyz && new_xyz), "pcl_group_linear_f32: Wx needs xyz and new_xyz");
+    PCL_REQUIRE(ldw >= (Wx ? 3 : 0) && ldw >= CF, "pcl_group_linear_f32: ldw=%d", ldw);
     PCL_REQUIRE(B >= 1 && N >= 1 && m >= 1 && ns >= 1 && ns < 32768 && C1 >= 1 && C1 <= 64 * GL_MAXH,
                 "pcl_group_linear_f32: bad sizes B=%d N=%d m=%d ns=%d C1=%d (C1 <= %d)", B, N, m, ns, C1, 64 * GL_MAXH);
     const int G = B * m;
@@ -588,25 +609,27 @@ extern "C" int pcl_group_linear_f32(const float* xyz, const float* new_xyz, cons
     const dim3 grid(GL_BLOCKS), block(256);
     const bool al16 = ((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(Uf)) & 15) == 0;
     if (al16 && (C1 == 64 || C1 == 128 || C1 == 256)) {
-        if (C1 == 64) hipLaunchKernelGGL(group_linear_v4_kernel<16>, grid, block, 0, st, Uf, Wx, Wf_small, CF, rl, rf, row_src, group_off + G, Y, stats_ws);
-        else if (C1 == 128) hipLaunchKernelGGL(group_linear_v4_kernel<32>, grid, block, 0, st, Uf, Wx, Wf_small, CF, rl, rf, row_src, group_off + G, Y, stats_ws);
-        else hipLaunchKernelGGL(group_linear_v4_kernel<64>, grid, block, 0, st, Uf, Wx, Wf_small, CF, rl, rf, row_src, group_off + G, Y, stats_ws);
+        if (C1 == 64) hipLaunchKernelGGL(group_linear_v4_kernel<16>, grid, block, 0, st, Uf, Wx, Wf_small, CF, ldw, rl, rf, row_src, group_off + G, Y, stats_ws);
+        else if (C1 == 128) hipLaunchKernelGGL(group_linear_v4_kernel<32>, grid, block, 0, st, Uf, Wx, Wf_small, CF, ldw, rl, rf, row_src, group_off + G, Y, stats_ws);
+        else hipLaunchKernelGGL(group_linear_v4_kernel<64>, grid, block, 0, st, Uf, Wx, Wf_small, CF, ldw, rl, rf, row_src, group_off + G, Y, stats_ws);
         return check_launch("pcl_group_linear_f32");
     }
-    if (C1 <= 64) hipLaunchKernelGGL(group_linear_kernel<1>, grid, block, 0, st, Uf, Wx, Wf_small, CF, rl, rf, row_src, group_off + G, C1, Y, stats_ws);
-    else if (C1 <= 128) hipLaunchKernelGGL(group_linear_kernel<2>, grid, block, 0, st, Uf, Wx, Wf_small, CF, rl, rf, row_src, group_off + G, C1, Y, stats_ws);
-    else hipLaunchKernelGGL(group_linear_kernel<4>, grid, block, 0, st, Uf, Wx, Wf_small, CF, rl, rf, row_src, group_off + G, C1, Y, stats_ws);
+    if (C1 <= 64) hipLaunchKernelGGL(group_linear_kernel<1>, grid, block, 0, st, Uf, Wx, Wf_small, CF, ldw, rl, rf, row_src, group_off + G, C1, Y, stats_ws);
+    else if (C1 <= 128) hipLaunchKernelGGL(group_linear_kernel<2>, grid, block, 0, st, Uf, Wx, Wf_small, CF, ldw, rl, rf, row_src, group_off + G, C1, Y, stats_ws);
+    else hipLaunchKernelGGL(group_linear_kernel<4>, grid, block, 0, st, Uf, Wx, Wf_small, CF, ldw, rl, rf, row_src, group_off + G, C1, Y, stats_ws);
     return check_launch("pcl_group_linear_f32");
 }
 
 extern "C" int pcl_group_linear_bwd_f32(const float* row_loc, const float* row_feat, int CF, const float* dU, const float* Y,
                                         const float* a, const float* k1, const float* k2, const float* mu, const int32_t* row_src,
                                         const int32_t* n_rows_dev, int B, int N, int C1, float* dUf, float* dWx_part,
-                                        float* dWf_part, void* stream) {
+                                        float* dWf_part, float* dW0, int ldw, int off, void* stream) {
     PCL_REQUIRE(row_loc && dU && Y && a && k1 && k2 && mu && row_src && n_rows_dev, "pcl_group_linear_bwd_f32: null pointer");
     PCL_REQUIRE(dUf || dWx_part || dWf_part, "pcl_group_linear_bwd_f32: nothing to compute");
     PCL_REQUIRE(!dWf_part || (row_feat && CF >= 1 && CF <= GL_CF), "pcl_group_linear_bwd_f32: dWf needs row_feat, CF=%d", CF);
     PCL_REQUIRE(B >= 1 && N >= 1 && C1 >= 1 && C1 <= 64 * GL_MAXH, "pcl_group_linear_bwd_f32: bad sizes");
+    PCL_REQUIRE(!dW0 || ((dWx_part || dWf_part) && ldw >= (dWx_part ? 3 : 0) && off >= 0 && ldw >= off + (dWf_part ? CF : 0)),
+                "pcl_group_linear_bwd_f32: dW0 needs the partial buffers and ldw=%d >= off=%d + CF", ldw, off);
     hipStream_t st = as_stream(stream);
     if (dUf) {
         hipError_t e = hipMemsetAsync(dUf, 0, sizeof(float) * (size_t)B * N * C1, st);
@@ -622,10 +645,12 @@ extern "C" int pcl_group_linear_bwd_f32(const float* row_loc, const float* row_f
         if (C1 == 64) hipLaunchKernelGGL(group_linear_bwd_v4_kernel<16>, grid, block, 0, st, rl, rf, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, dUf, dWx_part, dWf_part);
         else if (C1 == 128) hipLaunchKernelGGL(group_linear_bwd_v4_kernel<32>, grid, block, 0, st, rl, rf, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, dUf, dWx_part, dWf_part);
         else hipLaunchKernelGGL(group_linear_bwd_v4_kernel<64>, grid, block, 0, st, rl, rf, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, dUf, dWx_part, dWf_part);
-        return check_launch("pcl_group_linear_bwd_f32");
-    }
-    if (C1 <= 64) hipLaunchKernelGGL(group_linear_bwd_kernel<1>, grid, block, 0, st, rl, rf, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, C1, dUf, dWx_part, dWf_part);
+    } else if (C1 <= 64) hipLaunchKernelGGL(group_linear_bwd_kernel<1>, grid, block, 0, st, rl, rf, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, C1, dUf, dWx_part, dWf_part);
     else if (C1 <= 128) hipLaunchKernelGGL(group_linear_bwd_kernel<2>, grid, block, 0, st, rl, rf, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, C1, dUf, dWx_part, dWf_part);
     else hipLaunchKernelGGL(group_linear_bwd_kernel<4>, grid, block, 0, st, rl, rf, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, C1, dUf, dWx_part, dWf_part);
-    return check_launch("pcl_group_linear_bwd_f32");
+    int rc = check_launch("pcl_group_linear_bwd_f32");
+    if (rc || !dW0) return rc;
+    const int n = (dWx_part ? C1 * 3 : 0) + (dWf_part ? C1 * CF : 0);
+    hipLaunchKernelGGL(group_linear_dw_kernel, dim3((n + 3) / 4), block, 0, st, dWx_part, dWf_part, GL_BLOCKS, C1, CF, off, ldw, dW0);
+    return check_launch("pcl_group_linear_bwd_f32(dW)");
 }

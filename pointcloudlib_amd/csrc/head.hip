@@ -119,9 +119,13 @@ __global__ __launch_bounds__(256) void head_bwd_col_kernel(const float* __restri
                                                            const float* __restrict__ invstd, int R, int K, int N, int bn_mode,
                                                            float slope, float* __restrict__ dY, float* __restrict__ dW,
                                                            float* __restrict__ dbias, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta) {
+                                                           float* __restrict__ dbeta, float* __restrict__ dX_zero) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x;
+    if (dX_zero) {                         // the dX kernel that follows accumulates with atomics: clear its target here
+        const int total = R * K, chunk = (total + N - 1) / N;
+        for (int e = n * chunk + threadIdx.x; e < min((n + 1) * chunk, total); e += 256) dX_zero[e] = 0.f;
+    }
     const bool in = lane < R;
     const size_t o = (size_t)min(lane, R - 1) * N + n;
     float du = in ? dOUT[o] : 0.f;
@@ -232,16 +236,65 @@ extern "C" int pcl_head_layer_bwd_f32(const float* X, const float* W, const floa
     const dim3 grid(N), block(256);
     if (R <= 32)
         hipLaunchKernelGGL(head_bwd_col_kernel<32>, grid, block, 0, st, X, dOUT, OUT, Ypre, gamma, mean, invstd, R, K, N, bn_mode, slope, dY_ws,
-                           dW, dbias, dgamma, dbeta);
+                           dW, dbias, dgamma, dbeta, dX);
     else
         hipLaunchKernelGGL(head_bwd_col_kernel<64>, grid, block, 0, st, X, dOUT, OUT, Ypre, gamma, mean, invstd, R, K, N, bn_mode, slope, dY_ws,
-                           dW, dbias, dgamma, dbeta);
+                           dW, dbias, dgamma, dbeta, dX);
     int rc = check_launch("pcl_head_layer_bwd_f32(col)");
     if (rc || !dX) return rc;
-    hipError_t e = hipMemsetAsync(dX, 0, sizeof(float) * (size_t)R * K, st);
-    if (e != hipSuccess) return fail(PCL_EHIP, "pcl_head_layer_bwd_f32: memset: %s", hipGetErrorString(e));
     const dim3 g2((K + 63) / 64, (N + 4 * HD_NS - 1) / (4 * HD_NS));
     if (R <= 32) hipLaunchKernelGGL(head_bwd_dx_kernel<32>, g2, block, 0, st, dY_ws, W, R, K, N, dX);
     else hipLaunchKernelGGL(head_bwd_dx_kernel<64>, g2, block, 0, st, dY_ws, W, R, K, N, dX);
     return check_launch("pcl_head_layer_bwd_f32(dx)");
+}
+
+// ---- label-smoothed cross entropy of the classifier (train_cls.py:31-51) --------------------------------------------
+//   w = one_hot*(1-eps) + (1-one_hot)*eps/(C-1);  loss = -mean_r sum_c w[r,c] log_softmax(x)[r,c]
+// One workgroup: a wave per row (lanes over classes), row losses folded through LDS.  Also writes the gradient of the
+// mean loss, (softmax - w)/R, so that backward is a scale.  (The reference builds it from ~12 elementwise launches.)
+namespace pcl {
+__global__ __launch_bounds__(1024) void soft_ce_kernel(const float* __restrict__ x, const int64_t* __restrict__ target, float eps,
+                                                       int R, int C, float* __restrict__ loss, float* __restrict__ dx) {
+    __shared__ float part[16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float lo = C > 1 ? eps / (float)(C - 1) : 0.f, hi = 1.f - eps, invR = 1.f / (float)R;
+    float acc = 0.f;
+    for (int r = wave; r < R; r += 16) {
+        const float* xr = x + (size_t)r * C;
+        const int t = (int)target[r];
+        float mx = -INFINITY;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, xr[c]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float se = 0.f;
+        for (int c = lane; c < C; c += 64) se += expf(xr[c] - mx);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+        const float lse = logf(se);
+        float l = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float lp = xr[c] - mx - lse, w = c == t ? hi : lo;
+            l -= w * lp;
+            if (dx) dx[(size_t)r * C + c] = (expf(lp) - w) * invR;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+        acc += l;
+    }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int j = 0; j < 16; ++j) s += part[j];
+        *loss = s * invR;
+    }
+}
+}  // namespace pcl
+
+extern "C" int pcl_soft_ce_f32(const float* logits, const int64_t* target, float eps, int R, int C, float* loss, float* dlogits,
+                               void* stream) {
+    PCL_REQUIRE(logits && target && loss, "pcl_soft_ce_f32: null pointer");
+    PCL_REQUIRE(R >= 1 && R <= 65536 && C >= 1 && eps >= 0.f && eps < 1.f, "pcl_soft_ce_f32: bad sizes R=%d C=%d eps=%g", R, C, (double)eps);
+    hipLaunchKernelGGL(pcl::soft_ce_kernel, dim3(1), dim3(1024), 0, as_stream(stream), logits, target, eps, R, C, loss, dlogits);
+    return check_launch("pcl_soft_ce_f32");
 }

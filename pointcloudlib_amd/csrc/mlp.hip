@@ -820,8 +820,8 @@ static void launch_dw_t(const DwArgs& d, dim3 grid, int tm, int tn, hipStream_t 
     else launch_dw_t2<AM, VEC, false>(d, grid, tm, tn, st);
 }
 
-// out[e] = sum_r part[r][e]: 32 outputs x 8 row-lanes per 256-thread block (partials are L2-resident).
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int rows, size_t n,
+// out[e] = sum_r part[r][e] (out rows of ncols elements, ldo apart): 32 outputs x 8 row-lanes per 256-thread block (partials are L2-resident).
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int rows, size_t n, int ncols, int ldo,
                                                           float* __restrict__ out) {
     __shared__ float red[8][33];
     const int el = threadIdx.x & 31, ry = threadIdx.x >> 5;
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
         float t = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) t += red[j][el];
-        out[e] = t;
+        out[ldo == ncols ? e : (e / ncols) * ldo + e % ncols] = t;
     }
 }
 
@@ -1185,22 +1185,23 @@ extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const
                                           const int32_t* arg, const float* gz, int ns, const float* Xprev,
                                           const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
                                           int Cin, float* dW, void* workspace, size_t workspace_bytes, const int32_t* row_meta,
-                                          const int32_t* n_rows_dev, void* stream);
+                                          const int32_t* n_rows_dev, int dw_ld, void* stream);
 
 extern "C" int pcl_linear_bwd_dw_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2, const float* mu,
                                      const int32_t* arg, const float* gz, int ns, const float* Xprev,
                                      const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
                                      int Cin, float* dW, void* workspace, size_t workspace_bytes, void* stream) {
     return pcl_linear_bwd_dw_rows_f32(dU, Y, a_, k1, k2, mu, arg, gz, ns, Xprev, prev_scale, prev_shift, prev_slope, P, Cout, Cin, dW,
-                                      workspace, workspace_bytes, nullptr, nullptr, stream);
+                                      workspace, workspace_bytes, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2, const float* mu,
                                           const int32_t* arg, const float* gz, int ns, const float* Xprev,
                                           const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
                                           int Cin, float* dW, void* workspace, size_t workspace_bytes, const int32_t* row_meta,
-                                          const int32_t* n_rows_dev, void* stream) {
+                                          const int32_t* n_rows_dev, int dw_ld, void* stream) {
     PCL_REQUIRE(Y && a_ && k1 && k2 && mu && Xprev && dW, "pcl_linear_bwd_dw_f32: null pointer");
+    PCL_REQUIRE(dw_ld == 0 || dw_ld >= Cin, "pcl_linear_bwd_dw_f32: dw_ld=%d < Cin=%d", dw_ld, Cin);
     PCL_REQUIRE((dU != nullptr) != (arg != nullptr && gz != nullptr), "pcl_linear_bwd_dw_f32: pass dU or (arg,gz)");
     PCL_REQUIRE((prev_scale == nullptr) == (prev_shift == nullptr), "pcl_linear_bwd_dw_f32: scale/shift together");
     PCL_REQUIRE(P >= 1 && Cin >= 1 && Cout >= 1 && (dU || ns >= 1), "pcl_linear_bwd_dw_f32: bad sizes");
@@ -1224,7 +1225,7 @@ extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const
     if (rc) return rc;
     const size_t n = (size_t)Cout * Cin;
     const int blocks = (int)((n + 31) / 32);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(blocks), dim3(256), 0, st, d.part, gx, n, dW);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(blocks), dim3(256), 0, st, d.part, gx, n, Cin, dw_ld ? dw_ld : Cin, dW);
     return check_launch("pcl_linear_bwd_dw_f32(reduce)");
 }
 

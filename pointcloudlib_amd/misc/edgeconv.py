@@ -119,7 +119,7 @@ class _PointLinear(torch.autograd.Function):
             ws = torch.empty(((nbytes + 3) // 4,), device=dev)
             dWcat = torch.empty((C2, C), device=dev)
             _lib.call("pcl_linear_bwd_dw_rows_f32", _p(dUV), _p(dUV), _p(one), _p(zero), _p(zero), _p(zero), None, None, 1, _p(x),
-                      None, None, 0.0, P, C2, C, _p(dWcat), _p(ws), nbytes, None, None, st, tag=f"uvdw{C2}x{C}")
+                      None, None, 0.0, P, C2, C, _p(dWcat), _p(ws), nbytes, None, None, 0, st, tag=f"uvdw{C2}x{C}")
             dW = torch.cat([dWcat[:Co] - dWcat[Co:], dWcat[Co:]], dim=1)           # Wcat = [Wa ; Wb - Wa]
         if ctx.needs_input_grad[0]:
             dx = torch.empty((B, N, C), device=dev)

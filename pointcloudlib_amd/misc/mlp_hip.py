@@ -238,7 +238,7 @@ class _FusedMLP(torch.autograd.Function):
             dW = _empty((cout, cin), dev)
             _lib.call("pcl_linear_bwd_dw_rows_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(means[l]), _P(arg) if sparse else None,
                       _P(gz) if sparse else None, ns or 1, _P(Xprev), _P(psc), _P(psh), slope, P, cout, cin, _P(dW), _P(ws),
-                      nbytes, _P(rmeta), _P(nrows), st,
+                      nbytes, _P(rmeta), _P(nrows), 0, st,
                       algo_bytes=_rows_cost(nrows, P, 4 * (cin + (cout if sparse else 2 * cout)), 4 * cin * cout),
                       algo_flops=_rows_cost(nrows, P, 2 * cin * cout, 0), tag=f"dw{cout}x{cin}")
             grads[6 * l] = dW if cin == fan_in else dW[:, :fan_in].contiguous()
@@ -333,9 +333,10 @@ class _GroupLinear(torch.autograd.Function):
         dev = idx.device
         cap = B * m * ns
         st = _stream()
-        Wx = W0[:, :3].contiguous() if use_xyz else None
-        Wf = W0[:, off:].contiguous() if C else None
         inline = 0 < C <= 4 and not feature.requires_grad
+        W0 = W0.contiguous()
+        Wx = W0[:, :3] if use_xyz else None                    # views: the kernels take the stored weight with its row stride
+        Wf = (W0[:, off:] if inline else W0[:, off:].contiguous()) if C else None       # the point GEMM wants it dense
         feat2 = feature.reshape(B * N, C).contiguous() if C else None
         Uf = None
         if C and not inline:
@@ -351,13 +352,14 @@ class _GroupLinear(torch.autograd.Function):
         row_loc = _empty((cap, 4), dev)
         row_feat = _empty((cap, 4), dev) if inline else None
         _lib.call("pcl_group_linear_f32", _P(xyz), _P(new_xyz), _P(Uf), _P(Wx), _P(feat2) if inline else None,
-                  _P(Wf) if inline else None, C if inline else 0, _P(idx), _P(cnt), _P(group_off), B, N, m, ns, C1, _P(Y),
+                  _P(Wf) if inline else None, C if inline else 0, W0.shape[1], _P(idx), _P(cnt), _P(group_off), B, N, m, ns, C1, _P(Y),
                   _P(row_meta), _P(row_src), _P(row_loc), _P(row_feat), _P(stats), st)
         link.stats, link.rows = stats, rows
         ctx.link = link
         ctx.dims = (B, N, m, ns, C1, C, off, inline, rows)
         ctx.mark_non_differentiable(row_meta, row_src)
-        ctx.save_for_backward(group_off, Y, row_src, row_loc, row_feat, feat2, Wf)
+        ctx.set_materialize_grads(False)          # no zero tensors for the (integer) metadata outputs
+        ctx.save_for_backward(group_off, Y, row_src, row_loc, row_feat, feat2, None if inline else Wf)
         return Y, row_meta, row_src
 
     @staticmethod
@@ -369,18 +371,21 @@ class _GroupLinear(torch.autograd.Function):
         dev = Y.device
         st = _stream()
         lib = _lib.lib()
+        if du is None:
+            return (None,) * 9
         need_w = ctx.needs_input_grad[3]
         wide = C > 0 and not inline
+        fan_in = off + C
         dUf = _empty((B * N, C1), dev) if wide else None
         dWxp = _empty((rows, C1, 3), dev) if (off and need_w) else None
         dWfp = _empty((rows, C1, C), dev) if (inline and need_w) else None
+        dW0 = _empty((C1, fan_in), dev) if need_w else None
         if dUf is not None or dWxp is not None or dWfp is not None:
+            fin = dW0 is not None and (dWxp is not None or dWfp is not None)       # partial sums -> dW0 columns, in the same call
             _lib.call("pcl_group_linear_bwd_f32", _P(row_loc), _P(row_feat), C if inline else 0, _P(du.contiguous()), _P(Y),
-                      _P(a), _P(k1), _P(k2), _P(mu), _P(row_src), _P(group_off[B * m:]), B, N, C1, _P(dUf), _P(dWxp), _P(dWfp), st)
-        dfeat = dW0 = None
-        parts = []
-        if need_w and off:
-            parts.append(dWxp.sum(0))
+                      _P(a), _P(k1), _P(k2), _P(mu), _P(row_src), _P(group_off[B * m:]), B, N, C1, _P(dUf), _P(dWxp), _P(dWfp),
+                      _P(dW0) if fin else None, fan_in, off, st)
+        dfeat = None
         if wide:
             # plain GEMMs through the BatchNorm-backward entry points with a = 1, k1 = k2 = 0 (dy == dUf)
             one, zero = _const_vec(dev, C1, 1.0), _const_vec(dev, C1, 0.0)
@@ -388,19 +393,14 @@ class _GroupLinear(torch.autograd.Function):
             if need_w:
                 nbytes = lib.pcl_linear_bwd_dw_workspace_bytes(P, C1, C)
                 ws = _empty(((nbytes + 3) // 4,), dev)
-                dWf = _empty((C1, C), dev)
                 _lib.call("pcl_linear_bwd_dw_rows_f32", _P(dUf), _P(dUf), _P(one), _P(zero), _P(zero), _P(zero), None, None, 1,
-                          _P(feat2), None, None, 0.0, P, C1, C, _P(dWf), _P(ws), nbytes, None, None, st, tag=f"ptdw{C1}x{C}")
-                parts.append(dWf)
+                          _P(feat2), None, None, 0.0, P, C1, C, _P(dW0[:, off:]), _P(ws), nbytes, None, None, fan_in, st,
+                          tag=f"ptdw{C1}x{C}")
             if ctx.needs_input_grad[2]:
                 dfeat = _empty((P, C), dev)
                 _lib.call("pcl_linear_bwd_dx_rows_f32", _P(dUf), _P(dUf), _P(one), _P(zero), _P(zero), _P(zero), None, None, 1,
                           _P(Wf), P, C1, C, None, None, None, 0.0, _P(dfeat), None, None, None, 0, 0, st, tag=f"ptdx{C1}x{C}")
                 dfeat = dfeat.view(B, N, C)
-        elif inline and need_w:
-            parts.append(dWfp.sum(0))
-        if need_w:
-            dW0 = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
         return None, None, dfeat, dW0, None, None, None, None, None
 
 

@@ -16,11 +16,36 @@ seg_num = [4, 2, 2, 4, 4, 3, 3, 2, 4, 2, 6, 2, 3, 3, 3, 3]
 index_start = [0, 4, 6, 8, 12, 16, 19, 22, 24, 28, 30, 36, 38, 41, 44, 47]
 
 
+class _SoftCE(torch.autograd.Function):
+    """pcl_soft_ce_f32: the loss and its gradient from one launch."""
+
+    @staticmethod
+    def forward(ctx, output, target, eps):
+        from . import _lib
+        R, C = output.shape
+        x = output.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        _lib.call("pcl_soft_ce_f32", x.data_ptr(), target.data_ptr(), float(eps), R, C, loss.data_ptr(),
+                  None if dx is None else dx.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        ctx.save_for_backward(dx)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dx, = ctx.saved_tensors
+        return dx * g, None, None
+
+
 def soft_cross_entropy_loss(output, target, smoothing=True):
+    """train_cls.py:31-51 (eps = 0.2).  On the GPU the smoothed loss is one HIP kernel (forward + gradient); CPU tensors
+    take the composite below, which is also what the kernel is tested against."""
     target = target.reshape(-1).long()
     if not smoothing:
         return F.cross_entropy(output, target)
     eps = 0.2
+    if output.is_cuda and output.dtype == torch.float32 and output.shape[0] <= 65536:
+        return _SoftCE.apply(output, target.contiguous(), eps)
     n_class = output.shape[1]
     one_hot = torch.zeros_like(output).scatter_(1, target[:, None], 1.0)
     one_hot = one_hot * (1 - eps) + (1 - one_hot) * eps / (n_class - 1)

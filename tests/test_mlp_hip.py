@@ -249,3 +249,22 @@ def test_head_layer_matches_torch(dev, R, K, N, bn, slope, bias):
         for m in (lin, b):
             if m is not None:
                 m.zero_grad()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,C", [(32, 40), (1, 40), (7, 2), (300, 130), (64, 1000)])
+def test_soft_ce_kernel_matches_composite(R, C):
+    """pcl_soft_ce_f32 (loss + gradient, one launch) vs the composite restatement of train_cls.py:31-51 in fp64."""
+    from pointcloudlib_amd.train_utils import soft_cross_entropy_loss
+    torch.manual_seed(R * 131 + C)
+    x = (torch.randn(R, C, device="cuda") * 4).requires_grad_(True)
+    t = torch.randint(0, C, (R,), device="cuda")
+    loss = soft_cross_entropy_loss(x, t)
+    (loss * 1.7).backward()
+    xd = x.detach().double().cpu().requires_grad_(True)
+    ref = soft_cross_entropy_loss(xd, t.cpu())            # CPU tensors take the composite path
+    (ref * 1.7).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert torch.allclose(x.grad.cpu().double(), xd.grad, rtol=1e-5, atol=1e-7)
+    with torch.no_grad():                                  # no gradient requested: forward only
+        assert abs(float(soft_cross_entropy_loss(x.detach(), t)) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
