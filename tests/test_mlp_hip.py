@@ -264,7 +264,7 @@ def test_soft_ce_kernel_matches_composite(R, C):
     xd = x.detach().double().cpu().requires_grad_(True)
     ref = soft_cross_entropy_loss(xd, t.cpu())            # CPU tensors take the composite path
     (ref * 1.7).backward()
-    assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert abs(loss.item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
     assert torch.allclose(x.grad.cpu().double(), xd.grad, rtol=1e-5, atol=1e-7)
     with torch.no_grad():                                  # no gradient requested: forward only
-        assert abs(float(soft_cross_entropy_loss(x.detach(), t)) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+        assert abs(float(soft_cross_entropy_loss(x.detach(), t)) - float(ref)) <= 2e-6 * max(1.0, abs(ref.item()))

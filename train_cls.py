@@ -63,7 +63,7 @@ def run_epoch(net, name, loader, dev, optimizer=None):
                 optimizer.zero_grad(set_to_none=True)
                 loss.backward()
                 optimizer.step()
-                loss_sum += float(loss) * len(labels)
+                loss_sum += loss.item() * len(labels)
         correct += int((out.argmax(1) == labels).sum())
         seen += len(labels)
     torch.cuda.synchronize()

@@ -79,7 +79,7 @@ def run_epoch(net, name, loader, dev, seg_num_all, optimizer=None):
                 optimizer.zero_grad(set_to_none=True)
                 loss.backward()
                 optimizer.step()
-        loss_sum += float(loss) * data.shape[0]
+        loss_sum += loss.item() * data.shape[0]
         count += data.shape[0]
         true_seg.append(seg.cpu().numpy())
         pred_seg.append(scores.argmax(2).cpu().numpy())
