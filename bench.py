@@ -30,12 +30,13 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 FP32_PEAK_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
 
 
-def make_batches(B, N, n_batches, rank, dev):
+def make_batches(B, N, n_batches, rank, dev, dist="gauss_ball"):
     from pointcloudlib_amd import synth
+    cloud = getattr(synth, dist)
     out = []
     for i in range(n_batches):
         seed = 20242 + 1000 * rank + i
-        out.append((torch.from_numpy(synth.gauss_ball(B, N, seed)).to(dev),
+        out.append((torch.from_numpy(cloud(B, N, seed)).to(dev),
                     torch.from_numpy(synth.unit_normals(B, N, seed + 500)).to(dev),
                     torch.from_numpy(synth.labels(B, 40, seed + 900)).to(dev)))
     return out
@@ -106,6 +107,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the main stream's part of a step as ONE captured HIP graph instead of enqueueing it from Python "
                          "(measured: 2.90 vs 2.86 ms/step eager on ROCm 7.2 -- the replay is not faster, so it is opt-in)")
+    ap.add_argument("--dist", choices=["gauss_ball", "sphere_shell"], default="gauss_ball",
+                    help="synthetic cloud distribution (SURVEY 8d): gauss_ball = the ModelNet40 loader's statistics (headline), "
+                         "sphere_shell = never-saturating ball queries, ~80 %% padded duplicates")
     ap.add_argument("--dp-bucket-bytes", type=int, default=0, help="cut the gradient exchange (N>1) into buckets of this size; 0 = one all-reduce")
     ap.add_argument("--dp-overlap", action="store_true",
                     help="send gradient buckets from autograd hooks during backward (measured slower, see pointcloudlib_amd/dp.py)")
@@ -137,7 +141,7 @@ def main():
     state0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     dp = FlatBucketDP(net, bucket_bytes=args.dp_bucket_bytes, overlap=args.dp_overlap)
     opt = make_sgd(net.parameters(), lr=0.02, momentum=0.9)   # train_cls.py:374-377,404
-    batches = make_batches(B, N, 4, rank, dev)
+    batches = make_batches(B, N, 4, rank, dev, args.dist)
 
     side = torch.cuda.Stream(priority=-1) if args.prefetch_sampling else None     # high priority: short latency-bound chain
     pending = {}
@@ -296,7 +300,8 @@ def main():
             traffic, traffic_src = None, None          # PMC HBM bytes per launch, from the committed profile (a separate
             try:                                       # rocprofv3 --pmc pass of this same command; see profiles/)
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-                traffic = tj["per_launch_hbm_bytes"].get(f"{key[0]}:{key[1]}")
+                if (B, N, args.dist) == (32, 1024, "gauss_ball"):        # the workload the counters were collected on
+                    traffic = tj["per_launch_hbm_bytes"].get(f"{key[0]}:{key[1]}")
                 traffic_src = tj["source"] if traffic is not None else None
             except Exception:
                 pass
@@ -315,7 +320,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"PointNet++ SSG cls train step (fwd+bwd+SGD), B={B}/GPU, N={N} xyz+normal, "
-                                   "gauss_ball clouds (BASELINE configs[1])",
+                                   f"{args.dist} clouds (BASELINE configs[1])",
                        "global_batch": world * B, "n_points": N, "parallelism": f"dp{world}",
                        "sampling": "indices of batch t+1 on a side stream during backward of batch t" if args.prefetch_sampling
                        else "inline",
