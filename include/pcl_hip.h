@@ -250,11 +250,12 @@ int pcl_bn_act_bwd_f32(const float* gz, const float* Y, const float* scale, cons
 int pcl_maxgrad_prep_f32(const float* gout, const float* out, const float* ymax, float slope, int G, int C,
                          float* gz, double* stats_ws, int* stat_rows_out, void* stream);
 /* BatchNorm backward constants from (sum du, sum du*y): dgamma, dbeta (nullable) and a, k1, k2 with
- * dy = a*du - k1 - k2*(y - mean)   (k1 = a*dbeta/P, k2 = a*dgamma*invstd/P; y is centred where it is used). */
+ * dy = a*du - k1 - k2*(y - mean)   (k1 = a*dbeta/P, k2 = a*dgamma*invstd/P; y is centred where it is used).
+ * dbias_zero [C] (nullable) is cleared: the gradient of a conv bias that feeds training-mode BatchNorm is exactly 0. */
 /* reference: gradient of training-mode nn.BatchNorm, networks/cls/pointnet2.py:28 */
 int pcl_bn_bwd_consts_f32(const double* stats_ws, int stat_rows, const float* gamma, const float* mean,
                           const float* invstd, int P, int C, float* dgamma, float* dbeta, float* a_out,
-                          float* k1, float* k2, void* stream);
+                          float* k1, float* k2, float* dbias_zero, void* stream);
 /* dUprev[P,Cin] = act'_prev(.) * (dy[P,Cout] W[Cout,Cin]), dy = a*du - k1 - k2*(Y - mu) formed on the fly from
  * dU (dense) or from (arg, gz, ns) (sparse max gradient; pass dU = NULL).  With Yprev: masked by the layer
  * below's activation and stats_ws gets (sum dUprev, sum dUprev*Yprev); Yprev NULL: plain store (input grad).

@@ -900,7 +900,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
 __global__ __launch_bounds__(256) void bn_bwd_consts_kernel(const double* __restrict__ stats, int rows, const float* __restrict__ gamma,
                                      const float* __restrict__ mean, const float* __restrict__ invstd, int P, int C,
                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ a_out,
-                                     float* __restrict__ k1, float* __restrict__ k2) {
+                                     float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ dbias_zero) {
     __shared__ double red[2 * 64 * 4];
     const int c = blockIdx.x * 4 + (threadIdx.x & 3), ry = threadIdx.x >> 2;
     double s1, s2;
@@ -913,6 +913,7 @@ __global__ __launch_bounds__(256) void bn_bwd_consts_kernel(const double* __rest
     const double kk2 = a * dg * is / P;
     if (dgamma) dgamma[c] = (float)dg;
     if (dbeta) dbeta[c] = (float)s1;
+    if (dbias_zero) dbias_zero[c] = 0.f;         // a conv bias under training-mode BatchNorm has an exactly zero gradient
     a_out[c] = (float)a;
     k2[c] = (float)kk2;
     k1[c] = (float)(a * s1 / P);
@@ -1241,11 +1242,11 @@ extern "C" int pcl_bn_finalize_f32(const double* stats_ws, int stat_rows, const 
 
 extern "C" int pcl_bn_bwd_consts_f32(const double* stats_ws, int stat_rows, const float* gamma, const float* mean,
                                      const float* invstd, int P, int C, float* dgamma, float* dbeta, float* a_out,
-                                     float* k1, float* k2, void* stream) {
+                                     float* k1, float* k2, float* dbias_zero, void* stream) {
     PCL_REQUIRE(stats_ws && mean && invstd && a_out && k1 && k2, "pcl_bn_bwd_consts_f32: null pointer");
     PCL_REQUIRE(P >= 1 && C >= 1 && stat_rows >= 1, "pcl_bn_bwd_consts_f32: bad sizes");
     hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), stats_ws, stat_rows,
-                       gamma, mean, invstd, P, C, dgamma, dbeta, a_out, k1, k2);
+                       gamma, mean, invstd, P, C, dgamma, dbeta, a_out, k1, k2, dbias_zero);
     return check_launch("pcl_bn_bwd_consts_f32");
 }
 

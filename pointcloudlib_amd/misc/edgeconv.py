@@ -69,7 +69,7 @@ class _EdgeConvPool(torch.autograd.Function):
         if training:
             dgamma, dbeta = torch.empty((C,), device=dev), torch.empty((C,), device=dev)
             _lib.call("pcl_bn_bwd_consts_f32", _p(stats), rows, _p(gamma), _p(mean), _p(invstd), G * k, C, _p(dgamma), _p(dbeta),
-                      _p(a), _p(k1), _p(k2), st)
+                      _p(a), _p(k1), _p(k2), None, st)
         else:
             s = stats[:rows].sum(0)
             a.copy_(scale); k1.zero_(); k2.zero_()

@@ -211,18 +211,18 @@ class _FusedMLP(torch.autograd.Function):
             a, k1, k2 = (_empty((cout,), dev) for _ in range(3))
             if bn and training:
                 dgamma, dbeta = _empty((cout,), dev), _empty((cout,), dev)
+                dbias = _empty((cout,), dev) if bias is not None else None        # exactly zero under BatchNorm: cleared there
                 _lib.call("pcl_bn_bwd_consts_f32", _P(stats), rows, _P(gamma), _P(means[l]), _P(invstds[l]), P, cout,
-                          _P(dgamma), _P(dbeta), _P(a), _P(k1), _P(k2), st)
-                grads[6 * l + 2], grads[6 * l + 3] = dgamma, dbeta
+                          _P(dgamma), _P(dbeta), _P(a), _P(k1), _P(k2), _P(dbias), st)
+                grads[6 * l + 1], grads[6 * l + 2], grads[6 * l + 3] = dbias, dgamma, dbeta
             else:
                 s = stats[:rows].sum(0)
                 a.copy_(scales[l]); k1.zero_(); k2.zero_()
                 if bn:   # eval-mode BatchNorm: affine with constant statistics
                     grads[6 * l + 3] = s[0].float()
                     grads[6 * l + 2] = ((s[1] - means[l].double() * s[0]) * invstds[l].double()).float()
-            if bias is not None:
-                # bias feeds BatchNorm -> its gradient is exactly zero; without BatchNorm it is sum(du)
-                grads[6 * l + 1] = torch.zeros_like(bias) if (bn and training) else stats[:rows, 0].sum(0).float() * a
+            if bias is not None and not (bn and training):
+                grads[6 * l + 1] = stats[:rows, 0].sum(0).float() * a             # without BatchNorm statistics: sum(du)
             if l == 0 and ctx.link is not None:
                 # hand the BatchNorm-backward constants of the folded first layer to _GroupLinear.backward, which forms
                 # dy = a*du - w*(k1 + k2*(y - mean)) itself; what flows back as "the gradient of x" is du (protocol

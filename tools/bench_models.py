@@ -4,13 +4,15 @@ import argparse, json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointcloudlib_amd import synth
-from pointcloudlib_amd.train_utils import soft_cross_entropy_loss
+from pointcloudlib_amd.train_utils import make_sgd, soft_cross_entropy_loss
+from pointcloudlib_amd.affinity import pin_to_gpu_node
+pin_to_gpu_node(0)
 
 
 def run(name, make, inputs, loss_fn, steps, warmup=3):
     torch.manual_seed(0)
     net = make().cuda().train()
-    opt = torch.optim.SGD(net.parameters(), lr=0.02, momentum=0.9)
+    opt = make_sgd(net.parameters(), lr=0.02, momentum=0.9)
     def step():
         opt.zero_grad(set_to_none=True)
         loss_fn(net(*inputs)).backward()

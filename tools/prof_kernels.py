@@ -3,7 +3,9 @@
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointcloudlib_amd import synth
-from pointcloudlib_amd.train_utils import soft_cross_entropy_loss
+from pointcloudlib_amd.train_utils import make_sgd, soft_cross_entropy_loss
+from pointcloudlib_amd.affinity import pin_to_gpu_node
+pin_to_gpu_node(0)
 which = sys.argv[1]
 rows = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 dev = "cuda"
@@ -38,7 +40,7 @@ else:
     elif which == "dgcnn":
         from pointcloudlib_amd.networks.cls.dgcnn import DGCNN as M; args = (xt,)
 net = M().to(dev).train()
-opt = torch.optim.SGD(net.parameters(), lr=0.02, momentum=0.9)
+opt = make_sgd(net.parameters(), lr=0.02, momentum=0.9)
 def step():
     opt.zero_grad(set_to_none=True); lf(net(*args)).backward(); opt.step()
 for _ in range(3): step()
