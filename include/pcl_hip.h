@@ -176,16 +176,24 @@ int pcl_soft_ce_f32(const float* logits, const int64_t* target, float eps, int R
  *   pcl_edgeconv_gather_f32: per point and channel max/min of y over the k neighbours and their positions (the sign of
  *     the BatchNorm scale is not known yet; pcl_group_minmax_finalize_f32 picks), plus the BatchNorm batch sums of y over
  *     all B*N*k edges as pcl_edgeconv_stat_rows(B,N) fp64 partial rows [rows][2][C] (pcl_bn_finalize_f32 consumes them).
+ *     sumU [B*N,C] (nullable): SU[i] = sum_j U[nbr(i,j)], which the backward uses.
  *   pcl_edgeconv_scatter_f32: dy = [j == arg] a*gz - k1 - k2*(y - mu) for every edge, summed into dUV (U half: over the
- *     edges pointing at a point; V half: over a point's own edges).  idx [B*N,k] int32 neighbour index within the cloud. */
+ *     edges pointing at a point; V half: over a point's own edges).  idx [B*N,k] int32 neighbour index within the cloud.
+ *     With the transposed lists of pcl_knn_transpose_i32 and sumU the sums are formed without touching the edges:
+ *     dV[i] = a gz[i] - k k1 - k2 (k (V[i]-mu) + SU[i]),  dU[n] = hits[n] - deg k1 - k2 (deg (U[n]-mu) + sum_{i->n} V[i]),
+ *     hits by one atomic per (point, channel); with in_off = in_src = sumU = NULL: one atomic per (edge, channel).
+ *   pcl_knn_transpose_i32: idx [B,N,k] -> in_off [B*N+1] (global offsets into in_src), in_src [B*N*k] (for every point the
+ *     sources i, index within the cloud, of the edges i->n, ascending).  N <= 8192. */
 int pcl_edgeconv_stat_rows(int B, int N);
 /* reference: replaces get_graph_feature + conv + max over k, networks/cls/dgcnn.py:29-50, :72-83, :100-111 */
 int pcl_edgeconv_gather_f32(const float* UV, const int32_t* idx, int B, int N, int k, int C, float* ymax, float* ymin,
-                            int32_t* jmax, int32_t* jmin, double* stats_ws, void* stream);
+                            int32_t* jmax, int32_t* jmin, double* stats_ws, float* sumU, void* stream);
 /* reference: gradient of the same composition (networks/cls/dgcnn.py:100-111) */
 int pcl_edgeconv_scatter_f32(const float* UV, const int32_t* idx, const float* gz, const int32_t* arg, const float* a,
-                             const float* k1, const float* k2, const float* mu, int B, int N, int k, int C, float* dUV,
-                             void* stream);
+                             const float* k1, const float* k2, const float* mu, int B, int N, int k, int C,
+                             const int32_t* in_off, const int32_t* in_src, const float* sumU, float* dUV, void* stream);
+/* reference: no counterpart (the transpose of the kNN graph of networks/cls/dgcnn.py:29-35, needed only by the backward) */
+int pcl_knn_transpose_i32(const int32_t* idx, int B, int N, int k, int32_t* in_off, int32_t* in_src, void* stream);
 
 /* PointConv's density-weighted contraction (misc/pointconv_utils.py:393-394, :319-320):
  *   out[g,c,m] = sum_s feat[g,s,c] * density[g,s] * weights[g,s,m]      feat [G,ns,C], density [G,ns], weights [G,ns,M],

@@ -10,8 +10,14 @@
 //   * edgeconv_gather_kernel: y = U[nbr] + V on the fly; per channel the BatchNorm batch sums (fp64 partial rows, same
 //     workspace layout as the GEMM epilogues in mlp.hip) and, per point, max/min of y over the neighbours with their
 //     positions (the sign of the BatchNorm scale is not known yet; pcl_group_minmax_finalize_f32 picks afterwards);
-//   * edgeconv_scatter_kernel: BatchNorm + max backward for every edge, dy = [j == arg] a gz - k1 - k2 (y - mean),
-//     accumulated into dU[nbr] (atomics) and dV[i].
+//   * backward of BatchNorm + max for every edge, d(i,j) = [j == arg] a gz[i] - k1 - k2 (U[nbr] + V[i] - mean), summed into
+//     dV[i] over the edges of i and into dU[n] over the edges that END in n.  Linear again, so neither sum needs the edges:
+//         dV[i] = a gz[i] - k k1 - k2 (k (V[i] - mean) + SU[i]),         SU[i] = sum_j U[nbr(i,j)]   (from the forward gather)
+//         dU[n] = hits[n] - deg(n) k1 - k2 (deg(n) (U[n] - mean) + SV[n]), SV[n] = sum_{i : n in nbr(i)} V[i]
+//     hits[n] = sum of a gz[i] over the (i, channel) pairs whose arg neighbour is n: one atomic per point and channel
+//     instead of one per edge and channel; SV walks the TRANSPOSED neighbour lists (knn_transpose_kernel: per cloud a
+//     counting sort of the N*k edges by end point, lists sorted by source so that the sum order is fixed).
+//     edgeconv_scatter_kernel (one atomic per edge and channel, 1.08 ms per DGCNN step) stays as the path without lists.
 // Summation order differs from the reference's conv (y is formed from two fp32 products instead of one), within 1e-6.
 #include "common.h"
 
@@ -23,7 +29,8 @@ constexpr int EC_PB = 32;        // points per workgroup == BatchNorm partial ro
 __global__ __launch_bounds__(256) void edgeconv_gather_kernel(const float* __restrict__ UV, const int32_t* __restrict__ idx,
                                                               int N, int k, int C, size_t P /* B*N */, float* __restrict__ ymax,
                                                               float* __restrict__ ymin, int32_t* __restrict__ jmax,
-                                                              int32_t* __restrict__ jmin, double* __restrict__ stats) {
+                                                              int32_t* __restrict__ jmin, double* __restrict__ stats,
+                                                              float* __restrict__ sumU) {
     extern __shared__ double ssum[];                 // [2][C]
     const int tid = threadIdx.x;
     for (int c = tid; c < 2 * C; c += 256) ssum[c] = 0.0;
@@ -40,6 +47,7 @@ __global__ __launch_bounds__(256) void edgeconv_gather_kernel(const float* __res
         float vmax = -INFINITY, vmin = INFINITY;
         int imax = 0, imin = 0;
         double s = 0.0, q = 0.0;
+        float su = 0.f;
         int j = 0;
         for (; j + 4 <= k; j += 4) {                 // four gathers in flight
             float u[4];
@@ -47,6 +55,7 @@ __global__ __launch_bounds__(256) void edgeconv_gather_kernel(const float* __res
             for (int t = 0; t < 4; ++t) u[t] = UV[(base + I[j + t]) * 2 * C + c];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                su += u[t];
                 const float y = u[t] + v;
                 s += (double)y; q += (double)y * (double)y;
                 if (y > vmax) { vmax = y; imax = j + t; }
@@ -54,13 +63,16 @@ __global__ __launch_bounds__(256) void edgeconv_gather_kernel(const float* __res
             }
         }
         for (; j < k; ++j) {
-            const float y = UV[(base + I[j]) * 2 * C + c] + v;
+            const float u = UV[(base + I[j]) * 2 * C + c];
+            const float y = u + v;
+            su += u;
             s += (double)y; q += (double)y * (double)y;
             if (y > vmax) { vmax = y; imax = j; }
             if (y < vmin) { vmin = y; imin = j; }
         }
         const size_t o = p * C + c;
         ymax[o] = vmax; ymin[o] = vmin; jmax[o] = imax; jmin[o] = imin;
+        if (sumU) sumU[o] = su;
         atomicAdd(&ssum[c], s); atomicAdd(&ssum[C + c], q);
     }
     __syncthreads();
@@ -113,6 +125,208 @@ __global__ __launch_bounds__(256) void edgeconv_scatter_kernel(const float* __re
     }
 }
 
+// ---- transposed neighbour lists -------------------------------------------------------------------------------------
+// idx [B,N,k] (neighbour n of point i, position j) -> for every point n of a cloud the SOURCES i of the edges ending in
+// n: in_off [B*N+1] (offsets into in_src, global), in_src [B*N*k] (source point index within the cloud), each list
+// ascending.  One workgroup per cloud: LDS histogram, LDS scan, fill through LDS cursors (list order as the atomics
+// fall); knn_lists_sort_kernel puts every list in ascending order so that sums over a list have a fixed order.
+constexpr int KT_MAXN = 8192;
+__global__ __launch_bounds__(1024) void knn_transpose_kernel(const int32_t* __restrict__ idx, int N, int k, int B,
+                                                             int32_t* __restrict__ in_off, int32_t* __restrict__ in_src) {
+    __shared__ int cnt[KT_MAXN];
+    __shared__ int part[1024];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int E = N * k;
+    const int32_t* I = idx + (size_t)b * E;
+    int32_t* S = in_src + (size_t)b * E;
+    for (int n = t; n < N; n += 1024) cnt[n] = 0;
+    __syncthreads();
+    for (int e = t; e < E; e += 1024) atomicAdd(&cnt[I[e]], 1);
+    __syncthreads();
+    // exclusive scan of cnt[0..N): per-thread chunks + scan of the chunk sums
+    const int per = (N + 1023) / 1024, lo = min(t * per, N), hi = min(lo + per, N);
+    int s = 0;
+    for (int n = lo; n < hi; ++n) s += cnt[n];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int n = lo; n < hi; ++n) {
+        const int c = cnt[n];
+        in_off[(size_t)b * N + n] = b * E + run;
+        cnt[n] = run;                                  // becomes the fill cursor
+        run += c;
+    }
+    if (b == B - 1 && t == 1023) in_off[(size_t)B * N] = B * E;
+    __syncthreads();
+    for (int e = t; e < E; e += 1024) {
+        const int pos = atomicAdd(&cnt[I[e]], 1);
+        S[pos] = e / k;
+    }
+}
+
+// Bitonic sort of 64*R ints held as v[r] of lane l = element r*64 + l (ascending).
+template <int R>
+__device__ __forceinline__ void wave_sort(int (&v)[R], int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64 * R; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int pr = r ^ (j >> 6);
+                    if (pr > r) {
+                        const bool up = (((r * 64 + lane) & k2) == 0);
+                        const int lo = min(v[r], v[pr]), hi = max(v[r], v[pr]);
+                        v[r] = up ? lo : hi;
+                        v[pr] = up ? hi : lo;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int other = __shfl_xor(v[r], j);
+                    const bool up = (((r * 64 + lane) & k2) == 0), lower = (lane & j) == 0;
+                    v[r] = (lower == up) ? min(v[r], other) : max(v[r], other);
+                }
+            }
+        }
+    }
+}
+
+// Every list ascending (the fill order above depends on the LDS atomics): one wave per list, in registers up to 256
+// entries, one lane by insertion beyond that (in-degrees of a kNN graph average k).
+__global__ __launch_bounds__(256) void knn_lists_sort_kernel(const int32_t* __restrict__ in_off, size_t P, int32_t* __restrict__ in_src) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t p = (size_t)blockIdx.x * 4 + wave;
+    if (p >= P) return;
+    const int beg = in_off[p], len = in_off[p + 1] - beg;
+    int32_t* S = in_src + beg;
+    if (len <= 1) return;
+    if (len <= 64) {
+        int v[1] = {lane < len ? S[lane] : INT_MAX};
+        wave_sort<1>(v, lane);
+        if (lane < len) S[lane] = v[0];
+    } else if (len <= 256) {
+        int v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = r * 64 + lane < len ? S[r * 64 + lane] : INT_MAX;
+        wave_sort<4>(v, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r * 64 + lane < len) S[r * 64 + lane] = v[r];
+    } else if (lane == 0) {
+        for (int a = 1; a < len; ++a) {
+            const int x = S[a];
+            int q = a - 1;
+            while (q >= 0 && S[q] > x) { S[q + 1] = S[q]; --q; }
+            S[q + 1] = x;
+        }
+    }
+}
+
+// dUV[:, :C] += a gz[i] at the arg neighbour of (i, c); the U half must be zero on entry.  The V half is written:
+//   dV[i] = a gz[i] - k k1 - k2 (k (V[i] - mean) + SU[i])
+__global__ __launch_bounds__(256) void edgeconv_hits_kernel(const float* __restrict__ UV, const int32_t* __restrict__ idx,
+                                                            const float* __restrict__ gz, const int32_t* __restrict__ arg,
+                                                            const float* __restrict__ sumU, const float* __restrict__ a_,
+                                                            const float* __restrict__ k1_, const float* __restrict__ k2_,
+                                                            const float* __restrict__ mu_, int N, int k, int C, size_t P,
+                                                            float* __restrict__ dUV) {
+    const size_t total = P * C;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t p = e / C;
+        const int c = (int)(e - p * C);
+        const size_t base = (p / N) * N;
+        const float g = a_[c] * gz[e];
+        const int n = idx[p * k + arg[e]];
+        if (g != 0.f) unsafeAtomicAdd(&dUV[(base + n) * 2 * C + c], g);
+        const float v = UV[p * 2 * C + C + c];
+        dUV[p * 2 * C + C + c] = g - (float)k * k1_[c] - k2_[c] * fmaf((float)k, v - mu_[c], sumU[e]);
+    }
+}
+
+// The same through LDS: workgroup (cloud b, chunk of CH channels) owns hits[:, c0..c0+CH) of its cloud -- LDS float
+// atomics instead of 64 scattered global ones per wave instruction (arg differs per channel, so a wave's 64 lanes end in
+// 64 different rows: 520 us per DGCNN step with global atomics), then plain coalesced stores: no memset either.
+__global__ __launch_bounds__(1024) void edgeconv_hits_lds_kernel(const float* __restrict__ UV, const int32_t* __restrict__ idx,
+                                                                const float* __restrict__ gz, const int32_t* __restrict__ arg,
+                                                                const float* __restrict__ sumU, const float* __restrict__ a_,
+                                                                const float* __restrict__ k1_, const float* __restrict__ k2_,
+                                                                const float* __restrict__ mu_, int N, int k, int C, int CH,
+                                                                float* __restrict__ dUV) {
+    extern __shared__ float hits[];                  // [N][CH]
+    const int b = blockIdx.x, c0 = blockIdx.y * CH, tid = threadIdx.x;
+    const int n_el = N * CH;
+    for (int e = tid; e < n_el; e += 1024) hits[e] = 0.f;
+    __syncthreads();
+    for (int e0 = tid; e0 < n_el; e0 += 4096) {       // four independent (point, channel) pairs in flight per lane
+        float g[4], v[4], su[4];
+        int n[4], cc[4];
+        size_t o2[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 1024;
+            const int i = min(e, n_el - 1) / CH;
+            cc[u] = min(e, n_el - 1) - i * CH;
+            const int c = c0 + cc[u];
+            ok[u] = e < n_el && c < C;
+            const size_t p = (size_t)b * N + i, o = p * C + min(c, C - 1);
+            o2[u] = p * 2 * C + C + min(c, C - 1);
+            g[u] = a_[min(c, C - 1)] * gz[o];
+            n[u] = idx[p * k + arg[o]];
+            v[u] = UV[o2[u]];
+            su[u] = sumU[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            const int c = c0 + cc[u];
+            if (g[u] != 0.f) atomicAdd(&hits[n[u] * CH + cc[u]], g[u]);
+            dUV[o2[u]] = g[u] - (float)k * k1_[c] - k2_[c] * fmaf((float)k, v[u] - mu_[c], su[u]);
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < n_el; e += 1024) {
+        const int n = e / CH, cc = e - n * CH;
+        if (c0 + cc < C) dUV[((size_t)b * N + n) * 2 * C + c0 + cc] = hits[e];
+    }
+}
+
+// dU[n] = hits[n] (already in place) - deg k1 - k2 (deg (U[n] - mean) + sum over the list of n of V[src]); one wave per
+// point, lanes over channels, four list entries in flight.
+__global__ __launch_bounds__(256) void edgeconv_insum_kernel(const float* __restrict__ UV, const int32_t* __restrict__ in_off,
+                                                             const int32_t* __restrict__ in_src, const float* __restrict__ k1_,
+                                                             const float* __restrict__ k2_, const float* __restrict__ mu_,
+                                                             int N, int C, size_t P, float* __restrict__ dUV) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t p = (size_t)blockIdx.x * 4 + wave;
+    if (p >= P) return;
+    const size_t base = (p / N) * N;
+    const int beg = in_off[p], end = in_off[p + 1];
+    const float deg = (float)(end - beg);
+    for (int c = lane; c < C; c += 64) {
+        float sv = 0.f;
+        int e = beg;
+        for (; e + 4 <= end; e += 4) {
+            float v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = UV[(base + in_src[e + t]) * 2 * C + C + c];
+            sv += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        for (; e < end; ++e) sv += UV[(base + in_src[e]) * 2 * C + C + c];
+        const size_t o = p * 2 * C + c;
+        dUV[o] = dUV[o] - deg * k1_[c] - k2_[c] * fmaf(deg, UV[o] - mu_[c], sv);
+    }
+}
+
 }  // namespace pcl
 using namespace pcl;
 
@@ -122,26 +336,60 @@ extern "C" int pcl_edgeconv_stat_rows(int B, int N) {
 }
 
 extern "C" int pcl_edgeconv_gather_f32(const float* UV, const int32_t* idx, int B, int N, int k, int C, float* ymax, float* ymin,
-                                       int32_t* jmax, int32_t* jmin, double* stats_ws, void* stream) {
+                                       int32_t* jmax, int32_t* jmin, double* stats_ws, float* sumU, void* stream) {
     PCL_REQUIRE(UV && idx && ymax && ymin && jmax && jmin && stats_ws, "pcl_edgeconv_gather_f32: null pointer");
     PCL_REQUIRE(B >= 1 && N >= 1 && k >= 1 && k <= N && C >= 1 && C <= 2048, "pcl_edgeconv_gather_f32: bad sizes B=%d N=%d k=%d C=%d", B, N, k, C);
     const size_t P = (size_t)B * N;
     const int blocks = pcl_edgeconv_stat_rows(B, N);
     hipLaunchKernelGGL(edgeconv_gather_kernel, dim3(blocks), dim3(256), sizeof(double) * 2 * C, as_stream(stream), UV, idx, N, k, C, P,
-                       ymax, ymin, jmax, jmin, stats_ws);
+                       ymax, ymin, jmax, jmin, stats_ws, sumU);
     return check_launch("pcl_edgeconv_gather_f32");
 }
 
+extern "C" int pcl_knn_transpose_i32(const int32_t* idx, int B, int N, int k, int32_t* in_off, int32_t* in_src, void* stream) {
+    PCL_REQUIRE(idx && in_off && in_src, "pcl_knn_transpose_i32: null pointer");
+    PCL_REQUIRE(B >= 1 && N >= 1 && N <= KT_MAXN && k >= 1 && (size_t)B * N * k < (size_t)1 << 31,
+                "pcl_knn_transpose_i32: bad sizes B=%d N=%d k=%d (N <= %d)", B, N, k, KT_MAXN);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(knn_transpose_kernel, dim3(B), dim3(1024), 0, st, idx, N, k, B, in_off, in_src);
+    int rc = check_launch("pcl_knn_transpose_i32");
+    if (rc) return rc;
+    const size_t P = (size_t)B * N;
+    hipLaunchKernelGGL(knn_lists_sort_kernel, dim3((int)((P + 3) / 4)), dim3(256), 0, st, in_off, P, in_src);
+    return check_launch("pcl_knn_transpose_i32(sort)");
+}
+
 extern "C" int pcl_edgeconv_scatter_f32(const float* UV, const int32_t* idx, const float* gz, const int32_t* arg, const float* a,
-                                        const float* k1, const float* k2, const float* mu, int B, int N, int k, int C, float* dUV,
-                                        void* stream) {
+                                        const float* k1, const float* k2, const float* mu, int B, int N, int k, int C,
+                                        const int32_t* in_off, const int32_t* in_src, const float* sumU, float* dUV, void* stream) {
     PCL_REQUIRE(UV && idx && gz && arg && a && k1 && k2 && mu && dUV, "pcl_edgeconv_scatter_f32: null pointer");
     PCL_REQUIRE(B >= 1 && N >= 1 && k >= 1 && k <= N && C >= 1, "pcl_edgeconv_scatter_f32: bad sizes B=%d N=%d k=%d C=%d", B, N, k, C);
+    PCL_REQUIRE((in_off == nullptr) == (in_src == nullptr) && (in_off == nullptr) == (sumU == nullptr),
+                "pcl_edgeconv_scatter_f32: in_off, in_src and sumU go together");
     const size_t P = (size_t)B * N;
     hipStream_t st = as_stream(stream);
-    hipError_t e = hipMemsetAsync(dUV, 0, sizeof(float) * P * 2 * C, st);
-    if (e != hipSuccess) return fail(PCL_EHIP, "pcl_edgeconv_scatter_f32: memset: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(edgeconv_scatter_kernel, dim3((int)((P + EC_PB - 1) / EC_PB)), dim3(256), 0, st, UV, idx, gz, arg, a, k1, k2, mu, N, k,
-                       C, P, dUV);
-    return check_launch("pcl_edgeconv_scatter_f32");
+    int CH = 16;                                      // channels per workgroup of the LDS path: N*CH floats <= 64 KiB
+    while (CH > 1 && (size_t)N * CH * sizeof(float) > 65536) CH >>= 1;
+    const bool lds = in_off && (size_t)N * CH * sizeof(float) <= 65536;
+    if (!lds) {
+        hipError_t e = hipMemsetAsync(dUV, 0, sizeof(float) * P * 2 * C, st);
+        if (e != hipSuccess) return fail(PCL_EHIP, "pcl_edgeconv_scatter_f32: memset: %s", hipGetErrorString(e));
+    }
+    if (!in_off) {
+        hipLaunchKernelGGL(edgeconv_scatter_kernel, dim3((int)((P + EC_PB - 1) / EC_PB)), dim3(256), 0, st, UV, idx, gz, arg, a, k1, k2, mu,
+                           N, k, C, P, dUV);
+        return check_launch("pcl_edgeconv_scatter_f32");
+    }
+    if (lds) {
+        hipLaunchKernelGGL(edgeconv_hits_lds_kernel, dim3(B, (C + CH - 1) / CH), dim3(1024), sizeof(float) * N * CH, st, UV, idx, gz, arg, sumU,
+                           a, k1, k2, mu, N, k, C, CH, dUV);
+    } else {
+        size_t blocks = (P * C + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(edgeconv_hits_kernel, dim3((int)blocks), dim3(256), 0, st, UV, idx, gz, arg, sumU, a, k1, k2, mu, N, k, C, P, dUV);
+    }
+    int rc = check_launch("pcl_edgeconv_scatter_f32(hits)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(edgeconv_insum_kernel, dim3((int)((P + 3) / 4)), dim3(256), 0, st, UV, in_off, in_src, k1, k2, mu, N, C, P, dUV);
+    return check_launch("pcl_edgeconv_scatter_f32(insum)");
 }

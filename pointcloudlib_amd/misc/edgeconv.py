@@ -32,8 +32,16 @@ class _EdgeConvPool(torch.autograd.Function):
         stats = torch.empty((rows, 2, C), dtype=torch.float64, device=dev)
         ymax, ymin = torch.empty((G, C), device=dev), torch.empty((G, C), device=dev)
         jmax, jmin = torch.empty((G, C), dtype=torch.int32, device=dev), torch.empty((G, C), dtype=torch.int32, device=dev)
-        _lib.call("pcl_edgeconv_gather_f32", _p(UV), _p(idx), B, N, k, C, _p(ymax), _p(ymin), _p(jmax), _p(jmin), _p(stats), st,
-                  algo_bytes=4 * G * (2 * C + k + 4 * C), tag=f"edge{C}")
+        need_grad = ctx.needs_input_grad[0]
+        sumU = torch.empty((G, C), device=dev) if need_grad else None          # SU[i] = sum_j U[nbr(i,j)] for the backward
+        _lib.call("pcl_edgeconv_gather_f32", _p(UV), _p(idx), B, N, k, C, _p(ymax), _p(ymin), _p(jmax), _p(jmin), _p(stats),
+                  _p(sumU), st, algo_bytes=4 * G * (2 * C + k + 4 * C), tag=f"edge{C}")
+        in_off = in_src = None
+        if need_grad and N <= 8192:
+            # the neighbour lists transposed (who points at me), once per graph: the backward sums over them without atomics
+            in_off = torch.empty((G + 1,), dtype=torch.int32, device=dev)
+            in_src = torch.empty((G * k,), dtype=torch.int32, device=dev)
+            _lib.call("pcl_knn_transpose_i32", _p(idx), B, N, k, _p(in_off), _p(in_src), st)
         if training:
             scale, shift, mean, invstd = (torch.empty((C,), device=dev) for _ in range(4))
             _lib.call("pcl_bn_finalize_f32", _p(stats), rows, _p(gamma), _p(beta), G * k, C, eps, momentum, _p(scale), _p(shift),
@@ -49,13 +57,13 @@ class _EdgeConvPool(torch.autograd.Function):
         _lib.call("pcl_group_minmax_finalize_f32", _p(ymax), _p(ymin), _p(jmax), _p(jmin), _p(scale), _p(shift), slope, G, C,
                   _p(out), _p(arg), _p(ysel), st)
         ctx.cfg = (slope, training, B, N, k, C)
-        ctx.save_for_backward(UV, idx, out, arg, ysel, gamma, mean, invstd, scale)
+        ctx.save_for_backward(UV, idx, out, arg, ysel, gamma, mean, invstd, scale, in_off, in_src, sumU)
         return out.view(B, N, C)
 
     @staticmethod
     def backward(ctx, gout):
         slope, training, B, N, k, C = ctx.cfg
-        UV, idx, out, arg, ysel, gamma, mean, invstd, scale = ctx.saved_tensors
+        UV, idx, out, arg, ysel, gamma, mean, invstd, scale, in_off, in_src, sumU = ctx.saved_tensors
         dev = UV.device
         G = B * N
         st = _stream()
@@ -76,8 +84,9 @@ class _EdgeConvPool(torch.autograd.Function):
             dbeta = s[0].float()
             dgamma = ((s[1] - mean.double() * s[0]) * invstd.double()).float()
         dUV = torch.empty_like(UV)
+        lists = in_off is not None
         _lib.call("pcl_edgeconv_scatter_f32", _p(UV), _p(idx), _p(gz), _p(arg), _p(a), _p(k1), _p(k2), _p(mean), B, N, k, C,
-                  _p(dUV), st)
+                  _p(in_off), _p(in_src), _p(sumU) if lists else None, _p(dUV), st)
         return dUV, None, dgamma, dbeta, None, None, None
 
 

@@ -258,6 +258,56 @@ def test_edgeconv_factorised_matches_edge_tensor(oracle, dev, B, N, C, Cout, k):
         assert torch.allclose(getattr(mlp, b).double(), getattr(ref, b), rtol=1e-5, atol=1e-6), b
 
 
+@pytest.mark.parametrize("B,N,k", [(3, 64, 5), (2, 1024, 20), (1, 300, 40), (2, 17, 17)])
+def test_knn_transpose_lists(dev, B, N, k):
+    """pcl_knn_transpose_i32: for every point the ascending list of the points that name it as a neighbour."""
+    from pointcloudlib_amd import _lib
+    rng = np.random.default_rng(B * 1000 + N + k)
+    idx_np = np.stack([np.stack([rng.permutation(N)[:k] for _ in range(N)]) for _ in range(B)]).astype(np.int32)   # distinct per row
+    idx = torch.from_numpy(idx_np).to(dev)
+    in_off = torch.empty((B * N + 1,), dtype=torch.int32, device=dev)
+    in_src = torch.empty((B * N * k,), dtype=torch.int32, device=dev)
+    _lib.call("pcl_knn_transpose_i32", idx.data_ptr(), B, N, k, in_off.data_ptr(), in_src.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    off, src = in_off.cpu().numpy(), in_src.cpu().numpy()
+    assert off[0] == 0 and off[-1] == B * N * k and (np.diff(off) >= 0).all()
+    for b in range(B):
+        for n in range(N):
+            want = np.sort(np.nonzero((idx_np[b] == n).any(axis=1))[0])
+            got = src[off[b * N + n]:off[b * N + n + 1]]
+            assert got.tolist() == want.tolist(), (b, n)
+
+
+def test_edgeconv_backward_lists_match_per_edge_atomics(oracle, dev):
+    """pcl_edgeconv_scatter_f32: the transposed-list formulation against the per-edge atomic one (same inputs)."""
+    from pointcloudlib_amd import _lib
+    B, N, C, k = 2, 256, 64, 20
+    torch.manual_seed(5)
+    UV = torch.randn(B * N, 2 * C, device=dev)
+    xn = torch.randn(B, 3, N).numpy()
+    idx = torch.from_numpy(oracle.knn(xn, xn, k).transpose(0, 2, 1).copy()).to(dev).contiguous()
+    gz = torch.randn(B * N, C, device=dev)
+    arg = torch.randint(0, k, (B * N, C), dtype=torch.int32, device=dev)
+    a, k1, k2, mu = (torch.randn(C, device=dev) * s for s in (1.0, 0.01, 0.01, 0.5))
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: t.data_ptr()
+    stats = torch.empty((_lib.lib().pcl_edgeconv_stat_rows(B, N), 2, C), dtype=torch.float64, device=dev)
+    ymax, ymin = torch.empty(B * N, C, device=dev), torch.empty(B * N, C, device=dev)
+    jmax, jmin = torch.empty(B * N, C, dtype=torch.int32, device=dev), torch.empty(B * N, C, dtype=torch.int32, device=dev)
+    sumU = torch.empty(B * N, C, device=dev)
+    _lib.call("pcl_edgeconv_gather_f32", P(UV), P(idx), B, N, k, C, P(ymax), P(ymin), P(jmax), P(jmin), P(stats), P(sumU), st)
+    nb = UV.view(B, N, 2 * C)[torch.arange(B, device=dev)[:, None, None], idx.long()][..., :C]          # [B,N,k,C]
+    assert torch.allclose(sumU.view(B, N, C), nb.sum(2), rtol=1e-5, atol=1e-5)
+    in_off = torch.empty((B * N + 1,), dtype=torch.int32, device=dev)
+    in_src = torch.empty((B * N * k,), dtype=torch.int32, device=dev)
+    _lib.call("pcl_knn_transpose_i32", P(idx), B, N, k, P(in_off), P(in_src), st)
+    d_edges, d_lists = torch.empty_like(UV), torch.empty_like(UV)
+    _lib.call("pcl_edgeconv_scatter_f32", P(UV), P(idx), P(gz), P(arg), P(a), P(k1), P(k2), P(mu), B, N, k, C, None, None, None, P(d_edges), st)
+    _lib.call("pcl_edgeconv_scatter_f32", P(UV), P(idx), P(gz), P(arg), P(a), P(k1), P(k2), P(mu), B, N, k, C, P(in_off), P(in_src),
+              P(sumU), P(d_lists), st)
+    scale = d_edges.abs().max().item()
+    assert (d_edges - d_lists).abs().max().item() <= 2e-5 * max(1.0, scale)
+
+
 def test_graphed_step_matches_eager_step(dev):
     """graph_step.GraphedStep (main stream captured as a HIP graph, sampling of the next batch eager on a side stream)
     trains like the plain eager loop: same losses for the first steps (later ones drift through fp32 atomics)."""
