@@ -962,21 +962,38 @@ __global__ __launch_bounds__(256) void group_minmax_finalize_kernel(const float*
 }
 
 // gz[g,c] = gout[g,c] * act'(out[g,c]); per-workgroup partial sums of gz and gz*ymax -> stats rows.
-__global__ __launch_bounds__(256) void maxgrad_prep_kernel(const float* __restrict__ gout, const float* __restrict__ out,
-                                                           const float* __restrict__ ymax, float slope, int G, int C,
-                                                           float* __restrict__ gz, double* __restrict__ stats) {
-    // grid.x = channel blocks of 256, grid.y = row slices (<= STAT_ROWS)
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int g = blockIdx.y; g < G; g += gridDim.y) {
-        const size_t e = (size_t)g * C + c;
-        const float v = gout[e] * (out[e] > 0.f ? 1.f : slope);
-        gz[e] = v;
-        s1 += v; s2 += (double)v * ymax[e];
+// Thread layout of the two elementwise backward kernels below: CW = min(256, next power of two >= C) lanes over the
+// channels, 256/CW rows per pass, so that narrow layers (WeightNet: 8 and 16 channels) still use every lane and a wave
+// touches contiguous memory; the row-lanes of a block are folded through LDS into its one partial row.
+__device__ __forceinline__ void fold_row_lanes(double s1, double s2, int c, int rsub, int RS, int CW, int C, double* red,
+                                               double* __restrict__ dst) {
+    if (RS > 1) {
+        red[(size_t)rsub * CW + (threadIdx.x % CW)] = s1;
+        red[(size_t)(RS + rsub) * CW + (threadIdx.x % CW)] = s2;
+        __syncthreads();
+        if (rsub == 0) {
+            for (int j = 1; j < RS; ++j) { s1 += red[(size_t)j * CW + threadIdx.x]; s2 += red[(size_t)(RS + j) * CW + threadIdx.x]; }
+        }
     }
-    stats[(size_t)blockIdx.y * 2 * C + c] = s1;
-    stats[(size_t)blockIdx.y * 2 * C + C + c] = s2;
+    if (rsub == 0 && c < C) { dst[c] = s1; dst[C + c] = s2; }
+}
+
+__global__ __launch_bounds__(256) void maxgrad_prep_kernel(const float* __restrict__ gout, const float* __restrict__ out,
+                                                           const float* __restrict__ ymax, float slope, int G, int C, int CW,
+                                                           float* __restrict__ gz, double* __restrict__ stats) {
+    // grid.x = channel blocks of CW, grid.y = row slices (<= STAT_ROWS)
+    __shared__ double red[2 * 256];
+    const int RS = 256 / CW, rsub = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + threadIdx.x % CW;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int g = blockIdx.y * RS + rsub; g < G; g += gridDim.y * RS) {
+            const size_t e = (size_t)g * C + c;
+            const float v = gout[e] * (out[e] > 0.f ? 1.f : slope);
+            gz[e] = v;
+            s1 += v; s2 += (double)v * ymax[e];
+        }
+    fold_row_lanes(s1, s2, c, rsub, RS, CW, C, red, stats + (size_t)blockIdx.y * 2 * C);
 }
 
 // z = lrelu(scale*y+shift) on [P,C] (used where the activation itself is a module output)
@@ -992,21 +1009,23 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ Y
 // du = gz * act'(scale*y+shift) on [P,C] with per-workgroup partials of sum(du), sum(du*y)
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict__ gz, const float* __restrict__ Y,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         float slope, int P, int C, float* __restrict__ du,
+                                                         float slope, int P, int C, int CW, float* __restrict__ du,
                                                          double* __restrict__ stats) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const float a = scale[c], b = shift[c];
+    __shared__ double red[2 * 256];
+    const int RS = 256 / CW, rsub = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + threadIdx.x % CW;
     double s1 = 0.0, s2 = 0.0;
-    for (int r = blockIdx.y; r < P; r += gridDim.y) {
-        const size_t e = (size_t)r * C + c;
-        const float y = Y[e];
-        const float v = gz[e] * (fmaf(a, y, b) > 0.f ? 1.f : slope);
-        du[e] = v;
-        s1 += v; s2 += (double)v * y;
+    if (c < C) {
+        const float a = scale[c], b = shift[c];
+        for (int r = blockIdx.y * RS + rsub; r < P; r += gridDim.y * RS) {
+            const size_t e = (size_t)r * C + c;
+            const float y = Y[e];
+            const float v = gz[e] * (fmaf(a, y, b) > 0.f ? 1.f : slope);
+            du[e] = v;
+            s1 += v; s2 += (double)v * y;
+        }
     }
-    stats[(size_t)blockIdx.y * 2 * C + c] = s1;
-    stats[(size_t)blockIdx.y * 2 * C + C + c] = s2;
+    fold_row_lanes(s1, s2, c, rsub, RS, CW, C, red, stats + (size_t)blockIdx.y * 2 * C);
 }
 
 static void linear_grid(int M, int N, bool bwd, bool rag, int& gx, int& n_tiles, bool& narrow, bool& low) {
@@ -1266,10 +1285,13 @@ extern "C" int pcl_maxgrad_prep_f32(const float* gout, const float* out, const f
                                     float* gz, double* stats_ws, int* stat_rows_out, void* stream) {
     PCL_REQUIRE(gout && out && ymax && gz && stats_ws && stat_rows_out, "pcl_maxgrad_prep_f32: null pointer");
     PCL_REQUIRE(G >= 1 && C >= 1, "pcl_maxgrad_prep_f32: bad sizes");
-    int rows = G < 512 ? G : 512;
+    int CW = 256;
+    while (CW / 2 >= C && CW > 1) CW >>= 1;            // lanes over channels: next power of two >= C, at most 256
+    const int RS = 256 / CW;
+    int rows = (G + RS - 1) / RS < 512 ? (G + RS - 1) / RS : 512;
     *stat_rows_out = rows;
-    hipLaunchKernelGGL(maxgrad_prep_kernel, dim3((C + 255) / 256, rows), dim3(256), 0, as_stream(stream), gout, out, ymax,
-                       slope, G, C, gz, stats_ws);
+    hipLaunchKernelGGL(maxgrad_prep_kernel, dim3((C + CW - 1) / CW, rows), dim3(256), 0, as_stream(stream), gout, out, ymax,
+                       slope, G, C, CW, gz, stats_ws);
     return check_launch("pcl_maxgrad_prep_f32");
 }
 
@@ -1286,9 +1308,12 @@ extern "C" int pcl_bn_act_f32(const float* Y, const float* scale, const float* s
 extern "C" int pcl_bn_act_bwd_f32(const float* gz, const float* Y, const float* scale, const float* shift, float slope,
                                   int P, int C, float* du, double* stats_ws, int* stat_rows_out, void* stream) {
     PCL_REQUIRE(gz && Y && scale && shift && du && stats_ws && stat_rows_out && P >= 1 && C >= 1, "pcl_bn_act_bwd_f32: bad arguments");
-    int rows = P < STAT_ROWS ? P : STAT_ROWS;
+    int CW = 256;
+    while (CW / 2 >= C && CW > 1) CW >>= 1;
+    const int RS = 256 / CW;
+    int rows = (P + RS - 1) / RS < STAT_ROWS ? (P + RS - 1) / RS : STAT_ROWS;
     *stat_rows_out = rows;
-    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3((C + 255) / 256, rows), dim3(256), 0, as_stream(stream), gz, Y, scale, shift,
-                       slope, P, C, du, stats_ws);
+    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3((C + CW - 1) / CW, rows), dim3(256), 0, as_stream(stream), gz, Y, scale, shift,
+                       slope, P, C, CW, du, stats_ws);
     return check_launch("pcl_bn_act_bwd_f32");
 }
