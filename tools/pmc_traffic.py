@@ -25,7 +25,7 @@ def family_series(path, counter):
         if r["Counter_Name"] != counter:
             continue
         for fam in FAMILY:
-            if fam in r["Kernel_Name"]:
+            if f"pcl::{fam}<" in r["Kernel_Name"]:          # not group_linear_dw_kernel & co.
                 out[fam].append(float(r["Counter_Value"]))
     return out
 
