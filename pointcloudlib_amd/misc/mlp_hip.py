@@ -139,7 +139,8 @@ class _FusedMLP(torch.autograd.Function):
                           _P(in_shift), out_slope, G, cin, _P(out), _P(arg), _P(ymax), st)
             elif rowset is not None:
                 _lib.call("pcl_bn_act_max_rows_f32", _P(cur), _P(rowset.group_off), _P(in_scale), _P(in_shift), out_slope, G,
-                          cin, _P(out), _P(arg), _P(ymax), st)
+                          cin, _P(out), _P(arg), _P(ymax), st, algo_bytes=_rows_cost(nrows, P, 4 * cin, 12 * G * cin),
+                          tag=f"maxrows{cin}")
             else:
                 _lib.call("pcl_bn_act_max_f32", _P(cur), _P(in_scale), _P(in_shift), out_slope, G, ns, cin, _P(out), _P(arg),
                           _P(ymax), st, algo_bytes=4 * P * cin + 12 * G * cin, tag=f"max{cin}")
@@ -353,7 +354,9 @@ class _GroupLinear(torch.autograd.Function):
         row_feat = _empty((cap, 4), dev) if inline else None
         _lib.call("pcl_group_linear_f32", _P(xyz), _P(new_xyz), _P(Uf), _P(Wx), _P(feat2) if inline else None,
                   _P(Wf) if inline else None, C if inline else 0, W0.shape[1], _P(idx), _P(cnt), _P(group_off), B, N, m, ns, C1, _P(Y),
-                  _P(row_meta), _P(row_src), _P(row_loc), _P(row_feat), _P(stats), st)
+                  _P(row_meta), _P(row_src), _P(row_loc), _P(row_feat), _P(stats), st,
+                  # per distinct row: Y written, Uf row gathered (L2), 16-byte records; idx read once
+                  algo_bytes=_rows_cost(group_off[B * m:], cap, 4 * C1 * (2 if Uf is not None else 1) + 36, 4 * cap), tag=f"glin{C1}")
         link.stats, link.rows = stats, rows
         ctx.link = link
         ctx.dims = (B, N, m, ns, C1, C, off, inline, rows)
@@ -384,7 +387,8 @@ class _GroupLinear(torch.autograd.Function):
             fin = dW0 is not None and (dWxp is not None or dWfp is not None)       # partial sums -> dW0 columns, in the same call
             _lib.call("pcl_group_linear_bwd_f32", _P(row_loc), _P(row_feat), C if inline else 0, _P(du.contiguous()), _P(Y),
                       _P(a), _P(k1), _P(k2), _P(mu), _P(row_src), _P(group_off[B * m:]), B, N, C1, _P(dUf), _P(dWxp), _P(dWfp),
-                      _P(dW0) if fin else None, fan_in, off, st)
+                      _P(dW0) if fin else None, fan_in, off, st,
+                      algo_bytes=_rows_cost(group_off[B * m:], B * m * ns, 4 * C1 * (3 if wide else 2) + 36, 0), tag=f"glinbwd{C1}")
         dfeat = None
         if wide:
             # plain GEMMs through the BatchNorm-backward entry points with a = 1, k1 = k2 = 0 (dy == dUf)
