@@ -33,6 +33,8 @@ CASES = [
     ([6, 64], (2, 40, 20), 20, False, 0.2),                 # DGCNN edge conv: LeakyReLU(0.2), max over k
     ([64, 40, 24], (3, 70), None, True, 0.0),               # FP-style: bias + BN + ReLU, no max, N < 128
     ([12, 8, 8, 16], (2, 33, 8), None, True, 0.0),          # WeightNet-sized
+    ([10, 300], (2, 7, 8), 8, False, 0.0),                  # > 256 channels with a max: two channel blocks in the backward prep
+    ([7, 5, 3], (4, 50), None, True, 0.2),                  # 3 output channels: 4 channel-lanes x 64 row-lanes per block
 ]
 
 
