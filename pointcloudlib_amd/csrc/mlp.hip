@@ -65,7 +65,26 @@ struct LinArgs {
     int n_begin;         // first output column computed (columns below it are never written): input-gradient
                          // GEMMs skip the xyz columns of a grouped tensor, which have no consumer
     int a_mode, e_mode;
+    int gx, nt;          // logical grid: gx persistent row-workgroups x nt column tiles (see tile_of_block)
 };
+
+// XCD-aware block -> (row-workgroup, column tile).  The hardware hands consecutive workgroup ids to the 8 XCDs round
+// robin, each XCD has its own L2.  With a 2-D grid the nt column tiles of a row tile are gx ids apart: they land on the
+// same XCD only by accident and run a whole grid pass apart, so the shared A rows come from HBM / Infinity Cache nt
+// times (PMC: 571 MB for 361 MB algorithmic on dx 256->128).  Here ids 8 apart share the row-workgroup index: same XCD,
+// dispatched back to back, resident together -- the second tile's A rows are L2 hits.
+__device__ __forceinline__ void tile_of_block(int id, int gx, int nt, int& bx, int& by) {
+    const int full = gx & ~7;                       // row-workgroups in complete groups of 8
+    if (id < full * nt) {
+        const int j = id >> 3;
+        by = j % nt;
+        bx = (j / nt) * 8 + (id & 7);
+    } else {
+        const int r = id - full * nt, rem = gx - full;
+        bx = full + r % rem;
+        by = r / rem;
+    }
+}
 
 // Duplicate-compacted ("ragged") rows: ball query pads a group with copies of its first hit (misc/ops.py:321-324);
 // identical input rows give identical activations, so the stack runs once per DISTINCT row and carries the
@@ -329,7 +348,9 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
     int wmeta = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int n0 = p.n_begin + blockIdx.y * TBN;
+    int bx, by;
+    tile_of_block(blockIdx.x, p.gx, p.nt, bx, by);
+    const int n0 = p.n_begin + by * TBN;
     const int m_tiles = (p.M + TBM - 1) / TBM;
     const int lr = lane & 31, lh = lane >> 5;
     // rows of C (and Yprev) can be moved as 16-byte pieces
@@ -350,14 +371,14 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
 
     Stage<VEC, TBM> ra;
     Stage<VEC, TBN> rb;
-    int mt = blockIdx.x;
+    int mt = bx;
     int staged_k0 = 0;
     if (mt < m_tiles) {
         load_a<AM, VEC, TBM, RAG>(p, mt * TBM, 0, tid, ra);
         load_b<VEC, TBN, BT>(p, n0, 0, tid, rb);
         if constexpr (NEEDW) wmeta = p.rmeta[min(mt * TBM + (tid & (TBM - 1)), p.M - 1)].y;
     }
-    for (; mt < m_tiles; mt += gridDim.x) {
+    for (; mt < m_tiles; mt += p.gx) {
         const int m0 = mt * TBM;
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -376,7 +397,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
             // request the next step's operands (next k block, or the first k block of this workgroup's next tile)
             {
                 int nk = k0 + BK, nmt = mt;
-                if (nk >= p.K) { nk = 0; nmt = mt + gridDim.x; }
+                if (nk >= p.K) { nk = 0; nmt = mt + p.gx; }
                 staged_k0 = nk;
                 if (nmt < m_tiles) {
                     load_a<AM, VEC, TBM, RAG>(p, nmt * TBM, nk, tid, ra);
@@ -562,7 +583,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                     const int wv = w * 2 + wcc;
                     s += red[((wv * TN + tn) * 32 + l) * 2 + 0]; q += red[((wv * TN + tn) * 32 + l) * 2 + 1];
                 }
-                double* dst = p.stats + (size_t)blockIdx.x * 2 * p.N;
+                double* dst = p.stats + (size_t)bx * 2 * p.N;
                 dst[col] = s; dst[p.N + col] = q;
             }
         }
@@ -581,6 +602,7 @@ struct DwArgs {
     const int2* rmeta;                          // optional per-row meta of compacted rows (see row_meta)
     int P, I, J;
     int a_mode, b_mode;                         // a: A_DY / A_DY_SPARSE ; b: A_PLAIN / A_BNACT
+    int gx, ti, tj;                             // logical grid: gx row-chunk workgroups x (ti x tj) output tiles
 };
 
 constexpr int DW_BP = 32;
@@ -731,7 +753,11 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p_in) 
     __shared__ __attribute__((aligned(16))) float sB[DW_BP * (WJ + 4)];   // [p][j]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, lh = lane >> 5;
-    const int i0 = blockIdx.y * WI, j0 = blockIdx.z * WJ;
+    // same XCD-aware decode as the forward / dX kernel: the ti*tj tiles fed by the same rows sit 8 ids apart (one XCD,
+    // dispatched together), so the operand columns they share (all of X for tiles along i) are L2 hits
+    int bx, bt;
+    tile_of_block(blockIdx.x, p.gx, p.ti * p.tj, bx, bt);
+    const int i0 = (bt % p.ti) * WI, j0 = (bt / p.ti) * WJ;
     const int chunks = (p.P + DW_BP - 1) / DW_BP;
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -760,14 +786,14 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p_in) 
 
     DwStage<VEC, WI> ra;
     DwStage<VEC, WJ> rb;
-    int ch = blockIdx.x;
+    int ch = bx;
     if (ch < chunks) { dw_load_a<AM, VEC, WI, RAG>(p, ch * DW_BP, i0, tid, ra); dw_load_b<VEC, WJ>(p, ch * DW_BP, j0, tid, rb); }
-    for (; ch < chunks; ch += gridDim.x) {
+    for (; ch < chunks; ch += p.gx) {
         __syncthreads();
         dw_store_a<AM, VEC, WI>(p, sA, i0, tid, ra, asc, ash, ak2, amu);
         dw_store_b<VEC, WJ>(p, sB, j0, tid, rb, bsc, bsh);
         __syncthreads();
-        const int nch = ch + gridDim.x;
+        const int nch = ch + p.gx;
         if (nch < chunks) { dw_load_a<AM, VEC, WI, RAG>(p, nch * DW_BP, i0, tid, ra); dw_load_b<VEC, WJ>(p, nch * DW_BP, j0, tid, rb); }
 #pragma unroll 4
         for (int ks = 0; ks < DW_BP / 2; ++ks) {
@@ -784,7 +810,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p_in) 
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
         }
     }
-    float* out = p.part + (size_t)blockIdx.x * p.I * p.J;
+    float* out = p.part + (size_t)bx * p.I * p.J;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -1045,13 +1071,15 @@ static void linear_grid(int M, int N, bool bwd, bool rag, int& gx, int& n_tiles,
 }
 
 template <int AM, int EM, int GM = 0, bool RAG = false>
-static int launch_linear_t(const LinArgs& a, hipStream_t st) {
+static int launch_linear_t(const LinArgs& a_in, hipStream_t st) {
+    LinArgs a = a_in;
     const bool vec = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0) && (!a.A2 || (reinterpret_cast<uintptr_t>(a.A2) & 15) == 0) &&
                      (AM < A_DY || a.ldb % 4 == 0);
     int gx, n_tiles; bool narrow, low;
     linear_grid(a.M, a.N - a.n_begin, AM >= A_DY, RAG, gx, n_tiles, narrow, low);
-    dim3 grid(gx, n_tiles);
+    a.gx = gx; a.nt = n_tiles;
+    dim3 grid(gx * n_tiles);
     if constexpr (!RAG && GM == 0) {
         if (low) {
             if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, 0, false, 1>), grid, dim3(MLP_T), 0, st, a);
@@ -1238,7 +1266,8 @@ extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const
     d.a_mode = dU ? A_DY : A_DY_SPARSE; d.b_mode = prev_scale ? A_BNACT : A_PLAIN;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const bool vec = (Cout % 4 == 0) && (Cin % 4 == 0) && al16(Y) && al16(Xprev) && (!dU || al16(dU)) && (!gz || (al16(gz) && al16(arg)));
-    dim3 grid(gx, ti, tj);
+    d.gx = gx; d.ti = ti; d.tj = tj;
+    dim3 grid(gx * ti * tj);
     if (dU) { if (vec) launch_dw_t<A_DY, true>(d, grid, tm, tn, st); else launch_dw_t<A_DY, false>(d, grid, tm, tn, st); }
     else { if (vec) launch_dw_t<A_DY_SPARSE, true>(d, grid, tm, tn, st); else launch_dw_t<A_DY_SPARSE, false>(d, grid, tm, tn, st); }
     int rc = check_launch("pcl_linear_bwd_dw_f32");
