@@ -581,7 +581,8 @@ extern "C" int pcl_scatter_rows_add_f32(const float* grows, const int32_t* row_s
     return check_launch("pcl_scatter_rows_add_f32");
 }
 
-constexpr int GL_BLOCKS = 2048;      // 8 workgroups of 4 waves per CU; also the number of BatchNorm / dWx partial rows
+constexpr int GL_BLOCKS = 1024;     // 4 workgroups of 4 waves per CU = one resident round at 4 waves/SIMD; also the number of
+                                     // BatchNorm / dWx partial rows (2048: step +10 us, 512: same step, forward of the 128-wide level slower)
 
 extern "C" int pcl_group_linear_stat_rows(int B, int m) { return (B < 1 || m < 1) ? 0 : GL_BLOCKS; }
 
