@@ -53,6 +53,47 @@ __device__ __forceinline__ void head_col_dot(const float* __restrict__ X, const 
     }
 }
 
+// Column epilogue of a forward layer, executed by one full wave: lane r holds y[r,n] (pre-bias).  bn_mode: 0 none, 1 batch
+// statistics (training), 2 running statistics (eval); +4: running_var receives the BIASED batch variance (the
+// BatchNorm of the set-abstraction stacks, pcl_bn_finalize_f32) instead of torch's unbiased one.
+__device__ __forceinline__ void head_epilogue(float y, int lane, int n, const float* __restrict__ bias, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                              int R, int N, int bn_mode_full, float eps, float momentum, float slope,
+                                              float* __restrict__ Ypre, float* __restrict__ OUT, float* __restrict__ mean_out,
+                                              float* __restrict__ invstd_out) {
+    const int bn_mode = bn_mode_full & 3;
+    const bool biased = (bn_mode_full & 4) != 0;
+    const bool in = lane < R;
+    y = in ? y + (bias ? bias[n] : 0.f) : 0.f;
+    float out = y;
+    if (bn_mode != 0) {
+        float mean, invstd;
+        if (bn_mode == 1) {
+            float s = y, q = 0.f;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+            mean = s / (float)R;
+            const float d = in ? y - mean : 0.f;
+            q = d * d;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+            const float var = q / (float)R;
+            invstd = 1.0f / sqrtf(var + eps);
+            if (lane == 0) {
+                if (rmean) rmean[n] += (mean - rmean[n]) * momentum;
+                if (rvar) rvar[n] += (((R > 1 && !biased) ? q / (float)(R - 1) : var) - rvar[n]) * momentum;
+            }
+        } else {
+            mean = rmean[n];
+            invstd = 1.0f / sqrtf(rvar[n] + eps);
+        }
+        if (lane == 0) { mean_out[n] = mean; invstd_out[n] = invstd; }
+        out = fmaf((y - mean) * invstd, gamma ? gamma[n] : 1.f, beta ? beta[n] : 0.f);
+    }
+    out = out > 0.f ? out : out * slope;
+    if (in) { Ypre[(size_t)lane * N + n] = y; OUT[(size_t)lane * N + n] = out; }
+}
+
 // Y_pre [R,N] (pre-BatchNorm, kept for backward), OUT [R,N] = act(BN(Y_pre)); mean/invstd [N] saved.
 template <int RMAX>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
@@ -77,37 +118,70 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     }
     __syncthreads();
     if (wave != 0) return;
-    const bool in = lane < R;
     float y = 0.f;
     if (lane < RMAX) y = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    y = in ? y + (bias ? bias[n] : 0.f) : 0.f;
-    float out = y;
-    if (bn_mode != 0) {
-        float mean, invstd;
-        if (bn_mode == 1) {
-            float s = y, q = 0.f;
+    head_epilogue(y, lane, n, bias, gamma, beta, rmean, rvar, R, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out);
+}
+
+// Wide layers (K >= 4096: PointConv's per-point Linear on the GroupAll level is 32 x 16384 -> 1024): with one column per
+// workgroup every column re-reads all of X from L2 (2 MB x 1024 columns).  Here a workgroup takes 8 columns (two per
+// wave) and stages X 256 k at a time through LDS, so X crosses L2 once per 8 columns and W streams once.  R <= 32.
+constexpr int HW_CB = 8, HW_KC = 256;
+__global__ __launch_bounds__(256) void head_fwd_wide_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ rmean,
+                                                            float* __restrict__ rvar, int R, int K, int N, int bn_mode, float eps,
+                                                            float momentum, float slope, float* __restrict__ Ypre,
+                                                            float* __restrict__ OUT, float* __restrict__ mean_out,
+                                                            float* __restrict__ invstd_out) {
+    constexpr int RMAX = 32;
+    __shared__ __attribute__((aligned(16))) float sX[RMAX][HW_KC + 4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n0 = blockIdx.x * HW_CB + wave * 2;
+    const int na = min(n0, N - 1), nb = min(n0 + 1, N - 1);
+    float acc0[RMAX], acc1[RMAX];
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-            mean = s / (float)R;
-            const float d = in ? y - mean : 0.f;
-            q = d * d;
+    for (int r = 0; r < RMAX; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const int xr = tid >> 6, xk = (tid & 63) * 4;             // staging: 4 rows per pass, 64 lanes x 16 B per row
+    float4 px[RMAX / 4];
+    auto load_x = [&](int k0) {
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
-            const float var = q / (float)R;
-            invstd = 1.0f / sqrtf(var + eps);
-            if (lane == 0) {
-                if (rmean) rmean[n] += (mean - rmean[n]) * momentum;
-                if (rvar) rvar[n] += ((R > 1 ? q / (float)(R - 1) : var) - rvar[n]) * momentum;
-            }
-        } else {
-            mean = rmean[n];
-            invstd = 1.0f / sqrtf(rvar[n] + eps);
+        for (int i = 0; i < RMAX / 4; ++i) {
+            const int r = i * 4 + xr;
+            const float4 v = *reinterpret_cast<const float4*>(X + (size_t)min(r, R - 1) * K + min(k0 + xk, K - 4));
+            px[i] = (r < R && k0 + xk < K) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (lane == 0) { mean_out[n] = mean; invstd_out[n] = invstd; }
-        out = fmaf((y - mean) * invstd, gamma ? gamma[n] : 1.f, beta ? beta[n] : 0.f);
+    };
+    load_x(0);
+    for (int k0 = 0; k0 < K; k0 += HW_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RMAX / 4; ++i) *reinterpret_cast<float4*>(&sX[i * 4 + xr][xk]) = px[i];
+        const int k = k0 + 4 * lane;
+        const bool kin = k < K;                                // K % 4 == 0 (checked by the caller)
+        const float4 wa = *reinterpret_cast<const float4*>(W + (size_t)na * K + min(k, K - 4));
+        const float4 wb = *reinterpret_cast<const float4*>(W + (size_t)nb * K + min(k, K - 4));
+        if (k0 + HW_KC < K) load_x(k0 + HW_KC);
+        __syncthreads();
+        if (kin) {
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) {
+                const float4 x = *reinterpret_cast<const float4*>(&sX[r][4 * lane]);
+                acc0[r] = fmaf(wa.w, x.w, fmaf(wa.z, x.z, fmaf(wa.y, x.y, fmaf(wa.x, x.x, acc0[r]))));
+                acc1[r] = fmaf(wb.w, x.w, fmaf(wb.z, x.z, fmaf(wb.y, x.y, fmaf(wb.x, x.x, acc1[r]))));
+            }
+        }
     }
-    out = out > 0.f ? out : out * slope;
-    if (in) { Ypre[(size_t)lane * N + n] = y; OUT[(size_t)lane * N + n] = out; }
+    float ya = 0.f, yb = 0.f;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        float u = acc0[r], v = acc1[r];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { u += __shfl_xor(u, off); v += __shfl_xor(v, off); }
+        if (lane == r) { ya = u; yb = v; }
+    }
+    if (n0 < N) head_epilogue(ya, lane, n0, bias, gamma, beta, rmean, rvar, R, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out);
+    if (n0 + 1 < N) head_epilogue(yb, lane, n0 + 1, bias, gamma, beta, rmean, rvar, R, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out);
 }
 
 // backward, column part: dy[:,n], dW[n,:], dbias[n], dgamma[n], dbeta[n].  One workgroup per column; every wave forms
@@ -172,6 +246,95 @@ __global__ __launch_bounds__(256) void head_bwd_col_kernel(const float* __restri
     }
 }
 
+// Wide layers, backward column part (see head_fwd_wide_kernel): 8 columns per workgroup, two per wave; every wave forms
+// the dy of its two columns (lane r), the eight dy columns meet in LDS, then X is staged 256 k at a time and
+// dW[n, k..k+3] = sum_r dy[r,n] X[r, k..k+3] for the wave's two columns is written as 16-byte pieces.  R <= 32.
+__device__ __forceinline__ float head_col_dy(int lane, int n, const float* __restrict__ dOUT, const float* __restrict__ OUT,
+                                             const float* __restrict__ Ypre, const float* __restrict__ gamma,
+                                             const float* __restrict__ mean, const float* __restrict__ invstd, int R, int N,
+                                             int bn_mode, float slope, float* __restrict__ dY, float* __restrict__ dbias,
+                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const bool in = lane < R;
+    const size_t o = (size_t)min(lane, R - 1) * N + n;
+    float du = in ? dOUT[o] : 0.f;
+    du = OUT[o] > 0.f ? du : du * slope;
+    float dy = du;
+    if (bn_mode != 0) {
+        const float g = gamma ? gamma[n] : 1.f, mu = mean[n], is = invstd[n];
+        const float xh = in ? (Ypre[o] - mu) * is : 0.f;
+        float s1 = du, s2 = du * xh;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+        if (lane == 0) { if (dgamma) dgamma[n] = s2; if (dbeta) dbeta[n] = s1; }
+        dy = bn_mode == 1 ? g * is * (du - s1 / (float)R - xh * s2 / (float)R) : g * is * du;
+        if (!in) dy = 0.f;
+    }
+    if (in) dY[o] = dy;
+    if (dbias) {
+        float sb = dy;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sb += __shfl_xor(sb, off);
+        if (lane == 0) dbias[n] = sb;
+    }
+    return dy;
+}
+
+__global__ __launch_bounds__(256) void head_bwd_col_wide_kernel(const float* __restrict__ X, const float* __restrict__ dOUT,
+                                                                const float* __restrict__ OUT, const float* __restrict__ Ypre,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, int R, int K, int N, int bn_mode,
+                                                                float slope, float* __restrict__ dY, float* __restrict__ dW,
+                                                                float* __restrict__ dbias, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, float* __restrict__ dX_zero) {
+    constexpr int RMAX = 32;
+    __shared__ __attribute__((aligned(16))) float sX[RMAX][HW_KC + 4];
+    __shared__ float sdy[HW_CB][RMAX];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nblk = (int)gridDim.x;
+    if (dX_zero) {
+        const int total = R * K, chunk = (total + nblk - 1) / nblk;
+        for (int e = blockIdx.x * chunk + tid; e < min(((int)blockIdx.x + 1) * chunk, total); e += 256) dX_zero[e] = 0.f;
+    }
+    const int n0 = blockIdx.x * HW_CB + wave * 2;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        float dy = 0.f;
+        if (n0 + c < N) dy = head_col_dy(lane, n0 + c, dOUT, OUT, Ypre, gamma, mean, invstd, R, N, bn_mode & 3, slope, dY, dbias, dgamma, dbeta);
+        if (lane < RMAX) sdy[wave * 2 + c][lane] = dy;
+    }
+    const int xr = tid >> 6, xk = (tid & 63) * 4;
+    float4 px[RMAX / 4];
+    auto load_x = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < RMAX / 4; ++i) {
+            const int r = i * 4 + xr;
+            const float4 v = *reinterpret_cast<const float4*>(X + (size_t)min(r, R - 1) * K + min(k0 + xk, K - 4));
+            px[i] = (r < R && k0 + xk < K) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load_x(0);
+    for (int k0 = 0; k0 < K; k0 += HW_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RMAX / 4; ++i) *reinterpret_cast<float4*>(&sX[i * 4 + xr][xk]) = px[i];
+        if (k0 + HW_KC < K) load_x(k0 + HW_KC);
+        __syncthreads();
+        const int k = k0 + 4 * lane;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const float4 x = *reinterpret_cast<const float4*>(&sX[r][4 * lane]);
+            const float d0 = sdy[wave * 2][r], d1 = sdy[wave * 2 + 1][r];
+            a0.x = fmaf(d0, x.x, a0.x); a0.y = fmaf(d0, x.y, a0.y); a0.z = fmaf(d0, x.z, a0.z); a0.w = fmaf(d0, x.w, a0.w);
+            a1.x = fmaf(d1, x.x, a1.x); a1.y = fmaf(d1, x.y, a1.y); a1.z = fmaf(d1, x.z, a1.z); a1.w = fmaf(d1, x.w, a1.w);
+        }
+        if (k < K) {
+            if (n0 < N) *reinterpret_cast<float4*>(dW + (size_t)n0 * K + k) = a0;
+            if (n0 + 1 < N) *reinterpret_cast<float4*>(dW + (size_t)(n0 + 1) * K + k) = a1;
+        }
+    }
+}
+
 // dX[r,k] += sum_{n in this wave's range} dy[r,n] * W[n,k]; grid (ceil(K/64), N splits of HD_NS)
 constexpr int HD_NS = 8;
 template <int RMAX>
@@ -203,6 +366,49 @@ __global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restric
     }
 }
 
+// Wide layers, dX: workgroup = 64 consecutive k, its four waves split the N columns in quarters (no further split, so
+// 4 atomics per output instead of N/8); a wave stages 64 columns of dy at a time in its own LDS slab ([n][r], rows
+// contiguous: eight broadcast 16-byte reads give the 32 row gradients of a column) and streams W[n, k] coalesced.  R <= 32.
+__global__ __launch_bounds__(256) void head_bwd_dx_wide_kernel(const float* __restrict__ dY, const float* __restrict__ W, int R, int K,
+                                                               int N, float* __restrict__ dX) {
+    constexpr int RMAX = 32, LD = 36;
+    __shared__ __attribute__((aligned(16))) float sD[4][64][LD];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 64 + lane, kc = min(k, K - 1);
+    const int per = (N + 3) / 4, nlo = wave * per, nhi = min(N, nlo + per);
+    float acc[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) acc[r] = 0.f;
+    for (int n0 = nlo; n0 < nhi; n0 += 64) {
+        const int cn = min(64, nhi - n0);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) sD[wave][lane][r] = (r < R && lane < cn) ? dY[(size_t)r * N + n0 + lane] : 0.f;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+        for (int j = 0; j < cn; ++j) {
+            const float w = W[(size_t)(n0 + j) * K + kc];
+            const float4* q = reinterpret_cast<const float4*>(&sD[wave][j][0]);
+#pragma unroll
+            for (int i = 0; i < RMAX / 4; ++i) {
+                const float4 d = q[i];
+                acc[4 * i] = fmaf(d.x, w, acc[4 * i]); acc[4 * i + 1] = fmaf(d.y, w, acc[4 * i + 1]);
+                acc[4 * i + 2] = fmaf(d.z, w, acc[4 * i + 2]); acc[4 * i + 3] = fmaf(d.w, w, acc[4 * i + 3]);
+            }
+        }
+    }
+    if (k < K) {
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r)
+            if (r < R) unsafeAtomicAdd(&dX[(size_t)r * K + k], acc[r]);
+    }
+}
+
+// the 8-columns-per-workgroup kernels: few rows, a long reduction, 16-byte rows
+static bool head_wide(int R, int K, const float* X, const float* W) {
+    return R <= 32 && K >= 2048 && K % 4 == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
+}
+
 }  // namespace pcl
 using namespace pcl;
 
@@ -212,11 +418,14 @@ extern "C" int pcl_head_layer_fwd_f32(const float* X, const float* W, const floa
                                       void* stream) {
     PCL_REQUIRE(X && W && Ypre && OUT, "pcl_head_layer_fwd_f32: null pointer");
     PCL_REQUIRE(R >= 1 && R <= 64 && K >= 1 && N >= 1, "pcl_head_layer_fwd_f32: bad sizes R=%d K=%d N=%d (R <= 64)", R, K, N);
-    PCL_REQUIRE(bn_mode >= 0 && bn_mode <= 2 && (bn_mode == 0 || (mean_out && invstd_out)) && (bn_mode != 2 || (running_mean && running_var)),
-                "pcl_head_layer_fwd_f32: bn_mode=%d", bn_mode);
+    PCL_REQUIRE((bn_mode & ~7) == 0 && (bn_mode & 3) <= 2 && ((bn_mode & 3) == 0 || (mean_out && invstd_out)) &&
+                ((bn_mode & 3) != 2 || (running_mean && running_var)), "pcl_head_layer_fwd_f32: bn_mode=%d", bn_mode);
     hipStream_t st = as_stream(stream);
     const dim3 grid(N), block(256);
-    if (R <= 32)
+    if (head_wide(R, K, X, W))
+        hipLaunchKernelGGL(head_fwd_wide_kernel, dim3((N + HW_CB - 1) / HW_CB), block, 0, st, X, W, bias, gamma, beta, running_mean, running_var,
+                           R, K, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out);
+    else if (R <= 32)
         hipLaunchKernelGGL(head_fwd_kernel<32>, grid, block, 0, st, X, W, bias, gamma, beta, running_mean, running_var, R, K, N, bn_mode, eps,
                            momentum, slope, Ypre, OUT, mean_out, invstd_out);
     else
@@ -231,19 +440,23 @@ extern "C" int pcl_head_layer_bwd_f32(const float* X, const float* W, const floa
                                       void* stream) {
     PCL_REQUIRE(X && W && dOUT && OUT && Ypre && dY_ws && dW, "pcl_head_layer_bwd_f32: null pointer");
     PCL_REQUIRE(R >= 1 && R <= 64 && K >= 1 && N >= 1, "pcl_head_layer_bwd_f32: bad sizes R=%d K=%d N=%d (R <= 64)", R, K, N);
-    PCL_REQUIRE(bn_mode == 0 || (mean && invstd), "pcl_head_layer_bwd_f32: BatchNorm needs mean / invstd");
+    PCL_REQUIRE((bn_mode & 3) == 0 || (mean && invstd), "pcl_head_layer_bwd_f32: BatchNorm needs mean / invstd");
     hipStream_t st = as_stream(stream);
     const dim3 grid(N), block(256);
-    if (R <= 32)
-        hipLaunchKernelGGL(head_bwd_col_kernel<32>, grid, block, 0, st, X, dOUT, OUT, Ypre, gamma, mean, invstd, R, K, N, bn_mode, slope, dY_ws,
+    if (head_wide(R, K, X, W) && (reinterpret_cast<uintptr_t>(dW) & 15) == 0)
+        hipLaunchKernelGGL(head_bwd_col_wide_kernel, dim3((N + HW_CB - 1) / HW_CB), block, 0, st, X, dOUT, OUT, Ypre, gamma, mean, invstd, R, K,
+                           N, bn_mode, slope, dY_ws, dW, dbias, dgamma, dbeta, dX);
+    else if (R <= 32)
+        hipLaunchKernelGGL(head_bwd_col_kernel<32>, grid, block, 0, st, X, dOUT, OUT, Ypre, gamma, mean, invstd, R, K, N, bn_mode & 3, slope, dY_ws,
                            dW, dbias, dgamma, dbeta, dX);
     else
-        hipLaunchKernelGGL(head_bwd_col_kernel<64>, grid, block, 0, st, X, dOUT, OUT, Ypre, gamma, mean, invstd, R, K, N, bn_mode, slope, dY_ws,
+        hipLaunchKernelGGL(head_bwd_col_kernel<64>, grid, block, 0, st, X, dOUT, OUT, Ypre, gamma, mean, invstd, R, K, N, bn_mode & 3, slope, dY_ws,
                            dW, dbias, dgamma, dbeta, dX);
     int rc = check_launch("pcl_head_layer_bwd_f32(col)");
     if (rc || !dX) return rc;
     const dim3 g2((K + 63) / 64, (N + 4 * HD_NS - 1) / (4 * HD_NS));
-    if (R <= 32) hipLaunchKernelGGL(head_bwd_dx_kernel<32>, g2, block, 0, st, dY_ws, W, R, K, N, dX);
+    if (R <= 32 && K >= 2048 && N >= 256) hipLaunchKernelGGL(head_bwd_dx_wide_kernel, dim3((K + 63) / 64), block, 0, st, dY_ws, W, R, K, N, dX);
+    else if (R <= 32) hipLaunchKernelGGL(head_bwd_dx_kernel<32>, g2, block, 0, st, dY_ws, W, R, K, N, dX);
     else hipLaunchKernelGGL(head_bwd_dx_kernel<64>, g2, block, 0, st, dY_ws, W, R, K, N, dX);
     return check_launch("pcl_head_layer_bwd_f32(dx)");
 }

@@ -603,6 +603,7 @@ struct DwArgs {
     int P, I, J;
     int a_mode, b_mode;                         // a: A_DY / A_DY_SPARSE ; b: A_PLAIN / A_BNACT
     int gx, ti, tj;                             // logical grid: gx row-chunk workgroups x (ti x tj) output tiles
+    int ldo;                                    // row stride of an output tile in `part` (J, or dW's own when gx == 1)
 };
 
 constexpr int DW_BP = 32;
@@ -819,7 +820,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p_in) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wr * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < p.I && col < p.J) out[(size_t)row * p.J + col] = acc[tm][tn][r];
+                if (row < p.I && col < p.J) out[(size_t)row * p.ldo + col] = acc[tm][tn][r];
             }
         }
 }
@@ -1266,12 +1267,16 @@ extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const
     d.a_mode = dU ? A_DY : A_DY_SPARSE; d.b_mode = prev_scale ? A_BNACT : A_PLAIN;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const bool vec = (Cout % 4 == 0) && (Cin % 4 == 0) && al16(Y) && al16(Xprev) && (!dU || al16(dU)) && (!gz || (al16(gz) && al16(arg)));
-    d.gx = gx; d.ti = ti; d.tj = tj;
+    d.gx = gx; d.ti = ti; d.tj = tj; d.ldo = Cin;
+    // one row-chunk workgroup per output tile (few rows, a large weight: the per-point Linear of PointConv's GroupAll
+    // level is 32 x 16384 -> 1024): nothing to reduce, the tiles go straight into dW instead of through the workspace
+    const bool direct = gx == 1;
+    if (direct) { d.part = dW; d.ldo = dw_ld ? dw_ld : Cin; }
     dim3 grid(gx * ti * tj);
     if (dU) { if (vec) launch_dw_t<A_DY, true>(d, grid, tm, tn, st); else launch_dw_t<A_DY, false>(d, grid, tm, tn, st); }
     else { if (vec) launch_dw_t<A_DY_SPARSE, true>(d, grid, tm, tn, st); else launch_dw_t<A_DY_SPARSE, false>(d, grid, tm, tn, st); }
     int rc = check_launch("pcl_linear_bwd_dw_f32");
-    if (rc) return rc;
+    if (rc || direct) return rc;
     const size_t n = (size_t)Cout * Cin;
     const int blocks = (int)((n + 31) / 32);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(blocks), dim3(256), 0, st, d.part, gx, n, Cin, dw_ld ? dw_ld : Cin, dW);

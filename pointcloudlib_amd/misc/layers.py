@@ -116,6 +116,17 @@ class PointwiseMLP(nn.Module):
         if rowset is not None and backend != "hip":
             raise RuntimeError("duplicate-compacted rows are a HIP-backend feature")
         if backend == "hip":
+            K = x.shape[-1]
+            if (group_max is None and rowset is None and self.n_layers == 1 and self.bn and K >= 2048 and K % 4 == 0
+                    and x.numel() // K <= 32 and x.is_cuda):
+                # a handful of rows against a long reduction (PointConv's Linear(16*C, C) on the GroupAll level: 32 x 16384):
+                # 128x64 GEMM tiles give 16 workgroups here; the head kernels (csrc/head.hip) share X between 8 columns per
+                # workgroup and stream the weight once.  +4: running_var takes the biased variance like pcl_bn_finalize_f32.
+                from .head import _HeadLayer
+                cfg = ((1 if self.training else 2) | 4, self.eps, self.momentum, self.slope if self.last_act else 1.0)
+                y = _HeadLayer.apply(x.reshape(-1, K), self.weights[0], None if self.biases is None else self.biases[0],
+                                     self.gammas[0], self.betas[0], self.running_mean_0, self.running_var_0, cfg)
+                return y.reshape(*x.shape[:-1], y.shape[-1])
             from . import mlp_hip
             return mlp_hip.pointwise_mlp(self, x, group_max, rowset, x_grad_from)
         if backend != "torch":

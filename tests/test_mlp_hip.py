@@ -270,3 +270,29 @@ def test_soft_ce_kernel_matches_composite(R, C):
     assert torch.allclose(x.grad.cpu().double(), xd.grad, rtol=1e-5, atol=1e-7)
     with torch.no_grad():                                  # no gradient requested: forward only
         assert abs(float(soft_cross_entropy_loss(x.detach(), t)) - float(ref)) <= 2e-6 * max(1.0, abs(ref.item()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,K,N,bias", [(32, 16384, 1024, True), (7, 2048, 20, False), (32, 4096, 130, True)])
+def test_wide_single_layer_takes_head_kernels(dev, R, K, N, bias):
+    """PointwiseMLP([K, N]) on <= 32 rows with K >= 2048 (PointConv's per-point Linear on the GroupAll level) runs on the
+    8-columns-per-workgroup head kernels: forward, all gradients and the (biased-variance) running statistics against the
+    fp64 PyTorch restatement."""
+    torch.manual_seed(R + N)
+    m64 = PointwiseMLP([K, N], bias=bias).double()
+    m = copy.deepcopy(m64).float().to(dev)
+    m64.backend = "torch"
+    x = torch.randn(2, R // 2 if R % 2 == 0 else R, K, dtype=torch.float64)[:1 if R % 2 else 2]
+    x = x.reshape(-1, K)[:R].contiguous()
+    g = torch.randn(R, N, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    want = m64(xr); want.backward(g)
+    xg = x.float().to(dev).requires_grad_(True)
+    got = m(xg); got.backward(g.float().to(dev))
+    tol = lambda t: 3e-5 * max(1.0, t.abs().max().item())
+    assert (got.double().cpu() - want).abs().max().item() <= tol(want)
+    assert (xg.grad.double().cpu() - xr.grad).abs().max().item() <= tol(xr.grad)
+    for (n, p), (_, q) in zip(m.named_parameters(), m64.named_parameters()):
+        assert (p.grad.double().cpu() - q.grad).abs().max().item() <= tol(q.grad), n
+    for b in ("running_mean_0", "running_var_0"):
+        assert torch.allclose(getattr(m, b).double().cpu(), getattr(m64, b), rtol=1e-5, atol=1e-6), b
