@@ -18,6 +18,7 @@ from pointcloudlib_amd.affinity import pin_to_gpu_node
 
 pin_to_gpu_node(int(os.environ.get("LOCAL_RANK", "0")))      # before torch / HIP start threads (pointcloudlib_amd/affinity.py)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from pointcloudlib_amd.data_utils.modelnet40_loader import ModelNet40, SyntheticModelNet40
@@ -81,6 +82,7 @@ def main():
     ap.add_argument("--data_root", default=None)
     ap.add_argument("--lr_decay", action="store_true")
     ap.add_argument("--synthetic_items", type=int, default=512)
+    ap.add_argument("--seed", type=int, default=0, help="numpy (shuffles, augmentation: freeze_random_seed, train_cls.py:27-28) and torch (init)")
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("train_cls.py needs a GPU (the HIP path has no CPU fallback)")
@@ -92,7 +94,8 @@ def main():
         print(f"[train_cls] {e}\n[train_cls] -> synthetic clouds")
         train_set = SyntheticModelNet40(a.num_points, True, a.batch_size, shuffle=True, n_items=a.synthetic_items)
         val_set = SyntheticModelNet40(a.num_points, False, a.batch_size, n_items=max(a.batch_size, a.synthetic_items // 4), seed=1)
-    torch.manual_seed(0)
+    np.random.seed(a.seed)
+    torch.manual_seed(a.seed)
     net = build_model(a.model).to(dev)
     opt = make_sgd(net.parameters(), lr=a.lr, momentum=a.momentum)
     best = 0.0

@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=200)
     ap.add_argument("--data_root", default=None)
     ap.add_argument("--synthetic_items", type=int, default=128)
+    ap.add_argument("--seed", type=int, default=0, help="numpy (shuffles) and torch (init)")
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("train_partseg.py needs a GPU (the HIP path has no CPU fallback)")
@@ -114,7 +115,8 @@ def main():
         print(f"[train_partseg] {e}\n[train_partseg] -> synthetic shapes")
         train_set = SyntheticShapeNetPart(a.num_points, "trainval", None, a.batch_size, shuffle=True, n_items=a.synthetic_items)
         test_set = SyntheticShapeNetPart(a.num_points, "test", None, a.batch_size, n_items=max(a.batch_size, a.synthetic_items // 4), seed=1)
-    torch.manual_seed(0)
+    np.random.seed(a.seed)
+    torch.manual_seed(a.seed)
     net = build_model(a.model).to(dev)
     opt = make_sgd(net.parameters(), lr=a.lr, momentum=a.momentum, weight_decay=1e-4)
     for epoch in range(a.epochs):
