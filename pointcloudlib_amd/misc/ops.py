@@ -38,7 +38,8 @@ def _p(t):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # the raw hipStream_t of torch's current stream (torch.cuda.current_stream().cuda_stream costs ~10 us of Python per call)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def optimal_block(batch_size):

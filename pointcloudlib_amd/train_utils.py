@@ -27,7 +27,7 @@ class _SoftCE(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         _lib.call("pcl_soft_ce_f32", x.data_ptr(), target.data_ptr(), float(eps), R, C, loss.data_ptr(),
-                  None if dx is None else dx.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                  None if dx is None else dx.data_ptr(), torch._C._cuda_getCurrentRawStream(x.device.index))
         ctx.save_for_backward(dx)
         return loss
 
