@@ -4,6 +4,7 @@ There is NO fallback: if the HIP library is missing or a call fails, we raise.  
 ``oracle/`` is test infrastructure and is never imported from here.
 """
 import ctypes
+import functools
 import os
 import re
 import subprocess
@@ -180,16 +181,30 @@ class KernelTimer:
         return out
 
 
+@functools.lru_cache(maxsize=None)
+def size_query(name, *ints):
+    """Pure size functions of the ABI (``pcl_mlp_stat_rows``, ``pcl_linear_bwd_dw_workspace_bytes``, ...): asked once per shape."""
+    return getattr(lib(), name)(*ints)
+
+
+_FN = {}            # entry point name -> bound ctypes function
+
+
 def call(name, *args, algo_bytes=0, algo_flops=0, tag=""):
     """Invoke one C-ABI entry point; raises on a non-zero return code."""
-    fn = getattr(lib(), name)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(lib(), name)
     prof = PROFILER
-    if prof is not None:
-        tag = tag or (name if callable(algo_bytes) else f"{algo_bytes}")
-    if prof is not None and prof.want(name, tag):
-        start = prof.begin()
+    if prof is None:                               # normal operation: straight through
         rc = fn(*args)
-        prof.end(name, tag, start, algo_bytes, algo_flops)
     else:
-        rc = fn(*args)
-    check(rc, name)
+        tag = tag or (name if callable(algo_bytes) else f"{algo_bytes}")
+        if prof.want(name, tag):
+            start = prof.begin()
+            rc = fn(*args)
+            prof.end(name, tag, start, algo_bytes, algo_flops)
+        else:
+            rc = fn(*args)
+    if rc != 0:
+        check(rc, name)

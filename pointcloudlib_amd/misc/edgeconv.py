@@ -28,7 +28,7 @@ class _EdgeConvPool(torch.autograd.Function):
         dev = UV.device
         G = B * N
         st = _stream()
-        rows = _lib.lib().pcl_edgeconv_stat_rows(B, N)
+        rows = _lib.size_query("pcl_edgeconv_stat_rows", B, N)
         stats = torch.empty((rows, 2, C), dtype=torch.float64, device=dev)
         ymax, ymin = torch.empty((G, C), device=dev), torch.empty((G, C), device=dev)
         jmax, jmin = torch.empty((G, C), dtype=torch.int32, device=dev), torch.empty((G, C), dtype=torch.int32, device=dev)
@@ -103,7 +103,7 @@ class _PointLinear(torch.autograd.Function):
         Wcat = torch.cat([W[:, :C], W[:, C:] - W[:, :C]], dim=0).contiguous()       # [2*Cout, C]
         P = B * N
         UV = torch.empty((B, N, 2 * Co), device=dev)
-        rows = _lib.lib().pcl_mlp_stat_rows(P, 2 * Co, 0)
+        rows = _lib.size_query("pcl_mlp_stat_rows", P, 2 * Co, 0)
         _lib.call("pcl_linear_fwd_rows_f32", _p(x), _p(Wcat), None, None, None, 0.0, P, C, 2 * Co, _p(UV),
                   _p(torch.empty((rows, 2, 2 * Co), dtype=torch.float64, device=dev)), None, None, _stream(), tag=f"uv{C}x{2 * Co}")
         ctx.save_for_backward(x, Wcat)
@@ -124,7 +124,7 @@ class _PointLinear(torch.autograd.Function):
         zero = torch.zeros(C2, device=dev)
         dx = dW = None
         if ctx.needs_input_grad[1]:
-            nbytes = lib.pcl_linear_bwd_dw_workspace_bytes(P, C2, C)
+            nbytes = _lib.size_query("pcl_linear_bwd_dw_workspace_bytes", P, C2, C)
             ws = torch.empty(((nbytes + 3) // 4,), device=dev)
             dWcat = torch.empty((C2, C), device=dev)
             _lib.call("pcl_linear_bwd_dw_rows_f32", _p(dUV), _p(dUV), _p(one), _p(zero), _p(zero), _p(zero), None, None, 1, _p(x),

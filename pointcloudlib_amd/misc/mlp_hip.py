@@ -98,7 +98,7 @@ class _FusedMLP(torch.autograd.Function):
                 Y, stats, rows = x, link.stats, link.rows
             else:
                 Y = _empty((P, cout), dev)
-                rows = _lib.lib().pcl_mlp_stat_rows(P, cout, 2 if rowset is not None else 0)
+                rows = _lib.size_query("pcl_mlp_stat_rows", P, cout, 2 if rowset is not None else 0)
                 stats = _empty((rows, 2, cout), dev, torch.float64)
             if folded:
                 pass                       # nothing to launch: the grouping kernel already produced Y and its sums
@@ -235,7 +235,7 @@ class _FusedMLP(torch.autograd.Function):
             Xprev = Ys[l - 1] if l > 0 else x
             psc = scales[l - 1] if l > 0 else None
             psh = shifts[l - 1] if l > 0 else None
-            nbytes = lib.pcl_linear_bwd_dw_workspace_bytes(P, cout, cin)
+            nbytes = _lib.size_query("pcl_linear_bwd_dw_workspace_bytes", P, cout, cin)
             ws = _empty(((nbytes + 3) // 4,), dev)
             dW = _empty((cout, cin), dev)
             _lib.call("pcl_linear_bwd_dw_rows_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(means[l]), _P(arg) if sparse else None,
@@ -247,7 +247,7 @@ class _FusedMLP(torch.autograd.Function):
             if l > 0 or need_x:
                 dUp = _empty((P, cin), dev)
                 if l > 0:
-                    rows_n = lib.pcl_mlp_stat_rows(P, cin, 1 | (2 if rmeta is not None else 0))
+                    rows_n = _lib.size_query("pcl_mlp_stat_rows", P, cin, 1 | (2 if rmeta is not None else 0))
                     stats_n = _empty((rows_n, 2, cin), dev, torch.float64)
                 else:
                     rows_n, stats_n = rows, None
@@ -343,13 +343,13 @@ class _GroupLinear(torch.autograd.Function):
         Uf = None
         if C and not inline:
             Uf = _empty((B * N, C1), dev)
-            rows_u = _lib.lib().pcl_mlp_stat_rows(B * N, C1, 0)
+            rows_u = _lib.size_query("pcl_mlp_stat_rows", B * N, C1, 0)
             _lib.call("pcl_linear_fwd_rows_f32", _P(feat2), _P(Wf), None, None, None, 0.0, B * N, C, C1, _P(Uf),
                       _P(_empty((rows_u, 2, C1), dev, torch.float64)), None, None, st, tag=f"pt{C}x{C1}")
         Y = _empty((cap, C1), dev)
         row_meta = _empty((cap, 2), dev, torch.int32)
         row_src = _empty((cap,), dev, torch.int32)
-        rows = _lib.lib().pcl_group_linear_stat_rows(B, m)
+        rows = _lib.size_query("pcl_group_linear_stat_rows", B, m)
         stats = _empty((rows, 2, C1), dev, torch.float64)
         row_loc = _empty((cap, 4), dev)
         row_feat = _empty((cap, 4), dev) if inline else None
@@ -396,7 +396,7 @@ class _GroupLinear(torch.autograd.Function):
             one, zero = _const_vec(dev, C1, 1.0), _const_vec(dev, C1, 0.0)
             P = B * N
             if need_w:
-                nbytes = lib.pcl_linear_bwd_dw_workspace_bytes(P, C1, C)
+                nbytes = _lib.size_query("pcl_linear_bwd_dw_workspace_bytes", P, C1, C)
                 ws = _empty(((nbytes + 3) // 4,), dev)
                 _lib.call("pcl_linear_bwd_dw_rows_f32", _P(dUf), _P(dUf), _P(one), _P(zero), _P(zero), _P(zero), None, None, 1,
                           _P(feat2), None, None, 0.0, P, C1, C, _P(dW0[:, off:]), _P(ws), nbytes, None, None, fan_in, st,
