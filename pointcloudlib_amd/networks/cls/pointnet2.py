@@ -95,25 +95,9 @@ class PointnetModuleMSG(PointNetModuleBase):
             self.mlps.append(self.build_mlps(mlp, use_xyz, bn))
 
 
-class PointNet2_cls(nn.Module):
-    def __init__(self, n_classes=40, use_xyz=True):
-        super().__init__()
-        self.n_classes = n_classes
-        self.use_xyz = use_xyz
-        self.build_model()
-
-    def build_model(self):
-        self.pointnet_modules = nn.ModuleList()
-        self.pointnet_modules.append(PointnetModule(n_points=512, radius=0.2, n_samples=64, mlp=[3, 64, 64, 128],
-                                                    use_xyz=self.use_xyz))                       # :111-119
-        self.pointnet_modules.append(PointnetModule(n_points=128, radius=0.4, n_samples=64, mlp=[128, 128, 128, 256],
-                                                    use_xyz=self.use_xyz))                       # :121-129
-        self.pointnet_modules.append(PointnetModule(mlp=[256, 256, 512, 1024], use_xyz=self.use_xyz))   # :131-136
-        self.fc_layer = nn.Sequential(                                                           # :138-147
-            nn.Linear(1024, 512, bias=False), nn.BatchNorm1d(512), nn.ReLU(),
-            nn.Linear(512, 256, bias=False), nn.BatchNorm1d(256), nn.ReLU(),
-            nn.Dropout(0.5), nn.Linear(256, self.n_classes),
-        )
+class SamplingPrefetch:
+    """For networks with a ``pointnet_modules`` list: every index-producing op (FPS + ball query per level) depends on xyz
+    only, so the set for a batch can be produced ahead of its forward pass, on another stream."""
 
     def precompute_sampling(self, xyz, stream=None):
         """Run every index-producing op of the network (FPS + ball query per level: they depend on xyz only) for a
@@ -137,15 +121,42 @@ class PointNet2_cls(nn.Module):
             ev.record(stream)
         return {"levels": out, "event": ev, "stream": stream}
 
+    @staticmethod
+    def adopt_sampling(sampling):
+        """Make the current stream wait for a handle produced on another stream (and tell the allocator about the use)."""
+        if sampling is None:
+            return
+        cur = torch.cuda.current_stream()
+        if sampling.get("event") is not None and sampling["stream"] != cur:
+            cur.wait_event(sampling["event"])
+            for new_xyz, idxs in sampling["levels"]:              # allocator safety across streams
+                for t in [new_xyz] + [u for ic in idxs if ic is not None for u in ic]:
+                    if t is not None:
+                        t.record_stream(cur)
+
+
+class PointNet2_cls(SamplingPrefetch, nn.Module):
+    def __init__(self, n_classes=40, use_xyz=True):
+        super().__init__()
+        self.n_classes = n_classes
+        self.use_xyz = use_xyz
+        self.build_model()
+
+    def build_model(self):
+        self.pointnet_modules = nn.ModuleList()
+        self.pointnet_modules.append(PointnetModule(n_points=512, radius=0.2, n_samples=64, mlp=[3, 64, 64, 128],
+                                                    use_xyz=self.use_xyz))                       # :111-119
+        self.pointnet_modules.append(PointnetModule(n_points=128, radius=0.4, n_samples=64, mlp=[128, 128, 128, 256],
+                                                    use_xyz=self.use_xyz))                       # :121-129
+        self.pointnet_modules.append(PointnetModule(mlp=[256, 256, 512, 1024], use_xyz=self.use_xyz))   # :131-136
+        self.fc_layer = nn.Sequential(                                                           # :138-147
+            nn.Linear(1024, 512, bias=False), nn.BatchNorm1d(512), nn.ReLU(),
+            nn.Linear(512, 256, bias=False), nn.BatchNorm1d(256), nn.ReLU(),
+            nn.Dropout(0.5), nn.Linear(256, self.n_classes),
+        )
+
     def forward(self, xyz, feature, sampling=None):
-        if sampling is not None:
-            cur = torch.cuda.current_stream()
-            if sampling.get("event") is not None and sampling["stream"] != cur:
-                cur.wait_event(sampling["event"])
-                for new_xyz, idxs in sampling["levels"]:              # allocator safety across streams
-                    for t in [new_xyz] + [u for ic in idxs if ic is not None for u in ic]:
-                        if t is not None:
-                            t.record_stream(cur)
+        self.adopt_sampling(sampling)
         for i, module in enumerate(self.pointnet_modules):
             xyz, feature = module(xyz, feature, None if sampling is None else sampling["levels"][i])
         feature = feature.squeeze(dim=1)                                                         # :157

@@ -13,10 +13,10 @@ from torch import nn
 
 from ...misc.layers import PointwiseMLP
 from ...misc.ops import PointNetFeaturePropagation
-from ..cls.pointnet2 import PointnetModule, PointnetModuleMSG
+from ..cls.pointnet2 import PointnetModule, PointnetModuleMSG, SamplingPrefetch
 
 
-class PointNet2_partseg(nn.Module):
+class PointNet2_partseg(SamplingPrefetch, nn.Module):
     def __init__(self, part_num=50, use_xyz=True):
         super().__init__()
         self.part_num = part_num
@@ -40,12 +40,15 @@ class PointNet2_partseg(nn.Module):
         self.drop = nn.Dropout(0.5)
         self.head2 = PointwiseMLP([128, self.part_num], bias=True, bn=False, last_act=False)   # Conv1d(128, part_num, 1)
 
-    def forward(self, xyz, feature, cls_label):
-        """xyz [B,N,3], feature [B,N,3], cls_label one-hot [B,16] -> [B,part_num,N]."""
+    def forward(self, xyz, feature, cls_label, sampling=None):
+        """xyz [B,N,3], feature [B,N,3], cls_label one-hot [B,16] -> [B,part_num,N].  ``sampling``: a handle from
+        ``precompute_sampling(xyz)`` (the encoder's FPS / ball-query indices produced ahead, e.g. on a side stream)."""
         B, N, _ = xyz.shape
-        l1_xyz, l1_feature = self.pointnet_modules[0](xyz, feature)
-        l2_xyz, l2_feature = self.pointnet_modules[1](l1_xyz, l1_feature)
-        _, l3_feature = self.pointnet_modules[2](l2_xyz, l2_feature)
+        self.adopt_sampling(sampling)
+        lv = [None, None, None] if sampling is None else sampling["levels"]
+        l1_xyz, l1_feature = self.pointnet_modules[0](xyz, feature, lv[0])
+        l2_xyz, l2_feature = self.pointnet_modules[1](l1_xyz, l1_feature, lv[1])
+        _, l3_feature = self.pointnet_modules[2](l2_xyz, l2_feature, lv[2])
         l3_xyz = torch.zeros((B, 1, 3), device=xyz.device, dtype=xyz.dtype)          # :55
         l2_feature = self.fp3(l2_xyz, l3_xyz, l2_feature, l3_feature)                 # :168
         l1_feature = self.fp2(l1_xyz, l2_xyz, l1_feature, l2_feature)                 # :169

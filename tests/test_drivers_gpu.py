@@ -25,10 +25,10 @@ def test_train_cls_driver():
     assert len(losses) == 3 and all(l == l and l < 10 for l in losses) and min(losses[1:]) < losses[0], out
 
 
-@pytest.mark.parametrize("model", ["pointnet2", "dgcnn"])
-def test_train_partseg_driver(model):
+@pytest.mark.parametrize("model,extra", [("pointnet2", ()), ("pointnet2", ("--prefetch_sampling",)), ("dgcnn", ())])
+def test_train_partseg_driver(model, extra):
     out = _run("train_partseg.py", "--model", model, "--epochs", "3", "--batch_size", "8", "--num_points", "512",
-               "--synthetic_items", "32", "--data_root", "/nonexistent")
+               "--synthetic_items", "32", "--data_root", "/nonexistent", *extra)
     tr = re.findall(r"Train \d+, loss: ([\d.]+), train acc: ([\d.]+), train avg acc: ([\d.]+), train iou: ([\d.]+)", out)
     te = re.findall(r"Test \d+, loss: ([\d.]+), test acc: ([\d.]+), test avg acc: ([\d.]+), test iou: ([\d.]+)", out)
     assert len(tr) == 3 and len(te) == 3, out

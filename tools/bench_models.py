@@ -30,6 +30,33 @@ def run(name, make, inputs, loss_fn, steps, warmup=3):
     return r
 
 
+def run_prefetch(name, make, inputs, loss_fn, steps, warmup=3):
+    """Same, with the encoder's FPS / ball query of the next batch issued on a side stream beside the backward pass
+    (networks with ``precompute_sampling``; the input is the same tensor every step, the work is not)."""
+    torch.manual_seed(0)
+    net = make().cuda().train()
+    opt = make_sgd(net.parameters(), lr=0.02, momentum=0.9)
+    side = torch.cuda.Stream(priority=-1)
+    pending = [None]
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = net(*inputs, sampling=pending[0])
+        pending[0] = net.precompute_sampling(inputs[0], stream=side)
+        loss_fn(out).backward()
+        opt.step()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    B = inputs[0].shape[0]
+    r = {"config": name, "ms_per_step": round(dt * 1e3, 3), "clouds_per_s": round(B / dt, 1), "batch": B,
+         "params": sum(p.numel() for p in net.parameters())}
+    print(json.dumps(r), flush=True)
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=40)
@@ -58,6 +85,8 @@ def main():
     seg = torch.randint(0, 50, (16, 2048), device=dev)
     res.append(run("cfg4 PointNet++ SSG part-seg B=16 N=2048", PointNet2_partseg, (xs, xs, oh),
                    lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps))
+    res.append(run_prefetch("cfg4 PointNet++ SSG part-seg B=16 N=2048, sampling of batch t+1 on a side stream", PointNet2_partseg, (xs, xs, oh),
+                            lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps))
     from pointcloudlib_amd.networks.seg.pointnet2_partseg import PointNetMSG
     res.append(run("cfg4' PointNet++ MSG part-seg B=16 N=2048 (FP widths corrected, see DESIGN 7)", PointNetMSG, (xs, xs, oh),
                    lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps))

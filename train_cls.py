@@ -49,16 +49,34 @@ def forward(net, name, pts, normals):
     return net(pts)
 
 
-def run_epoch(net, name, loader, dev, optimizer=None):
+def lookahead(loader, dev):
+    """(batch on the device, next batch on the device or None): the next batch's sampling can be issued one step ahead."""
+    it = iter(loader)
+    cur = next(it, None)
+    cur = None if cur is None else tuple(t.to(dev) for t in cur)
+    while cur is not None:
+        nxt = next(it, None)
+        nxt = None if nxt is None else tuple(t.to(dev) for t in nxt)
+        yield cur, nxt
+        cur = nxt
+
+
+def run_epoch(net, name, loader, dev, optimizer=None, side=None):
     train = optimizer is not None
     net.train(train)
     seen = correct = 0
     loss_sum = 0.0
+    prefetch = side is not None and hasattr(net, "precompute_sampling")
+    pending = None
     t0 = time.perf_counter()
-    for pts, normals, labels in loader:
-        pts, normals, labels = pts.to(dev), normals.to(dev), labels.to(dev)
+    for (pts, normals, labels), nxt in lookahead(loader, dev):
         with torch.set_grad_enabled(train):
-            out = forward(net, name, pts, normals)
+            if prefetch:
+                out = net(pts, normals, sampling=pending)
+                # FPS / ball query of the NEXT batch on the side stream, beside this batch's backward
+                pending = net.precompute_sampling(nxt[0], stream=side) if nxt is not None else None
+            else:
+                out = forward(net, name, pts, normals)
             if train:
                 loss = soft_cross_entropy_loss(out, labels)
                 optimizer.zero_grad(set_to_none=True)
@@ -98,13 +116,14 @@ def main():
     torch.manual_seed(a.seed)
     net = build_model(a.model).to(dev)
     opt = make_sgd(net.parameters(), lr=a.lr, momentum=a.momentum)
+    side = torch.cuda.Stream(priority=-1) if a.model == "pointnet2" else None     # sampling of batch t+1 beside batch t
     best = 0.0
     for epoch in range(a.epochs):
         if a.lr_decay and epoch and epoch % 20 == 0:
             for g in opt.param_groups:
                 g["lr"] *= 0.7
-        acc, loss, rate = run_epoch(net, a.model, train_set, dev, opt)
-        vacc, _, vrate = run_epoch(net, a.model, val_set, dev)
+        acc, loss, rate = run_epoch(net, a.model, train_set, dev, opt, side)
+        vacc, _, vrate = run_epoch(net, a.model, val_set, dev, None, side)
         best = max(best, vacc)
         print(f"epoch {epoch}: train loss {loss:.3f} acc {100 * acc:.2f} ({rate:.0f} clouds/s)   val acc {100 * vacc:.2f} "
               f"(best {100 * best:.2f}, {vrate:.0f} clouds/s)", flush=True)
