@@ -35,6 +35,9 @@ CASES = [
     ([12, 8, 8, 16], (2, 33, 8), None, True, 0.0),          # WeightNet-sized
     ([10, 300], (2, 7, 8), 8, False, 0.0),                  # > 256 channels with a max: two channel blocks in the backward prep
     ([7, 5, 3], (4, 50), None, True, 0.2),                  # 3 output channels: 4 channel-lanes x 64 row-lanes per block
+    ([64, 64, 128], (13, 8, 16), 16, False, 0.0),           # 1664 rows = 26 row tiles: full groups of 8 AND a remainder in the
+                                                            # XCD-aware block -> tile mapping, two column tiles
+    ([32, 192], (11, 3, 32), None, False, 0.0),             # 1056 rows, three column tiles, no max
 ]
 
 
