@@ -19,11 +19,11 @@ def _bn_train(y, gamma, beta, eps=1e-5):
 def sa_module_cpu(xyz, feat, weights, gammas, betas, n_points, radius, n_samples, tie_stride, return_aux=False):
     """xyz [B,N,3] (torch cpu), feat [B,N,C] -> (new_xyz, new_feat[B,m,Cout]); weights: list of [Cout,Cin]."""
     B, N, _ = xyz.shape
-    xyz_np = xyz.detach().numpy()
+    xyz_np = np.ascontiguousarray(xyz.detach().float().numpy())      # index ops are fp32 by definition (misc/ops.py CUDA text)
     if n_points is not None:
         fidx, new_xyz_np = _o.fps(xyz_np, n_points, block_size=tie_stride, return_xyz=True)
         idx = _o.ball_query(new_xyz_np, xyz_np, radius, n_samples)
-        new_xyz = torch.from_numpy(new_xyz_np)
+        new_xyz = torch.from_numpy(new_xyz_np).to(xyz.dtype)
         bi = torch.arange(B)[:, None, None]
         li = torch.from_numpy(idx.astype(np.int64))
         g_xyz = xyz[bi, li] - new_xyz[:, :, None, :]
@@ -47,22 +47,27 @@ class PointNet2ClsCPU(torch.nn.Module):
 
     SA = [(512, 0.2, 64), (128, 0.4, 64), (None, None, None)]
 
-    def __init__(self, gpu_model_state, n_classes=40, tie_stride=8):
+    def __init__(self, gpu_model_state, n_classes=40, tie_stride=8, dtype=torch.float32):
+        """``dtype=torch.float64``: the same composition with every dense op in double precision (index ops stay fp32) --
+        the ground truth the fp32 restatement AND the HIP path are both measured against in the gradient-parity tests."""
         super().__init__()
         self.tie_stride = tie_stride
+        self.dtype = dtype
         self.p = torch.nn.ParameterDict()
         self.keys = {}
         for k, v in gpu_model_state.items():
             if "running" in k or "num_batches" in k:
                 continue
             nk = k.replace(".", "__")
-            self.p[nk] = torch.nn.Parameter(v.detach().cpu().float().clone())
+            self.p[nk] = torch.nn.Parameter(v.detach().cpu().to(dtype).clone())
             self.keys[k] = nk
 
     def g(self, k):
         return self.p[self.keys[k]]
 
     def forward(self, xyz, feat, return_aux=False):
+        xyz = xyz.to(self.dtype)
+        feat = None if feat is None else feat.to(self.dtype)
         aux = []
         for i, (m, r, ns) in enumerate(self.SA):
             pre = f"pointnet_modules.{i}.mlps.0."

@@ -10,7 +10,8 @@ import re
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_PKG, "libpcl_hip.so")
+# PCL_HIP_SO: developer knob for timing experiments (a variant build of the same sources, csrc/Makefile EXP=n)
+_SO = os.environ.get("PCL_HIP_SO") or os.path.join(_PKG, "libpcl_hip.so")
 _HEADER = os.path.join(os.path.dirname(_PKG), "include", "pcl_hip.h")
 _lib = None
 

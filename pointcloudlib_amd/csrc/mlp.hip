@@ -25,6 +25,11 @@
 #include <cstdlib>
 #include "common.h"
 
+// PCL_EXP: timing experiments only (csrc/Makefile EXP=n builds a separate library; the product build has PCL_EXP == 0)
+#ifndef PCL_EXP
+#define PCL_EXP 0
+#endif
+
 namespace pcl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -109,18 +114,57 @@ struct Stage {
     int4 vi[VEC ? NI : 1];
     float s[VEC ? 1 : NI], s2[VEC ? 1 : NI], sg[VEC ? 1 : NI];
     int si[VEC ? 1 : NI];
-    float rw[NI];                  // row multiplicity (ragged rows), 1 otherwise
-    int rs[NI];                    // row-in-group (sparse max gradient)
     float4 c_sc, c_sh, c_k2, c_mu; // per-k constants of this step (vector path)
     float f_sc, f_sh, f_k2, f_mu;  // (scalar path)
     int m0;                        // first row of the staged tile (for the sparse row-in-group test)
 };
 
+// Per-row metadata of the tile being staged (group id, row-in-group, multiplicity).  It depends on the ROW only, so it
+// is fetched once per tile -- one tile ahead, as raw int2 records -- instead of once per K step: with compacted rows the
+// sparse loader needs the group id before it can address (arg, gz), and a metadata load inside every K step put a full
+// memory round trip between the barrier and the MFMAs of that step (the dominant dX launch ran at 0.40 of the MFMA roof).
+template <bool VEC, int ROWS>
+struct RowInfo {
+    static constexpr int NI = VEC ? ROWS / 32 : ROWS / 8;
+    int g[NI];                     // group id (sparse max gradient)
+    int rs[NI];                    // row-in-group
+    float rw[NI];                  // row multiplicity (ragged rows), 1 otherwise
+    int2 raw[NI];                  // prefetched records of the tile after the staged one
+};
+
+template <int AM, bool VEC, int ROWS, bool RAG>
+__device__ __forceinline__ void rowinfo_fetch(const LinArgs& p, int m0, int tid, RowInfo<VEC, ROWS>& ri) {
+    if constexpr (AM >= A_DY && RAG) {
+#pragma unroll
+        for (int i = 0; i < RowInfo<VEC, ROWS>::NI; ++i) {
+            const int r = min(m0 + (VEC ? (tid >> 3) + 32 * i : (tid >> 5) + 8 * i), p.M - 1);
+            ri.raw[i] = p.rmeta[r];
+        }
+    }
+}
+
+template <int AM, bool VEC, int ROWS, bool RAG>
+__device__ __forceinline__ void rowinfo_adopt(const LinArgs& p, int m0, int tid, RowInfo<VEC, ROWS>& ri) {
+    if constexpr (AM >= A_DY) {
+#pragma unroll
+        for (int i = 0; i < RowInfo<VEC, ROWS>::NI; ++i) {
+            int g = 0, srow = 0;
+            float w = 1.f;
+            if constexpr (RAG) row_meta(ri.raw[i], g, srow, w);
+            else if constexpr (AM == A_DY_SPARSE) {
+                const int r = min(m0 + (VEC ? (tid >> 3) + 32 * i : (tid >> 5) + 8 * i), p.M - 1);
+                g = r / p.ns; srow = r - g * p.ns;
+            }
+            ri.g[i] = g; ri.rs[i] = srow; ri.rw[i] = w;
+        }
+    }
+}
+
 // All staging loads are UNCONDITIONAL with clamped (always valid) addresses: a load under a divergent branch
 // makes hipcc drain vmcnt(0) at the branch join, which would serialise the prefetch against the MFMAs.
 // Out-of-range elements are zeroed later, in the transform/store stage.
 template <int AM, bool VEC, int ROWS, bool RAG>
-__device__ __forceinline__ void load_a(const LinArgs& p, int m0, int k0, int tid, Stage<VEC, ROWS>& st) {
+__device__ __forceinline__ void load_a(const LinArgs& p, int m0, int k0, int tid, Stage<VEC, ROWS>& st, const RowInfo<VEC, ROWS>& ri) {
     st.m0 = m0;
     if constexpr (VEC) {
         const int k = min(k0 + (tid & 7) * 4, p.K - 4);
@@ -133,13 +177,7 @@ __device__ __forceinline__ void load_a(const LinArgs& p, int m0, int k0, int tid
         for (int i = 0; i < ROWS / 32; ++i) {
             const int r = min(m0 + (tid >> 3) + 32 * i, p.M - 1);
             const size_t off = (size_t)r * p.K + k;
-            int g = 0, srow = 0;
-            float w = 1.f;
-            if constexpr (AM >= A_DY) {
-                if constexpr (RAG) row_meta(p.rmeta[r], g, srow, w);
-                else if constexpr (AM == A_DY_SPARSE) { g = r / p.ns; srow = r - g * p.ns; }
-                st.rw[i] = w; st.rs[i] = srow;
-            }
+            const int g = ri.g[i];
             if constexpr (AM == A_PLAIN || AM == A_BNACT) {
                 st.v[i] = *reinterpret_cast<const float4*>(p.A + off);
             } else if constexpr (AM == A_DY) {
@@ -162,13 +200,7 @@ __device__ __forceinline__ void load_a(const LinArgs& p, int m0, int k0, int tid
         for (int i = 0; i < ROWS / 8; ++i) {
             const int r = min(m0 + (tid >> 5) + 8 * i, p.M - 1);
             const size_t off = (size_t)r * p.K + k;
-            int g = 0, srow = 0;
-            float w = 1.f;
-            if constexpr (AM >= A_DY) {
-                if constexpr (RAG) row_meta(p.rmeta[r], g, srow, w);
-                else if constexpr (AM == A_DY_SPARSE) { g = r / p.ns; srow = r - g * p.ns; }
-                st.rw[i] = w; st.rs[i] = srow;
-            }
+            const int g = ri.g[i];
             if constexpr (AM == A_PLAIN || AM == A_BNACT) {
                 st.s[i] = p.A[off];
             } else if constexpr (AM == A_DY) {
@@ -188,7 +220,7 @@ __device__ __forceinline__ void load_a(const LinArgs& p, int m0, int k0, int tid
 // must stay exactly zero (they feed MFMAs whose results are discarded or masked, but k-padding feeds real
 // outputs), so the affine modes are applied only to in-range elements.
 template <int AM, bool VEC, int ROWS>
-__device__ __forceinline__ void store_a(const LinArgs& p, float* sX, int k0, int tid, const Stage<VEC, ROWS>& st) {
+__device__ __forceinline__ void store_a(const LinArgs& p, float* sX, int k0, int tid, const Stage<VEC, ROWS>& st, const RowInfo<VEC, ROWS>& ri) {
     if constexpr (VEC) {
         const bool kin = k0 + (tid & 7) * 4 < p.K;
         const float4 sc = st.c_sc, sh = st.c_sh, k2 = st.c_k2, mu = st.c_mu;
@@ -208,14 +240,14 @@ __device__ __forceinline__ void store_a(const LinArgs& p, float* sX, int k0, int
                     float4 du;
                     if constexpr (AM == A_DY) du = st.v[i];
                     else {
-                        const int srow = st.rs[i];
+                        const int srow = ri.rs[i];
                         const int4 ar = st.vi[i];
                         const float4 gz = st.vg[i];
                         du.x = ar.x == srow ? gz.x : 0.f; du.y = ar.y == srow ? gz.y : 0.f;
                         du.z = ar.z == srow ? gz.z : 0.f; du.w = ar.w == srow ? gz.w : 0.f;
                     }
                     const float4 y = st.v2[i];
-                    const float w = st.rw[i];            // dense BatchNorm term counts once per duplicate
+                    const float w = ri.rw[i];            // dense BatchNorm term counts once per duplicate
                     a.x = fmaf(sc.x, du.x, -w * fmaf(k2.x, y.x - mu.x, sh.x)); a.y = fmaf(sc.y, du.y, -w * fmaf(k2.y, y.y - mu.y, sh.y));
                     a.z = fmaf(sc.z, du.z, -w * fmaf(k2.z, y.z - mu.z, sh.z)); a.w = fmaf(sc.w, du.w, -w * fmaf(k2.w, y.w - mu.w, sh.w));
                 }
@@ -236,8 +268,8 @@ __device__ __forceinline__ void store_a(const LinArgs& p, float* sX, int k0, int
                 else {
                     float du;
                     if constexpr (AM == A_DY) du = st.s[i];
-                    else du = st.si[i] == st.rs[i] ? st.sg[i] : 0.f;
-                    a = fmaf(sc, du, -st.rw[i] * fmaf(k2, st.s2[i] - mu, sh));
+                    else du = st.si[i] == ri.rs[i] ? st.sg[i] : 0.f;
+                    a = fmaf(sc, du, -ri.rw[i] * fmaf(k2, st.s2[i] - mu, sh));
                 }
             }
             sX[rl * LDS_LD + (tid & 31)] = a;
@@ -350,6 +382,9 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
     const int wr = wave >> 1, wc = wave & 1;
     int bx, by;
     tile_of_block(blockIdx.x, p.gx, p.nt, bx, by);
+#if PCL_EXP == 5
+    if ((blockIdx.x >> 8) & 1) { __builtin_amdgcn_s_sleep(40); __builtin_amdgcn_s_sleep(40); }     // ~5k cycles: co-resident workgroups out of phase
+#endif
     const int n0 = p.n_begin + by * TBN;
     const int m_tiles = (p.M + TBM - 1) / TBM;
     const int lr = lane & 31, lh = lane >> 5;
@@ -371,10 +406,14 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
 
     Stage<VEC, TBM> ra;
     Stage<VEC, TBN> rb;
+    RowInfo<VEC, TBM> ri;
     int mt = bx;
     int staged_k0 = 0;
     if (mt < m_tiles) {
-        load_a<AM, VEC, TBM, RAG>(p, mt * TBM, 0, tid, ra);
+        rowinfo_fetch<AM, VEC, TBM, RAG>(p, mt * TBM, tid, ri);
+        rowinfo_adopt<AM, VEC, TBM, RAG>(p, mt * TBM, tid, ri);
+        rowinfo_fetch<AM, VEC, TBM, RAG>(p, (mt + p.gx) * TBM, tid, ri);      // clamped addresses: always valid
+        load_a<AM, VEC, TBM, RAG>(p, mt * TBM, 0, tid, ra, ri);
         load_b<VEC, TBN, BT>(p, n0, 0, tid, rb);
         if constexpr (NEEDW) wmeta = p.rmeta[min(mt * TBM + (tid & (TBM - 1)), p.M - 1)].y;
     }
@@ -389,18 +428,38 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         for (int k0 = 0; k0 < p.K; k0 += BK) {
+#if PCL_EXP == 1 || PCL_EXP == 2
+            const bool exp_stage = (k0 == 0 && mt == bx);      // stage once (valid LDS contents), then MFMA loop + epilogue only
+#else
+            constexpr bool exp_stage = true;
+#endif
+#if PCL_EXP != 2
             __syncthreads();                       // previous step's fragment reads are done
-            store_a<AM, VEC, TBM>(p, sA, staged_k0, tid, ra);
+#endif
+            if (exp_stage) {
+            store_a<AM, VEC, TBM>(p, sA, staged_k0, tid, ra, ri);
             store_b<VEC, TBN, BT>(p, sB, n0, staged_k0, tid, rb);
+            }
             if constexpr (NEEDW) { if (tid < TBM) sW[tid] = (float)(wmeta >> 16); }
+#if PCL_EXP != 2
             __syncthreads();
+#else
+            if (exp_stage) __syncthreads();
+#endif
             // request the next step's operands (next k block, or the first k block of this workgroup's next tile)
+#if PCL_EXP == 1 || PCL_EXP == 2
+            if (false)
+#endif
             {
                 int nk = k0 + BK, nmt = mt;
                 if (nk >= p.K) { nk = 0; nmt = mt + p.gx; }
                 staged_k0 = nk;
                 if (nmt < m_tiles) {
-                    load_a<AM, VEC, TBM, RAG>(p, nmt * TBM, nk, tid, ra);
+                    if (nk == 0) {       // the staged tile changes: adopt its prefetched row records, request the tile after
+                        rowinfo_adopt<AM, VEC, TBM, RAG>(p, nmt * TBM, tid, ri);
+                        rowinfo_fetch<AM, VEC, TBM, RAG>(p, (nmt + p.gx) * TBM, tid, ri);
+                    }
+                    load_a<AM, VEC, TBM, RAG>(p, nmt * TBM, nk, tid, ra, ri);
                     load_b<VEC, TBN, BT>(p, n0, nk, tid, rb);
                     if constexpr (NEEDW) wmeta = p.rmeta[min(nmt * TBM + (tid & (TBM - 1)), p.M - 1)].y;
                 }
@@ -423,7 +482,11 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn) {
                             const float bv = s == 0 ? b4[tn].x : s == 1 ? b4[tn].y : s == 2 ? b4[tn].z : b4[tn].w;
+#if PCL_EXP == 3
+                            acc[tm][tn][s] = fmaf(av, bv, acc[tm][tn][s]);          // no matrix work: one VALU op keeps the fragment reads alive
+#else
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tm][tn], 0, 0, 0);
+#endif
                         }
                     }
                 }
@@ -621,8 +684,19 @@ struct DwStage {
     int si[VEC ? 1 : NI];
     float rw[NI];
     int rs[NI];
+    int2 raw[NI];                  // row records of the chunk AFTER the staged one (prefetched: the sparse loader needs
+                                   // the group id before it can address (arg, gz) -- see RowInfo above)
     int p0;
 };
+
+template <bool VEC, int W, bool RAG>
+__device__ __forceinline__ void dw_fetch_meta(const DwArgs& p, int p0, int tid, DwStage<VEC, W>& st) {
+    using S = DwStage<VEC, W>;
+    if constexpr (RAG) {
+#pragma unroll
+        for (int i = 0; i < S::NI; ++i) st.raw[i] = p.rmeta[min(p0 + tid / S::CPR + S::RP * i, p.P - 1)];
+    }
+}
 
 template <int AM, bool VEC, int W, bool RAG>
 __device__ __forceinline__ void dw_load_a(const DwArgs& p, int p0, int c0, int tid, DwStage<VEC, W>& st) {
@@ -635,7 +709,7 @@ __device__ __forceinline__ void dw_load_a(const DwArgs& p, int p0, int c0, int t
         const size_t off = (size_t)r * p.I + c;
         int g = 0, srow = 0;
         float w = 1.f;
-        if constexpr (RAG) row_meta(p.rmeta[r], g, srow, w);
+        if constexpr (RAG) row_meta(st.raw[i], g, srow, w);          // records fetched one chunk ahead (dw_fetch_meta)
         else if constexpr (AM == A_DY_SPARSE) { g = r / p.ns; srow = r - g * p.ns; }
         st.rw[i] = w; st.rs[i] = srow;
         if constexpr (VEC) {
@@ -788,14 +862,23 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p_in) 
     DwStage<VEC, WI> ra;
     DwStage<VEC, WJ> rb;
     int ch = bx;
-    if (ch < chunks) { dw_load_a<AM, VEC, WI, RAG>(p, ch * DW_BP, i0, tid, ra); dw_load_b<VEC, WJ>(p, ch * DW_BP, j0, tid, rb); }
+    if (ch < chunks) {
+        dw_fetch_meta<VEC, WI, RAG>(p, ch * DW_BP, tid, ra);
+        dw_load_a<AM, VEC, WI, RAG>(p, ch * DW_BP, i0, tid, ra);
+        dw_fetch_meta<VEC, WI, RAG>(p, (ch + p.gx) * DW_BP, tid, ra);       // clamped addresses: always valid
+        dw_load_b<VEC, WJ>(p, ch * DW_BP, j0, tid, rb);
+    }
     for (; ch < chunks; ch += p.gx) {
         __syncthreads();
         dw_store_a<AM, VEC, WI>(p, sA, i0, tid, ra, asc, ash, ak2, amu);
         dw_store_b<VEC, WJ>(p, sB, j0, tid, rb, bsc, bsh);
         __syncthreads();
         const int nch = ch + p.gx;
-        if (nch < chunks) { dw_load_a<AM, VEC, WI, RAG>(p, nch * DW_BP, i0, tid, ra); dw_load_b<VEC, WJ>(p, nch * DW_BP, j0, tid, rb); }
+        if (nch < chunks) {
+            dw_load_a<AM, VEC, WI, RAG>(p, nch * DW_BP, i0, tid, ra);
+            dw_fetch_meta<VEC, WI, RAG>(p, (nch + p.gx) * DW_BP, tid, ra);
+            dw_load_b<VEC, WJ>(p, nch * DW_BP, j0, tid, rb);
+        }
 #pragma unroll 4
         for (int ks = 0; ks < DW_BP / 2; ++ks) {
             const int pr = ks * 2 + lh;                 // lanes 0-31: row 2ks, lanes 32-63: row 2ks+1
@@ -1081,19 +1164,24 @@ static int launch_linear_t(const LinArgs& a_in, hipStream_t st) {
     linear_grid(a.M, a.N - a.n_begin, AM >= A_DY, RAG, gx, n_tiles, narrow, low);
     a.gx = gx; a.nt = n_tiles;
     dim3 grid(gx * n_tiles);
+#if PCL_EXP == 4
+#define PCL_DYN_LDS (96 * 1024)          // one workgroup per CU
+#else
+#define PCL_DYN_LDS 0
+#endif
     if constexpr (!RAG && GM == 0) {
         if (low) {
-            if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, 0, false, 1>), grid, dim3(MLP_T), 0, st, a);
-            else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1, 0, false, 1>), grid, dim3(MLP_T), 0, st, a);
+            if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, 0, false, 1>), grid, dim3(MLP_T), PCL_DYN_LDS, st, a);
+            else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1, 0, false, 1>), grid, dim3(MLP_T), PCL_DYN_LDS, st, a);
             return check_launch("pcl_linear");
         }
     }
     if (narrow) {
-        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
-        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
+        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, GM, RAG>), grid, dim3(MLP_T), PCL_DYN_LDS, st, a);
+        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1, GM, RAG>), grid, dim3(MLP_T), PCL_DYN_LDS, st, a);
     } else {
-        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 2, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
-        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 2, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
+        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 2, GM, RAG>), grid, dim3(MLP_T), PCL_DYN_LDS, st, a);
+        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 2, GM, RAG>), grid, dim3(MLP_T), PCL_DYN_LDS, st, a);
     }
     return check_launch("pcl_linear");
 }
