@@ -1,0 +1,69 @@
+"""Shared pieces of the CPU network restatements (cpu_model.py, cpu_dgcnn.py, cpu_partseg.py, cpu_pointconv.py) --
+TEST INFRASTRUCTURE / CPU BASELINE ONLY (see oracle/__init__.py).
+
+The reference's dense layers are ``nn.Conv(kernel_size=1)`` / ``nn.Conv1d(k=1)`` / ``nn.Linear`` + ``nn.BatchNorm`` (training
+mode: batch mean, biased batch variance, eps 1e-5) + ReLU / LeakyReLU (e.g. networks/cls/pointnet2.py:25-29,
+networks/cls/dgcnn.py:72-86, misc/ops.py:61-64).  A 1x1 conv over [B,C,...] is a row-wise linear map over channel-last
+rows, which is how it is written here, on plain PyTorch-CPU ops.  ``dtype=torch.float64`` gives the same composition in
+double precision: the value both fp32 pipelines (this restatement in fp32, and the HIP path) are measured against.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def bn_train(y, gamma, beta, eps=1e-5):
+    """training-mode BatchNorm over the rows of y [P,C] (batch statistics, biased variance)"""
+    return F.batch_norm(y, None, None, gamma, beta, True, 0.0, eps)
+
+
+def act(y, slope):
+    return F.relu(y) if slope == 0.0 else F.leaky_relu(y, slope)
+
+
+class ParamBag(torch.nn.Module):
+    """A state_dict of one of pointcloudlib_amd's networks as CPU parameters of one dtype, addressed by the original keys."""
+
+    def __init__(self, state, dtype=torch.float32):
+        super().__init__()
+        self.dtype = dtype
+        self.p = torch.nn.ParameterDict()
+        self.keys = {}
+        for k, v in state.items():
+            if "running" in k or "num_batches" in k:
+                continue
+            nk = k.replace(".", "__")
+            self.p[nk] = torch.nn.Parameter(v.detach().cpu().to(dtype).clone())
+            self.keys[k] = nk
+
+    def has(self, k):
+        return k in self.keys
+
+    def g(self, k):
+        return self.p[self.keys[k]]
+
+    def grad(self, k):
+        return self.p[self.keys[k]].grad
+
+    def mlp(self, prefix, y, slope=0.0, last_act=True, bn=True):
+        """``PointwiseMLP`` stack stored under ``prefix`` (weights.i / biases.i / gammas.i / betas.i) on rows y [P,C0]."""
+        n = 0
+        while self.has(f"{prefix}weights.{n}"):
+            n += 1
+        for i in range(n):
+            b = self.g(f"{prefix}biases.{i}") if self.has(f"{prefix}biases.{i}") else None
+            y = F.linear(y, self.g(f"{prefix}weights.{i}"), b)
+            if bn:
+                y = bn_train(y, self.g(f"{prefix}gammas.{i}"), self.g(f"{prefix}betas.{i}"))
+            if i < n - 1 or last_act:
+                y = act(y, slope)
+        return y
+
+    def fc_bn_act(self, x, lin, bn=None, slope=None):
+        """nn.Linear [+ nn.BatchNorm1d] [+ (Leaky)ReLU] stored as ``<lin>.weight/.bias``, ``<bn>.weight/.bias``."""
+        b = self.g(f"{lin}.bias") if self.has(f"{lin}.bias") else None
+        x = F.linear(x, self.g(f"{lin}.weight"), b)
+        if bn is not None:
+            x = bn_train(x, self.g(f"{bn}.weight"), self.g(f"{bn}.bias"))
+        if slope is not None:
+            x = act(x, slope)
+        return x

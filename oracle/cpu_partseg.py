@@ -1,0 +1,95 @@
+"""CPU restatement of PointNet++ part segmentation, SSG and MSG (BASELINE configs[3]) -- TEST INFRASTRUCTURE / CPU BASELINE ONLY.
+
+Follows /root/reference/networks/seg/pointnet2_partseg.py: encoder = set-abstraction modules :40-68 (FPS once per module,
+one ball-query grouper + conv/BN/ReLU stack + max per scale, concat over the scales :66), GroupAll level reporting
+``new_xyz = zeros[B,1,3]`` :55; decoder = three ``PointNetFeaturePropagation`` (misc/ops.py:54-107: 3-NN inverse-distance
+interpolation, concat with the skip features, Conv1d(k=1, bias)+BatchNorm1d+ReLU per entry) :168-173; head Conv1d 128->128
++ BatchNorm1d (no activation) + Dropout + Conv1d 128->part_num :151-156.  Index ops come from pcl_oracle.c; the 3-NN search
+uses the direct-form squared distance with ties to the lower index (the build's documented definition -- the reference's
+matmul-form distance + full argsort order is unpinnable, see pclo_three_nn_f32).  Dropout is skipped on both sides.
+
+The MSG variant uses the consistent decoder widths 1664/576 of pointcloudlib_amd (upstream's PointNetMSG keeps the SSG
+widths and cannot run).  The module structure is read from the state dict, so one class serves both.
+"""
+import numpy as np
+import torch
+
+from . import oracle as _o
+from .cpu_common import ParamBag
+
+
+class PointNet2PartSegCPU(ParamBag):
+    """state_dict-compatible with pointcloudlib_amd.networks.seg.pointnet2_partseg.{PointNet2_partseg, PointNetMSG}.
+    ``sa_spec``: per encoder module (n_points | None, [radius per scale], [n_samples per scale])."""
+
+    SSG = [(512, [0.2], [64]), (128, [0.4], [64]), (None, [None], [None])]
+    MSG = [(512, [0.1, 0.2, 0.4], [16, 32, 128]), (128, [0.2, 0.4, 0.8], [32, 64, 128]), (None, [None], [None])]
+
+    def __init__(self, state, sa_spec, tie_stride=8, dtype=torch.float32):
+        super().__init__(state, dtype)
+        self.sa_spec = sa_spec
+        self.tie_stride = tie_stride
+
+    def sa_module(self, i, xyz, feat, aux):
+        """xyz [B,N,3], feat [B,N,C] -> (new_xyz | None, [B,m,sum C_out])"""
+        m, radii, nss = self.sa_spec[i]
+        B = xyz.shape[0]
+        xyz_np = np.ascontiguousarray(xyz.detach().float().numpy())
+        outs, rec = [], {}
+        if m is None:
+            grouped = torch.cat([xyz, feat], -1)[:, None]                                          # GroupAll (misc/ops.py:410-419)
+            y = self.mlp(f"pointnet_modules.{i}.mlps.0.", grouped.reshape(-1, grouped.shape[-1]))
+            outs.append(y.reshape(B, 1, grouped.shape[2], -1).max(dim=2)[0])
+            new_xyz = None
+        else:
+            fidx, new_xyz_np = _o.fps(xyz_np, m, block_size=self.tie_stride, return_xyz=True)      # :55
+            new_xyz = torch.from_numpy(new_xyz_np).to(self.dtype)
+            rec["fps_idx"], rec["bq_idx"] = fidx, []
+            bi = torch.arange(B)[:, None, None]
+            for j, (r, ns) in enumerate(zip(radii, nss)):
+                idx = _o.ball_query(new_xyz_np, xyz_np, r, ns)
+                rec["bq_idx"].append(idx)
+                li = torch.from_numpy(idx.astype(np.int64))
+                g_xyz = xyz[bi, li] - new_xyz[:, :, None, :]                                       # misc/ops.py:383-407
+                grouped = torch.cat([g_xyz, feat[bi, li]], -1) if feat is not None else g_xyz
+                y = self.mlp(f"pointnet_modules.{i}.mlps.{j}.", grouped.reshape(-1, grouped.shape[-1]))
+                outs.append(y.reshape(B, m, ns, -1).max(dim=2)[0])                                 # :63
+        rec["feat"] = outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1)                      # :66
+        aux.append(rec)
+        return new_xyz, rec["feat"]
+
+    def fp(self, name, xyz1, xyz2, points1, points2, aux):
+        """misc/ops.py:66-107 -> [B,N,mlp[-1]]"""
+        B, N, _ = xyz1.shape
+        S = xyz2.shape[1]
+        if S == 1:
+            interp = points2.expand(B, N, points2.shape[2])                                        # :83-84
+        else:
+            idx, w = _o.three_nn(xyz1.detach().float().numpy(), xyz2.detach().float().numpy())     # :86-92
+            aux.append({"three_nn": idx, "weights": w})
+            li = torch.from_numpy(idx.astype(np.int64))
+            nb = points2[torch.arange(B)[:, None, None], li]                                       # [B,N,3,D]
+            interp = (nb * torch.from_numpy(w).to(self.dtype)[..., None]).sum(dim=2)               # :93
+        new_points = torch.cat([points1, interp], dim=-1) if points1 is not None else interp      # :97
+        y = self.mlp(f"{name}.mlp.", new_points.reshape(B * N, -1))                                # conv(bias) + bn + relu :103-106
+        return y.reshape(B, N, -1)
+
+    def forward(self, xyz, feature, cls_label, return_aux=False):
+        """xyz [B,N,3], feature [B,N,3], cls_label one-hot [B,16] -> [B,part_num,N]"""
+        xyz, feature, cls_label = xyz.to(self.dtype), feature.to(self.dtype), cls_label.to(self.dtype)
+        B, N, _ = xyz.shape
+        aux, fp_aux = [], []
+        l1_xyz, l1_f = self.sa_module(0, xyz, feature, aux)
+        l2_xyz, l2_f = self.sa_module(1, l1_xyz, l1_f, aux)
+        _, l3_f = self.sa_module(2, l2_xyz, l2_f, aux)
+        l3_xyz = torch.zeros((B, 1, 3), dtype=self.dtype)
+        l2_f = self.fp("fp3", l2_xyz, l3_xyz, l2_f, l3_f, fp_aux)                                  # :168
+        l1_f = self.fp("fp2", l1_xyz, l2_xyz, l1_f, l2_f, fp_aux)                                  # :169
+        one_hot = cls_label.view(B, 1, 16).expand(B, N, 16)                                        # :170
+        f0 = self.fp("fp1", xyz, l1_xyz, torch.cat([one_hot, xyz, feature], 2), l1_f, fp_aux)      # :173
+        x = self.mlp("head1.", f0.reshape(B * N, -1), last_act=False)                              # Conv1d + BatchNorm1d  :152-153
+        x = self.mlp("head2.", x, last_act=False, bn=False)                                        # Conv1d 128 -> part_num :155
+        out = x.reshape(B, N, -1).permute(0, 2, 1)
+        if return_aux:
+            return out, {"sa": aux, "fp": fp_aux, "decoder": [l2_f, l1_f, f0]}
+        return out

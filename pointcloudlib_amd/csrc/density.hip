@@ -5,21 +5,24 @@
 // The reference materialises the dense [B,N,N] matrix (134 MB at N=1024) in matmul form; here one lane per
 // point i streams the cloud from LDS (SoA, broadcast reads) and keeps a running sum -- nothing N^2 touches HBM.
 // d2 is evaluated in direct form (x_i-x_j)^2+... (the matmul form -2ab+a^2+b^2 differs in the last ulps); the sum
-// runs over j ascending.  Float parity with the oracle is to tolerance (expf), not bits.
+// runs over j ascending and is kept in fp64: a running fp32 sum of N terms is ~1e-5 relative off, and DensityNet's
+// BatchNorm over this ONE channel divides by its spread (mean/std amplification) -- measured at B=32, N=1024 as a 7x
+// larger DensityNet weight-gradient error than the fp32 CPU restatement's.  Float parity with the oracle is to tolerance
+// (expf), not bits.
 #include "common.h"
 
 namespace pcl {
 
 constexpr int DEN_T = 256, DEN_CHUNK = 2048;
 
-__global__ __launch_bounds__(DEN_T) void density_kernel(const float* __restrict__ xyz, int N, float inv_2bw2, float norm,
+__global__ __launch_bounds__(DEN_T) void density_kernel(const float* __restrict__ xyz, int N, float inv_2bw2, double norm,
                                                         float* __restrict__ out) {
     __shared__ float sx[DEN_CHUNK], sy[DEN_CHUNK], sz[DEN_CHUNK];
     const int b = blockIdx.y, i = blockIdx.x * DEN_T + threadIdx.x;
     const float* P = xyz + (size_t)b * N * 3;
     float px = 0.f, py = 0.f, pz = 0.f;
     if (i < N) { px = P[3 * i]; py = P[3 * i + 1]; pz = P[3 * i + 2]; }
-    float acc = 0.f;
+    double acc = 0.0;
     for (int j0 = 0; j0 < N; j0 += DEN_CHUNK) {
         const int len = min(DEN_CHUNK, N - j0);
         __syncthreads();
@@ -31,10 +34,10 @@ __global__ __launch_bounds__(DEN_T) void density_kernel(const float* __restrict_
         __syncthreads();
         for (int k = 0; k < len; ++k) {
             const float d = sq_dist3(px, py, pz, sx[k], sy[k], sz[k]);
-            acc += expf(-d * inv_2bw2);
+            acc += (double)expf(-d * inv_2bw2);
         }
     }
-    if (i < N) out[(size_t)b * N + i] = acc * norm;
+    if (i < N) out[(size_t)b * N + i] = (float)(acc * norm);
 }
 
 }  // namespace pcl
@@ -45,7 +48,7 @@ extern "C" int pcl_density_f32(const float* xyz, int B, int N, float bandwidth, 
     PCL_REQUIRE(B >= 0 && N >= 1 && bandwidth > 0.f && B <= 65535, "pcl_density_f32: bad arguments B=%d N=%d bw=%f", B, N, bandwidth);
     if (B == 0) return PCL_OK;
     const float inv_2bw2 = 1.0f / (2.0f * bandwidth * bandwidth);
-    const float norm = 1.0f / (2.5f * bandwidth) / (float)N;
+    const double norm = 1.0 / (2.5 * (double)bandwidth) / (double)N;
     hipLaunchKernelGGL(density_kernel, dim3((N + DEN_T - 1) / DEN_T, B), dim3(DEN_T), 0, as_stream(stream), xyz, N, inv_2bw2, norm,
                        density_out);
     return check_launch("pcl_density_f32");

@@ -51,13 +51,18 @@ class DGCNN(nn.Module):
         self.dp2 = nn.Dropout(p=0.5)
         self.linear3 = nn.Linear(256, n_classes)
 
-    def forward(self, x):
-        """x [B,3,N] -> logits [B,n_classes]."""
+    def forward(self, x, lists=None, return_stages=False):
+        """x [B,3,N] -> logits [B,n_classes].  ``lists``: optional neighbour lists [4] x int32 [B,N,k] used instead of the
+        network's own kNN (the reference's ``get_graph_feature(..., idx=...)`` argument, dgcnn.py:29,33): whole-network
+        comparisons between two fp32 pipelines share one set of lists, because a near-tie in a FEATURE-space kNN orders
+        two neighbours differently for inputs that agree to 1e-6."""
         x = x.transpose(1, 2).contiguous()                                 # channel-last
-        x1 = edge_conv(self.conv1, x, knn_graph(x, self.knn))       # :100-102
-        x2 = edge_conv(self.conv2, x1, knn_graph(x1, self.knn))     # :103-105
-        x3 = edge_conv(self.conv3, x2, knn_graph(x2, self.knn))     # :106-108
-        x4 = edge_conv(self.conv4, x3, knn_graph(x3, self.knn))     # :109-111
+        g = (lambda i, t: knn_graph(t, self.knn)) if lists is None else (lambda i, t: lists[i])
+        x1 = edge_conv(self.conv1, x, g(0, x))                      # :100-102
+        x2 = edge_conv(self.conv2, x1, g(1, x1))                    # :103-105
+        x3 = edge_conv(self.conv3, x2, g(2, x2))                    # :106-108
+        x4 = edge_conv(self.conv4, x3, g(3, x3))                    # :109-111
+        stages = (x1, x2, x3, x4)
         x = torch.cat((x1, x2, x3, x4), dim=2)                              # [B,N,512]   :112
         x = self.conv5(x)                                                   # [B,N,1024]  :113
         x = torch.cat((x.max(dim=1)[0], x.mean(dim=1)), dim=1)              # :114-116
@@ -65,7 +70,8 @@ class DGCNN(nn.Module):
         x = self.dp1(x)
         x = head_layer(x, self.linear2, self.bn7, 0.2)
         x = self.dp2(x)
-        return head_layer(x, self.linear3)
+        x = head_layer(x, self.linear3)
+        return (x, stages) if return_stages else x
 
     def execute(self, *a, **k):
         return self(*a, **k)

@@ -1,0 +1,66 @@
+"""GPU: PointConv cls (BASELINE configs[4]: 1024 points, density-weighted grouped conv, B=32) against oracle/cpu_pointconv.py
+at the stated size.  FPS indices (caller-supplied start index, no origin skip) and k-NN groups exact at both sampled levels,
+level outputs and logits within 1e-5 of the fp64 value, gradients of every parameter by the fp64 yardstick
+(oracle/parity.py).  Reference: misc/pointconv_utils.py:133-170,:361-400, networks/cls/pointconv.py:8-34.
+"""
+import numpy as np
+import pytest
+import torch
+
+from pointcloudlib_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _no_dropout(model):
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return model
+
+
+def test_pointconv_cls_b32_n1024(oracle, dev):
+    from oracle.cpu_pointconv import PointConvClsCPU
+    from oracle.parity import Report
+    from pointcloudlib_amd.misc import pointconv_utils as pu
+    from pointcloudlib_amd.networks.cls.pointconv import PointConvDensityClsSsg
+    from pointcloudlib_amd.train_utils import soft_cross_entropy_loss
+    B, N = 32, 1024
+    torch.manual_seed(0)
+    pts, lab = synth.gauss_ball(B, N, 20245), synth.labels(B, 40, 21145)
+    rng = np.random.default_rng(9)
+    start = [rng.integers(0, N, B).astype(np.int32), rng.integers(0, 512, B).astype(np.int32)]
+    net = _no_dropout(PointConvDensityClsSsg().to(dev)).train()
+    state = net.state_dict()
+    r32, r64 = PointConvClsCPU(state), PointConvClsCPU(state, dtype=torch.float64)
+    xin_c = torch.from_numpy(pts).transpose(1, 2).contiguous()
+    o32, a32 = r32(xin_c, start, return_aux=True)
+    o64, a64 = r64(xin_c, start, return_aux=True)
+    soft_cross_entropy_loss(o32, torch.from_numpy(lab)).backward()
+    soft_cross_entropy_loss(o64, torch.from_numpy(lab)).backward()
+
+    xin, y = xin_c.to(dev), torch.from_numpy(lab).to(dev)
+    st = [torch.from_numpy(s).to(dev) for s in start]
+    report = Report(f"PointConv cls B={B} N={N}")
+    with torch.no_grad():
+        cur_xyz, cur_p = xin, None
+        for i, sa in enumerate((net.sa1, net.sa2, net.sa3)):
+            if not sa.group_all:
+                xyz_cl = cur_xyz.permute(0, 2, 1).contiguous()
+                fidx = pu.farthest_point_sample(xyz_cl, sa.npoint, st[i])
+                assert np.array_equal(fidx.cpu().numpy(), a32[i]["fps_idx"]), f"sa{i + 1}: FPS indices differ"
+                kidx = pu.knn_point(sa.nsample, xyz_cl, pu.index_points(xyz_cl, fidx))
+                assert np.array_equal(kidx.cpu().numpy(), a32[i]["knn_idx"]), f"sa{i + 1}: k-NN groups differ"
+            cur_xyz, cur_p = sa(cur_xyz, cur_p, st[i] if i < 2 else None)
+            report.feature(cur_p.permute(0, 2, 1), a32[i]["feat"], a64[i]["feat"], f"sa{i + 1} output")
+            if not sa.group_all:
+                assert np.array_equal(cur_xyz.permute(0, 2, 1).cpu().numpy(), a32[i]["new_xyz"].numpy()), f"sa{i + 1}: centres differ"
+    out = net(xin, st)
+    report.feature(out, o32, o64, "logits")
+    loss = soft_cross_entropy_loss(out, y)
+    loss.backward()
+    g_hip = {n: p.grad for n, p in net.named_parameters()}
+    assert all(v is not None for v in g_hip.values())
+    report.grads(g_hip, {n: r32.grad(n) for n in g_hip}, {n: r64.grad(n) for n in g_hip})
+    report.check(abs(loss.item() - soft_cross_entropy_loss(o64, torch.from_numpy(lab)).item()) <= 1e-5, 'loss differs from the fp64 restatement')
+    report.finish()
