@@ -112,7 +112,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
 
     // NOTE: nothing is stored to global memory inside the chain: a global store per step would be drained
     // (vmcnt(0)) by every __syncthreads(), adding an HBM round trip to each of the m-1 dependent steps.
-    int old = start_idx ? start_idx[b] : 0;
+    int old = start_idx ? min(max(start_idx[b], 0), N - 1) : 0;      // a caller's start index is clamped into the cloud, never trusted
     if (tid == 0) s_out[0] = old;
     const int lane = tid & 63, wid = tid >> 6;
 
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(T) void fps_kernel_lds(const float* __restrict__ xy
         s_md[k] = ((double)mag <= skip_thr) ? -1.0f : 1e10f;
     }
     __syncthreads();
-    int old = start_idx ? start_idx[b] : 0;
+    int old = start_idx ? min(max(start_idx[b], 0), N - 1) : 0;      // a caller's start index is clamped into the cloud, never trusted
     if (tid == 0) out[0] = old;
     const int lane = tid & 63, wid = tid >> 6;
     for (int step = 1; step < m; ++step) {

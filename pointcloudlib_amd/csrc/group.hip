@@ -9,6 +9,10 @@
 
 namespace pcl {
 
+// caller-supplied point indices are clamped into [0, N) before they address memory (the reference's CUDA would read or
+// atomically add out of bounds); valid lists are unaffected
+__device__ __forceinline__ int in_cloud(int k, int N) { return min(max(k, 0), N - 1); }
+
 constexpr int GT = 256;
 
 __global__ __launch_bounds__(GT) void group_fwd_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
@@ -22,7 +26,7 @@ __global__ __launch_bounds__(GT) void group_fwd_kernel(const float* __restrict__
         const int c = (int)(g - row * D);
         const size_t bj = row / ns;             // b*m + j
         const size_t b = bj / m;
-        const int k = idx[row];
+        const int k = in_cloud(idx[row], N);
         float v;
         if (c < off) v = __fsub_rn(xyz[(b * N + k) * 3 + c], new_xyz[bj * 3 + c]);
         else v = feat[(b * N + k) * C + (c - off)];
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(GT) void group_bwd_kernel(const float* __restrict__
         const size_t row = g / C;
         const int c = (int)(g - row * C);
         const size_t b = row / ((size_t)m * ns);
-        const int k = idx[row];
+        const int k = in_cloud(idx[row], N);
         unsafeAtomicAdd(&gfeat[(b * N + k) * C + c], gout[row * D + off + c]);
     }
 }
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(GT) void gather_rows_kernel(const float* __restrict
         const size_t row = g / C;               // b*M + i
         const int c = (int)(g - row * C);
         const size_t b = row / M;
-        out[g] = src[(b * N + idx[row]) * C + c];
+        out[g] = src[(b * N + in_cloud(idx[row], N)) * C + c];
     }
 }
 
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(GT) void gather_rows_bwd_kernel(const float* __rest
         const size_t row = g / C;
         const int c = (int)(g - row * C);
         const size_t b = row / M;
-        unsafeAtomicAdd(&gsrc[(b * N + idx[row]) * C + c], gout[g]);
+        unsafeAtomicAdd(&gsrc[(b * N + in_cloud(idx[row], N)) * C + c], gout[g]);
     }
 }
 
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(GT) void edge_feature_kernel(const float* __restric
         const int c = (int)(g - row * D);
         const size_t bn = row / k;               // b*N + n
         const size_t b = bn / N;
-        if (c < C) out[g] = __fsub_rn(x[(b * N + idx[row]) * C + c], x[bn * C + c]);
+        if (c < C) out[g] = __fsub_rn(x[(b * N + in_cloud(idx[row], N)) * C + c], x[bn * C + c]);
         else out[g] = x[bn * C + (c - C)];
     }
 }
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(GT) void edge_feature_bwd_nbr_kernel(const float* _
         const size_t row = g / C;
         const int c = (int)(g - row * C);
         const size_t b = row / ((size_t)N * k);
-        unsafeAtomicAdd(&gx[(b * N + idx[row]) * C + c], gout[row * D + c]);
+        unsafeAtomicAdd(&gx[(b * N + in_cloud(idx[row], N)) * C + c], gout[row * D + c]);
     }
 }
 

@@ -25,6 +25,10 @@ class GraphedStep:
         self.net, self.loss_fn, self.opt, self.dp = net, loss_fn, optimizer, dp
         dp.overlap = False                                    # no collectives from autograd hooks inside a capture
         self.side = side_stream
+        if getattr(dp, "active", False) and getattr(dp, "world", 1) > 1 and capture_optimizer:
+            # a captured opt.step() would run before any gradient exchange: the replicas would silently diverge
+            raise ValueError("GraphedStep: capture_optimizer=True cannot be combined with an active multi-rank FlatBucketDP; "
+                             "pass capture_optimizer=False (the all-reduce and the update then run eagerly after the replay)")
         self.capture_optimizer = capture_optimizer
         self.inputs = [torch.empty_like(t) for t in example_batch]
         for d, s in zip(self.inputs, example_batch):

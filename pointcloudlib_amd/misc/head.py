@@ -76,7 +76,8 @@ def head_layer(x, linear, bn=None, act=None):
     if bn is None:
         cfg = (0, 0.0, 0.0, slope)
         return _HeadLayer.apply(x, linear.weight, linear.bias, None, None, None, None, cfg)
-    mode = 1 if bn.training else 2
+    # | 4: running_var follows Jittor's rule (biased batch variance) like PointwiseMLP / pcl_bn_finalize_f32
+    mode = (1 if bn.training else 2) | 4
     momentum = 0.1 if bn.momentum is None else bn.momentum
     cfg = (mode, bn.eps, momentum, slope)
     return _HeadLayer.apply(x, linear.weight, linear.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, cfg)

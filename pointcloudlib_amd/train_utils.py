@@ -45,6 +45,8 @@ def soft_cross_entropy_loss(output, target, smoothing=True):
         return F.cross_entropy(output, target)
     eps = 0.2
     if output.is_cuda and output.dtype == torch.float32 and output.shape[0] <= 65536:
+        if target.device != output.device:          # a loader's CPU labels: the kernel would dereference a host pointer
+            target = target.to(output.device)
         return _SoftCE.apply(output, target.contiguous(), eps)
     n_class = output.shape[1]
     one_hot = torch.zeros_like(output).scatter_(1, target[:, None], 1.0)

@@ -104,6 +104,10 @@ def main():
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("train_cls.py needs a GPU (the HIP path has no CPU fallback)")
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # the reference driver is single-process (train_cls.py:54-75); this one has no gradient exchange wired in, so N copies
+        # under torchrun would train N unrelated replicas on cuda:0.  The data-parallel step lives in bench.py / dp.py.
+        raise SystemExit("train_cls.py is a single-process driver: do not launch it under torchrun (WORLD_SIZE > 1)")
     dev = torch.device("cuda")
     try:
         train_set = ModelNet40(a.num_points, True, a.batch_size, shuffle=True, root=a.data_root)
