@@ -382,9 +382,6 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
     const int wr = wave >> 1, wc = wave & 1;
     int bx, by;
     tile_of_block(blockIdx.x, p.gx, p.nt, bx, by);
-#if PCL_EXP == 5
-    if ((blockIdx.x >> 8) & 1) { __builtin_amdgcn_s_sleep(40); __builtin_amdgcn_s_sleep(40); }     // ~5k cycles: co-resident workgroups out of phase
-#endif
     const int n0 = p.n_begin + by * TBN;
     const int m_tiles = (p.M + TBM - 1) / TBM;
     const int lr = lane & 31, lh = lane >> 5;
@@ -428,28 +425,12 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         for (int k0 = 0; k0 < p.K; k0 += BK) {
-#if PCL_EXP == 1 || PCL_EXP == 2
-            const bool exp_stage = (k0 == 0 && mt == bx);      // stage once (valid LDS contents), then MFMA loop + epilogue only
-#else
-            constexpr bool exp_stage = true;
-#endif
-#if PCL_EXP != 2
             __syncthreads();                       // previous step's fragment reads are done
-#endif
-            if (exp_stage) {
             store_a<AM, VEC, TBM>(p, sA, staged_k0, tid, ra, ri);
             store_b<VEC, TBN, BT>(p, sB, n0, staged_k0, tid, rb);
-            }
             if constexpr (NEEDW) { if (tid < TBM) sW[tid] = (float)(wmeta >> 16); }
-#if PCL_EXP != 2
             __syncthreads();
-#else
-            if (exp_stage) __syncthreads();
-#endif
             // request the next step's operands (next k block, or the first k block of this workgroup's next tile)
-#if PCL_EXP == 1 || PCL_EXP == 2
-            if (false)
-#endif
             {
                 int nk = k0 + BK, nmt = mt;
                 if (nk >= p.K) { nk = 0; nmt = mt + p.gx; }
@@ -482,11 +463,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn) {
                             const float bv = s == 0 ? b4[tn].x : s == 1 ? b4[tn].y : s == 2 ? b4[tn].z : b4[tn].w;
-#if PCL_EXP == 3
-                            acc[tm][tn][s] = fmaf(av, bv, acc[tm][tn][s]);          // no matrix work: one VALU op keeps the fragment reads alive
-#else
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tm][tn], 0, 0, 0);
-#endif
                         }
                     }
                 }
@@ -1164,24 +1141,19 @@ static int launch_linear_t(const LinArgs& a_in, hipStream_t st) {
     linear_grid(a.M, a.N - a.n_begin, AM >= A_DY, RAG, gx, n_tiles, narrow, low);
     a.gx = gx; a.nt = n_tiles;
     dim3 grid(gx * n_tiles);
-#if PCL_EXP == 4
-#define PCL_DYN_LDS (96 * 1024)          // one workgroup per CU
-#else
-#define PCL_DYN_LDS 0
-#endif
     if constexpr (!RAG && GM == 0) {
         if (low) {
-            if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, 0, false, 1>), grid, dim3(MLP_T), PCL_DYN_LDS, st, a);
-            else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1, 0, false, 1>), grid, dim3(MLP_T), PCL_DYN_LDS, st, a);
+            if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, 0, false, 1>), grid, dim3(MLP_T), 0, st, a);
+            else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1, 0, false, 1>), grid, dim3(MLP_T), 0, st, a);
             return check_launch("pcl_linear");
         }
     }
     if (narrow) {
-        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, GM, RAG>), grid, dim3(MLP_T), PCL_DYN_LDS, st, a);
-        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1, GM, RAG>), grid, dim3(MLP_T), PCL_DYN_LDS, st, a);
+        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
+        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
     } else {
-        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 2, GM, RAG>), grid, dim3(MLP_T), PCL_DYN_LDS, st, a);
-        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 2, GM, RAG>), grid, dim3(MLP_T), PCL_DYN_LDS, st, a);
+        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 2, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
+        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 2, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
     }
     return check_launch("pcl_linear");
 }

@@ -3,7 +3,7 @@
 import re, subprocess, sys
 src = sys.argv[1]; sub = sys.argv[2] if len(sys.argv) > 2 else ""
 r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                    "-munsafe-fp-atomics", "-c", "--cuda-device-only", "-o", "/dev/null", src,
+                    "-munsafe-fp-atomics", *sys.argv[3:], "-c", "--cuda-device-only", "-o", "/dev/null", src,
                     "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
 cur, rows = None, {}
 for l in r.stderr.splitlines():
