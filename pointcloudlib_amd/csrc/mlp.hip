@@ -160,6 +160,168 @@ __device__ __forceinline__ void rowinfo_adopt(const LinArgs& p, int m0, int tid,
     }
 }
 
+// ---- vector path: buffer (descriptor) addressing -------------------------------------------------------------------------
+// fp32-input MFMA executes on the vector ALU datapath of gfx950: an MFMA-only wave and a VALU-only wave on one SIMD take
+// the SUM of their times, not the max (tools/ubench/coissue.hip: 1726 us + 1357 us -> 3177 us), so every VALU instruction
+// of the staging and the epilogue is paid in matrix throughput, one for one.  The vector path therefore spends none on
+// addresses or masks: operands are read through buffer descriptors rebased per tile (32-bit per-lane offsets computed once
+// per kernel, the k block in the scalar offset), and the hardware range check returns zeros for rows past M, rows of W
+// past N and k past K.  What is left unmasked is harmless: a zero-filled A row becomes act(shift) or a nonzero dy, but a
+// C row depends on its own A row only, is not stored (partial tiles take the checked epilogue) and is not summed; an
+// A value at k >= K multiplies a zero of B.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr unsigned BUF_OOB = 0xfffffff0u;           // a per-lane offset no descriptor here covers: reads 0
+
+// descriptor over [base + first_byte, base + total_bytes); both wave-uniform (read-first-laned so that hipcc can prove it)
+__device__ __forceinline__ rsrc_t buf_rsrc(const void* base, size_t first_byte, size_t total_bytes) {
+    const size_t left = total_bytes > first_byte ? total_bytes - first_byte : 0;
+    const unsigned n = left > 0xffffffffull ? 0xffffffffu : (unsigned)left;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(base) + first_byte;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* q = reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ int4 buf_ld4i(rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w);
+}
+__device__ __forceinline__ float buf_ld1(rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st1(rsrc_t r, unsigned voff, unsigned soff, float x) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0);
+}
+__device__ __forceinline__ int2 buf_ld2i(rsrc_t r, unsigned voff) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+    return make_int2((int)v.x, (int)v.y);
+}
+
+// per-thread offsets (bytes) of the vector path, computed once per kernel: A rows (tid>>3)+32i at k quad tid&7;
+// B forward: rows n = (tid>>3)+32i of W[N][K]; B backward (BT): row k = tid&31, four n at (tid>>5)*4+32i of W[K][ldb]
+template <int TBM, int TBN, bool BT>
+struct VecOff {
+    unsigned a[TBM / 32], b[TBN / 32], kq;
+    __device__ __forceinline__ void init(const LinArgs& p, int tid) {
+        const unsigned rowb = (unsigned)p.K * 4;
+        kq = (tid & 7) * 16;
+#pragma unroll
+        for (int i = 0; i < TBM / 32; ++i) a[i] = ((tid >> 3) + 32 * i) * rowb + kq;
+#pragma unroll
+        for (int i = 0; i < TBN / 32; ++i)
+            b[i] = BT ? ((tid & 31) * (unsigned)p.ldb + (tid >> 5) * 4 + 32 * i) * 4u : ((tid >> 3) + 32 * i) * rowb + kq;
+    }
+};
+
+// descriptors of the staged tile (A side: rebuilt when the tile changes) and of the whole-kernel operands
+struct VecRsrc { rsrc_t A, A2, R, B, arg, gz, sc, sh, k2, mu; };
+
+template <int AM, bool BT, bool RAG>
+__device__ __forceinline__ void vec_rsrc_kernel(const LinArgs& p, int n0, VecRsrc& r) {
+    const size_t rowb = (size_t)p.K * 4;
+    r.B = BT ? buf_rsrc(p.B, (size_t)n0 * 4, (size_t)p.K * p.ldb * 4) : buf_rsrc(p.B, (size_t)n0 * rowb, (size_t)p.N * rowb);
+    r.sc = buf_rsrc(p.sc, 0, AM != A_PLAIN ? rowb : 0); r.sh = buf_rsrc(p.sh, 0, AM != A_PLAIN ? rowb : 0);
+    r.k2 = buf_rsrc(p.k2, 0, AM >= A_DY ? rowb : 0); r.mu = buf_rsrc(p.mu, 0, AM >= A_DY ? rowb : 0);
+    // [groups][K] tables of the sparse max gradient: group ids come from the row records (or r / ns): always valid
+    r.arg = buf_rsrc(p.arg, 0, AM == A_DY_SPARSE ? 0xffffffffull : 0); r.gz = buf_rsrc(p.gz, 0, AM == A_DY_SPARSE ? 0xffffffffull : 0);
+}
+template <int AM, bool RAG>
+__device__ __forceinline__ void vec_rsrc_tile(const LinArgs& p, int m0, VecRsrc& r) {
+    const size_t rowb = (size_t)p.K * 4;
+    r.A = buf_rsrc(p.A, (size_t)m0 * rowb, AM != A_DY_SPARSE ? (size_t)p.M * rowb : 0);
+    r.A2 = buf_rsrc(p.A2, (size_t)m0 * rowb, AM >= A_DY ? (size_t)p.M * rowb : 0);
+}
+
+template <int AM, int ROWS, bool RAG>
+__device__ __forceinline__ void vload_a(const LinArgs& p, const VecRsrc& r, const unsigned (&voff)[ROWS / 32], unsigned kq, int m0, int k0,
+                                        Stage<true, ROWS>& st, const RowInfo<true, ROWS>& ri) {
+    st.m0 = m0;
+    const unsigned kb = (unsigned)k0 * 4;
+    if constexpr (AM != A_PLAIN) {
+        st.c_sc = buf_ld4(r.sc, kb + kq, 0); st.c_sh = buf_ld4(r.sh, kb + kq, 0);
+        if constexpr (AM >= A_DY) { st.c_k2 = buf_ld4(r.k2, kb + kq, 0); st.c_mu = buf_ld4(r.mu, kb + kq, 0); }
+    }
+    // k tail (K not a multiple of 32): a lane whose k quad lies past K must read zeros, not the next row
+    const bool kin = kb + kq < (unsigned)p.K * 4;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const unsigned vo = kin ? voff[i] : BUF_OOB;
+        if constexpr (AM != A_DY_SPARSE) st.v[i] = buf_ld4(r.A, vo, kb);
+        if constexpr (AM >= A_DY) st.v2[i] = buf_ld4(r.A2, vo, kb);
+        if constexpr (AM == A_DY_SPARSE) {
+            const unsigned go = (unsigned)ri.g[i] * ((unsigned)p.K * 4) + kq;
+            st.vi[i] = buf_ld4i(r.arg, go, kb);
+            st.vg[i] = buf_ld4(r.gz, go, kb);
+        }
+    }
+}
+
+template <int ROWS, bool BT>
+__device__ __forceinline__ void vload_b(const LinArgs& p, const VecRsrc& r, const unsigned (&voff)[ROWS / 32], unsigned kq, int k0,
+                                        Stage<true, ROWS>& st) {
+    if constexpr (BT) {
+#pragma unroll
+        for (int i = 0; i < ROWS / 32; ++i) st.v[i] = buf_ld4(r.B, voff[i], (unsigned)k0 * (unsigned)p.ldb * 4u);     // k >= K: past the end -> 0
+    } else {
+        const unsigned kb = (unsigned)k0 * 4;
+        const bool kin = kb + kq < (unsigned)p.K * 4;
+#pragma unroll
+        for (int i = 0; i < ROWS / 32; ++i) st.v[i] = buf_ld4(r.B, kin ? voff[i] : BUF_OOB, kb);
+    }
+}
+
+// fused transform + LDS store, vector path: no masks (see the section header).  lrelu(t) = max(t, slope*t), 0 <= slope <= 1.
+template <int AM, int ROWS>
+__device__ __forceinline__ void vstore_a(const LinArgs& p, float* sX, int tid, const Stage<true, ROWS>& st, const RowInfo<true, ROWS>& ri) {
+    const float4 sc = st.c_sc, sh = st.c_sh, k2 = st.c_k2, mu = st.c_mu;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        float4 a;
+        if constexpr (AM == A_PLAIN) {
+            a = st.v[i];
+        } else if constexpr (AM == A_BNACT) {
+            const float4 x = st.v[i];
+            const float tx = fmaf(sc.x, x.x, sh.x), ty = fmaf(sc.y, x.y, sh.y), tz = fmaf(sc.z, x.z, sh.z), tw = fmaf(sc.w, x.w, sh.w);
+            a.x = fmaxf(tx, tx * p.slope); a.y = fmaxf(ty, ty * p.slope); a.z = fmaxf(tz, tz * p.slope); a.w = fmaxf(tw, tw * p.slope);
+        } else {
+            float4 du;
+            if constexpr (AM == A_DY) du = st.v[i];
+            else {
+                const int srow = ri.rs[i];
+                const int4 ar = st.vi[i];
+                const float4 gz = st.vg[i];
+                du.x = ar.x == srow ? gz.x : 0.f; du.y = ar.y == srow ? gz.y : 0.f;
+                du.z = ar.z == srow ? gz.z : 0.f; du.w = ar.w == srow ? gz.w : 0.f;
+            }
+            const float4 y = st.v2[i];
+            const float w = ri.rw[i];            // dense BatchNorm term counts once per duplicate
+            a.x = fmaf(sc.x, du.x, -w * fmaf(k2.x, y.x - mu.x, sh.x)); a.y = fmaf(sc.y, du.y, -w * fmaf(k2.y, y.y - mu.y, sh.y));
+            a.z = fmaf(sc.z, du.z, -w * fmaf(k2.z, y.z - mu.z, sh.z)); a.w = fmaf(sc.w, du.w, -w * fmaf(k2.w, y.w - mu.w, sh.w));
+        }
+        *reinterpret_cast<float4*>(&sX[((tid >> 3) + 32 * i) * LDS_LD + (tid & 7) * 4]) = a;
+    }
+}
+
+template <int ROWS, bool BT>
+__device__ __forceinline__ void vstore_b(float* sX, int tid, const Stage<true, ROWS>& st) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const float4 v = st.v[i];
+        if constexpr (BT) {              // W[k][4 n] -> [n][k]: lanes run over k, the four dword writes are conflict-free
+            const int rl = (tid >> 5) * 4 + 32 * i;
+            sX[(rl + 0) * LDS_LD + (tid & 31)] = v.x; sX[(rl + 1) * LDS_LD + (tid & 31)] = v.y;
+            sX[(rl + 2) * LDS_LD + (tid & 31)] = v.z; sX[(rl + 3) * LDS_LD + (tid & 31)] = v.w;
+        } else {
+            *reinterpret_cast<float4*>(&sX[((tid >> 3) + 32 * i) * LDS_LD + (tid & 7) * 4]) = v;
+        }
+    }
+}
+
 // All staging loads are UNCONDITIONAL with clamped (always valid) addresses: a load under a divergent branch
 // makes hipcc drain vmcnt(0) at the branch join, which would serialise the prefetch against the MFMAs.
 // Out-of-range elements are zeroed later, in the transform/store stage.
@@ -404,16 +566,46 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
     Stage<VEC, TBM> ra;
     Stage<VEC, TBN> rb;
     RowInfo<VEC, TBM> ri;
+    VecOff<TBM, TBN, BT> vo;
+    VecRsrc vr;
+    if constexpr (VEC) { vo.init(p, tid); vec_rsrc_kernel<AM, BT, RAG>(p, n0, vr); }
+    // row records of a tile through its own descriptor (vector path): rows past M read 0 = {group 0, row 0, multiplicity 0}
+    auto vec_fetch_rows = [&](int m0) {
+        if constexpr (VEC && RAG && (AM >= A_DY || NEEDW)) {
+            vr.R = buf_rsrc(p.rmeta, (size_t)m0 * 8, (size_t)p.M * 8);
+            if constexpr (AM >= A_DY) {
+#pragma unroll
+                for (int i = 0; i < TBM / 32; ++i) ri.raw[i] = buf_ld2i(vr.R, ((tid >> 3) + 32 * i) * 8);
+            }
+        }
+    };
+    // request the operands of step (tile mt_, k block k0_); `newtile`: the staged tile changes with this step
+    auto request = [&](int mt_, int k0_, bool newtile, bool first) {
+        const int m0_ = mt_ * TBM;
+        if constexpr (VEC) {
+            if (newtile) {
+                if (first) vec_fetch_rows(m0_);
+                rowinfo_adopt<AM, VEC, TBM, RAG>(p, m0_, tid, ri);        // the records fetched one tile ahead
+                if constexpr (NEEDW) wmeta = buf_ld2i(vr.R, (tid & (TBM - 1)) * 8).y;   // (vr.R still describes this tile)
+                vec_rsrc_tile<AM, RAG>(p, m0_, vr);
+            }
+            vload_a<AM, TBM, RAG>(p, vr, vo.a, vo.kq, m0_, k0_, ra, ri);
+            vload_b<TBN, BT>(p, vr, vo.b, vo.kq, k0_, rb);
+            if (newtile) vec_fetch_rows((mt_ + p.gx) * TBM);              // after this step's loads: nothing waits for them early
+        } else {
+            if (newtile) {
+                if (first) rowinfo_fetch<AM, VEC, TBM, RAG>(p, m0_, tid, ri);
+                rowinfo_adopt<AM, VEC, TBM, RAG>(p, m0_, tid, ri);
+                rowinfo_fetch<AM, VEC, TBM, RAG>(p, (mt_ + p.gx) * TBM, tid, ri);      // clamped addresses: always valid
+                if constexpr (NEEDW) wmeta = p.rmeta[min(m0_ + (tid & (TBM - 1)), p.M - 1)].y;
+            }
+            load_a<AM, VEC, TBM, RAG>(p, m0_, k0_, tid, ra, ri);
+            load_b<VEC, TBN, BT>(p, n0, k0_, tid, rb);
+        }
+    };
     int mt = bx;
     int staged_k0 = 0;
-    if (mt < m_tiles) {
-        rowinfo_fetch<AM, VEC, TBM, RAG>(p, mt * TBM, tid, ri);
-        rowinfo_adopt<AM, VEC, TBM, RAG>(p, mt * TBM, tid, ri);
-        rowinfo_fetch<AM, VEC, TBM, RAG>(p, (mt + p.gx) * TBM, tid, ri);      // clamped addresses: always valid
-        load_a<AM, VEC, TBM, RAG>(p, mt * TBM, 0, tid, ra, ri);
-        load_b<VEC, TBN, BT>(p, n0, 0, tid, rb);
-        if constexpr (NEEDW) wmeta = p.rmeta[min(mt * TBM + (tid & (TBM - 1)), p.M - 1)].y;
-    }
+    if (mt < m_tiles) request(mt, 0, true, true);
     for (; mt < m_tiles; mt += p.gx) {
         const int m0 = mt * TBM;
         f32x16 acc[TM][TN];
@@ -426,8 +618,13 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
 
         for (int k0 = 0; k0 < p.K; k0 += BK) {
             __syncthreads();                       // previous step's fragment reads are done
-            store_a<AM, VEC, TBM>(p, sA, staged_k0, tid, ra, ri);
-            store_b<VEC, TBN, BT>(p, sB, n0, staged_k0, tid, rb);
+            if constexpr (VEC) {
+                vstore_a<AM, TBM>(p, sA, tid, ra, ri);
+                vstore_b<TBN, BT>(sB, tid, rb);
+            } else {
+                store_a<AM, VEC, TBM>(p, sA, staged_k0, tid, ra, ri);
+                store_b<VEC, TBN, BT>(p, sB, n0, staged_k0, tid, rb);
+            }
             if constexpr (NEEDW) { if (tid < TBM) sW[tid] = (float)(wmeta >> 16); }
             __syncthreads();
             // request the next step's operands (next k block, or the first k block of this workgroup's next tile)
@@ -435,15 +632,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                 int nk = k0 + BK, nmt = mt;
                 if (nk >= p.K) { nk = 0; nmt = mt + p.gx; }
                 staged_k0 = nk;
-                if (nmt < m_tiles) {
-                    if (nk == 0) {       // the staged tile changes: adopt its prefetched row records, request the tile after
-                        rowinfo_adopt<AM, VEC, TBM, RAG>(p, nmt * TBM, tid, ri);
-                        rowinfo_fetch<AM, VEC, TBM, RAG>(p, (nmt + p.gx) * TBM, tid, ri);
-                    }
-                    load_a<AM, VEC, TBM, RAG>(p, nmt * TBM, nk, tid, ra, ri);
-                    load_b<VEC, TBN, BT>(p, n0, nk, tid, rb);
-                    if constexpr (NEEDW) wmeta = p.rmeta[min(nmt * TBM + (tid & (TBM - 1)), p.M - 1)].y;
-                }
+                if (nmt < m_tiles) request(nmt, nk, nk == 0, false);     // a new tile adopts its prefetched row records
             }
             const int kc = min(BK, p.K - k0);
             const int nkk = (kc + 7) >> 3;
@@ -474,13 +663,64 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
         // Full tiles take a branch-free path (a store or load under a per-element branch makes hipcc wait
         // vmcnt(0) at every join, serialising the 64 stores of a lane).
         const bool full = (m0 + TBM <= p.M) && (n0 + TBN <= p.N);
+        float tw_all = 0.f;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int col = n0 + wc * 32 * TN + tn * 32 + lr;
             const bool cin = col < p.N;
             const float bias = ep_bias[tn], esc = ep_sc[tn], esh = ep_sh[tn];
             float ts = 0.f, tq = 0.f, tw = 0.f, piv = 0.f;
-            if (full) {
+            if (full && VEC) {
+                // Vector path: the tile leaves (and Yprev arrives) in the MFMA C/D layout as dword buffer accesses -- a lane's 16
+                // values of a 32x32 tile sit in one column, a wave instruction covers two full 128-byte row segments -- with the
+                // row of register r in the SCALAR offset: no address arithmetic and no quad transposes on the vector ALU,
+                // which is the matrix pipe here (section header of the vector path).  16 dword stores per 32x32 tile instead
+                // of 4 x 16-byte stores + 64 VALU: the stores queue beside the other wave's MFMAs, the VALU work would not.
+                const unsigned ldcb = (unsigned)p.ldc * 4;
+                const rsrc_t rC = buf_rsrc(p.C, (size_t)m0 * ldcb, (size_t)p.M * ldcb);
+                const unsigned vC = (unsigned)(wr * (32 * TM) + 4 * lh) * ldcb + (unsigned)col * 4;
+                float yv[EM == E_MASK_STORE_STATS ? TM : 1][16];
+                if constexpr (EM == E_MASK_STORE_STATS) {          // (Yprev has the row stride of C there)
+                    const rsrc_t rY = buf_rsrc(p.Yprev, (size_t)m0 * ldcb, (size_t)p.M * ldcb);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) yv[tm][r] = buf_ld1(rY, vC, (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * ldcb);
+                }
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    if (tm == 0) piv = EM == E_MASK_STORE_STATS ? yv[0][0] : acc[0][tn][0] + bias;
+                    float wv[16];
+                    if constexpr (NEEDW) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 t = *reinterpret_cast<const float4*>(&sW[wr * (32 * TM) + tm * 32 + 8 * q + 4 * lh]);
+                            wv[4 * q] = t.x; wv[4 * q + 1] = t.y; wv[4 * q + 2] = t.z; wv[4 * q + 3] = t.w;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float c = acc[tm][tn][r] + bias;
+                        if constexpr (EM == E_MASK_STORE_STATS) {
+                            const float y = yv[tm][r];
+                            c = fmaf(esc, y, esh) > 0.f ? c : c * p.eslope;
+                            ts += c; tq = fmaf(c, y - piv, tq);
+                        } else if constexpr (EM == E_STORE_STATS) {
+                            const float d = c - piv;
+                            if constexpr (RAG) { const float w = wv[r]; if (tn == 0) tw += w; ts = fmaf(w, d, ts); tq = fmaf(w * d, d, tq); }
+                            else { ts += d; tq = fmaf(d, d, tq); }
+                        }
+                        buf_st1(rC, vC, (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * ldcb, c);
+                    }
+                }
+                if constexpr (RAG && EM == E_STORE_STATS) { if (tn == 0) tw_all = tw; else tw = tw_all; }     // sum of multiplicities: same for every column
+                if constexpr (EM == E_MASK_STORE_STATS) {
+                    st_s[tn] += (double)ts; st_q[tn] += (double)tq + (double)piv * (double)ts;
+                } else if constexpr (EM == E_STORE_STATS) {
+                    const double n = RAG ? (double)tw : 16.0 * TM, pv = piv;
+                    st_s[tn] += (double)ts + n * pv; st_q[tn] += (double)tq + 2.0 * pv * (double)ts + n * pv * pv;
+                }
+            } else if (full) {
                 const bool b0 = lane & 1, b1 = lane & 2;
                 const int qcol = n0 + wc * 32 * TN + tn * 32 + (lr & ~3);      // first of this lane's 4 columns after the transpose
 #pragma unroll

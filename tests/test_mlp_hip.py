@@ -234,6 +234,7 @@ def test_head_layer_matches_torch(dev, R, K, N, bn, slope, bias):
                 m.train(training)
         x = torch.randn(R, K, device=dev, requires_grad=True)
         g = torch.randn(R, N, device=dev)
+        rv0 = b_d.running_var.clone() if bn else None
         out = head_layer(x, lin, b, act)
         out.backward(g)
         xd = x.detach().double().requires_grad_(True)
@@ -246,8 +247,13 @@ def test_head_layer_matches_torch(dev, R, K, N, bn, slope, bias):
         if bias:
             pairs.append(("db", lin.bias.grad, lin_d.bias.grad))
         if bn:
+            # running_var follows Jittor's nn.BatchNorm: r += (biased batch variance - r) * momentum, where
+            # torch's BatchNorm1d uses the unbiased one -- redo the reference's update with the biased variance
+            rvar_ref = b_d.running_var
+            if training:
+                rvar_ref = rv0 + (lin_d(xd).detach().var(dim=0, unbiased=False) - rv0) * b_d.momentum
             pairs += [("dgamma", b.weight.grad, b_d.weight.grad), ("dbeta", b.bias.grad, b_d.bias.grad),
-                      ("rmean", b.running_mean, b_d.running_mean), ("rvar", b.running_var, b_d.running_var)]
+                      ("rmean", b.running_mean, b_d.running_mean), ("rvar", b.running_var, rvar_ref)]
         for name, a, r in pairs:
             s = max(1.0, r.abs().max().item())
             assert (a.double() - r).abs().max().item() <= 2e-5 * s, (name, training)
