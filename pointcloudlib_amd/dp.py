@@ -15,8 +15,9 @@ over no exchange, two buckets after backward the same, two buckets with the earl
 early issue lands in the part of backward where the GPU runs short kernels (head, GroupAll level) and waits for the
 host, so ProcessGroupNCCL's ~0.1 ms of host work per collective is fully exposed there, more than the ~0.1 ms an
 8-rank 5.9 MB all-reduce costs when left exposed.  Hence overlap is off by default.
-BatchNorm statistics stay per-rank (weak scaling, per-GPU batch = the reference's batch; a synchronised BatchNorm for
-strong-scaling parity is not built).
+BatchNorm statistics stay per-rank by default (weak scaling, per-GPU batch = the reference's batch); ``sync_bn=True``
+all-reduces the fp64 batch sums of every BatchNorm (pointcloudlib_amd/syncbn.py): the G-rank step then equals the 1-rank step
+on the concatenated batch (tests/test_syncbn_gpu.py).
 """
 import torch
 import torch.distributed as dist
@@ -40,10 +41,14 @@ class FlatBucketDP:
     (then: one ``backward()`` per ``zero_grad()``, no gradient accumulation across backward calls).
     Without an initialised process group nothing is copied or communicated at all."""
 
-    def __init__(self, module, process_group=None, broadcast=True, bucket_bytes=None, overlap=False):
+    def __init__(self, module, process_group=None, broadcast=True, bucket_bytes=None, overlap=False, sync_bn=False):
         self.module = module
         self.group = process_group
         self.active = dist.is_available() and dist.is_initialized()        # a 1-rank group still runs the collective
+        self.sync_bn = bool(sync_bn) and self.active
+        if self.sync_bn:
+            from . import syncbn
+            syncbn.enable(process_group)
         self.world = dist.get_world_size(process_group) if self.active else 1
         self.overlap = overlap
         self.params = [p for p in module.parameters() if p.requires_grad]

@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .. import _lib
+from .. import _lib, syncbn
 from .ops import _p, _stream
 
 MAX_ROWS = 64
@@ -72,6 +72,11 @@ def head_layer(x, linear, bn=None, act=None):
         y = linear(x)
         if bn is not None:
             y = bn(y)
+        return y if slope == 1.0 else F.leaky_relu(y, slope)
+    if bn is not None and bn.training and syncbn.active():
+        # synchronised statistics over all ranks' rows: the one-kernel layer computes its batch statistics inside the kernel,
+        # so this case (R <= 64 rows per rank) runs the library GEMM + syncbn.batch_norm_1d (fp64 sums, biased running variance)
+        y = syncbn.batch_norm_1d(linear(x), bn)
         return y if slope == 1.0 else F.leaky_relu(y, slope)
     if bn is None:
         cfg = (0, 0.0, 0.0, slope)

@@ -9,7 +9,7 @@ import ctypes
 
 import torch
 
-from .. import _lib
+from .. import _lib, syncbn
 
 _P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
 
@@ -117,7 +117,8 @@ class _FusedMLP(torch.autograd.Function):
                           algo_flops=_rows_cost(nrows, P, 2 * cin * cout, 0), tag=f"fwd{cin}x{cout}")
             if bn and training:
                 scale, shift, mean, invstd = _empty((4, cout), dev).unbind(0)     # one allocation: the host enqueues ~2 us per torch.empty
-                _lib.call("pcl_bn_finalize_f32", _P(stats), rows, _P(gamma), _P(beta), Pbn, cout, eps, momentum, _P(scale),
+                f_stats, f_rows, f_P = (stats, rows, Pbn) if not syncbn.active() else syncbn.reduce_rows(stats, rows, Pbn)
+                _lib.call("pcl_bn_finalize_f32", _P(f_stats), f_rows, _P(gamma), _P(beta), f_P, cout, eps, momentum, _P(scale),
                           _P(shift), _P(mean), _P(invstd), _P(rmean), _P(rvar), st)
             elif bn:
                 invstd = torch.rsqrt(rvar + eps)
@@ -216,6 +217,12 @@ class _FusedMLP(torch.autograd.Function):
                 dbias = _empty((cout,), dev) if bias is not None else None        # exactly zero under BatchNorm: cleared there
                 _lib.call("pcl_bn_bwd_consts_f32", _P(stats), rows, _P(gamma), _P(means[l]), _P(invstds[l]), P, cout,
                           _P(dgamma), _P(dbeta), _P(a), _P(k1), _P(k2), _P(dbias), st)
+                if syncbn.active():
+                    # dgamma / dbeta above: sums over THIS rank's rows (the gradient all-reduce averages them); the constants
+                    # of dy = a*du - k1 - k2*(y - mean) come from the global sums over the global row count (syncbn.py)
+                    g_stats, g_rows, g_P = syncbn.reduce_rows(stats, rows, P)
+                    _lib.call("pcl_bn_bwd_consts_f32", _P(g_stats), g_rows, _P(gamma), _P(means[l]), _P(invstds[l]), g_P, cout,
+                              None, None, _P(a), _P(k1), _P(k2), None, st)
                 grads[6 * l + 1], grads[6 * l + 2], grads[6 * l + 3] = dbias, dgamma, dbeta
             else:
                 s = stats[:rows].sum(0)

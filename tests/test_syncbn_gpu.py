@@ -1,0 +1,109 @@
+"""GPU: data-parallel step with synchronised BatchNorm == the single-process step on the concatenated batch
+(SURVEY.md section 8e).  Two ranks over gloo, BOTH on cuda:0 (a gpurun box has one GPU), the real PointNet2_cls:
+2 x B=16 against 1 x B=32 with the FPS tie stride passed explicitly (the reference derives it from the LOCAL batch size).
+Sampled indices must be identical (they are per cloud); logits and the averaged gradients of all parameters must agree
+to fp32 summation order: BatchNorm sums are exchanged as fp64 (pointcloudlib_amd/syncbn.py), so what differs is the order
+in which each rank's GEMM tiles and atomics add up."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+B, N, TIE = 32, 1024, 8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(dev):
+    from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
+    torch.manual_seed(0)
+    net = PointNet2_cls().to(dev).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, "tie_stride"):
+            m.tie_stride = TIE
+    return net
+
+
+def _batch(dev):
+    from pointcloudlib_amd import synth
+    return (torch.from_numpy(synth.gauss_ball(B, N, 31)).to(dev), torch.from_numpy(synth.unit_normals(B, N, 32)).to(dev),
+            torch.from_numpy(synth.labels(B, 40, 33)).to(dev))
+
+
+def _step(net, x, f, y, dp=None):
+    from pointcloudlib_amd.train_utils import soft_cross_entropy_loss
+    if dp is not None:
+        dp.zero_grad()
+    out = net(x, f)
+    soft_cross_entropy_loss(out, y).backward()
+    if dp is not None:
+        dp.all_reduce()
+    return out.detach()
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    from pointcloudlib_amd.dp import FlatBucketDP, shard_batch
+    net = _build(dev)
+    dp = FlatBucketDP(net, sync_bn=True)
+    x, f, y = shard_batch(_batch(dev), rank, world)
+    out = _step(net, x.contiguous(), f.contiguous(), y.contiguous(), dp)
+    torch.cuda.synchronize()
+    state = {"out": out.cpu(), "grads": {n: p.grad.detach().cpu() for n, p in net.named_parameters()},
+             "running": {n: b.detach().cpu() for n, b in net.named_buffers() if "running" in n}}
+    torch.save(state, os.path.join(outdir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_syncbn_equal_one_rank_on_the_whole_batch(dev):
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        r0, r1 = torch.load(os.path.join(d, "rank0.pt")), torch.load(os.path.join(d, "rank1.pt"))
+    net = _build(dev)
+    x, f, y = _batch(dev)
+    out = _step(net, x, f, y).cpu()
+    got = torch.cat([r0["out"], r1["out"]])
+    err = (got - out).abs().max().item()
+    assert err <= 1e-5 * max(1.0, out.abs().max().item()), f"logits: {err:.3e}"
+    rows = []
+    for n, p in net.named_parameters():
+        a, b, ref = r0["grads"][n], r1["grads"][n], p.grad.detach().cpu()
+        assert torch.equal(a, b), f"{n}: the ranks hold different averaged gradients"
+        rel_l2 = ((a - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+        rel_max = (a - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+        rows.append((n, rel_l2, rel_max, (a - ref).abs().max().item()))
+    gscale = max(p.grad.abs().max().item() for p in net.parameters())
+    rows.sort(key=lambda t: -t[1])
+    print(f"\n[syncbn] 2 x B=16 vs 1 x B=32: max |logit diff| {err:.2e}; gradient differences (relative L2 / max-norm), worst first:")
+    for n, e2, em, ea in rows[:6]:
+        print(f"    {n:44s} {e2:.2e} / {em:.2e}   (max |diff| {ea:.1e}; largest gradient entry of the model {gscale:.1e})")
+    # fp32 summation order (GEMM tiles, fp64 partial rows added in another order, fp32 atomics of the gradient scatters) moves
+    # pre-BatchNorm outputs by ~1e-7, which flips a few max-pool winners between rows that tie to an ulp -- the same mechanism
+    # and size as the HIP-vs-fp64 gradient error of tests/test_parity_pointnet2_gpu.py (relative L2 5e-4 .. 3e-3 there).
+    # A missing 1/world or unsynchronised statistics shows as O(1) / O(1e-1).  Tensors whose exact value is ~0 by an invariance
+    # (the beta in front of the max-pool that feeds the head's bias-free Linear + BatchNorm1d: sum_b of its gradient
+    # vanishes) are rounding noise in both runs: judged by |diff| against 1e-6 of the model's largest gradient entry.
+    bad = [(n, e2, em, ea) for n, e2, em, ea in rows if (e2 > 5e-3 or em > 2e-2) and ea > 1e-6 * gscale]
+    assert not bad, bad
+    for n, buf in net.named_buffers():
+        if "running" in n:
+            assert torch.allclose(r0["running"][n], buf.cpu(), rtol=1e-5, atol=1e-6), n
+            assert torch.equal(r0["running"][n], r1["running"][n]), n
