@@ -30,6 +30,9 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 FP32_PEAK_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
 
 
+from pointcloudlib_amd.buildinfo import csrc_sha  # noqa: E402
+
+
 def make_batches(B, N, n_batches, rank, dev, dist="gauss_ball"):
     from pointcloudlib_amd import synth
     cloud = getattr(synth, dist)
@@ -42,9 +45,10 @@ def make_batches(B, N, n_batches, rank, dev, dist="gauss_ball"):
     return out
 
 
-def cpu_baseline(state, B, N, budget_s=12.0, max_steps=3):
+def cpu_baseline(state, B, N, n_steps=10, n_warm=3):
     """The CPU restatement (oracle index ops, OpenMP over clouds + PyTorch-CPU fp32 dense ops) timed on the
-    host cores on a bounded sample of the same workload."""
+    host cores on a bounded sample of the same workload: SURVEY 8d's protocol, `n_warm` warm-up steps then the MEDIAN of
+    `n_steps` (>= 10) full fwd+bwd+SGD steps (~2 s each on the GPU box's host: ~30 s in all)."""
     import oracle
     from oracle.cpu_model import PointNet2ClsCPU
     from pointcloudlib_amd import synth
@@ -64,7 +68,7 @@ def cpu_baseline(state, B, N, budget_s=12.0, max_steps=3):
         opt.step()
 
     # PyTorch-CPU does not scale to hundreds of threads on ops this small: pick the fastest of a few thread counts
-    # with one untimed step each (these double as warm-up), then time the bounded sample with that count.
+    # with one untimed step each (the first of them after one plain step: these are the warm-up), then time with that count.
     step()
     best_t, cores = None, 1
     for c in sorted({min(ncpu, c) for c in (16, 32, 64, 128)}):
@@ -75,18 +79,21 @@ def cpu_baseline(state, B, N, budget_s=12.0, max_steps=3):
         if best_t is None or dt < best_t:
             best_t, cores = dt, c
     torch.set_num_threads(cores)
-    t0 = time.perf_counter()
-    n = 0
-    while n < max_steps and (n == 0 or time.perf_counter() - t0 < budget_s):
+    for _ in range(max(0, n_warm - 1)):
         step()
-        n += 1
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(n_steps):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    n, dt = 1, times[len(times) // 2]                     # median step
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
     return {"value": round(B * n / dt, 3), "unit": "point-clouds/s", "cores": cores, "kind": "port",
-            "sample": f"{n} fwd+bwd+SGD steps of PointNet++ SSG B={B} N={N} after warm-up; best of 16/32/64/128 "
+            "sample": f"median of {n_steps} fwd+bwd+SGD steps (min {times[0]:.2f} s, max {times[-1]:.2f} s) of PointNet++ SSG B={B} N={N} after {n_warm}+ warm-ups; best of 16/32/64/128 "
                       f"PyTorch threads = {cores} of {ncpu} logical CPUs (oracle FPS/ball-query: OpenMP over the {B} "
                       f"clouds; dense ops: PyTorch-CPU fp32; {model})",
             "label": "CPU restatement of reference semantics (Jittor not runnable)"}
@@ -275,8 +282,24 @@ def main():
         it += 1
     fence()
     dt = time.perf_counter() - t0
-    gc.enable()
     _lib.PROFILER = None
+    # host side of a step (untimed extras): the time Python needs to ENQUEUE one step with the stream empty behind it (4
+    # steps back to back without a sync; the launch queue is deeper than that), and the number of own C-ABI launches
+    host_ms = own_launches = None
+    if gs is None:
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        for _ in range(4):
+            step(it); it += 1
+        host_ms = (time.perf_counter() - h0) / 4 * 1e3
+        fence()
+        counter = _lib.KernelTimer(names=[])            # matches nothing: counts through .order without recording events
+        _lib.PROFILER = counter
+        step(it); it += 1
+        _lib.PROFILER = None
+        own_launches = counter.calls
+        fence()
+    gc.enable()
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -297,10 +320,13 @@ def main():
             else:
                 ach = r["algo_flops"] / (r["avg_ms"] * 1e-3) / 1e12
                 peak, unit = FP32_PEAK_TFLOPS, "TFLOP/s"
-            traffic, traffic_src = None, None          # PMC HBM bytes per launch, from the committed profile (a separate
-            try:                                       # rocprofv3 --pmc pass of this same command; see profiles/)
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-                if (B, N, args.dist) == (32, 1024, "gauss_ball"):        # the workload the counters were collected on
+            # PMC HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py ->
+            # profiles/r02_traffic.json).  They are only valid for the kernel sources they were measured on: the file records
+            # the git blob hashes of csrc/*.hip + common.h, and a mismatch (or another workload) prints null.
+            traffic, traffic_src = None, None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+                if (B, N, args.dist) == (32, 1024, "gauss_ball") and tj.get("csrc_sha") == csrc_sha():
                     traffic = tj["per_launch_hbm_bytes"].get(f"{key[0]}:{key[1]}")
                 traffic_src = tj["source"] if traffic is not None else None
             except Exception:
@@ -324,7 +350,11 @@ def main():
                        "global_batch": world * B, "n_points": N, "parallelism": f"dp{world}",
                        "sampling": "indices of batch t+1 on a side stream during backward of batch t" if args.prefetch_sampling
                        else "inline",
-                       "launch": launch, "grad_bucket_bytes": dp.bucket_nbytes, "grad_overlap": bool(dp.overlap and dp.active), "cpu_affinity": CPU_AFFINITY},
+                       "launch": launch, "grad_bucket_bytes": dp.bucket_nbytes, "grad_overlap": bool(dp.overlap and dp.active), "cpu_affinity": CPU_AFFINITY,
+                       "world_size": dist.get_world_size() if distributed else 1, "backend": dist.get_backend() if distributed else None,
+                       "rccl": ".".join(map(str, torch.cuda.nccl.version())) if distributed else None,
+                       "sync_bn": bool(getattr(dp, "sync_bn", False))},
+            "own_launches_per_step": own_launches, "host_enqueue_ms": None if host_ms is None else round(host_ms, 3),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

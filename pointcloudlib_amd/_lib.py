@@ -144,8 +144,10 @@ class KernelTimer:
         self.max_records = max_records                           # per (name, tag): timing events perturb the stream
         self.records = {}                                        # (each record is a marker packet), so bound them
         self.order = []                                          # (name, tag) in launch order
+        self.calls = 0                                           # every C-ABI call seen, recorded or not
 
     def want(self, name, tag=None):
+        self.calls += 1
         if self.names is not None and name not in self.names:
             return False
         if self.tags is not None and tag is not None and tag not in self.tags:

@@ -10,8 +10,11 @@ Every GEMM entry point launches exactly one kernel of its family (linear_nt_kern
 dW), in the same order every step, so the k-th family launch of a step belongs to the k-th such call of bench.py's launch
 order.  hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: units are KiB and gfx950 reports half of a wide coalesced read
 (MI355X_MICROARCH.md, HBM section)."""
-import csv, json, sys
+import csv, json, os, sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pointcloudlib_amd.buildinfo import csrc_sha  # noqa: E402
 
 FAMILY = {"linear_nt_kernel": ("pcl_linear_fwd_rows_f32", "pcl_linear_fwd_gmax_f32", "pcl_linear_fwd_f32", "pcl_linear_bwd_dx_rows_f32"),
           "linear_dw_kernel": ("pcl_linear_bwd_dw_rows_f32",)}
@@ -53,6 +56,7 @@ def main():
         for l in lines:
             fh.write(f"{l[0]},{l[1]},{l[2]},{l[3]:.1f},{l[4]:.1f},{l[5]:.0f}\n")
     json.dump({"source": out_csv, "workload": "PointNet++ SSG cls B=32 N=1024, duplicate-compacted padded rows",
+               "csrc_sha": csrc_sha(),          # bench.py prints these numbers only for the same kernel sources
                "per_launch_hbm_bytes": per_tag}, open(out_json, "w"), indent=1)
     for l in lines:
         print(f"{l[0]:30s} {l[1]:14s} {l[5] / 1e6:8.1f} MB")
