@@ -1168,6 +1168,325 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     }
 }
 
+// ---- fused backward of one layer: dX and dW from ONE pass over (dU | arg,gz ; Y ; Yprev) ---------------------------------
+// The two backward GEMMs of a layer both need dy = a*du - w*(k1 + k2*(y - mean)): formed separately, dy costs its VALU twice
+// (VALU time IS matrix time on gfx950, see the vector-path header) and (dU, Y) are read from HBM twice -- 2 of the 7
+// P-sized streams of a layer's backward.  Here a persistent workgroup (8 waves, two per SIMD so that one wave's LDS and
+// barrier waits are the other's issue slots) walks row tiles of R = 64 rows (128 when Cin = 64); per tile
+//   1. dy[R x Cout] is formed once into LDS (row-major, 4 dwords of padding) and Yprev[R x Cin] is staged raw;
+//   2. dX = dy W: eight 32x32 output tiles, one per wave, K = Cout; the weight (as stored, [k][n]) is LDS-resident for the
+//      whole kernel when it fits (<= 64 KB) -- then this loop is LDS reads and MFMAs only, no VALU, no barrier -- and is
+//      otherwise (256 x 128) streamed in chunks of 32 rows through a double-buffered stage; the epilogue masks with
+//      relu'(BN(Yprev)) read from LDS, sums (du, du*Yprev) for the BatchNorm below and stores dU_prev in the C/D layout;
+//   3. dW += dy^T z, z = lrelu(BN(Yprev)) applied while reading the staged Yprev: K = the tile's rows, A = dy columns, B = z
+//      columns, single-dword LDS reads of the same tiles; the [Cout x Cin] accumulators stay in registers for the whole
+//      kernel (1-4 32x32 tiles per wave; 64 x 64 has only four, so there two wave groups take half of the rows each) and
+//      leave once, as this workgroup's partial tile(s).
+// The next tile's raw operands are requested into registers as soon as nothing else is queued behind them in the wave's
+// in-order memory counter: right after the tile's LDS image is complete (resident weight), or after the dX loop (streamed
+// weight: a weight chunk waited for behind a row-tile prefetch would wait for all of it).
+// Supported: (Cout, Cin) in {64,128} x {64,128} and 256 x 128, a masked (non-first) layer.
+constexpr int FB_T = 512;
+__host__ __device__ constexpr int fb_rows(int Cin) { return Cin == 64 ? 128 : 64; }
+__host__ __device__ constexpr bool fb_resident(int Cout, int Cin) { return Cout * Cin * 4 <= 64 * 1024; }
+__host__ __device__ constexpr int fb_ksplit(int Cout, int Cin) { return (Cout / 32) * (Cin / 32) < 8 ? 8 / ((Cout / 32) * (Cin / 32)) : 1; }
+
+struct FbArgs {
+    const float* dU; const float* Y;                            // [P,Cout] (dU null in the sparse mode)
+    const float* a; const float* k1; const float* k2; const float* mu;       // [Cout]
+    const int32_t* arg; const float* gz; int ns;                // sparse max-pool gradient [P/ns or groups, Cout]
+    const float* W;                                             // [Cout][Cin]
+    const float* Yprev; const float* psc; const float* psh; float pslope;     // layer below: pre-BN output [P,Cin], folded BN
+    float* dUprev;                                              // [P,Cin]
+    double* stats;                                              // [gx][2][Cin]
+    float* part;                                                // [gx * ksplit][Cout][Cin] partial dW tiles
+    const int* p_dev; const int2* rmeta;                        // compacted rows
+    int P, gx;
+};
+
+template <bool SPARSE, bool RAG, int CO, int CI>
+__global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_in) {
+    FbArgs p = p_in;
+    if (p.p_dev) p.P = __builtin_amdgcn_readfirstlane(*p.p_dev);
+    constexpr int COUT = 64 * CO, CIN = 64 * CI, R = fb_rows(CIN);
+    constexpr bool WRES = fb_resident(COUT, CIN);
+    constexpr int DLD = COUT + 4, YLD = CIN + 4, WLD = CIN + 4;          // LDS row strides (dwords)
+    constexpr int WROWS = WRES ? COUT : 64;                              // resident weight, or two stages of 32 rows
+    // staging maps: thread -> (16-byte column piece, rows row0 + RP*i)
+    constexpr int CPR_O = COUT / 4, RP_O = FB_T / CPR_O, NI_O = R / RP_O;
+    constexpr int CPR_I = CIN / 4, RP_I = FB_T / CPR_I, NI_I = R / RP_I;
+    constexpr int NWB = (WRES ? COUT : 32) * CIN / 4 / FB_T;             // 16-byte weight pieces per thread (all of it | one chunk)
+    // dX: (R/32) x (CIN/32) = 8 output tiles, wave -> (rbx, cbx)
+    constexpr int CB = CIN / 32;
+    static_assert((R / 32) * CB == 8, "one dX tile per wave");
+    // dW: NTI x NTJ accumulator tiles over KW row groups of WPG waves; wave (wa, wb) of a group owns TMW x TNW tiles
+    constexpr int NTI = COUT / 32, NTJ = CIN / 32, KW = fb_ksplit(COUT, CIN), WPG = 8 / KW;
+    constexpr int WA = NTI < 4 ? NTI : 4, WB = WPG / WA, TMW = NTI / WA, TNW = NTJ / WB;
+    static_assert(WA * WB == WPG && TMW * WA == NTI && TNW * WB == NTJ, "dW tiling");
+    constexpr int KR = R / KW;                                           // rows of a tile one wave group accumulates
+    __shared__ __attribute__((aligned(16))) float lds[R * DLD + R * YLD + WROWS * WLD + 2 * R * 2];
+    float* const sDY = lds;
+    float* const sY = sDY + R * DLD;
+    float* const sWb = sY + R * YLD;
+    int2* const sMeta = reinterpret_cast<int2*>(sWb + WROWS * WLD);      // [2][R] row records {group, row-in-group | mult << 16}
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int bx = blockIdx.x;
+    const int tiles = (p.P + R - 1) / R;
+    const unsigned orow = COUT * 4u, irow = CIN * 4u;                    // bytes per row
+    // per-thread constants of the dy transform (this thread's 4 columns, fixed for the whole kernel)
+    const int oc4 = (tid % CPR_O) * 4, orow0 = tid / CPR_O;
+    const int ic4 = (tid % CPR_I) * 4, irow0 = tid / CPR_I;
+    const float4 ca = *reinterpret_cast<const float4*>(p.a + oc4), ck1 = *reinterpret_cast<const float4*>(p.k1 + oc4);
+    const float4 ck2 = *reinterpret_cast<const float4*>(p.k2 + oc4), cmu = *reinterpret_cast<const float4*>(p.mu + oc4);
+    const rsrc_t rArg = buf_rsrc(p.arg, 0, SPARSE ? 0xffffffffull : 0), rGz = buf_rsrc(p.gz, 0, SPARSE ? 0xffffffffull : 0);
+    const rsrc_t rW = buf_rsrc(p.W, 0, (size_t)COUT * irow);
+    // dX tile of this wave and the per-lane constants of its column (mask of the layer below); dW tiles and their z transform
+    const int rbx = wave / CB, cbx = wave % CB;
+    const int xcol = cbx * 32 + lr;
+    const float xsc = p.psc[xcol], xsh = p.psh[xcol];
+    const int kq = wave / WPG, wq = wave % WPG, wa = wq % WA, wb = wq / WA;
+    float zsc[TNW], zsh[TNW];
+#pragma unroll
+    for (int b = 0; b < TNW; ++b) { zsc[b] = p.psc[(wb * TNW + b) * 32 + lr]; zsh[b] = p.psh[(wb * TNW + b) * 32 + lr]; }
+    f32x16 accw[TMW][TNW];
+#pragma unroll
+    for (int a = 0; a < TMW; ++a)
+#pragma unroll
+        for (int b = 0; b < TNW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accw[a][b][r] = 0.f;
+    double st_s = 0.0, st_q = 0.0;
+
+    // ---- raw operands of one tile in registers.  256 x 128 sparse: 64 accumulator registers + 112 of prefetch do not fit
+    // beside the dW loop, so there only the first half of the (arg, gz) rows travels with the prefetch; the second half
+    // (L2 hits: a group's rows are neighbours) is requested at the top of the deposit and lands while the first is transformed.
+    constexpr int NPRE = SPARSE && COUT * CIN > 128 * 128 ? NI_O / 2 : NI_O;
+    float4 rY[NI_O], rU[SPARSE ? 1 : NI_O], rG[SPARSE ? NI_O : 1], rP[NI_I];
+    int4 rA[SPARSE ? NI_O : 1];
+    int2 rM = make_int2(0, 0);                       // row record of row tid (< R) of the tile after the requested one
+    auto record_of = [&](int tile) -> int2 {         // row record of row tid of `tile`
+        // a row past P gets multiplicity 0 and a row-in-group no `arg` entry can equal: du = 0 and dy = 0 exactly
+        const int row = tile * R + tid;
+        const bool in = tid < R && row < p.P;
+        int2 rec;
+        if constexpr (RAG) {
+            const rsrc_t rR = buf_rsrc(p.rmeta, 0, (size_t)p.P * 8);
+            rec = buf_ld2i(rR, in ? (unsigned)row * 8u : BUF_OOB);
+        } else {
+            const int g = SPARSE ? row / p.ns : 0;
+            rec = make_int2(g, (SPARSE ? row - g * p.ns : 0) | (1 << 16));
+        }
+        return in ? rec : make_int2(0, 0xffff);
+    };
+    auto request = [&](int tile, int mb) {           // issue the loads of `tile` (its row records are in sMeta[mb])
+        // rows orow0 + RP*i: the row step goes into the scalar offset (one per-lane offset for all i, no VALU per load); the
+        // hardware range check covers per-lane + scalar offset (measured: tools/ubench/bufcheck.hip), so rows past P read 0
+        const int m0 = tile * R;
+        const rsrc_t rYb = buf_rsrc(p.Y, (size_t)m0 * orow, (size_t)p.P * orow);
+        const rsrc_t rUb = buf_rsrc(p.dU, (size_t)m0 * orow, SPARSE ? 0 : (size_t)p.P * orow);
+        const rsrc_t rPb = buf_rsrc(p.Yprev, (size_t)m0 * irow, (size_t)p.P * irow);
+        const unsigned vo = (unsigned)orow0 * orow + (unsigned)oc4 * 4, vi = (unsigned)irow0 * irow + (unsigned)ic4 * 4;
+        const int2* mrow = sMeta + mb * R + orow0;
+#pragma unroll
+        for (int i = 0; i < NI_O; ++i) {
+            rY[i] = buf_ld4(rYb, vo, (unsigned)(RP_O * i) * orow);
+            if constexpr (SPARSE) {
+                if (i < NPRE) {
+                    const unsigned go = (unsigned)mrow[RP_O * i].x * orow + (unsigned)oc4 * 4;
+                    rA[i] = buf_ld4i(rArg, go, 0);
+                    rG[i] = buf_ld4(rGz, go, 0);
+                }
+            } else rU[i] = buf_ld4(rUb, vo, (unsigned)(RP_O * i) * orow);
+        }
+#pragma unroll
+        for (int i = 0; i < NI_I; ++i) rP[i] = buf_ld4(rPb, vi, (unsigned)(RP_I * i) * irow);
+    };
+    auto deposit = [&](int mb) {                     // registers -> LDS image of the requested tile: dy (transformed), Yprev (raw)
+        // (base pointer + compile-time step: the steps fold into the DS offset fields; indexed from the array start hipcc
+        // hoists one address register per row out of the tile loop and spills them)
+        const int2* mrow = sMeta + mb * R + orow0;
+        float* const dst = sDY + orow0 * DLD + oc4;
+        float* const dsty = sY + irow0 * YLD + ic4;
+        if constexpr (SPARSE) {
+#pragma unroll
+            for (int i = NPRE; i < NI_O; ++i) {
+                const unsigned go = (unsigned)mrow[RP_O * i].x * orow + (unsigned)oc4 * 4;
+                rA[i] = buf_ld4i(rArg, go, 0);
+                rG[i] = buf_ld4(rGz, go, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI_O; ++i) {
+            const int my = mrow[RP_O * i].y;
+            const float w = (float)(my >> 16);
+            float4 du;
+            if constexpr (SPARSE) {
+                const int srow = my & 0xffff;
+                du.x = rA[i].x == srow ? rG[i].x : 0.f; du.y = rA[i].y == srow ? rG[i].y : 0.f;
+                du.z = rA[i].z == srow ? rG[i].z : 0.f; du.w = rA[i].w == srow ? rG[i].w : 0.f;
+            } else du = rU[i];
+            const float4 y = rY[i];
+            float4 d;            // rows past P: du = y = 0 (range-checked loads) and w = 0 -> dy = 0 exactly
+            d.x = fmaf(ca.x, du.x, -w * fmaf(ck2.x, y.x - cmu.x, ck1.x)); d.y = fmaf(ca.y, du.y, -w * fmaf(ck2.y, y.y - cmu.y, ck1.y));
+            d.z = fmaf(ca.z, du.z, -w * fmaf(ck2.z, y.z - cmu.z, ck1.z)); d.w = fmaf(ca.w, du.w, -w * fmaf(ck2.w, y.w - cmu.w, ck1.w));
+            *reinterpret_cast<float4*>(dst + RP_O * i * DLD) = d;
+        }
+#pragma unroll
+        for (int i = 0; i < NI_I; ++i) *reinterpret_cast<float4*>(dsty + RP_I * i * YLD) = rP[i];
+    };
+    // weight rows (32*kc ...) of W[Cout][Cin] -> registers -> LDS rows (32*buf ...): one chunk of 32, or (kc = buf = 0) all
+    float4 rWt[NWB];
+    auto w_request = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < NWB; ++i) {
+            // 16-byte piece tid + FB_T * i: row tid / CPR_I + (FB_T / CPR_I) * i (the uniform part goes into the scalar offset)
+            rWt[i] = buf_ld4(rW, (unsigned)(tid / CPR_I) * irow + (unsigned)(tid % CPR_I) * 16u, (unsigned)(kc * 32 + (FB_T / CPR_I) * i) * irow);
+        }
+    };
+    auto w_deposit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NWB; ++i) {
+            *reinterpret_cast<float4*>(sWb + buf * 32 * WLD + (tid / CPR_I) * WLD + (tid % CPR_I) * 4 + (FB_T / CPR_I) * i * WLD) = rWt[i];
+        }
+    };
+
+    constexpr int NCH = COUT / 32;                   // 32-row weight chunks (even; streamed: the chunk sequence is cyclic over the tiles)
+    int tile = bx, it = 0;
+    if (tile < tiles) {
+        if (tid < R) sMeta[tid] = record_of(tile);
+        rM = record_of(tile + p.gx);
+        w_request(0);
+        w_deposit(0);
+        __syncthreads();
+        request(tile, 0);
+    }
+    for (; tile < tiles; tile += p.gx, ++it) {
+        const int m0 = tile * R, mb = it & 1;
+        const bool more = tile + p.gx < tiles;
+        // ---- LDS image of this tile, row records of the next one
+        if (tid < R) sMeta[(mb ^ 1) * R + tid] = rM;                        // (its last readers passed barrier B of the tile before)
+        deposit(mb);
+        rM = record_of(tile + 2 * p.gx);
+        __syncthreads();                                                    // A: sDY, sY, sMeta[next] complete
+        if (WRES && more) request(tile + p.gx, mb ^ 1);                     // flies under this tile's MFMAs
+        // ---- dX = dy W
+        f32x16 accx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[r] = 0.f;
+        const float* sAx = sDY + (rbx * 32 + lr) * DLD + lh * 4;
+        if constexpr (WRES) {
+            const float* sBx = sWb + (lh * 4) * WLD + xcol;
+#pragma unroll 4
+            for (int k8 = 0; k8 < COUT / 8; ++k8) {
+                const float4 a4 = *reinterpret_cast<const float4*>(sAx + k8 * 8);
+                const float* q = sBx + k8 * 8 * WLD;
+                const float b0 = q[0], b1 = q[WLD], b2 = q[2 * WLD], b3 = q[3 * WLD];
+                accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, accx, 0, 0, 0);
+            }
+        } else {
+            for (int kc = 0; kc < NCH; ++kc) {
+                w_request(kc + 1 < NCH ? kc + 1 : 0);                       // (chunk 0 again: the next tile's first)
+                const float* sBx = sWb + ((kc & 1) * 32 + lh * 4) * WLD + xcol;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(sAx + kc * 32 + kk * 8);
+                    const float* q = sBx + kk * 8 * WLD;
+                    const float b0 = q[0], b1 = q[WLD], b2 = q[2 * WLD], b3 = q[3 * WLD];
+                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, accx, 0, 0, 0);
+                }
+                w_deposit((kc + 1) & 1);                                    // the other stage: its readers finished a chunk ago
+                __syncthreads();
+            }
+        }
+        // ---- dX epilogue: mask with relu'(BN(Yprev)), sums for the BatchNorm below, store in the C/D layout
+        {
+            // row rl of the tile goes into the scalar offset; rows past P are dropped by the range check
+            const rsrc_t rD = buf_rsrc(p.dUprev, (size_t)m0 * irow, (size_t)p.P * irow);
+            float ts = 0.f, tq = 0.f;
+            const float piv = sY[(rbx * 32 + 4 * lh) * YLD + xcol];
+            const unsigned v0 = (unsigned)(4 * lh) * irow + (unsigned)xcol * 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = rbx * 32 + (r & 3) + 8 * (r >> 2);           // + 4*lh
+                const float y = sY[(rl + 4 * lh) * YLD + xcol];
+                float c = accx[r];
+                c = fmaf(xsc, y, xsh) > 0.f ? c : c * p.pslope;
+                ts += c; tq = fmaf(c, y - piv, tq);
+                buf_st1(rD, v0, (unsigned)rl * irow, c);
+            }
+            asm volatile("" : "+v"(ts), "+v"(tq));   // (else hipcc sinks these sums below the dW loop and carries 32 values through it)
+            st_s += (double)ts; st_q += (double)tq + (double)piv * (double)ts;
+        }
+        if (!WRES && more) request(tile + p.gx, mb ^ 1);                    // flies under the dW MFMAs (no weight chunk queued behind it)
+        // ---- dW += dy^T z over this wave group's rows of the tile (rows past P have dy = 0)
+        {
+            const float* sAw = sDY + (kq * KR + lh) * DLD + wa * TMW * 32 + lr;
+            const float* sBw = sY + (kq * KR + lh) * YLD + wb * TNW * 32 + lr;
+#pragma unroll 4
+            for (int ks = 0; ks < KR / 2; ++ks) {
+                float av[TMW], bv[TNW];
+#pragma unroll
+                for (int a = 0; a < TMW; ++a) av[a] = sAw[2 * ks * DLD + a * 32];
+#pragma unroll
+                for (int b = 0; b < TNW; ++b) {
+                    const float t = fmaf(zsc[b], sBw[2 * ks * YLD + b * 32], zsh[b]);
+                    bv[b] = fmaxf(t, t * p.pslope);
+                }
+#pragma unroll
+                for (int a = 0; a < TMW; ++a)
+#pragma unroll
+                    for (int b = 0; b < TNW; ++b) accw[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], accw[a][b], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                                    // B: every wave is done with sDY / sY / sMeta[mb]
+    }
+    // ---- this workgroup's partial dW tile(s) and its row of the BatchNorm sums
+    float* out = p.part + ((size_t)bx * KW + kq) * COUT * CIN;
+#pragma unroll
+    for (int a = 0; a < TMW; ++a)
+#pragma unroll
+        for (int b = 0; b < TNW; ++b) {
+            const int col = (wb * TNW + b) * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[(size_t)((wa * TMW + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CIN + col] = accw[a][b][r];
+        }
+    {
+        double s = st_s, q = st_q;
+        s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+        double* red = reinterpret_cast<double*>(lds);           // [8 waves][32][2]
+        __syncthreads();
+        if (lh == 0) { red[(wave * 32 + lr) * 2] = s; red[(wave * 32 + lr) * 2 + 1] = q; }
+        __syncthreads();
+        if (tid < CIN) {
+            const int cb_ = tid / 32, l = tid & 31;
+            double ss = 0.0, qq = 0.0;
+#pragma unroll
+            for (int w = 0; w < R / 32; ++w) { ss += red[((w * CB + cb_) * 32 + l) * 2]; qq += red[((w * CB + cb_) * 32 + l) * 2 + 1]; }
+            double* dst = p.stats + (size_t)bx * 2 * CIN;
+            dst[tid] = ss; dst[CIN + tid] = qq;
+        }
+    }
+}
+
+static int fb_grid(int P, int Cin) {
+    const int R = fb_rows(Cin), tiles = (P + R - 1) / R;
+    // one persistent workgroup per CU; PCL_FB_MAX_BLOCKS caps it (tests: several row tiles per workgroup at sizes small enough
+    // for an fp64 comparison free of ReLU-mask flips; tuning)
+    const char* e = getenv("PCL_FB_MAX_BLOCKS");
+    const int cap = e ? atoi(e) : 0;
+    int gx = cap >= 1 && cap < 256 ? cap : 256;
+    if (gx > tiles) gx = tiles;
+    if (gx < 1) gx = 1;
+    return gx;
+}
+
 // ---- BatchNorm bookkeeping (tiny kernels, one thread per channel) ---------------------------------------
 // mean/var from the fp64 partials; folded scale/shift; Jittor-style running statistics (biased variance).
 // column sums of a [rows][2][C] fp64 partial workspace: 4 channels x 64 row-lanes per 256-thread block
@@ -1581,6 +1900,60 @@ extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const
     const int blocks = (int)((n + 31) / 32);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(blocks), dim3(256), 0, st, d.part, gx, n, Cin, dw_ld ? dw_ld : Cin, dW);
     return check_launch("pcl_linear_bwd_dw_f32(reduce)");
+}
+
+extern "C" int pcl_linear_bwd_fused_supported(int Cout, int Cin) {
+    return ((Cout == 64 || Cout == 128) && (Cin == 64 || Cin == 128)) || (Cout == 256 && Cin == 128);
+}
+extern "C" int pcl_linear_bwd_fused_stat_rows(int P, int Cin) { return P < 1 ? 1 : fb_grid(P, Cin); }
+extern "C" size_t pcl_linear_bwd_fused_workspace_bytes(int P, int Cout, int Cin) {
+    if (P < 1 || Cout < 1 || Cin < 1) return 0;
+    return sizeof(float) * (size_t)fb_grid(P, Cin) * fb_ksplit(Cout, Cin) * Cout * Cin;
+}
+
+template <bool SPARSE, bool RAG>
+static int launch_fb(const FbArgs& a, int Cout, int Cin, hipStream_t st) {
+    const dim3 grid(a.gx), blk(FB_T);
+#define PCL_FB(CO, CI) hipLaunchKernelGGL((linear_bwd_fused_kernel<SPARSE, RAG, CO, CI>), grid, blk, 0, st, a)
+    if (Cout == 64 && Cin == 64) PCL_FB(1, 1);
+    else if (Cout == 64 && Cin == 128) PCL_FB(1, 2);
+    else if (Cout == 128 && Cin == 64) PCL_FB(2, 1);
+    else if (Cout == 128 && Cin == 128) PCL_FB(2, 2);
+    else PCL_FB(4, 2);
+#undef PCL_FB
+    return check_launch("pcl_linear_bwd_fused_rows_f32");
+}
+
+extern "C" int pcl_linear_bwd_fused_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2, const float* mu,
+                                             const int32_t* arg, const float* gz, int ns, const float* W, int P, int Cout, int Cin,
+                                             const float* Yprev, const float* prev_scale, const float* prev_shift, float prev_slope,
+                                             float* dUprev, double* stats_ws, float* dW, void* workspace, size_t workspace_bytes,
+                                             const int32_t* row_meta, const int32_t* n_rows_dev, void* stream) {
+    PCL_REQUIRE(Y && a_ && k1 && k2 && mu && W && Yprev && prev_scale && prev_shift && dUprev && stats_ws && dW, "pcl_linear_bwd_fused_rows_f32: null pointer");
+    PCL_REQUIRE((dU != nullptr) != (arg != nullptr && gz != nullptr), "pcl_linear_bwd_fused_rows_f32: pass dU or (arg,gz)");
+    PCL_REQUIRE(P >= 1 && (dU || ns >= 1) && pcl_linear_bwd_fused_supported(Cout, Cin),
+                "pcl_linear_bwd_fused_rows_f32: unsupported sizes P=%d Cout=%d Cin=%d ((Cout, Cin) in {64,128} x {64,128} or 256 x 128)", P, Cout, Cin);
+    PCL_REQUIRE((row_meta == nullptr) == (n_rows_dev == nullptr), "pcl_linear_bwd_fused_rows_f32: row_meta and n_rows_dev come together");
+    PCL_REQUIRE(prev_slope >= 0.f && prev_slope <= 1.f, "pcl_linear_bwd_fused_rows_f32: slope %f outside [0,1]", prev_slope);
+    PCL_REQUIRE((size_t)P * (size_t)(Cout > Cin ? Cout : Cin) * 4 < 0xffffffffull, "pcl_linear_bwd_fused_rows_f32: tensors beyond 4 GiB need the two-kernel path");
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    PCL_REQUIRE(al16(Y) && al16(W) && al16(Yprev) && al16(a_) && al16(k1) && al16(k2) && al16(mu) && (!dU || al16(dU)) && (!gz || (al16(gz) && al16(arg))),
+                "pcl_linear_bwd_fused_rows_f32: operands must be 16-byte aligned");
+    const size_t need = pcl_linear_bwd_fused_workspace_bytes(P, Cout, Cin);
+    if (!workspace || workspace_bytes < need) return fail(PCL_EWS, "pcl_linear_bwd_fused_rows_f32: workspace %zu < %zu", workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    FbArgs f = {};
+    f.dU = dU; f.Y = Y; f.a = a_; f.k1 = k1; f.k2 = k2; f.mu = mu; f.arg = arg; f.gz = gz; f.ns = ns; f.W = W;
+    f.Yprev = Yprev; f.psc = prev_scale; f.psh = prev_shift; f.pslope = prev_slope; f.dUprev = dUprev; f.stats = stats_ws;
+    f.part = static_cast<float*>(workspace); f.p_dev = n_rows_dev; f.rmeta = reinterpret_cast<const int2*>(row_meta);
+    f.P = P; f.gx = fb_grid(P, Cin);
+    int rc;
+    if (dU) rc = row_meta ? launch_fb<false, true>(f, Cout, Cin, st) : launch_fb<false, false>(f, Cout, Cin, st);
+    else rc = row_meta ? launch_fb<true, true>(f, Cout, Cin, st) : launch_fb<true, false>(f, Cout, Cin, st);
+    if (rc) return rc;
+    const size_t n = (size_t)Cout * Cin;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((int)((n + 31) / 32)), dim3(256), 0, st, f.part, f.gx * fb_ksplit(Cout, Cin), n, Cin, Cin, dW);
+    return check_launch("pcl_linear_bwd_fused_rows_f32(reduce)");
 }
 
 extern "C" int pcl_bn_finalize_f32(const double* stats_ws, int stat_rows, const float* gamma, const float* beta, int P,

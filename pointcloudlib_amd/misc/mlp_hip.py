@@ -6,12 +6,14 @@ in backward, the masked gradients ``du_l``; BatchNorm + activation are folded in
 statistics and BatchNorm-backward sums come out of GEMM epilogues (see the header of mlp.hip).
 """
 import ctypes
+import os
 
 import torch
 
 from .. import _lib, syncbn
 
 _P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+_FUSED_BWD = os.environ.get("PCL_FUSED_BWD", "1") != "0"      # lab switch: 0 = separate dX and dW kernels
 
 
 def _stream():
@@ -242,6 +244,22 @@ class _FusedMLP(torch.autograd.Function):
             Xprev = Ys[l - 1] if l > 0 else x
             psc = scales[l - 1] if l > 0 else None
             psh = shifts[l - 1] if l > 0 else None
+            if l > 0 and cin == fan_in and _FUSED_BWD and _lib.size_query("pcl_linear_bwd_fused_supported", cout, cin):
+                # one pass forms dy once and produces BOTH the previous layer's du (+ its BatchNorm-backward sums) and dW
+                nbytes = _lib.size_query("pcl_linear_bwd_fused_workspace_bytes", P, cout, cin)
+                ws = _empty(((nbytes + 3) // 4,), dev)
+                dW, dUp = _empty((cout, cin), dev), _empty((P, cin), dev)
+                rows_n = _lib.size_query("pcl_linear_bwd_fused_stat_rows", P, cin)
+                stats_n = _empty((rows_n, 2, cin), dev, torch.float64)
+                per_row = 4 * (2 * cin + (cout if sparse else 2 * cout))
+                _lib.call("pcl_linear_bwd_fused_rows_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(means[l]),
+                          _P(arg) if sparse else None, _P(gz) if sparse else None, ns or 1, _P(W), P, cout, cin, _P(Xprev), _P(psc),
+                          _P(psh), slope, _P(dUp), _P(stats_n), _P(dW), _P(ws), nbytes, _P(rmeta), _P(nrows), st,
+                          algo_bytes=_rows_cost(nrows, P, per_row, 8 * cin * cout),
+                          algo_flops=_rows_cost(nrows, P, 4 * cin * cout, 0), tag=f"fb{cout}x{cin}")
+                grads[6 * l] = dW
+                dU, sparse, stats, rows = dUp, False, stats_n, rows_n
+                continue
             nbytes = _lib.size_query("pcl_linear_bwd_dw_workspace_bytes", P, cout, cin)
             ws = _empty(((nbytes + 3) // 4,), dev)
             dW = _empty((cout, cin), dev)

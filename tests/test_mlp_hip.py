@@ -41,8 +41,62 @@ CASES = [
 ]
 
 
+# the fused backward (dX + dW of a layer in one persistent kernel): every (Cout, Cin) instantiation, dense and sparse
+FB_CASES = [
+    ([16, 128, 64, 256], (5, 25, 32), 32, False, 0.0),      # 4000 rows: 256x64 sparse, 64x128 dense
+    ([16, 64, 128, 64], (3, 1111), None, False, 0.2),       # 3333 rows (ragged last tile), no max: 64x128 and 128x64 dense
+    ([9, 128, 128, 256], (2, 30, 48), 48, True, 0.0),       # 2880 rows: 256x128 sparse, 128x128 dense
+    ([5, 64, 64, 64, 128], (7, 9, 16), 16, False, 0.0),     # 1008 rows: 128x64 sparse, 64x64 dense twice
+]
+
+
 @pytest.mark.parametrize("spec,lead,ns,bias,slope", CASES)
 def test_fused_mlp_matches_reference(dev, spec, lead, ns, bias, slope):
+    _check_against_fp64(dev, spec, lead, ns, bias, slope)
+
+
+@pytest.mark.parametrize("blocks", [3, 256])
+@pytest.mark.parametrize("spec,lead,ns,bias,slope", FB_CASES)
+def test_fused_backward_tiles_per_block(dev, monkeypatch, spec, lead, ns, bias, slope, blocks):
+    """``blocks`` = 3: every workgroup of the persistent kernel walks many row tiles (prefetch of the next tile's operands,
+    the cyclic weight-chunk stage, the double-buffered row records), at a row count where an fp64 comparison is still free
+    of ReLU-mask flips (a pre-activation within fp32 rounding of 0 turns up about once per 10^7 elements)."""
+    from pointcloudlib_amd import _lib
+    monkeypatch.setenv("PCL_FB_MAX_BLOCKS", str(blocks))
+    _lib.size_query.cache_clear()
+    try:
+        _check_against_fp64(dev, spec, lead, ns, bias, slope)
+    finally:
+        monkeypatch.delenv("PCL_FB_MAX_BLOCKS")
+        _lib.size_query.cache_clear()
+
+
+@pytest.mark.parametrize("spec,lead,ns", [([16, 128, 64, 256], (8, 512, 32), 32), ([16, 64, 128, 64], (3, 44444), None),
+                                          ([9, 128, 128, 256], (4, 500, 48), 48)])
+def test_fused_backward_equals_split_kernels_at_size(dev, spec, lead, ns):
+    """Full-size rows (2-9 tiles per workgroup): the fused kernel against the separate dX and dW kernels.  Both take the
+    ReLU masks from the same stored pre-activations with the same arithmetic, so (unlike an fp64 reference at 10^5 rows)
+    no mask can differ and the two agree to summation-order rounding."""
+    from pointcloudlib_amd.misc import mlp_hip
+    torch.manual_seed(99)
+    m = PointwiseMLP(spec, bias=False, slope=0.0).to(dev)
+    x = torch.randn(*lead, spec[0], device=dev)
+    gout = torch.randn((*lead[:-1], spec[-1]) if ns else (*lead, spec[-1]), device=dev)
+    res = {}
+    for fused in (True, False):
+        old, mlp_hip._FUSED_BWD = mlp_hip._FUSED_BWD, fused
+        try:
+            res[fused] = run(copy.deepcopy(m), x, ns, gout, "hip")
+        finally:
+            mlp_hip._FUSED_BWD = old
+    f, s = res[True], res[False]
+    assert torch.equal(f[0], s[0])
+    for name, a, b in [("x", f[1], s[1])] + [(n, f[2][n], s[2][n]) for n in s[2]]:
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-5 * max(scale, 1e-6) + 1e-7, (name, (a - b).abs().max().item(), scale)
+
+
+def _check_against_fp64(dev, spec, lead, ns, bias, slope):
     torch.manual_seed(1234 + spec[0])
     m64 = PointwiseMLP(spec, bias=bias, slope=slope).double()
     with torch.no_grad():
