@@ -1221,7 +1221,8 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
     static_assert((R / 32) * CB == 8, "one dX tile per wave");
     // dW: NTI x NTJ accumulator tiles over KW row groups of WPG waves; wave (wa, wb) of a group owns TMW x TNW tiles
     constexpr int NTI = COUT / 32, NTJ = CIN / 32, KW = fb_ksplit(COUT, CIN), WPG = 8 / KW;
-    constexpr int WA = NTI < 4 ? NTI : 4, WB = WPG / WA, TMW = NTI / WA, TNW = NTJ / WB;
+    // (the z transform costs 3 VALU per B element read: as few B tiles per wave as the shape allows)
+    constexpr int WB = NTJ < WPG ? NTJ : WPG, WA = WPG / WB, TMW = NTI / WA, TNW = NTJ / WB;
     static_assert(WA * WB == WPG && TMW * WA == NTI && TNW * WB == NTJ, "dW tiling");
     constexpr int KR = R / KW;                                           // rows of a tile one wave group accumulates
     __shared__ __attribute__((aligned(16))) float lds[R * DLD + R * YLD + WROWS * WLD + 2 * R * 2];
@@ -1279,28 +1280,43 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
         }
         return in ? rec : make_int2(0, 0xffff);
     };
-    auto request = [&](int tile, int mb) {           // issue the loads of `tile` (its row records are in sMeta[mb])
-        // rows orow0 + RP*i: the row step goes into the scalar offset (one per-lane offset for all i, no VALU per load); the
-        // hardware range check covers per-lane + scalar offset (measured: tools/ubench/bufcheck.hip), so rows past P read 0
+    // The loads of a tile are a list of NREQ single requests (compile-time index n), issued a few at a time between the
+    // MFMAs of the loop the prefetch flies under: a wave that issues 20-28 16-byte loads back to back sits in the memory
+    // issue queue for thousands of cycles while the matrix pipe of its SIMD idles (both waves of a SIMD are in the same
+    // phase).  Rows orow0 + RP*i: the row step goes into the scalar offset (one per-lane offset for all i, no VALU per load);
+    // the hardware range check covers per-lane + scalar offset (measured: tools/ubench/bufcheck.hip), so rows past P --
+    // and every row when there is no next tile (`len` = 0) -- read 0 without touching memory.
+    constexpr int PER_O = SPARSE ? 3 : 2, NREQ = NI_O * PER_O + NI_I;
+    struct ReqCtx { rsrc_t y, u, pr; const int2* mrow; unsigned vo, vi; };
+    auto req_open = [&](int tile, int mb, bool live) -> ReqCtx {
         const int m0 = tile * R;
-        const rsrc_t rYb = buf_rsrc(p.Y, (size_t)m0 * orow, (size_t)p.P * orow);
-        const rsrc_t rUb = buf_rsrc(p.dU, (size_t)m0 * orow, SPARSE ? 0 : (size_t)p.P * orow);
-        const rsrc_t rPb = buf_rsrc(p.Yprev, (size_t)m0 * irow, (size_t)p.P * irow);
-        const unsigned vo = (unsigned)orow0 * orow + (unsigned)oc4 * 4, vi = (unsigned)irow0 * irow + (unsigned)ic4 * 4;
-        const int2* mrow = sMeta + mb * R + orow0;
-#pragma unroll
-        for (int i = 0; i < NI_O; ++i) {
-            rY[i] = buf_ld4(rYb, vo, (unsigned)(RP_O * i) * orow);
-            if constexpr (SPARSE) {
+        ReqCtx c;
+        c.y = buf_rsrc(p.Y, (size_t)m0 * orow, live ? (size_t)p.P * orow : 0);
+        c.u = buf_rsrc(p.dU, (size_t)m0 * orow, !SPARSE && live ? (size_t)p.P * orow : 0);
+        c.pr = buf_rsrc(p.Yprev, (size_t)m0 * irow, live ? (size_t)p.P * irow : 0);
+        c.mrow = sMeta + mb * R + orow0;
+        c.vo = (unsigned)orow0 * orow + (unsigned)oc4 * 4; c.vi = (unsigned)irow0 * irow + (unsigned)ic4 * 4;
+        return c;
+    };
+    auto req_one = [&](const ReqCtx& c, int n) {     // n: compile-time after unrolling
+        if (n < NI_O * PER_O) {
+            const int i = n / PER_O, kind = n % PER_O;
+            if (kind == 0) rY[i] = buf_ld4(c.y, c.vo, (unsigned)(RP_O * i) * orow);
+            else if constexpr (SPARSE) {
                 if (i < NPRE) {
-                    const unsigned go = (unsigned)mrow[RP_O * i].x * orow + (unsigned)oc4 * 4;
-                    rA[i] = buf_ld4i(rArg, go, 0);
-                    rG[i] = buf_ld4(rGz, go, 0);
+                    const unsigned go = (unsigned)c.mrow[RP_O * i].x * orow + (unsigned)oc4 * 4;
+                    if (kind == 1) rA[i] = buf_ld4i(rArg, go, 0);
+                    else rG[i] = buf_ld4(rGz, go, 0);
                 }
-            } else rU[i] = buf_ld4(rUb, vo, (unsigned)(RP_O * i) * orow);
+            } else rU[i] = buf_ld4(c.u, c.vo, (unsigned)(RP_O * i) * orow);
+        } else {
+            const int i = n - NI_O * PER_O;
+            rP[i] = buf_ld4(c.pr, c.vi, (unsigned)(RP_I * i) * irow);
         }
+    };
+    auto req_slice = [&](const ReqCtx& c, int j, int J) {        // slice j of J of the list
 #pragma unroll
-        for (int i = 0; i < NI_I; ++i) rP[i] = buf_ld4(rPb, vi, (unsigned)(RP_I * i) * irow);
+        for (int n = j * NREQ / J; n < (j + 1) * NREQ / J; ++n) req_one(c, n);
     };
     auto deposit = [&](int mb) {                     // registers -> LDS image of the requested tile: dy (transformed), Yprev (raw)
         // (base pointer + compile-time step: the steps fold into the DS offset fields; indexed from the array start hipcc
@@ -1352,6 +1368,12 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
     };
 
     constexpr int NCH = COUT / 32;                   // 32-row weight chunks (even; streamed: the chunk sequence is cyclic over the tiles)
+#if PCL_EXP == 7                                     // lab build: cycles per phase of the tile loop, printed by two waves of one workgroup
+    long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define FB_MARK(i) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tlast; tlast = t_; }
+#else
+#define FB_MARK(i)
+#endif
     int tile = bx, it = 0;
     if (tile < tiles) {
         if (tid < R) sMeta[tid] = record_of(tile);
@@ -1359,52 +1381,74 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
         w_request(0);
         w_deposit(0);
         __syncthreads();
-        request(tile, 0);
+        const ReqCtx c0 = req_open(tile, 0, true);
+        req_slice(c0, 0, 1);
     }
     for (; tile < tiles; tile += p.gx, ++it) {
         const int m0 = tile * R, mb = it & 1;
         const bool more = tile + p.gx < tiles;
         // ---- LDS image of this tile, row records of the next one
+        FB_MARK(6)
         if (tid < R) sMeta[(mb ^ 1) * R + tid] = rM;                        // (its last readers passed barrier B of the tile before)
         deposit(mb);
         rM = record_of(tile + 2 * p.gx);
+        FB_MARK(0)
         __syncthreads();                                                    // A: sDY, sY, sMeta[next] complete
-        if (WRES && more) request(tile + p.gx, mb ^ 1);                     // flies under this tile's MFMAs
+        FB_MARK(1)
+        const ReqCtx cn = req_open(tile + p.gx, mb ^ 1, more);              // the next tile: requested under this tile's MFMAs
         // ---- dX = dy W
+        auto phase_dx = [&]() {
         f32x16 accx;
 #pragma unroll
         for (int r = 0; r < 16; ++r) accx[r] = 0.f;
+        // (operands of step k+1 are read from LDS before the MFMAs of step k are issued -- pinned with sched_barrier: left to
+        // itself hipcc sinks every load down to its first use and the LDS / L2 latency of each step is exposed)
         const float* sAx = sDY + (rbx * 32 + lr) * DLD + lh * 4;
+        struct XOp { float4 a; float b0, b1, b2, b3; };
+        auto x_load = [&](const float* pa, const float* pb) -> XOp {
+            XOp o;
+            o.a = *reinterpret_cast<const float4*>(pa);
+            o.b0 = pb[0]; o.b1 = pb[WLD]; o.b2 = pb[2 * WLD]; o.b3 = pb[3 * WLD];
+            return o;
+        };
+        auto x_mfma = [&](const XOp& o) {
+            accx = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a.x, o.b0, accx, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a.y, o.b1, accx, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a.z, o.b2, accx, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a.w, o.b3, accx, 0, 0, 0);
+        };
         if constexpr (WRES) {
             const float* sBx = sWb + (lh * 4) * WLD + xcol;
-#pragma unroll 4
+            XOp cur = x_load(sAx, sBx);
+#pragma unroll
             for (int k8 = 0; k8 < COUT / 8; ++k8) {
-                const float4 a4 = *reinterpret_cast<const float4*>(sAx + k8 * 8);
-                const float* q = sBx + k8 * 8 * WLD;
-                const float b0 = q[0], b1 = q[WLD], b2 = q[2 * WLD], b3 = q[3 * WLD];
-                accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, accx, 0, 0, 0);
-                accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, accx, 0, 0, 0);
-                accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, accx, 0, 0, 0);
-                accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, accx, 0, 0, 0);
+                XOp nxt = cur;
+                if (k8 + 1 < COUT / 8) nxt = x_load(sAx + (k8 + 1) * 8, sBx + (k8 + 1) * 8 * WLD);
+                req_slice(cn, k8, COUT / 8);
+                __builtin_amdgcn_sched_barrier(0);
+                x_mfma(cur);
+                cur = nxt;
             }
         } else {
+#pragma unroll
             for (int kc = 0; kc < NCH; ++kc) {
                 w_request(kc + 1 < NCH ? kc + 1 : 0);                       // (chunk 0 again: the next tile's first)
                 const float* sBx = sWb + ((kc & 1) * 32 + lh * 4) * WLD + xcol;
+                XOp cur = x_load(sAx + kc * 32, sBx);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(sAx + kc * 32 + kk * 8);
-                    const float* q = sBx + kk * 8 * WLD;
-                    const float b0 = q[0], b1 = q[WLD], b2 = q[2 * WLD], b3 = q[3 * WLD];
-                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, accx, 0, 0, 0);
-                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, accx, 0, 0, 0);
-                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, accx, 0, 0, 0);
-                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, accx, 0, 0, 0);
+                    XOp nxt = cur;
+                    if (kk + 1 < 4) nxt = x_load(sAx + kc * 32 + (kk + 1) * 8, sBx + (kk + 1) * 8 * WLD);
+                    __builtin_amdgcn_sched_barrier(0);
+                    x_mfma(cur);
+                    cur = nxt;
                 }
                 w_deposit((kc + 1) & 1);                                    // the other stage: its readers finished a chunk ago
                 __syncthreads();
             }
         }
+        FB_MARK(2)
         // ---- dX epilogue: mask with relu'(BN(Yprev)), sums for the BatchNorm below, store in the C/D layout
         {
             // row rl of the tile goes into the scalar offset; rows past P are dropped by the range check
@@ -1424,29 +1468,57 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
             asm volatile("" : "+v"(ts), "+v"(tq));   // (else hipcc sinks these sums below the dW loop and carries 32 values through it)
             st_s += (double)ts; st_q += (double)tq + (double)piv * (double)ts;
         }
-        if (!WRES && more) request(tile + p.gx, mb ^ 1);                    // flies under the dW MFMAs (no weight chunk queued behind it)
+        FB_MARK(3)
+        };
         // ---- dW += dy^T z over this wave group's rows of the tile (rows past P have dy = 0)
+        auto phase_dw = [&]() {
         {
             const float* sAw = sDY + (kq * KR + lh) * DLD + wa * TMW * 32 + lr;
             const float* sBw = sY + (kq * KR + lh) * YLD + wb * TNW * 32 + lr;
-#pragma unroll 4
-            for (int ks = 0; ks < KR / 2; ++ks) {
-                float av[TMW], bv[TNW];
+            struct WOp { float a[TMW], b[TNW]; };
+            auto w_load = [&](int ks) -> WOp {
+                WOp o;
 #pragma unroll
-                for (int a = 0; a < TMW; ++a) av[a] = sAw[2 * ks * DLD + a * 32];
+                for (int a = 0; a < TMW; ++a) o.a[a] = sAw[2 * ks * DLD + a * 32];
+#pragma unroll
+                for (int b = 0; b < TNW; ++b) o.b[b] = sBw[2 * ks * YLD + b * 32];
+                return o;
+            };
+            WOp cur = w_load(0);
+#pragma unroll
+            for (int ks = 0; ks < KR / 2; ++ks) {
+                WOp nxt = cur;
+                if (ks + 1 < KR / 2) nxt = w_load(ks + 1);
+                if constexpr (!WRES) req_slice(cn, ks, KR / 2);             // (streamed weight: no weight chunk may queue behind these)
+                __builtin_amdgcn_sched_barrier(0);
+                float bv[TNW];
 #pragma unroll
                 for (int b = 0; b < TNW; ++b) {
-                    const float t = fmaf(zsc[b], sBw[2 * ks * YLD + b * 32], zsh[b]);
+                    const float t = fmaf(zsc[b], cur.b[b], zsh[b]);
                     bv[b] = fmaxf(t, t * p.pslope);
                 }
 #pragma unroll
                 for (int a = 0; a < TMW; ++a)
 #pragma unroll
-                    for (int b = 0; b < TNW; ++b) accw[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], accw[a][b], 0, 0, 0);
+                    for (int b = 0; b < TNW; ++b) accw[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[a], bv[b], accw[a][b], 0, 0, 0);
+                cur = nxt;
             }
         }
+        FB_MARK(4)
+        };
+        // The two phases only read the tile's LDS image, in any order: with a resident weight (no barrier inside dX) waves 4-7
+        // -- the second wave of every SIMD -- take dW first, so that one wave's epilogue (VALU, LDS reads, stores; no MFMA)
+        // runs under the other's MFMAs instead of both leaving the matrix pipe idle at the same time.
+        if (!WRES || wave < 4) { phase_dx(); phase_dw(); }
+        else { phase_dw(); phase_dx(); }
         __syncthreads();                                                    // B: every wave is done with sDY / sY / sMeta[mb]
+        FB_MARK(5)
     }
+#if PCL_EXP == 7
+    if (bx == 37 && (tid == 0 || tid == 448))
+        printf("fb<%d,%d,%d> wave %d tiles %d: deposit %lld | barA %lld | dX %lld | epi %lld | dW %lld | barB %lld | top %lld  (cycles/tile)\n", (int)SPARSE, CO, CI, wave, it,
+               tph[0] / it, tph[1] / it, tph[2] / it, tph[3] / it, tph[4] / it, tph[5] / it, tph[6] / it);
+#endif
     // ---- this workgroup's partial dW tile(s) and its row of the BatchNorm sums
     float* out = p.part + ((size_t)bx * KW + kq) * COUT * CIN;
 #pragma unroll
