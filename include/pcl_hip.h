@@ -277,10 +277,12 @@ int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a, const
                           int Cin, const float* Yprev, const float* prev_scale, const float* prev_shift,
                           float prev_slope, float* dUprev, double* stats_ws, void* stream);
 /* dW[Cout,Cin] = dy^T act_prev(Xprev);  workspace of pcl_linear_bwd_dw_workspace_bytes() bytes. */
-/* One pass for BOTH backward GEMMs of a non-first layer (Cout in {64,128,256}, Cin in {64,128}; 16-byte aligned operands):
- * dy is formed once from (dU | arg,gz ; Y) and feeds dUprev = mask_prev(dy W) (+ its two channel sums, stats_ws rows =
- * pcl_linear_bwd_fused_stat_rows(P, Cin)) and dW = dy^T lrelu(BN_prev(Yprev)); Yprev is read once.  Same arguments as
- * pcl_linear_bwd_dx_rows_f32 + pcl_linear_bwd_dw_rows_f32; `workspace`: pcl_linear_bwd_fused_workspace_bytes(P,Cout,Cin). */
+/* Fused backward of one hidden layer: ONE pass over the rows forms dy = a*du - w*(k1 + k2*(y - mu)) once and produces BOTH
+ * dU_prev = (dy W) * lrelu'(BN_prev(Yprev)) (+ its BatchNorm-backward sums, [pcl_linear_bwd_fused_stat_rows(P, Cin)][2][Cin]
+ * fp64) and this workgroup's partial of dW = dy^T lrelu(BN_prev(Yprev)) in `workspace`
+ * (pcl_linear_bwd_fused_workspace_bytes(P, Cout, Cin)); Yprev is read once.  Arguments as pcl_linear_bwd_dx_rows_f32.
+ * pcl_linear_bwd_fused_finish_f32 (second launch) sums the partial tiles into dW[Cout][Cin] and -- when stats_ws is given --
+ * computes the BatchNorm-backward constants of the layer below from those sums (what pcl_bn_bwd_consts_f32 does). */
 /* reference: the autograd backward of nn.Conv 1x1 + nn.BatchNorm + nn.ReLU, networks/cls/pointnet2.py:25-29 */
 int pcl_linear_bwd_fused_supported(int Cout, int Cin);
 int pcl_linear_bwd_fused_stat_rows(int P, int Cin);
@@ -288,8 +290,12 @@ size_t pcl_linear_bwd_fused_workspace_bytes(int P, int Cout, int Cin);
 int pcl_linear_bwd_fused_rows_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2, const float* mu,
                                   const int32_t* arg, const float* gz, int ns, const float* W, int P, int Cout, int Cin,
                                   const float* Yprev, const float* prev_scale, const float* prev_shift, float prev_slope,
-                                  float* dUprev, double* stats_ws, float* dW, void* workspace, size_t workspace_bytes,
+                                  float* dUprev, double* stats_ws, void* workspace, size_t workspace_bytes,
                                   const int32_t* row_meta, const int32_t* n_rows_dev, void* stream);
+int pcl_linear_bwd_fused_finish_f32(const void* workspace, size_t workspace_bytes, int P, int Cout, int Cin, float* dW,
+                                    const double* stats_ws, const float* gamma_prev, const float* mean_prev,
+                                    const float* invstd_prev, int P_bn, float* dgamma_prev, float* dbeta_prev, float* a_prev,
+                                    float* k1_prev, float* k2_prev, float* dbias_zero_prev, void* stream);
 /* reference: workspace of pcl_linear_bwd_dw_f32 (the reference lets Jittor allocate, networks/cls/pointnet2.py:25-29) */
 size_t pcl_linear_bwd_dw_workspace_bytes(int P, int Cout, int Cin);
 /* reference: gradient of nn.Conv 1x1 w.r.t. its weight, networks/cls/pointnet2.py:25-26 */

@@ -100,7 +100,8 @@ _SIGS = {
     "pcl_linear_bwd_fused_stat_rows": (c_int, [c_int, c_int]),
     "pcl_linear_bwd_fused_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "pcl_linear_bwd_fused_rows_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_float,
-                                               _P, _P, _P, _P, c_size_t, _P, _P, _P]),
+                                               _P, _P, _P, c_size_t, _P, _P, _P]),
+    "pcl_linear_bwd_fused_finish_f32": (c_int, [_P, c_size_t, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "pcl_linear_bwd_dw_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_float, c_int, c_int, c_int, _P,
                                       _P, c_size_t, _P]),
 }

@@ -1615,12 +1615,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
 // BatchNorm backward constants from sum(du) and sum(du*y):
 //   dbeta = S1, dgamma = (S2 - mean*S1)*invstd,  dy = a*du - k1 - k2*(y - mean) with a = gamma*invstd,
 //   k2 = a*dgamma*invstd/P, k1 = a*dbeta/P   (y is centred where it is used: |mean| >> std must not cost digits).
-__global__ __launch_bounds__(256) void bn_bwd_consts_kernel(const double* __restrict__ stats, int rows, const float* __restrict__ gamma,
-                                     const float* __restrict__ mean, const float* __restrict__ invstd, int P, int C,
-                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ a_out,
-                                     float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ dbias_zero) {
-    __shared__ double red[2 * 64 * 4];
-    const int c = blockIdx.x * 4 + (threadIdx.x & 3), ry = threadIdx.x >> 2;
+struct BnConstsArgs {
+    const double* stats; int rows; const float* gamma; const float* mean; const float* invstd; int P, C;
+    float* dgamma; float* dbeta; float* a_out; float* k1; float* k2; float* dbias_zero;
+};
+__device__ __forceinline__ void bn_bwd_consts_block(const BnConstsArgs& q, int block, double* red /*[2*64*4]*/) {
+    const double* __restrict__ stats = q.stats; const int rows = q.rows, P = q.P, C = q.C;
+    const float* __restrict__ gamma = q.gamma; const float* __restrict__ mean = q.mean; const float* __restrict__ invstd = q.invstd;
+    float* __restrict__ dgamma = q.dgamma; float* __restrict__ dbeta = q.dbeta; float* __restrict__ a_out = q.a_out;
+    float* __restrict__ k1 = q.k1; float* __restrict__ k2 = q.k2; float* __restrict__ dbias_zero = q.dbias_zero;
+    const int c = block * 4 + (threadIdx.x & 3), ry = threadIdx.x >> 2;
     double s1, s2;
     stat_colsum(stats, rows, C, c, ry, s1, s2, red);
     if (ry != 0 || c >= C) return;
@@ -1635,6 +1639,33 @@ __global__ __launch_bounds__(256) void bn_bwd_consts_kernel(const double* __rest
     a_out[c] = (float)a;
     k2[c] = (float)kk2;
     k1[c] = (float)(a * s1 / P);
+}
+__global__ __launch_bounds__(256) void bn_bwd_consts_kernel(const BnConstsArgs q) {
+    __shared__ double red[2 * 64 * 4];
+    bn_bwd_consts_block(q, blockIdx.x, red);
+}
+// second (and last) launch of the fused backward of a layer: blocks [0, nred) sum the workgroups' partial dW tiles (as
+// reduce_rows_kernel), the blocks after them turn the BatchNorm sums the fused kernel left into the constants of the layer below.
+__global__ __launch_bounds__(256) void fused_finish_kernel(const float* __restrict__ part, int rows, size_t n, int ncols, float* __restrict__ out,
+                                                           int nred, const BnConstsArgs q) {
+    __shared__ double red[2 * 64 * 4];
+    if ((int)blockIdx.x >= nred) { bn_bwd_consts_block(q, blockIdx.x - nred, red); return; }
+    float* redf = reinterpret_cast<float*>(red);            // [8][33]
+    const int el = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const size_t e = (size_t)blockIdx.x * 32 + el;
+    float acc = 0.f;
+    if (e < n) {
+#pragma unroll 8
+        for (int r = ry; r < rows; r += 8) acc += part[(size_t)r * n + e];
+    }
+    redf[ry * 33 + el] = acc;
+    __syncthreads();
+    if (ry == 0 && e < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += redf[j * 33 + el];
+        out[e] = t;
+    }
 }
 
 // out[g,c] = max_s lrelu(scale*y+shift); arg = first s attaining it; ymax = y at arg.  One thread per (g,c),
@@ -1999,9 +2030,9 @@ static int launch_fb(const FbArgs& a, int Cout, int Cin, hipStream_t st) {
 extern "C" int pcl_linear_bwd_fused_rows_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2, const float* mu,
                                              const int32_t* arg, const float* gz, int ns, const float* W, int P, int Cout, int Cin,
                                              const float* Yprev, const float* prev_scale, const float* prev_shift, float prev_slope,
-                                             float* dUprev, double* stats_ws, float* dW, void* workspace, size_t workspace_bytes,
+                                             float* dUprev, double* stats_ws, void* workspace, size_t workspace_bytes,
                                              const int32_t* row_meta, const int32_t* n_rows_dev, void* stream) {
-    PCL_REQUIRE(Y && a_ && k1 && k2 && mu && W && Yprev && prev_scale && prev_shift && dUprev && stats_ws && dW, "pcl_linear_bwd_fused_rows_f32: null pointer");
+    PCL_REQUIRE(Y && a_ && k1 && k2 && mu && W && Yprev && prev_scale && prev_shift && dUprev && stats_ws, "pcl_linear_bwd_fused_rows_f32: null pointer");
     PCL_REQUIRE((dU != nullptr) != (arg != nullptr && gz != nullptr), "pcl_linear_bwd_fused_rows_f32: pass dU or (arg,gz)");
     PCL_REQUIRE(P >= 1 && (dU || ns >= 1) && pcl_linear_bwd_fused_supported(Cout, Cin),
                 "pcl_linear_bwd_fused_rows_f32: unsupported sizes P=%d Cout=%d Cin=%d ((Cout, Cin) in {64,128} x {64,128} or 256 x 128)", P, Cout, Cin);
@@ -2022,10 +2053,28 @@ extern "C" int pcl_linear_bwd_fused_rows_f32(const float* dU, const float* Y, co
     int rc;
     if (dU) rc = row_meta ? launch_fb<false, true>(f, Cout, Cin, st) : launch_fb<false, false>(f, Cout, Cin, st);
     else rc = row_meta ? launch_fb<true, true>(f, Cout, Cin, st) : launch_fb<true, false>(f, Cout, Cin, st);
-    if (rc) return rc;
+    return rc;
+}
+
+extern "C" int pcl_linear_bwd_fused_finish_f32(const void* workspace, size_t workspace_bytes, int P, int Cout, int Cin, float* dW,
+                                               const double* stats_ws, const float* gamma_prev, const float* mean_prev,
+                                               const float* invstd_prev, int P_bn, float* dgamma_prev, float* dbeta_prev,
+                                               float* a_prev, float* k1_prev, float* k2_prev, float* dbias_zero_prev, void* stream) {
+    PCL_REQUIRE(workspace && dW && P >= 1 && pcl_linear_bwd_fused_supported(Cout, Cin), "pcl_linear_bwd_fused_finish_f32: bad arguments");
+    const size_t need = pcl_linear_bwd_fused_workspace_bytes(P, Cout, Cin);
+    if (workspace_bytes < need) return fail(PCL_EWS, "pcl_linear_bwd_fused_finish_f32: workspace %zu < %zu", workspace_bytes, need);
+    BnConstsArgs q = {};
+    int extra = 0;
+    if (stats_ws) {
+        PCL_REQUIRE(mean_prev && invstd_prev && a_prev && k1_prev && k2_prev && P_bn >= 1, "pcl_linear_bwd_fused_finish_f32: null pointer");
+        q = BnConstsArgs{stats_ws, fb_grid(P, Cin), gamma_prev, mean_prev, invstd_prev, P_bn, Cin, dgamma_prev, dbeta_prev, a_prev, k1_prev, k2_prev, dbias_zero_prev};
+        extra = (Cin + 3) / 4;
+    }
     const size_t n = (size_t)Cout * Cin;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((int)((n + 31) / 32)), dim3(256), 0, st, f.part, f.gx * fb_ksplit(Cout, Cin), n, Cin, Cin, dW);
-    return check_launch("pcl_linear_bwd_fused_rows_f32(reduce)");
+    const int nred = (int)((n + 31) / 32);
+    hipLaunchKernelGGL(fused_finish_kernel, dim3(nred + extra), dim3(256), 0, as_stream(stream), static_cast<const float*>(workspace),
+                       fb_grid(P, Cin) * fb_ksplit(Cout, Cin), n, Cin, dW, nred, q);
+    return check_launch("pcl_linear_bwd_fused_finish_f32");
 }
 
 extern "C" int pcl_bn_finalize_f32(const double* stats_ws, int stat_rows, const float* gamma, const float* beta, int P,
@@ -2043,8 +2092,8 @@ extern "C" int pcl_bn_bwd_consts_f32(const double* stats_ws, int stat_rows, cons
                                      float* k1, float* k2, float* dbias_zero, void* stream) {
     PCL_REQUIRE(stats_ws && mean && invstd && a_out && k1 && k2, "pcl_bn_bwd_consts_f32: null pointer");
     PCL_REQUIRE(P >= 1 && C >= 1 && stat_rows >= 1, "pcl_bn_bwd_consts_f32: bad sizes");
-    hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), stats_ws, stat_rows,
-                       gamma, mean, invstd, P, C, dgamma, dbeta, a_out, k1, k2, dbias_zero);
+    const BnConstsArgs q = {stats_ws, stat_rows, gamma, mean, invstd, P, C, dgamma, dbeta, a_out, k1, k2, dbias_zero};
+    hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), q);
     return check_launch("pcl_bn_bwd_consts_f32");
 }
 

@@ -205,6 +205,7 @@ class _FusedMLP(torch.autograd.Function):
         grads = [None] * (6 * L)
         need_x = ctx.needs_input_grad[0]
         gx = None
+        pre = None          # BatchNorm-backward constants of layer l, when the layer above already computed them
         for l in range(L - 1, -1, -1):
             W, bias, gamma, beta, _, _ = params[6 * l:6 * l + 6]
             fan_in = W.shape[1]
@@ -213,8 +214,13 @@ class _FusedMLP(torch.autograd.Function):
             if l == 0 and sv["W0p"] is not None:
                 W = sv["W0p"]
             cout, cin = W.shape
-            a, k1, k2 = _empty((3, cout), dev).unbind(0)
-            if bn and training:
+            if pre is not None:
+                # (the layer above ran the fused kernel: its second launch already turned the sums into these constants)
+                a, k1, k2, dgamma, dbeta, dbias = pre
+                pre = None
+                grads[6 * l + 1], grads[6 * l + 2], grads[6 * l + 3] = dbias, dgamma, dbeta
+            elif bn and training:
+                a, k1, k2 = _empty((3, cout), dev).unbind(0)
                 dgamma, dbeta = _empty((cout,), dev), _empty((cout,), dev)
                 dbias = _empty((cout,), dev) if bias is not None else None        # exactly zero under BatchNorm: cleared there
                 _lib.call("pcl_bn_bwd_consts_f32", _P(stats), rows, _P(gamma), _P(means[l]), _P(invstds[l]), P, cout,
@@ -227,12 +233,13 @@ class _FusedMLP(torch.autograd.Function):
                               None, None, _P(a), _P(k1), _P(k2), None, st)
                 grads[6 * l + 1], grads[6 * l + 2], grads[6 * l + 3] = dbias, dgamma, dbeta
             else:
+                a, k1, k2 = _empty((3, cout), dev).unbind(0)
                 s = stats[:rows].sum(0)
                 a.copy_(scales[l]); k1.zero_(); k2.zero_()
                 if bn:   # eval-mode BatchNorm: affine with constant statistics
                     grads[6 * l + 3] = s[0].float()
                     grads[6 * l + 2] = ((s[1] - means[l].double() * s[0]) * invstds[l].double()).float()
-            if bias is not None and not (bn and training):
+            if bias is not None and not (bn and training) and grads[6 * l + 1] is None:
                 grads[6 * l + 1] = stats[:rows, 0].sum(0).float() * a             # without BatchNorm statistics: sum(du)
             if l == 0 and ctx.link is not None:
                 # hand the BatchNorm-backward constants of the folded first layer to _GroupLinear.backward, which forms
@@ -254,9 +261,21 @@ class _FusedMLP(torch.autograd.Function):
                 per_row = 4 * (2 * cin + (cout if sparse else 2 * cout))
                 _lib.call("pcl_linear_bwd_fused_rows_f32", _P(dU), _P(Ys[l]), _P(a), _P(k1), _P(k2), _P(means[l]),
                           _P(arg) if sparse else None, _P(gz) if sparse else None, ns or 1, _P(W), P, cout, cin, _P(Xprev), _P(psc),
-                          _P(psh), slope, _P(dUp), _P(stats_n), _P(dW), _P(ws), nbytes, _P(rmeta), _P(nrows), st,
+                          _P(psh), slope, _P(dUp), _P(stats_n), _P(ws), nbytes, _P(rmeta), _P(nrows), st,
                           algo_bytes=_rows_cost(nrows, P, per_row, 8 * cin * cout),
                           algo_flops=_rows_cost(nrows, P, 4 * cin * cout, 0), tag=f"fb{cout}x{cin}")
+                # second launch: partial tiles -> dW and (training BatchNorm below, statistics local to this rank) the
+                # constants of layer l - 1 from the sums the fused kernel left
+                if bn and training and not syncbn.active():
+                    gprev, bprev = params[6 * (l - 1) + 2], params[6 * (l - 1) + 1]
+                    pa, pk1, pk2, pdg, pdb = _empty((5, cin), dev).unbind(0)
+                    pbias = _empty((cin,), dev) if bprev is not None else None
+                    _lib.call("pcl_linear_bwd_fused_finish_f32", _P(ws), nbytes, P, cout, cin, _P(dW), _P(stats_n), _P(gprev),
+                              _P(means[l - 1]), _P(invstds[l - 1]), P, _P(pdg), _P(pdb), _P(pa), _P(pk1), _P(pk2), _P(pbias), st)
+                    pre = (pa, pk1, pk2, pdg, pdb, pbias)
+                else:
+                    _lib.call("pcl_linear_bwd_fused_finish_f32", _P(ws), nbytes, P, cout, cin, _P(dW), None, None, None, None, 0,
+                              None, None, None, None, None, None, st)
                 grads[6 * l] = dW
                 dU, sparse, stats, rows = dUp, False, stats_n, rows_n
                 continue

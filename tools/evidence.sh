@@ -1,0 +1,24 @@
+#!/bin/bash
+# One GPU-box pass that regenerates the measured evidence of a round (run through gpurun; copies go to profiles/ by hand):
+#   bash tools/evidence.sh r02
+# kernel trace + stats, FETCH_SIZE / WRITE_SIZE passes (separate runs, counters only), SQ wave-state pass, the bench line.
+R=${1:-r02}; O=gpurun_out/$R; mkdir -p $O; cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+B="python bench.py --steps 20 --warmup 3 --no-settle --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o b -- $B > $O/kt.log 2>&1
+S="python bench.py --steps 3 --warmup 1 --no-settle --no-cpu-baseline --roofline-kernel none"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o b -- $S --dump-launch-order $O/order.json > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o b -- $S > $O/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
+    --output-format csv -d $O/sq -o b -- $S > $O/sq.log 2>&1
+F=$(find $O/fetch -name '*counter_collection.csv' | head -1); W=$(find $O/write -name '*counter_collection.csv' | head -1)
+python tools/pmc_traffic.py $F $W $O/order.json $O/${R}_pmc_hbm_traffic.csv $O/${R}_traffic.json > $O/traffic.txt 2>&1
+python tools/pmc_sq.py $(find $O/sq -name '*counter_collection.csv' | head -1) $O/${R}_pmc_sq_wave_states.csv
+cp $(find $O/kt -name '*kernel_stats.csv' | head -1) $O/${R}_bench_kernel_stats.csv
+T=$(find $O/kt -name '*kernel_trace.csv' | head -1)
+python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<true, true, 4, 2>' 1 0=fb256x128 > $O/${R}_dominant_kernel_by_shape.csv 2>&1
+python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<true, true, 2, 1>' 1 0=fb128x64 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
+python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 2, 2>' 1 0=fb128x128 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
+python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 1, 1>' 1 0=fb64x64 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
+rm -rf $O/kt/*/*.db $O/fetch $O/write $O/sq/*/*.db 2>/dev/null
+python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
+tail -3 $O/kt.log; cat $O/traffic.txt | head -40; cat $O/${R}_dominant_kernel_by_shape.csv; tail -1 $O/${R}_bench_line.json

@@ -7,7 +7,8 @@
         profiles/rNN_pmc_hbm_traffic.csv profiles/rNN_traffic.json
 
 Every GEMM entry point launches exactly one kernel of its family (linear_nt_kernel for forward / dX, linear_dw_kernel for
-dW), in the same order every step, so the k-th family launch of a step belongs to the k-th such call of bench.py's launch
+dW, linear_bwd_fused_kernel for the fused dX+dW pass; the partial-tile reductions that follow are separate small kernels and
+not counted here), in the same order every step, so the k-th family launch of a step belongs to the k-th such call of bench.py's launch
 order.  hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: units are KiB and gfx950 reports half of a wide coalesced read
 (MI355X_MICROARCH.md, HBM section)."""
 import csv, json, os, sys
@@ -17,7 +18,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointcloudlib_amd.buildinfo import csrc_sha  # noqa: E402
 
 FAMILY = {"linear_nt_kernel": ("pcl_linear_fwd_rows_f32", "pcl_linear_fwd_gmax_f32", "pcl_linear_fwd_f32", "pcl_linear_bwd_dx_rows_f32"),
-          "linear_dw_kernel": ("pcl_linear_bwd_dw_rows_f32",)}
+          "linear_dw_kernel": ("pcl_linear_bwd_dw_rows_f32",),
+          "linear_bwd_fused_kernel": ("pcl_linear_bwd_fused_rows_f32",)}
 
 
 def family_series(path, counter):
