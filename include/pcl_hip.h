@@ -35,6 +35,10 @@ extern "C" {
 #define PCL_EWS (-4)      /* workspace too small                                  */
 
 int pcl_version(void);
+/* Measurement hook: arm two hipEvent_t (created with timing enabled) for the NEXT GEMM-family kernel this thread launches
+ * (linear forward / dX / dW / fused backward); they receive that kernel's own begin and end timestamps.  No reference
+ * counterpart (bench.py's roofline leg). */
+void pcl_time_next_launch(void* start_event, void* stop_event);
 /* reference: no reference counterpart: the reference has no error channel (CUDA errors surface at the next Jittor sync, misc/ops.py:269-271 are Python asserts) */
 const char* pcl_last_error(void);
 

@@ -11,7 +11,17 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
 }
+TimeHook& time_hook() {
+    static thread_local TimeHook h = {nullptr, nullptr};
+    return h;
+}
 }  // namespace pcl
+
+extern "C" void pcl_time_next_launch(void* start_event, void* stop_event) {
+    pcl::TimeHook& h = pcl::time_hook();
+    h.start = static_cast<hipEvent_t>(start_event);
+    h.stop = static_cast<hipEvent_t>(stop_event);
+}
 
 extern "C" int pcl_version(void) { return 100; }   // 0.1.0
 extern "C" const char* pcl_last_error(void) { return pcl::g_err; }

@@ -1136,10 +1136,10 @@ static void dw_grid(int P, int I, int J, int& gx, int& ti, int& tj, int& tm, int
 
 template <int AM, bool VEC, bool RAG>
 static void launch_dw_t2(const DwArgs& d, dim3 grid, int tm, int tn, hipStream_t st) {
-    if (tm == 1 && tn == 1) hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 1, 1, RAG>), grid, dim3(MLP_T), 0, st, d);
-    else if (tm == 2 && tn == 1) hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 2, 1, RAG>), grid, dim3(MLP_T), 0, st, d);
-    else if (tm == 1 && tn == 2) hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 1, 2, RAG>), grid, dim3(MLP_T), 0, st, d);
-    else hipLaunchKernelGGL((linear_dw_kernel<AM, VEC, 2, 2, RAG>), grid, dim3(MLP_T), 0, st, d);
+    if (tm == 1 && tn == 1) PCL_LAUNCH_TIMED((linear_dw_kernel<AM, VEC, 1, 1, RAG>), grid, dim3(MLP_T), st, d);
+    else if (tm == 2 && tn == 1) PCL_LAUNCH_TIMED((linear_dw_kernel<AM, VEC, 2, 1, RAG>), grid, dim3(MLP_T), st, d);
+    else if (tm == 1 && tn == 2) PCL_LAUNCH_TIMED((linear_dw_kernel<AM, VEC, 1, 2, RAG>), grid, dim3(MLP_T), st, d);
+    else PCL_LAUNCH_TIMED((linear_dw_kernel<AM, VEC, 2, 2, RAG>), grid, dim3(MLP_T), st, d);
 }
 template <int AM, bool VEC>
 static void launch_dw_t(const DwArgs& d, dim3 grid, int tm, int tn, hipStream_t st) {
@@ -1805,17 +1805,17 @@ static int launch_linear_t(const LinArgs& a_in, hipStream_t st) {
     dim3 grid(gx * n_tiles);
     if constexpr (!RAG && GM == 0) {
         if (low) {
-            if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, 0, false, 1>), grid, dim3(MLP_T), 0, st, a);
-            else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1, 0, false, 1>), grid, dim3(MLP_T), 0, st, a);
+            if (vec) PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 1, 0, false, 1>), grid, dim3(MLP_T), st, a);
+            else PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, false, 1, 0, false, 1>), grid, dim3(MLP_T), st, a);
             return check_launch("pcl_linear");
         }
     }
     if (narrow) {
-        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 1, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
-        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 1, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
+        if (vec) PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 1, GM, RAG>), grid, dim3(MLP_T), st, a);
+        else PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, false, 1, GM, RAG>), grid, dim3(MLP_T), st, a);
     } else {
-        if (vec) hipLaunchKernelGGL((linear_nt_kernel<AM, EM, true, 2, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
-        else hipLaunchKernelGGL((linear_nt_kernel<AM, EM, false, 2, GM, RAG>), grid, dim3(MLP_T), 0, st, a);
+        if (vec) PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 2, GM, RAG>), grid, dim3(MLP_T), st, a);
+        else PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, false, 2, GM, RAG>), grid, dim3(MLP_T), st, a);
     }
     return check_launch("pcl_linear");
 }
@@ -2017,7 +2017,7 @@ extern "C" size_t pcl_linear_bwd_fused_workspace_bytes(int P, int Cout, int Cin)
 template <bool SPARSE, bool RAG>
 static int launch_fb(const FbArgs& a, int Cout, int Cin, hipStream_t st) {
     const dim3 grid(a.gx), blk(FB_T);
-#define PCL_FB(CO, CI) hipLaunchKernelGGL((linear_bwd_fused_kernel<SPARSE, RAG, CO, CI>), grid, blk, 0, st, a)
+#define PCL_FB(CO, CI) PCL_LAUNCH_TIMED((linear_bwd_fused_kernel<SPARSE, RAG, CO, CI>), grid, blk, st, a)
     if (Cout == 64 && Cin == 64) PCL_FB(1, 1);
     else if (Cout == 64 && Cin == 128) PCL_FB(1, 2);
     else if (Cout == 128 && Cin == 64) PCL_FB(2, 1);
