@@ -12,6 +12,7 @@
 // (Nr/64 per lane) and extracts the k winners by k rounds of {lane-local min, DPP wave min, ballot}
 // -- no per-thread serial insertion sort over global memory as in the reference.
 #include "common.h"
+#pragma clang fp contract(off)      // index-producing arithmetic: every operation rounds on its own
 
 namespace pcl {
 
@@ -136,12 +137,244 @@ __global__ __launch_bounds__(256) void knn_select_generic_kernel(float* __restri
     }
 }
 
+// ---- fused distance + select: no [Nq x Nr] matrix ---------------------------------------------------------------------
+// One wave owns QW queries of a cloud and ALL Nr reference points: lane l holds, per query, the PPT = Nr/64 running sums of
+// the references r = 256*J + 4*l + e (e < 4: one ds_read_b128 of the staged channel row per J), i.e. QW x PPT accumulators
+// in VGPRs (128 at every supported size).  The workgroup (4 waves, 4*QW queries) streams the cloud's reference matrix
+// [C][Nr] once through a double-buffered LDS stage in chunks of CK channels, queries ride along as a [CK][4*QW] tile read
+// back as broadcasts.  Arithmetic per (query, ref, channel) is the reference's: t = ref - qry; ssd = ssd + t*t, each
+// operation rounded separately, channels ascending (misc/ops.py:488-491) -- VALU, not MFMA, because a^2+b^2-2ab rounds
+// differently and reorders near-ties.  Then each query's row is in registers already and the k winners come out by k rounds
+// of {lane-local min, DPP wave min, ballot}, ascending by (distance, r) (misc/ops.py:528-550).
+// Traffic: the reference matrix is read Nq/(4*QW) times per cloud from L2 (C*Nr*4 bytes each), nothing else but the
+// queries and the k*Nq indices: no O(Nq*Nr) workspace.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int PPT>
+struct KnnCfg {
+    static constexpr int QW = 128 / PPT > 8 ? 8 : 128 / PPT;     // queries per wave
+    static constexpr int NRP = PPT * 64;                         // padded reference count
+    static constexpr int CK = 8192 / NRP > 32 ? 32 : 8192 / NRP; // channels per LDS stage (<= 32 KB of references)
+};
+
+template <int PPT>
+__global__ __launch_bounds__(256) void knn_fused_kernel(const float* __restrict__ ref, const float* __restrict__ qry, int C, int Nr,
+                                                        int Nq, int k, int32_t* __restrict__ idx_out) {
+    using Cfg = KnnCfg<PPT>;
+    constexpr int QW = Cfg::QW, NRP = Cfg::NRP, CK = Cfg::CK, QB = 4 * QW, NJ = PPT / 4;
+    constexpr int RV = CK * NRP / 4 / 256;                       // 16-byte reference pieces per thread and stage
+    constexpr int QV = (CK * QB + 255) / 256;                   // query values per thread and stage
+    static_assert(RV >= 1, "staging maps");
+    __shared__ __attribute__((aligned(16))) float sR[2][CK][NRP];
+    __shared__ __attribute__((aligned(16))) float sQ[2][CK][QB];
+    __shared__ uint2 sCand[4][64];                               // per wave: the candidates of the query being selected
+    const int b = blockIdx.y, q0 = blockIdx.x * QB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* R = ref + (size_t)b * C * Nr;
+    const float* Q = qry + (size_t)b * C * Nq;
+    const bool vec = (Nr & 3) == 0 && (reinterpret_cast<uintptr_t>(R) & 15) == 0;
+
+    // two references per register pair: v_pk_add_f32 / v_pk_mul_f32 are separately rounded like their scalar forms and run at
+    // twice the rate (contraction into an FMA is switched off for this file, whatever the command line says)
+    f32x2 acc[QW][PPT / 2];
+#pragma unroll
+    for (int i = 0; i < QW; ++i)
+#pragma unroll
+        for (int j = 0; j < PPT / 2; ++j) acc[i][j] = f32x2{0.f, 0.f};
+
+    // stage registers: piece e = tid + 256*v -> channel e / (NRP/4), references 4*(e % (NRP/4)) ..+3; one query value
+    float4 pr[RV];
+    float pq[QV];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int v = 0; v < RV; ++v) {
+            const int e = tid + 256 * v, cc = e / (NRP / 4), r = 4 * (e % (NRP / 4)), c = c0 + cc;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < C) {
+                const float* src = R + (size_t)c * Nr + r;
+                if (vec && r + 3 < Nr) x = *reinterpret_cast<const float4*>(src);
+                else {
+                    if (r < Nr) x.x = src[0];
+                    if (r + 1 < Nr) x.y = src[1];
+                    if (r + 2 < Nr) x.z = src[2];
+                    if (r + 3 < Nr) x.w = src[3];
+                }
+            }
+            pr[v] = x;
+        }
+#pragma unroll
+        for (int v = 0; v < QV; ++v) {
+            const int e = tid + 256 * v, cc = e / QB, qi = e % QB, c = c0 + cc;
+            pq[v] = (e < CK * QB && c < C && q0 + qi < Nq) ? Q[(size_t)c * Nq + q0 + qi] : 0.f;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int v = 0; v < RV; ++v) {
+            const int e = tid + 256 * v;
+            *reinterpret_cast<float4*>(&sR[buf][e / (NRP / 4)][4 * (e % (NRP / 4))]) = pr[v];
+        }
+#pragma unroll
+        for (int v = 0; v < QV; ++v) {
+            const int e = tid + 256 * v;
+            if (e < CK * QB) sQ[buf][e / QB][e % QB] = pq[v];
+        }
+    };
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = 0; c0 < C; c0 += CK, buf ^= 1) {
+        const bool more = c0 + CK < C;
+        if (more) fetch(c0 + CK);
+        // channels in pairs with two operand sets: the LDS reads of channel cc+1 are issued before the arithmetic of channel cc
+        // (2 waves per SIMD do not hide an LDS round trip per 4 reference registers).  A channel past C was staged as zeros on
+        // both sides: (0 - 0)^2 added to a sum >= +0 leaves it bit-identical, so an odd tail just runs one idle channel.
+        const int cend = ((C - c0 < CK ? C - c0 : CK) + 1) & ~1;
+        struct Ops { float qv[QW]; float4 rv[NJ]; };
+        auto ld = [&](int cc) -> Ops {
+            Ops o;
+#pragma unroll
+            for (int i = 0; i < QW; i += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(&sQ[buf][cc][wave * QW + i]);     // broadcast read
+                o.qv[i] = t.x;
+                if (i + 1 < QW) o.qv[i + 1] = t.y;
+                if (i + 2 < QW) o.qv[i + 2] = t.z;
+                if (i + 3 < QW) o.qv[i + 3] = t.w;
+            }
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) o.rv[J] = *reinterpret_cast<const float4*>(&sR[buf][cc][256 * J + 4 * lane]);
+            return o;
+        };
+        auto compute = [&](const Ops& o) {
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) {
+                const f32x2 r01 = {o.rv[J].x, o.rv[J].y}, r23 = {o.rv[J].z, o.rv[J].w};
+                // (three passes over the 2*QW pairs, not three dependent instructions per pair: back-to-back dependent packed
+                // ops cost wait states -- hipcc filled the fused form with 45 s_nop per channel)
+                f32x2 t[QW][2];
+#pragma unroll
+                for (int i = 0; i < QW; ++i) {
+                    const f32x2 qq = {o.qv[i], o.qv[i]};
+                    t[i][0] = r01 - qq; t[i][1] = r23 - qq;                                       // ref - query, :489
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < QW; ++i) { t[i][0] = t[i][0] * t[i][0]; t[i][1] = t[i][1] * t[i][1]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < QW; ++i) {                                                    // ssd += tmp*tmp, :490
+                    acc[i][2 * J] = acc[i][2 * J] + t[i][0];
+                    acc[i][2 * J + 1] = acc[i][2 * J + 1] + t[i][1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        Ops A = ld(0);
+        for (int cc = 0; cc < cend; cc += 2) {
+            const Ops B = ld(cc + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(A);
+            A = ld(cc + 2 < CK ? cc + 2 : 0);                   // (the wrap-around read of the last pair is unused)
+            __builtin_amdgcn_sched_barrier(0);
+            compute(B);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- select: per query the k smallest (distance bits, r), ascending; sums of squares are >= +0 -> bit-monotone
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+        const int q = q0 + wave * QW + i;
+        if (q >= Nq) break;                                        // (wave-uniform)
+        unsigned key[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int r = 256 * (j >> 2) + 4 * lane + (j & 3);
+            key[j] = r < Nr ? __float_as_uint(acc[i][j >> 1][j & 1]) : 0xFFFFFFFFu;
+        }
+        int32_t* out = idx_out + (size_t)b * k * Nq + q;
+        // Fast path (k <= 64): T = the k-th smallest of the 64 lane-local minima is an upper bound of the k-th smallest key
+        // (those are 64 distinct elements), found by a bitwise search with one ballot per bit; the keys <= T (>= k of
+        // them, typically ~1.5 k) are compacted into LDS and ranked by (key, r) -- ~400 issue slots instead of ~100 per
+        // extraction round.  More than 64 candidates (mass ties) or k > 64: the rounds below, same result.
+        bool done = false;
+        if (k <= 64) {
+            unsigned m = key[0];
+#pragma unroll
+            for (int j = 1; j < PPT; ++j) m = min(m, key[j]);
+            unsigned T = 0;
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned trial = T | (1u << bit);
+                if (__popcll(__ballot(m < trial)) < k) T = trial;            // (uniform)
+            }
+            int n = 0;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) n += __popcll(__ballot(key[j] <= T));
+            if (n <= 64) {
+                uint2* cand = sCand[wave];
+                int base = 0;
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) {
+                    const bool pred = key[j] <= T;
+                    const unsigned long long mask = __ballot(pred);
+                    if (mask) {                                              // (uniform)
+                        if (pred) cand[base + mbcnt(mask)] = make_uint2(key[j], 256u * (j >> 2) + 4u * lane + (j & 3u));
+                        base += __popcll(mask);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                const uint2 mine = cand[lane < n ? lane : 0];
+                int rank = 0;
+                for (int c = 0; c < n; ++c) {
+                    const uint2 o = cand[c];                                 // broadcast read
+                    rank += (o.x < mine.x || (o.x == mine.x && o.y < mine.y)) ? 1 : 0;
+                }
+                if (lane < n && rank < k) out[(size_t)rank * Nq] = (int32_t)mine.y;
+                __builtin_amdgcn_wave_barrier();                             // (the next query reuses the list)
+                done = true;
+            }
+        }
+        for (int t = 0; t < k && !done; ++t) {
+            unsigned bk = 0xFFFFFFFFu, bj = 0;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {                        // increasing j = increasing r within the lane
+                const bool take = key[j] < bk;                     // strict: lowest r kept on ties
+                bk = take ? key[j] : bk;
+                bj = take ? (unsigned)j : bj;
+            }
+            const unsigned br = 256u * (bj >> 2) + 4u * lane + (bj & 3u);
+            const unsigned wmin = wave_min_u32(bk);
+            const unsigned long long tied = __ballot(bk == wmin);
+            unsigned r;
+            if (__popcll(tied) == 1) {
+                const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)tied) - 1);
+                r = __builtin_amdgcn_readlane(br, l);
+            } else {
+                r = wave_min_u32(bk == wmin ? br : 0xFFFFFFFFu);
+            }
+            if (lane == 0) out[(size_t)t * Nq] = (int32_t)r;
+            const unsigned rj = 4u * (r >> 8) + (r & 3u), rl = (r & 255u) >> 2;
+            const bool mine = (unsigned)lane == rl;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j)
+                if ((unsigned)j == rj && mine) key[j] = 0xFFFFFFFFu;
+        }
+    }
+}
+
 }  // namespace pcl
 using namespace pcl;
 
+// Nr <= 4096: the fused kernel, no workspace.  Beyond that a query's row no longer fits the registers of a wave and the
+// two-pass form (distance matrix in a caller-provided workspace, then select) is used.
+constexpr int KNN_FUSED_MAX_NR = 4096;
 extern "C" size_t pcl_knn_workspace_bytes(int B, int C, int Nr, int Nq, int k) {
     (void)C; (void)k;
-    if (B <= 0 || Nr <= 0 || Nq <= 0) return 0;
+    if (B <= 0 || Nr <= 0 || Nq <= 0 || Nr <= KNN_FUSED_MAX_NR) return 0;
     return sizeof(float) * (size_t)B * Nr * Nq;
 }
 
@@ -152,6 +385,13 @@ extern "C" int pcl_knn_f32(const float* ref, const float* qry, int B, int C, int
     PCL_REQUIRE(k >= 1 && k <= Nr, "pcl_knn_f32: need 1 <= k <= Nr (k=%d Nr=%d)", k, Nr);
     PCL_REQUIRE(B <= 65535, "pcl_knn_f32: B=%d exceeds grid limit", B);
     if (B == 0) return PCL_OK;
+    if (Nr <= KNN_FUSED_MAX_NR) {
+        hipStream_t st = as_stream(stream);
+        const int ppt4 = (Nr + 255) / 256 * 4;                    // multiples of 4 registers per lane
+#define PCL_KF(P) if (ppt4 <= P) { hipLaunchKernelGGL(knn_fused_kernel<P>, dim3((Nq + 4 * KnnCfg<P>::QW - 1) / (4 * KnnCfg<P>::QW), B), dim3(256), 0, st, ref, qry, C, Nr, Nq, k, idx_out); return check_launch("pcl_knn_f32(fused)"); }
+        PCL_KF(4) PCL_KF(8) PCL_KF(16) PCL_KF(32) PCL_KF(64)
+#undef PCL_KF
+    }
     const size_t need = pcl_knn_workspace_bytes(B, C, Nr, Nq, k);
     if (!workspace || workspace_bytes < need)
         return fail(PCL_EWS, "pcl_knn_f32: workspace %zu bytes < required %zu", workspace_bytes, need);

@@ -71,8 +71,10 @@ def test_capi_argument_validation_needs_no_gpu():
     assert lib.pcl_fps_f32(p, 1, 8, 9, 1, 1e-3, None, p, None, None) == -1         # m > N
     assert lib.pcl_fps_f32(p, 1, 8, 4, 3, 1e-3, None, p, None, None) == -1         # tie_stride not a power of two
     assert lib.pcl_knn_f32(p, p, 1, 3, 8, 8, 9, p, None, 0, None) == -1            # k > Nr
-    assert lib.pcl_knn_f32(p, p, 1, 3, 8, 8, 2, p, None, 0, None) == -4            # workspace too small
-    assert lib.pcl_knn_workspace_bytes(2, 3, 8, 16, 2) == 2 * 8 * 16 * 4
+    assert lib.pcl_knn_workspace_bytes(2, 3, 8, 16, 2) == 0                        # fused distance + select: no [Nq, Nr] matrix
+    assert lib.pcl_knn_workspace_bytes(2, 3, 4096, 4096, 20) == 0
+    assert lib.pcl_knn_workspace_bytes(2, 3, 5000, 16, 2) == 2 * 5000 * 16 * 4     # beyond 4096 references: two passes
+    assert lib.pcl_knn_f32(p, p, 1, 3, 5000, 8, 2, p, None, 0, None) == -4         # workspace too small
 
 
 def test_ops_reject_cpu_tensors():

@@ -185,7 +185,9 @@ def test_group_all_and_modules(oracle, dev):
 # ------------------------------------------------------------------------------------ KNN
 @pytest.mark.parametrize("B,C,Nr,Nq,k", [(2, 3, 64, 64, 5), (2, 5, 33, 20, 33), (4, 3, 1024, 1024, 20),
                                          (2, 64, 1024, 1024, 20), (2, 128, 256, 1024, 200), (1, 7, 2048, 100, 40),
-                                         (1, 3, 5000, 70, 9)])
+                                         (1, 3, 5000, 70, 9),                                 # > 4096 references: two-pass form
+                                         (1, 4, 4096, 37, 17), (2, 6, 513, 77, 30), (1, 130, 300, 50, 7),   # fused: 64 values per
+                                         (3, 64, 1000, 1000, 20)])    # lane; odd Nr (scalar staging); channel tail; Nr % 256 != 0
 def test_knn_matches_oracle(oracle, dev, B, C, Nr, Nq, k):
     rng = np.random.default_rng(Nr + C)
     r = rng.standard_normal((B, C, Nr)).astype(np.float32)

@@ -21,4 +21,5 @@ python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 2, 2>' 
 python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 1, 1>' 1 0=fb64x64 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
 rm -rf $O/kt/*/*.db $O/fetch $O/write $O/sq/*/*.db 2>/dev/null
 python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
+python -m pytest tests/test_parity_pointnet2_gpu.py tests/test_parity_dgcnn_gpu.py tests/test_parity_partseg_gpu.py tests/test_parity_pointconv_gpu.py -m gpu -s -q 2>&1 | grep -v Warning > $O/${R}_parity_reports.txt
 tail -3 $O/kt.log; cat $O/traffic.txt | head -40; cat $O/${R}_dominant_kernel_by_shape.csv; tail -1 $O/${R}_bench_line.json
