@@ -353,6 +353,23 @@ int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const float* a, 
 int pcl_scatter_rows_add_f32(const float* grows, const int32_t* row_src, const int32_t* n_rows_dev, int rows_cap,
                              int D, int off, int C, int n_dst_rows, float* gfeat, void* stream);
 
+/* ---- PointCNN: the X-transform core of XConv --------------------------------------------------------------------------
+ * Per region r (R = B*P of them): FX = X[r] (K x K) . [F1[r] | F2[r]] (K x (C1+C2)) -- jt.matmul(X, fts_cat),
+ * misc/layers.py:505 with the concat of :486-489 -- then the depthwise (1,K) conv of SepConv (:151, groups = in_channels):
+ * D[r, c*dm + j] = bias[c*dm + j] + sum_k wd[c, j, k] * FX[k, c].  One pass, FX and the concat never exist in memory; D feeds
+ * the pointwise 1x1 conv (pcl_linear_fwd_f32).  Layouts: X [R,K,K], F1 [R,K,C1], F2 [R,K,C2] (or NULL, C2 = 0),
+ * wd [C, dm, K] (reference weight wd_ref[c*dm+j, 0, 0, k]), bias [C*dm], D [R, C*dm].
+ * Backward: dX [R,K,K], dF1, dF2 as the inputs; the tap / bias gradients come as per-workgroup partials
+ * dwd_part [pcl_xconv_core_partials(R, C)][C*dm*K], dbias_part [..][C*dm] that the caller sums (no atomics).
+ * Supported: K in {8, 12, 16}, dm in {1, 2, 4, 16} (pcl_xconv_core_supported). */
+int pcl_xconv_core_supported(int K, int dm, int C);
+int pcl_xconv_core_partials(int R, int C);
+int pcl_xconv_core_fwd_f32(const float* X, const float* F1, int C1, const float* F2, int C2, const float* wd, const float* bias,
+                           int R, int K, int dm, float* D, void* stream);
+int pcl_xconv_core_bwd_f32(const float* X, const float* F1, int C1, const float* F2, int C2, const float* wd, const float* dD,
+                           int R, int K, int dm, float* dX, float* dF1, float* dF2, float* dwd_part, float* dbias_part,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

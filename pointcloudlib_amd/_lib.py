@@ -45,6 +45,10 @@ _P = c_void_p
 _SIGS = {
     "pcl_version": (c_int, []),
     "pcl_time_next_launch": (None, [_P, _P]),
+    "pcl_xconv_core_supported": (c_int, [c_int, c_int, c_int]),
+    "pcl_xconv_core_partials": (c_int, [c_int, c_int]),
+    "pcl_xconv_core_fwd_f32": (c_int, [_P, _P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, _P, _P]),
+    "pcl_xconv_core_bwd_f32": (c_int, [_P, _P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "pcl_last_error": (ctypes.c_char_p, []),
     "pcl_optimal_block": (c_int, [c_int]),
     "pcl_fps_f32": (c_int, [_P, c_int, c_int, c_int, c_int, c_double, _P, _P, _P, _P]),

@@ -24,8 +24,9 @@ import math
 import torch
 from torch import nn
 
+from .. import _lib
 from .layers import PointwiseMLP, batch_norm_train
-from .ops import FurthestPointSampler, KNN, group_points, index_points
+from .ops import FurthestPointSampler, KNN, group_points, index_points, _p, _stream
 
 __all__ = ["Dense_Conv1d", "Dense_Conv2d", "Conv", "SepConv", "XConv", "PointCNN", "RandPointCNN",
            "RandPointCNN_Decoder"]
@@ -105,6 +106,7 @@ class SepConv(_Module):
         kh, K = kernel_size
         assert kh == 1
         self.K, self.dm = K, depth_multiplier
+        self.backend = "auto"                             # "auto" = the HIP kernels; "torch" only when a test names it
         bound = 1.0 / math.sqrt(K)                        # fan-in of a depthwise (1,K) filter
         self.depthwise = nn.Parameter(torch.empty(in_channels, depth_multiplier, K).uniform_(-bound, bound))
         self.depthwise_bias = nn.Parameter(torch.empty(in_channels * depth_multiplier).uniform_(-bound, bound))
@@ -120,6 +122,65 @@ class SepConv(_Module):
     def forward(self, x):
         y = self.pointwise(self.depthwise_conv(x))
         return self.bn(y) if self.bn is not None else y
+
+    def forward_x(self, X, F1, F2):
+        """``SepConv(X @ concat(F1, F2))`` with the matmul, the concat and the depthwise conv in one HIP kernel
+        (csrc/xconv.hip); the pointwise conv runs on the MFMA GEMM as before."""
+        if self.backend == "torch":      # plain PyTorch composite: runs only when a test asks for it by name
+            F = F1 if F2 is None else torch.cat((F1, F2), dim=-1)
+            return self.forward(torch.matmul(X, F))
+        y = self.pointwise(xconv_core(X, F1, F2, self.depthwise, self.depthwise_bias))
+        return self.bn(y) if self.bn is not None else y
+
+
+class _XConvCore(torch.autograd.Function):
+    """D[b,p,c*dm+j] = bias + sum_k wd[c,j,k] * (X[b,p] @ [F1|F2][b,p])[k,c]  (misc/layers.py:505 + the depthwise conv of :151)."""
+
+    @staticmethod
+    def forward(ctx, X, F1, F2, wd, bias):
+        B, P, K, _ = X.shape
+        C1, C2 = F1.shape[-1], (F2.shape[-1] if F2 is not None else 0)
+        C, dm = wd.shape[0], wd.shape[1]
+        assert C == C1 + C2 and wd.shape[2] == K
+        X, F1, wd, bias = X.contiguous(), F1.contiguous(), wd.contiguous(), bias.contiguous()
+        F2 = F2.contiguous() if F2 is not None else None
+        D = torch.empty((B, P, C * dm), dtype=torch.float32, device=X.device)
+        _lib.call("pcl_xconv_core_fwd_f32", _p(X), _p(F1), C1, _p(F2), C2, _p(wd), _p(bias), B * P, K, dm, _p(D), _stream(),
+                  algo_bytes=4 * B * P * (K * C + K * K + C * dm), algo_flops=2 * B * P * C * K * (K + dm), tag=f"xconv{K}x{C}x{dm}")
+        ctx.save_for_backward(X, F1, F2, wd)
+        return D
+
+    @staticmethod
+    def backward(ctx, dD):
+        X, F1, F2, wd = ctx.saved_tensors
+        B, P, K, _ = X.shape
+        C1, C2 = F1.shape[-1], (F2.shape[-1] if F2 is not None else 0)
+        C, dm = wd.shape[0], wd.shape[1]
+        dD = dD.contiguous()
+        dev = X.device
+        dX, dF1 = torch.empty_like(X), torch.empty_like(F1)
+        dF2 = torch.empty_like(F2) if F2 is not None else None
+        parts = _lib.size_query("pcl_xconv_core_partials", B * P, C)
+        dwd_part = torch.empty((parts, C, dm, K), dtype=torch.float32, device=dev)
+        db_part = torch.empty((parts, C * dm), dtype=torch.float32, device=dev)
+        _lib.call("pcl_xconv_core_bwd_f32", _p(X), _p(F1), C1, _p(F2), C2, _p(wd), _p(dD), B * P, K, dm, _p(dX), _p(dF1), _p(dF2),
+                  _p(dwd_part), _p(db_part), _stream(),
+                  algo_bytes=4 * B * P * (2 * K * C + 2 * K * K + C * dm), algo_flops=2 * B * P * C * K * (3 * K + 2 * dm),
+                  tag=f"xconvbwd{K}x{C}x{dm}")
+        return dX, dF1, dF2, dwd_part.sum(0), db_part.sum(0)
+
+
+def xconv_core(X, F1, F2, wd, bias):
+    """[B,P,K,K], [B,P,K,C1], [B,P,K,C2]|None, taps [C1+C2, dm, K], bias [(C1+C2)*dm] -> [B,P,(C1+C2)*dm]."""
+    if not X.is_cuda:
+        raise RuntimeError("xconv_core needs GPU tensors (no CPU fallback)")
+    K, C, dm = X.shape[-1], wd.shape[0], wd.shape[1]
+    if not _lib.size_query("pcl_xconv_core_supported", K, dm, C):
+        # shapes outside the kernel's instantiations (none in the reference's networks): the same arithmetic as separate GPU ops
+        F = F1 if F2 is None else torch.cat((F1, F2), dim=-1)
+        B, P = X.shape[:2]
+        return torch.einsum("bpkc,cjk->bpcj", torch.matmul(X, F), wd).reshape(B, P, C * dm) + bias
+    return _XConvCore.apply(X, F1, F2, wd, bias)
 
 
 class XConv(_Module):
@@ -145,11 +206,10 @@ class XConv(_Module):
             assert fts.shape[:3] == (B, P, K) and fts.shape[3] == self.C_in
         pts_local = pts_local.contiguous()
         fts_lifted = self.dense(pts_local)                                 # [B,P,K,C_mid]  :480-483
-        fts_cat = fts_lifted if fts is None else torch.cat((fts_lifted, fts), dim=-1)   # :486-489
         X = self.x_trans_2(self.x_trans_1(self.x_trans_0(pts_local)))     # [B,P,K*K]  :494-496
         X = X.reshape(B, P, K, K)                                          # :499-500
-        fts_X = torch.matmul(X, fts_cat)                                   # [B,P,K,C]  :505
-        return self.end_conv(fts_X)                                        # :509
+        # concat (:486-489), X @ fts_cat (:505) and the depthwise conv of end_conv (:509) in one kernel
+        return self.end_conv.forward_x(X, fts_lifted, fts)
 
 
 class PointCNN(_Module):

@@ -92,3 +92,36 @@ def test_pointcnn_partseg_network(oracle, dev):
     with torch.no_grad():
         want = ref.pointcnn_partseg(cpu_copy(net), torch.from_numpy(pts))
     assert (out.detach().cpu() - want).abs().max().item() <= 1e-3 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("K,C1,C2,dm,R", [(8, 12, 24, 16, (3, 50)), (12, 24, 48, 2, (2, 77)), (16, 48, 96, 2, (2, 40)),
+                                          (16, 96, 192, 2, (2, 33)), (8, 8, 0, 4, (5, 13)), (16, 300, 0, 1, (1, 9))])
+def test_xconv_core_matches_fp64_composite(dev, K, C1, C2, dm, R):
+    """csrc/xconv.hip (X @ [F1|F2], depthwise (1,K) conv, one kernel; misc/layers.py:505 + :151) forward and backward against
+    the same arithmetic in fp64 PyTorch: every classifier stage's shape, the 288-channel stage (two channel windows in
+    backward), no second feature tensor, dm = 1.  Tolerance: 1e-5 of the tensor's scale (fp32 sums of <= 16 + 16 terms)."""
+    from pointcloudlib_amd.misc.pointcnn import xconv_core
+    torch.manual_seed(K + C1)
+    B, P = R
+    C = C1 + C2
+    X = torch.randn(B, P, K, K, dtype=torch.float64)
+    F1 = torch.randn(B, P, K, C1, dtype=torch.float64)
+    F2 = torch.randn(B, P, K, C2, dtype=torch.float64) if C2 else None
+    wd = torch.randn(C, dm, K, dtype=torch.float64) * 0.3
+    bias = torch.randn(C * dm, dtype=torch.float64)
+    gD = torch.randn(B, P, C * dm, dtype=torch.float64)
+
+    def leaves(dt, device):
+        return [t.detach().to(device=device, dtype=dt).requires_grad_(True) if t is not None else None for t in (X, F1, F2, wd, bias)]
+
+    r = leaves(torch.float64, "cpu")
+    F = r[1] if r[2] is None else torch.cat((r[1], r[2]), dim=-1)
+    want = torch.einsum("bpkc,cjk->bpcj", torch.matmul(r[0], F), r[3]).reshape(B, P, C * dm) + r[4]
+    want.backward(gD)
+    h = leaves(torch.float32, dev)
+    got = xconv_core(*h)
+    got.backward(gD.float().to(dev))
+    pairs = [("D", got, want)] + [(n, a.grad, b.grad) for n, a, b in zip(("dX", "dF1", "dF2", "dwd", "dbias"), h, r) if a is not None]
+    for name, a, b in pairs:
+        scale = max(1.0, b.abs().max().item())
+        assert (a.detach().double().cpu() - b.detach()).abs().max().item() <= 1e-5 * scale, name
