@@ -9,7 +9,44 @@ from pointcloudlib_amd.affinity import pin_to_gpu_node
 pin_to_gpu_node(0)
 
 
+FP32_PEAK_TFLOPS, HBM_PEAK_GBS = 157.3, 8000.0        # MI355X_MICROARCH.md: dense fp32 MFMA, HBM3E
+ONLY = None                                            # --only: substring filter on the config names
+
+
+def roofline_of(step):
+    """Dominant own kernel of the step (every C-ABI entry point event-timed for two untimed steps; GEMM-family kernels report
+    their own begin / end timestamps) and its roofline, as bench.py does for the headline config."""
+    from pointcloudlib_amd import _lib
+    _lib.PROFILER = _lib.KernelTimer()
+    step(); step()
+    torch.cuda.synchronize()
+    summ = _lib.PROFILER.summary()
+    _lib.PROFILER = None
+    by_name = {}
+    for (n, t), v in summ.items():
+        if n != "pcl_fps_f32":                        # latency-bound chain, runs beside the GEMMs where sampling is prefetched
+            by_name[n] = by_name.get(n, 0.0) + v["total_ms"]
+    if not by_name:
+        return None
+    top = max(by_name, key=by_name.get)
+    key, r = max(((k, v) for k, v in summ.items() if k[0] == top), key=lambda kv: kv[1]["total_ms"])
+    own_ms = sum(v["total_ms"] for v in summ.values()) / 2
+    ai = r["algo_flops"] / max(1.0, r["algo_bytes"])
+    if ai > FP32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+        bound, ach, peak, unit = "mfma", r["algo_flops"] / (r["avg_ms"] * 1e-3) / 1e12, FP32_PEAK_TFLOPS, "TFLOP/s"
+    else:
+        bound, ach, peak, unit = "hbm", r["algo_bytes"] / (r["avg_ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+    return {"kernel": key[0], "shape": key[1], "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+            "frac": round(ach / peak, 4), "avg_launch_ms": round(r["avg_ms"], 5), "launches_per_step": r["launches"] / 2,
+            "entry_point_share_of_own_kernel_time": round(by_name[top] / 2 / own_ms, 3), "own_kernel_ms_per_step": round(own_ms, 3),
+            "traffic": None,
+            **({"note": "exact-rounding distances run on the fp32 VALU, not MFMA: ceiling 64.4 Tops/s measured (tools/ubench/pkrate.hip)",
+                "valu_peak_tops": 64.4, "frac_valu": round(ach / 64.4, 4)} if key[0] == "pcl_knn_f32" else {})}
+
+
 def run(name, make, inputs, loss_fn, steps, warmup=3):
+    if ONLY and ONLY not in name:
+        return None
     torch.manual_seed(0)
     net = make().cuda().train()
     opt = make_sgd(net.parameters(), lr=0.02, momentum=0.9)
@@ -25,12 +62,18 @@ def run(name, make, inputs, loss_fn, steps, warmup=3):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
     B = inputs[0].shape[0]
     r = {"config": name, "ms_per_step": round(dt * 1e3, 3), "clouds_per_s": round(B / dt, 1), "batch": B,
-         "params": sum(p.numel() for p in net.parameters())}
+         "params": sum(p.numel() for p in net.parameters()), "roofline": roofline_of(step)}
     print(json.dumps(r), flush=True)
     return r
 
 
 def run_prefetch(name, make, inputs, loss_fn, steps, warmup=3):
+    if ONLY and ONLY not in name:
+        return None
+    return _run_prefetch(name, make, inputs, loss_fn, steps, warmup)
+
+
+def _run_prefetch(name, make, inputs, loss_fn, steps, warmup=3):
     """Same, with the encoder's FPS / ball query of the next batch issued on a side stream beside the backward pass
     (networks with ``precompute_sampling``; the input is the same tensor every step, the work is not)."""
     torch.manual_seed(0)
@@ -61,7 +104,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--only", default=None, help="run only the configs whose name contains this (one config under rocprofv3)")
     a = ap.parse_args()
+    global ONLY
+    ONLY = a.only
     from pointcloudlib_amd.networks.cls.pointnet import PointNet
     from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
     from pointcloudlib_amd.networks.cls.dgcnn import DGCNN
@@ -103,8 +149,9 @@ def main():
     res.append(run("DGCNN part-seg B=16 N=2048 k=40", lambda: DGCNN_partseg(50), (xst, oh), lambda o: ce(o, seg), a.steps))
     res.append(run("PointCNN part-seg B=16 N=2048", PointCNN_partseg, (xs,), lambda o: ce(o, seg), a.steps))
     res.append(run("PointConv part-seg B=16 N=2048", PointConvDensity_partseg, (xs, oh), lambda o: ce(o.permute(0, 2, 1), seg), a.steps))
+    res = [r for r in res if r is not None]
     if a.out:
-        json.dump({"device": torch.cuda.get_device_name(0), "note": "1 GPU, fp32, synthetic gauss_ball clouds, fwd+bwd+SGD", "results": res},
+        json.dump({"device": torch.cuda.get_device_name(0), "note": "1 GPU, fp32, synthetic gauss_ball clouds, fwd+bwd+SGD; roofline = the dominant own kernel of each config (bench.py's rule)", "results": res},
                   open(a.out, "w"), indent=1)
 
 

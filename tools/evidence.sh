@@ -22,4 +22,11 @@ python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 1, 1>' 
 rm -rf $O/kt/*/*.db $O/fetch $O/write $O/sq/*/*.db 2>/dev/null
 python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
 python -m pytest tests/test_parity_pointnet2_gpu.py tests/test_parity_dgcnn_gpu.py tests/test_parity_partseg_gpu.py tests/test_parity_pointconv_gpu.py -m gpu -s -q 2>&1 | grep -v Warning > $O/${R}_parity_reports.txt
+# the other BASELINE configs: one line each with the roofline of its dominant kernel, and a kernel-stats CSV per config
+python tools/bench_models.py --steps 20 --out $O/${R}_other_configs.json > $O/other.log 2>&1
+for c in "cfg2'" cfg3 "cfg4 PointNet++ SSG part-seg B=16 N=2048" cfg5; do
+  t=$(echo "$c" | cut -c1-5 | tr -d "' " | sed "s/cfg2/cfg2_n4096/")
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$t -o b -- python tools/bench_models.py --steps 10 --only "$c" > $O/kt_$t.log 2>&1
+  cp $(find $O/kt_$t -name '*kernel_stats.csv' | head -1) $O/${R}_${t}_kernel_stats.csv; rm -rf $O/kt_$t
+done
 tail -3 $O/kt.log; cat $O/traffic.txt | head -40; cat $O/${R}_dominant_kernel_by_shape.csv; tail -1 $O/${R}_bench_line.json
