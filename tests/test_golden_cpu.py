@@ -73,6 +73,7 @@ def test_capi_argument_validation_needs_no_gpu():
     assert lib.pcl_knn_f32(p, p, 1, 3, 8, 8, 9, p, None, 0, None) == -1            # k > Nr
     assert lib.pcl_knn_workspace_bytes(2, 3, 8, 16, 2) == 0                        # fused distance + select: no [Nq, Nr] matrix
     assert lib.pcl_knn_workspace_bytes(2, 3, 4096, 4096, 20) == 0
+    assert lib.pcl_knn_workspace_bytes(2, 64, 1024, 1024, 20) == 0
     assert lib.pcl_knn_workspace_bytes(2, 3, 5000, 16, 2) == 2 * 5000 * 16 * 4     # beyond 4096 references: two passes
     assert lib.pcl_knn_f32(p, p, 1, 3, 5000, 8, 2, p, None, 0, None) == -4         # workspace too small
 
