@@ -128,3 +128,20 @@ def test_new_paths_refuse_cpu_tensors():
         PointwiseMLP([6, 8, 8]).forward_grouped(torch.randn(1, 9, 3), torch.randn(1, 2, 3), torch.randn(1, 9, 3),
                                                 torch.zeros(1, 2, 4, dtype=torch.int32), torch.ones(1, 2, dtype=torch.int32),
                                                 torch.zeros(3, dtype=torch.int32))
+
+
+def test_sa_level_fixture_is_reproduced_by_the_restatement():
+    """tests/golden/sa_level.npz: (input, weights) -> (idx, grouped, pooled) of one set-abstraction level."""
+    import torch
+    from oracle.cpu_model import sa_module_cpu
+    g = np.load(os.path.join(GOLD, "sa_level.npz"))
+    T = lambda a, dt: torch.from_numpy(np.asarray(a)).to(dt)
+    for dt, key, tol in ((torch.float64, "pooled_f64", 1e-12), (torch.float32, "pooled_f32", 1e-5)):
+        nx, y, aux = sa_module_cpu(T(g["xyz"], dt), T(g["feat"], dt), [T(g[f"w{i}"], dt) for i in range(3)],
+                                   [T(g[f"gamma{i}"], dt) for i in range(3)], [T(g[f"beta{i}"], dt) for i in range(3)],
+                                   int(g["n_points"]), float(g["radius"]), int(g["n_samples"]), int(g["tie_stride"]), return_aux=True)
+        assert np.array_equal(aux["fps_idx"], g["fps_idx"]) and np.array_equal(aux["bq_idx"], g["bq_idx"])
+        assert np.array_equal(aux["grouped"].float().numpy(), g["grouped"])
+        assert np.abs(y.double().numpy() - g[key]).max() <= tol
+    # the fp32 evaluation is within 1e-5 of the fp64 one (the tolerance the HIP path is held to)
+    assert np.abs(g["pooled_f32"].astype(np.float64) - g["pooled_f64"]).max() <= 1e-5 * max(1.0, np.abs(g["pooled_f64"]).max())

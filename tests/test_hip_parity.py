@@ -289,3 +289,30 @@ def test_degenerate_sizes(oracle, dev):
     assert np.array_equal(kk, oracle.knn(np.ascontiguousarray(pts.transpose(0, 2, 1)), np.ascontiguousarray(pts.transpose(0, 2, 1)), 3))
     with pytest.raises((ValueError, RuntimeError)):
         ops.furthest_point_sample(T(pts, dev), 4)                              # n_samples > N  (misc/ops.py:269)
+
+
+def test_sa_level_matches_golden_fixture(dev):
+    """One set-abstraction level through the product path (FPS -> ball query -> duplicate-compacted grouped rows -> fused MLP
+    -> max) against the committed fixture: indices exact, pooled features within 1e-5 of the fp64 values."""
+    from pointcloudlib_amd.networks.cls.pointnet2 import PointnetModule
+    g = np.load(os.path.join(GOLD, "sa_level.npz"))
+    spec = [int(g["feat"].shape[-1])] + [int(g[f"w{i}"].shape[0]) for i in range(3)]
+    mod = PointnetModule(spec, n_points=int(g["n_points"]), radius=float(g["radius"]), n_samples=int(g["n_samples"])).to(dev).train()
+    mlp = mod.mlps[0]
+    with torch.no_grad():
+        for i in range(3):
+            assert mlp.weights[i].shape == g[f"w{i}"].shape
+            mlp.weights[i].copy_(torch.from_numpy(g[f"w{i}"])); mlp.gammas[i].copy_(torch.from_numpy(g[f"gamma{i}"]))
+            mlp.betas[i].copy_(torch.from_numpy(g[f"beta{i}"]))
+    mod.sampler.tie_stride = int(g["tie_stride"])
+    xyz, feat = T(g["xyz"], dev), T(g["feat"], dev)
+    new_xyz, idxs = mod.sample(xyz)
+    assert np.array_equal(new_xyz.cpu().numpy(), g["new_xyz"])
+    assert np.array_equal(idxs[0][0].cpu().numpy(), g["bq_idx"])
+    grouped = ops.group_points(xyz, new_xyz, feat, idxs[0][0], True)
+    assert np.array_equal(grouped.cpu().numpy(), g["grouped"])
+    for compact in (True, False):
+        mod.compact_duplicates = compact
+        _, pooled = mod(xyz, feat)
+        err = np.abs(pooled.detach().double().cpu().numpy() - g["pooled_f64"]).max()
+        assert err <= 1e-5 * max(1.0, np.abs(g["pooled_f64"]).max()), (compact, err)

@@ -75,6 +75,32 @@ def main():
     kk = oracle.knn(x, x, 20)
     big["cfg3_knn_xyz"] = {"B": 8, "N": 1024, "seed": 20243, "k": 20, "knn_sha": sha(kk), "head": kk[0, :4, 0].tolist()}
     json.dump(big, open(os.path.join(OUT, "full_size_digests.json"), "w"), indent=1)
+
+    # --- one set-abstraction level end to end: (input, weights) -> (idx, grouped, pooled); SURVEY section 8a row 8.
+    # Restatement of PointnetModule.execute (networks/cls/pointnet2.py:45-57) in oracle/cpu_model.py, evaluated in fp64
+    # (the yardstick of the 1e-5 feature tolerance) and in fp32.
+    import torch
+    from oracle.cpu_model import sa_module_cpu
+    g = torch.Generator().manual_seed(20245)
+    B, N, m, ns, radius, S = 3, 256, 48, 16, 0.35, 2
+    xyz = synth.gauss_ball(B, N, 20245)
+    feat = torch.randn(B, N, 5, generator=g).numpy().astype(np.float32)
+    spec = [8, 32, 32, 64]
+    ws = [(torch.randn(spec[i + 1], spec[i], generator=g) / spec[i] ** 0.5).numpy().astype(np.float32) for i in range(3)]
+    gs = [torch.empty(c).uniform_(0.5, 1.5, generator=g).numpy().astype(np.float32) for c in spec[1:]]
+    bs = [torch.empty(c).uniform_(-0.3, 0.3, generator=g).numpy().astype(np.float32) for c in spec[1:]]
+    gs[1][::3] *= -1.0                               # negative gamma: the max must not assume a monotone BatchNorm
+    def level(dt):
+        T = lambda a: torch.from_numpy(a).to(dt)
+        return sa_module_cpu(T(xyz), T(feat), [T(w) for w in ws], [T(x) for x in gs], [T(x) for x in bs], m, radius, ns, S, return_aux=True)
+    nx64, y64, aux = level(torch.float64)
+    nx32, y32, _ = level(torch.float32)
+    sa = {"xyz": xyz, "feat": feat, "n_points": m, "radius": radius, "n_samples": ns, "tie_stride": S,
+          "fps_idx": aux["fps_idx"], "bq_idx": aux["bq_idx"], "new_xyz": nx32.numpy(), "grouped": aux["grouped"].float().numpy(),
+          "pooled_f64": y64.numpy(), "pooled_f32": y32.numpy()}
+    for i in range(3):
+        sa[f"w{i}"], sa[f"gamma{i}"], sa[f"beta{i}"] = ws[i], gs[i], bs[i]
+    np.savez_compressed(os.path.join(OUT, "sa_level.npz"), **sa)
     print("wrote", os.listdir(OUT))
 
 
