@@ -168,6 +168,16 @@ __device__ __forceinline__ float knn_ld1(__amdgpu_buffer_rsrc_t r, unsigned off)
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
 
+// Workgroup -> (cloud, query block), XCD-aware: hardware hands consecutive workgroup ids to the 8 XCDs round-robin, each with
+// its own 4 MB L2.  With the plain (x = query block, y = cloud) grid the 32 workgroups of a cloud land on all 8 XCDs and every
+// L2 sees every cloud's reference matrix (16 MB at C = 128: misses to the Infinity Cache on each of the Nq/32 passes).  Here
+// XCD j takes the clouds j, j+8, ...: one matrix (<= 2 MB) is streamed by workgroups that share an L2 and run back to back.
+__device__ __forceinline__ void knn_block(int gx, int B, int& b, int& qb) {
+    const int lin = blockIdx.y * gx + blockIdx.x;
+    if ((B & 7) == 0) { const int slot = lin >> 3; b = (lin & 7) + 8 * (slot / gx); qb = slot % gx; }
+    else { b = blockIdx.y; qb = blockIdx.x; }
+}
+
 template <int PPT>
 struct KnnCfg {
     static constexpr int QW = 128 / PPT > 8 ? 8 : 128 / PPT;     // queries per wave
@@ -179,7 +189,9 @@ template <int PPT>
 __global__ __launch_bounds__(256) void knn_fused_kernel(const float* __restrict__ ref, const float* __restrict__ qry, int C, int Nr,
                                                         int Nq, int k, int32_t* __restrict__ idx_out,
                                                         const unsigned char* __restrict__ redo) {
-    if (redo && !redo[(size_t)blockIdx.y * gridDim.x + blockIdx.x]) return;       // (second launch after the filter kernel)
+    int b, qblk;
+    knn_block(gridDim.x, gridDim.y, b, qblk);
+    if (redo && !redo[(size_t)b * gridDim.x + qblk]) return;                      // (second launch after the filter kernel)
     using Cfg = KnnCfg<PPT>;
     constexpr int QW = Cfg::QW, NRP = Cfg::NRP, CK = Cfg::CK, QB = 4 * QW, NJ = PPT / 4;
     constexpr int RV = CK * NRP / 4 / 256;                       // 16-byte reference pieces per thread and stage
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(const float* __restrict_
     __shared__ __attribute__((aligned(16))) float sR[2][CK][NRP];
     __shared__ __attribute__((aligned(16))) float sQ[2][CK][QB];
     __shared__ uint2 sCand[4][64];                               // per wave: the candidates of the query being selected
-    const int b = blockIdx.y, q0 = blockIdx.x * QB;
+    const int q0 = qblk * QB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* R = ref + (size_t)b * C * Nr;
     const float* Q = qry + (size_t)b * C * Nq;
@@ -410,7 +422,9 @@ __global__ __launch_bounds__(256) void knn_filter_kernel(const float* __restrict
     __shared__ float sNr[NRP], sNq[QB], sRed[4];
     __shared__ unsigned sCand[QB][64];
     __shared__ int sCnt[QB];
-    const int b = blockIdx.y, q0 = blockIdx.x * QB;
+    int b, qblk;
+    knn_block(gridDim.x, gridDim.y, b, qblk);
+    const int q0 = qblk * QB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
     const float* R = ref + (size_t)b * C * Nr;
@@ -579,7 +593,7 @@ __global__ __launch_bounds__(256) void knn_filter_kernel(const float* __restrict
         }
         if (lane == 0) sCnt[qi] = n;
     }
-    if (__ballot(bad) && lane == 0) redo[(size_t)b * gridDim.x + blockIdx.x] = 1;
+    if (__ballot(bad) && lane == 0) redo[(size_t)b * gridDim.x + qblk] = 1;
     __syncthreads();
 
     KF_MARK(2)
