@@ -21,6 +21,8 @@ python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 2, 2>' 
 python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 1, 1>' 1 0=fb64x64 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
 rm -rf $O/kt/*/*.db $O/fetch $O/write $O/sq/*/*.db 2>/dev/null
 python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
+# every C-ABI entry point event-timed (GEMM kernels: their own begin/end timestamps), algorithmic GB/s and TF per launch shape
+python bench.py --steps 20 --warmup 3 --profile-all --no-cpu-baseline --roofline-kernel none 2>&1 >/dev/null | grep -E "n/step|entry" > $O/${R}_entry_point_roofline.txt
 python -m pytest tests/test_parity_pointnet2_gpu.py tests/test_parity_dgcnn_gpu.py tests/test_parity_partseg_gpu.py tests/test_parity_pointconv_gpu.py -m gpu -s -q 2>&1 | grep -v Warning > $O/${R}_parity_reports.txt
 # the other BASELINE configs: one line each with the roofline of its dominant kernel, and a kernel-stats CSV per config
 python tools/bench_models.py --steps 20 --out $O/${R}_other_configs.json > $O/other.log 2>&1
