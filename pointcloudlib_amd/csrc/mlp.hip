@@ -1259,10 +1259,8 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
             for (int r = 0; r < 16; ++r) accw[a][b][r] = 0.f;
     double st_s = 0.0, st_q = 0.0;
 
-    // ---- raw operands of one tile in registers.  256 x 128 sparse: 64 accumulator registers + 112 of prefetch do not fit
-    // beside the dW loop, so there only the first half of the (arg, gz) rows travels with the prefetch; the second half
-    // (L2 hits: a group's rows are neighbours) is requested at the top of the deposit and lands while the first is transformed.
-    constexpr int NPRE = SPARSE && COUT * CIN > 128 * 128 ? NI_O / 2 : NI_O;
+    // ---- raw operands of one tile in registers (256 x 128 sparse: 64 accumulator + 112 prefetch registers; they fit because the
+    // requests are issued in slices through the dW loop -- all at once they spilled)
     float4 rY[NI_O], rU[SPARSE ? 1 : NI_O], rG[SPARSE ? NI_O : 1], rP[NI_I];
     int4 rA[SPARSE ? NI_O : 1];
     int2 rM = make_int2(0, 0);                       // row record of row tid (< R) of the tile after the requested one
@@ -1303,11 +1301,9 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
             const int i = n / PER_O, kind = n % PER_O;
             if (kind == 0) rY[i] = buf_ld4(c.y, c.vo, (unsigned)(RP_O * i) * orow);
             else if constexpr (SPARSE) {
-                if (i < NPRE) {
-                    const unsigned go = (unsigned)c.mrow[RP_O * i].x * orow + (unsigned)oc4 * 4;
-                    if (kind == 1) rA[i] = buf_ld4i(rArg, go, 0);
-                    else rG[i] = buf_ld4(rGz, go, 0);
-                }
+                const unsigned go = (unsigned)c.mrow[RP_O * i].x * orow + (unsigned)oc4 * 4;
+                if (kind == 1) rA[i] = buf_ld4i(rArg, go, 0);
+                else rG[i] = buf_ld4(rGz, go, 0);
             } else rU[i] = buf_ld4(c.u, c.vo, (unsigned)(RP_O * i) * orow);
         } else {
             const int i = n - NI_O * PER_O;
@@ -1324,14 +1320,6 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
         const int2* mrow = sMeta + mb * R + orow0;
         float* const dst = sDY + orow0 * DLD + oc4;
         float* const dsty = sY + irow0 * YLD + ic4;
-        if constexpr (SPARSE) {
-#pragma unroll
-            for (int i = NPRE; i < NI_O; ++i) {
-                const unsigned go = (unsigned)mrow[RP_O * i].x * orow + (unsigned)oc4 * 4;
-                rA[i] = buf_ld4i(rArg, go, 0);
-                rG[i] = buf_ld4(rGz, go, 0);
-            }
-        }
 #pragma unroll
         for (int i = 0; i < NI_O; ++i) {
             const int my = mrow[RP_O * i].y;
