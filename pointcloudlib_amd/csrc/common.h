@@ -53,6 +53,16 @@ TimeHook& time_hook();
         } else hipLaunchKernelGGL(kernel, grid, blk, 0, st, __VA_ARGS__);                                               \
     } while (0)
 
+// XCD-aware logical block id for a 1-D grid whose consecutive blocks walk the clouds one after another (`bpc` blocks per
+// cloud, nblk = clouds * bpc).  The hardware deals consecutive workgroup ids to the 8 XCDs round-robin, each with its own
+// 4 MB L2: with the plain id every XCD touches every cloud's table.  Here XCD j takes the clouds j, j+8, ... whole, one
+// after the other, so a cloud's table is gathered by workgroups that share an L2.  Identity when the shape does not divide.
+__device__ __forceinline__ unsigned xcd_cloud_block(unsigned lin, unsigned nblk, unsigned bpc) {
+    if (bpc == 0 || nblk % (8u * bpc) != 0) return lin;
+    const unsigned slot = lin >> 3;
+    return ((lin & 7u) + 8u * (slot / bpc)) * bpc + slot % bpc;
+}
+
 // ---------------------------------------------------------------- device helpers
 #define PCL_WAVE 64
 

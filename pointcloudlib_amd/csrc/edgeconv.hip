@@ -35,7 +35,9 @@ __global__ __launch_bounds__(256) void edgeconv_gather_kernel(const float* __res
     const int tid = threadIdx.x;
     for (int c = tid; c < 2 * C; c += 256) ssum[c] = 0.0;
     __syncthreads();
-    const size_t p0 = (size_t)blockIdx.x * EC_PB;
+    // (blocks of a cloud on one XCD: the U rows they gather stay in that L2; stats rows keep the logical block order)
+    const unsigned lb = (N % EC_PB == 0) ? xcd_cloud_block(blockIdx.x, gridDim.x, N / EC_PB) : blockIdx.x;
+    const size_t p0 = (size_t)lb * EC_PB;
     const int items = EC_PB * C;
     for (int e = tid; e < items; e += 256) {
         const int pi = e / C, c = e - pi * C;
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void edgeconv_gather_kernel(const float* __res
         atomicAdd(&ssum[c], s); atomicAdd(&ssum[C + c], q);
     }
     __syncthreads();
-    double* dst = stats + (size_t)blockIdx.x * 2 * C;
+    double* dst = stats + (size_t)lb * 2 * C;
     for (int c = tid; c < 2 * C; c += 256) dst[c] = ssum[c];
 }
 
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(256) void edgeconv_insum_kernel(const float* __rest
                                                              const float* __restrict__ k2_, const float* __restrict__ mu_,
                                                              int N, int C, size_t P, float* __restrict__ dUV) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t p = (size_t)blockIdx.x * 4 + wave;
+    const size_t p = (size_t)((N & 3) == 0 ? xcd_cloud_block(blockIdx.x, gridDim.x, N / 4) : blockIdx.x) * 4 + wave;
     if (p >= P) return;
     const size_t base = (p / N) * N;
     const int beg = in_off[p], end = in_off[p + 1];
