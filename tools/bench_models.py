@@ -44,7 +44,65 @@ def roofline_of(step):
                 "valu_peak_tops": 64.4, "frac_valu": round(ach / 64.4, 4)} if key[0] == "pcl_knn_f32" else {})}
 
 
-def run(name, make, inputs, loss_fn, steps, warmup=3):
+CPU_BASELINE = False                                   # --cpu-baseline: also time the CPU restatement of the config
+
+
+def cpu_baseline_of(kind, state, n_warm=1, n_steps=5):
+    """the CPU restatement of the reference semantics (oracle/: index ops in C with OpenMP over the clouds, dense ops
+    PyTorch-CPU fp32) on the same synthetic batch, fwd + bwd + SGD, median of `n_steps` after `n_warm` (a bounded sample:
+    these steps take seconds).  Test infrastructure used as the CPU leg only -- nothing of it runs in the GPU path."""
+    import statistics
+    import numpy as np
+    import oracle
+    from oracle.cpu_dgcnn import DGCNNCPU
+    from oracle.cpu_model import PointNet2ClsCPU
+    from oracle.cpu_partseg import PointNet2PartSegCPU
+    from oracle.cpu_pointconv import PointConvClsCPU
+    lab = lambda B: torch.from_numpy(synth.labels(B, 40, 1))
+    if kind == "cfg2_n4096":
+        B, N = 32, 4096
+        net = PointNet2ClsCPU(state, tie_stride=oracle.optimal_block(B)).train()
+        x, f, y = torch.from_numpy(synth.gauss_ball(B, N, 20242)), torch.from_numpy(synth.unit_normals(B, N, 7)), lab(B)
+        fwd = lambda: soft_cross_entropy_loss(net(x, f), y)
+    elif kind == "cfg3":
+        B, N = 32, 1024
+        net = DGCNNCPU(state, 20)
+        x, y = torch.from_numpy(synth.gauss_ball(B, N, 20242)).transpose(1, 2).contiguous(), lab(B)
+        fwd = lambda: soft_cross_entropy_loss(net(x), y)
+    elif kind == "cfg4":
+        B, N = 16, 2048
+        net = PointNet2PartSegCPU(state, PointNet2PartSegCPU.SSG, tie_stride=oracle.optimal_block(B))
+        x = torch.from_numpy(synth.gauss_ball(B, N, 20244))
+        oh = torch.zeros(B, 16); oh[torch.arange(B), torch.arange(B) % 16] = 1
+        seg = torch.from_numpy(np.random.default_rng(5).integers(0, 50, (B, N)))
+        fwd = lambda: torch.nn.functional.cross_entropy(net(x, x, oh), seg)
+    elif kind == "cfg5":
+        B, N = 32, 1024
+        net = PointConvClsCPU(state)
+        x, y = torch.from_numpy(synth.gauss_ball(B, N, 20242)).transpose(1, 2).contiguous(), lab(B)
+        rng = np.random.default_rng(9)
+        start = [rng.integers(0, N, B).astype(np.int32), rng.integers(0, 512, B).astype(np.int32)]
+        fwd = lambda: soft_cross_entropy_loss(net(x, start), y)
+    else:
+        return None
+    opt = torch.optim.SGD(net.parameters(), lr=0.02, momentum=0.9)
+    threads = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    times = []
+    for i in range(n_warm + n_steps):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        fwd().backward()
+        opt.step()
+        if i >= n_warm:
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": round(B / med, 3), "unit": "point-clouds/s", "cores": threads, "kind": "port",
+            "sample": f"median of {n_steps} fwd+bwd+SGD steps (min {min(times):.2f} s, max {max(times):.2f} s) after {n_warm} warm-up, "
+                      f"B={B} N={N}; CPU restatement of reference semantics (oracle/, Jittor not runnable), {threads} PyTorch threads"}
+
+
+def run(name, make, inputs, loss_fn, steps, warmup=3, cpu_kind=None):
     if ONLY and ONLY not in name:
         return None
     torch.manual_seed(0)
@@ -63,6 +121,9 @@ def run(name, make, inputs, loss_fn, steps, warmup=3):
     B = inputs[0].shape[0]
     r = {"config": name, "ms_per_step": round(dt * 1e3, 3), "clouds_per_s": round(B / dt, 1), "batch": B,
          "params": sum(p.numel() for p in net.parameters()), "roofline": roofline_of(step)}
+    if CPU_BASELINE and cpu_kind:
+        torch.cuda.synchronize()
+        r["cpu_baseline"] = cpu_baseline_of(cpu_kind, net.state_dict())
     print(json.dumps(r), flush=True)
     return r
 
@@ -104,10 +165,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU restatement of configs 2', 3, 4, 5 (tens of seconds each)")
     ap.add_argument("--only", default=None, help="run only the configs whose name contains this (one config under rocprofv3)")
     a = ap.parse_args()
-    global ONLY
-    ONLY = a.only
+    global ONLY, CPU_BASELINE
+    ONLY, CPU_BASELINE = a.only, a.cpu_baseline
     from pointcloudlib_amd.networks.cls.pointnet import PointNet
     from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
     from pointcloudlib_amd.networks.cls.dgcnn import DGCNN
@@ -124,19 +186,19 @@ def main():
     x = cloud(32, 1024, 20242)
     res.append(run("cfg2 PointNet++ SSG cls B=32 N=1024 (no sampling prefetch)", PointNet2_cls, (x, nrm(32, 1024, 7)), lambda o: soft_cross_entropy_loss(o, y32), a.steps))
     x4 = cloud(32, 4096, 20242)
-    res.append(run("cfg2' PointNet++ SSG cls B=32 N=4096", PointNet2_cls, (x4, nrm(32, 4096, 7)), lambda o: soft_cross_entropy_loss(o, y32), a.steps))
-    res.append(run("cfg3 DGCNN cls B=32 N=1024 k=20", DGCNN, (x.transpose(1, 2).contiguous(),), lambda o: soft_cross_entropy_loss(o, y32), a.steps))
+    res.append(run("cfg2' PointNet++ SSG cls B=32 N=4096", PointNet2_cls, (x4, nrm(32, 4096, 7)), lambda o: soft_cross_entropy_loss(o, y32), a.steps, cpu_kind="cfg2_n4096"))
+    res.append(run("cfg3 DGCNN cls B=32 N=1024 k=20", DGCNN, (x.transpose(1, 2).contiguous(),), lambda o: soft_cross_entropy_loss(o, y32), a.steps, cpu_kind="cfg3"))
     xs = cloud(16, 2048, 20244)
     oh = torch.zeros(16, 16, device=dev); oh[torch.arange(16), torch.arange(16) % 16] = 1
     seg = torch.randint(0, 50, (16, 2048), device=dev)
     res.append(run("cfg4 PointNet++ SSG part-seg B=16 N=2048", PointNet2_partseg, (xs, xs, oh),
-                   lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps))
+                   lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps, cpu_kind="cfg4"))
     res.append(run_prefetch("cfg4 PointNet++ SSG part-seg B=16 N=2048, sampling of batch t+1 on a side stream", PointNet2_partseg, (xs, xs, oh),
                             lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps))
     from pointcloudlib_amd.networks.seg.pointnet2_partseg import PointNetMSG
     res.append(run("cfg4' PointNet++ MSG part-seg B=16 N=2048 (FP widths corrected, see DESIGN 7)", PointNetMSG, (xs, xs, oh),
                    lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps))
-    res.append(run("cfg5 PointConv cls B=32 N=1024", PointConvDensityClsSsg, (x.transpose(1, 2).contiguous(),), lambda o: soft_cross_entropy_loss(o, y32), a.steps))
+    res.append(run("cfg5 PointConv cls B=32 N=1024", PointConvDensityClsSsg, (x.transpose(1, 2).contiguous(),), lambda o: soft_cross_entropy_loss(o, y32), a.steps, cpu_kind="cfg5"))
     from pointcloudlib_amd.networks.cls.pointcnn import PointCNNcls
     from pointcloudlib_amd.networks.seg.pointcnn_partseg import PointCNN_partseg
     from pointcloudlib_amd.networks.seg.pointnet_partseg import PointNet_partseg

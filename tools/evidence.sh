@@ -25,7 +25,7 @@ python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 3 --profile-all --no-cpu-baseline --roofline-kernel none 2>&1 >/dev/null | grep -E "n/step|entry" > $O/${R}_entry_point_roofline.txt
 python -m pytest tests/test_parity_pointnet2_gpu.py tests/test_parity_dgcnn_gpu.py tests/test_parity_partseg_gpu.py tests/test_parity_pointconv_gpu.py -m gpu -s -q 2>&1 | grep -v Warning > $O/${R}_parity_reports.txt
 # the other BASELINE configs: one line each with the roofline of its dominant kernel, and a kernel-stats CSV per config
-python tools/bench_models.py --steps 20 --out $O/${R}_other_configs.json > $O/other.log 2>&1
+python tools/bench_models.py --steps 20 --cpu-baseline --out $O/${R}_other_configs.json > $O/other.log 2>&1
 for c in "cfg2'" cfg3 "cfg4 PointNet++ SSG part-seg B=16 N=2048" cfg5; do
   t=$(echo "$c" | cut -c1-5 | tr -d "' " | sed "s/cfg2/cfg2_n4096/")
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$t -o b -- python tools/bench_models.py --steps 10 --only "$c" > $O/kt_$t.log 2>&1
