@@ -45,6 +45,7 @@ def roofline_of(step):
 
 
 CPU_BASELINE = False                                   # --cpu-baseline: also time the CPU restatement of the config
+CPU_JOBS = []                                          # (result dict, kind, CPU state dict), run after the GPU configs
 
 
 def cpu_baseline_of(kind, state, n_warm=1, n_steps=5):
@@ -122,8 +123,9 @@ def run(name, make, inputs, loss_fn, steps, warmup=3, cpu_kind=None):
     r = {"config": name, "ms_per_step": round(dt * 1e3, 3), "clouds_per_s": round(B / dt, 1), "batch": B,
          "params": sum(p.numel() for p in net.parameters()), "roofline": roofline_of(step)}
     if CPU_BASELINE and cpu_kind:
-        torch.cuda.synchronize()
-        r["cpu_baseline"] = cpu_baseline_of(cpu_kind, net.state_dict())
+        # (timed after ALL GPU configs: the CPU legs spin up 32 OpenMP / PyTorch threads that would compete with the Python
+        # launch thread of the host-bound configs that follow)
+        CPU_JOBS.append((r, cpu_kind, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}))
     print(json.dumps(r), flush=True)
     return r
 
@@ -212,6 +214,9 @@ def main():
     res.append(run("PointCNN part-seg B=16 N=2048", PointCNN_partseg, (xs,), lambda o: ce(o, seg), a.steps))
     res.append(run("PointConv part-seg B=16 N=2048", PointConvDensity_partseg, (xs, oh), lambda o: ce(o.permute(0, 2, 1), seg), a.steps))
     res = [r for r in res if r is not None]
+    for r, kind, state in CPU_JOBS:
+        r["cpu_baseline"] = cpu_baseline_of(kind, state)
+        print(json.dumps({"config": r["config"], "cpu_baseline": r["cpu_baseline"]}), flush=True)
     if a.out:
         json.dump({"device": torch.cuda.get_device_name(0), "note": "1 GPU, fp32, synthetic gauss_ball clouds, fwd+bwd+SGD; roofline = the dominant own kernel of each config (bench.py's rule)", "results": res},
                   open(a.out, "w"), indent=1)
