@@ -47,6 +47,8 @@ FB_CASES = [
     ([16, 64, 128, 64], (3, 1111), None, False, 0.2),       # 3333 rows (ragged last tile), no max: 64x128 and 128x64 dense
     ([9, 128, 128, 256], (2, 30, 48), 48, True, 0.0),       # 2880 rows: 256x128 sparse, 128x128 dense
     ([5, 64, 64, 64, 128], (7, 9, 16), 16, False, 0.0),     # 1008 rows: 128x64 sparse, 64x64 dense twice
+    ([4, 128, 128, 256], (2, 5, 4), 4, False, 0.0),         # 40 rows: one ragged tile, most workgroups of a capped grid idle
+    ([4, 64, 128, 64], (1, 65), None, True, 0.2),           # 65 rows: one full 64-row tile + 1 row (128-row tiles: one ragged)
 ]
 
 
