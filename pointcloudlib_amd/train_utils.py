@@ -55,11 +55,43 @@ def soft_cross_entropy_loss(output, target, smoothing=True):
     return -(one_hot * log_prb).sum(dim=1).mean()
 
 
+class _LeanFusedSGD(torch.optim.SGD):
+    """``torch.optim.SGD(fused=True)`` with the per-step Python bookkeeping (group walks, list building, hooks, profiler
+    records: ~150 us a step for ~100 parameters, when the whole GPU step takes 2 ms) done once: after the first step the
+    parameter and momentum-buffer lists are cached and ``step()`` is one call of the same multi-tensor kernel.  State,
+    ``param_groups`` (learning-rate schedules) and ``state_dict`` stay those of the parent class."""
+
+    def __init__(self, params, **kw):
+        super().__init__(params, fused=True, **kw)
+        self._lean = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None or len(self.param_groups) != 1:
+            return super().step(closure)
+        g = self.param_groups[0]
+        if self._lean is None:
+            out = super().step()                                       # creates the momentum buffers
+            ps = [p for p in g["params"] if p.grad is not None]
+            if g["momentum"] != 0 and len(ps) == len(g["params"]) and len({(p.device, p.dtype) for p in ps}) == 1:
+                self._lean = (ps, [self.state[p]["momentum_buffer"] for p in ps])
+            return out
+        ps, bufs = self._lean
+        grads = [p.grad for p in ps]
+        if any(x is None for x in grads):
+            return super().step()
+        torch._fused_sgd_(ps, grads, bufs, weight_decay=g["weight_decay"], momentum=g["momentum"], lr=g["lr"],
+                          dampening=g["dampening"], nesterov=g["nesterov"], maximize=g["maximize"], is_first_step=False,
+                          grad_scale=None, found_inf=None)
+        return None
+
+
 def make_sgd(params, lr=0.02, momentum=0.9, weight_decay=0.0):
     params = list(params)
     # one multi-tensor kernel for the whole update on the GPU (same arithmetic as the default three-kernel foreach path)
-    fused = bool(params) and all(p.is_cuda for p in params)
-    return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay, fused=fused)
+    if params and all(p.is_cuda for p in params):
+        return _LeanFusedSGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay)
+    return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay)
 
 
 def calculate_shape_IoU(pred_np, seg_np, label, class_choice=None):

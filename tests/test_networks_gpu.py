@@ -346,3 +346,31 @@ def test_graphed_step_matches_eager_step(dev):
     # step 0 sees identical weights; later steps drift (fp32 atomics in the gradient scatter + SGD on a tiny batch)
     assert abs(got[0] - eager[0]) <= 1e-4 * abs(eager[0]), (got, eager)
     assert all(abs(a - b) <= 0.15 * abs(b) for a, b in zip(got, eager)), (got, eager)
+
+
+def test_lean_sgd_is_torch_fused_sgd(dev):
+    """train_utils.make_sgd on GPU parameters caches the parameter / momentum lists after the first step and then calls the
+    same multi-tensor kernel torch.optim.SGD(fused=True) does: bit-identical parameters after several steps, with weight
+    decay, a learning-rate change through param_groups, and a step in which a parameter has no gradient."""
+    from pointcloudlib_amd.train_utils import make_sgd
+    torch.manual_seed(3)
+    ws = [torch.randn(s, device=dev) for s in ((7, 5), (11,), (3, 4, 2))]
+    pa = [torch.nn.Parameter(w.clone()) for w in ws]
+    pb = [torch.nn.Parameter(w.clone()) for w in ws]
+    oa = make_sgd(pa, lr=0.05, momentum=0.9, weight_decay=1e-3)
+    ob = torch.optim.SGD(pb, lr=0.05, momentum=0.9, weight_decay=1e-3, fused=True)
+    assert type(oa).__name__ == "_LeanFusedSGD"
+    for step in range(6):
+        gs = [torch.randn_like(w) for w in ws]
+        for p, q, g in zip(pa, pb, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        if step == 3:
+            for o in (oa, ob):
+                o.param_groups[0]["lr"] = 0.01
+        if step == 4:
+            pa[1].grad = None; pb[1].grad = None
+        oa.step(); ob.step()
+        for p, q in zip(pa, pb):
+            assert torch.equal(p.data, q.data), step
+    for p, q in zip(pa, pb):
+        assert torch.equal(oa.state[p]["momentum_buffer"], ob.state[q]["momentum_buffer"])
