@@ -9,5 +9,5 @@ by hand-derived known answers and by a second, independent NumPy restatement.
 """
 from .oracle import (  # noqa: F401
     lib_path, build, optimal_block, fps, ball_query, group, group_bwd, group_all, knn, three_nn,
-    three_interp, num_threads, density,
+    three_interp, num_threads, density, set_contract, get_contract, contract, knn_point_matmul,
 )

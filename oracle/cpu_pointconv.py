@@ -8,9 +8,13 @@ stack :384-389 -> ``WeightNet`` on the local coordinates :391-392 -> density mul
 :393-394 -> Linear + BatchNorm1d + ReLU :395-397; network head networks/cls/pointconv.py:27-34.
 
 Index ops come from pcl_oracle.c: FPS without the origin skip and with block size 1 (the NumPy-style loop of :74-116 has no
-block reduction: ties go to the lowest index, as ``jt.argmax`` returns the first maximum), k-NN by (direct-form squared
-distance, index) -- the reference's matmul-form distances + full argsort (:34-53, :129-130) are unpinnable to the last ulp;
-this is the build's documented definition.  ``sample_and_group_all`` is missing upstream (:380); the original PointConv
+block reduction: ties go to the lowest index, as ``jt.argmax`` returns the first maximum).  k-NN groups, two definitions:
+``knn="direct"`` (default) -- (direct-form squared distance, index), the library's documented definition;
+``knn="matmul"`` -- the reference's own arithmetic, ``square_distance`` in matmul form ``-2ab + a^2 + b^2`` (:34-53) + the
+first k of a stable ascending argsort (:16-32, :129-130), restated in ``pclo_knn_point_matmul_f32`` (Jittor's matmul /
+argsort rounding and tie order are outside /root/reference, so that restatement fixes: fma dot over c ascending, stable
+sort).  tests/test_parity_pointconv_gpu.py bounds how many groups differ between the two and runs the whole network, forward
+and backward, on BOTH sets of groups.  ``sample_and_group_all`` is missing upstream (:380); the original PointConv
 semantics are used (one group of all points, coordinates relative to the centroid), as in pointcloudlib_amd.
 """
 import numpy as np
@@ -24,6 +28,7 @@ class PointConvClsCPU(ParamBag):
     """state_dict-compatible with pointcloudlib_amd.networks.cls.pointconv.PointConvDensityClsSsg."""
 
     SA = [("sa1", 512, 32, 0.1), ("sa2", 128, 64, 0.2), ("sa3", None, None, 0.4)]
+    knn = "direct"
 
     def set_abstraction(self, name, npoint, nsample, bandwidth, xyz, points, start_idx, aux):
         """xyz [B,N,3], points [B,N,D] | None -> (new_xyz [B,S,3], new_points [B,S,C'])"""
@@ -42,8 +47,12 @@ class PointConvClsCPU(ParamBag):
             fidx = _o.fps(xyz_np, npoint, block_size=1, skip=False, start_idx=start_idx)        # :145
             bi = torch.arange(B)[:, None]
             new_xyz = xyz[bi, torch.from_numpy(fidx.astype(np.int64))]                          # :149
-            q = np.ascontiguousarray(new_xyz.detach().float().numpy().transpose(0, 2, 1))
-            idx = _o.knn(q, np.ascontiguousarray(xyz_np.transpose(0, 2, 1)), nsample).transpose(0, 2, 1)     # :152
+            q_np = np.ascontiguousarray(new_xyz.detach().float().numpy())
+            if self.knn == "matmul":
+                idx = _o.knn_point_matmul(nsample, xyz_np, q_np)                                # :152 as written (:34-53, :120-131)
+            else:
+                idx = _o.knn(np.ascontiguousarray(q_np.transpose(0, 2, 1)), np.ascontiguousarray(xyz_np.transpose(0, 2, 1)),
+                             nsample).transpose(0, 2, 1)                                        # :152, direct-form definition
             li = torch.from_numpy(np.ascontiguousarray(idx).astype(np.int64))
             b3 = torch.arange(B)[:, None, None]
             g_xyz = xyz[b3, li] - new_xyz[:, :, None, :]                                        # :156-157

@@ -137,6 +137,44 @@ def knn(x_q, x_r, k):
     return idx
 
 
+def set_contract(mode):
+    """0: every fp32 operation of the index-producing distances rounded on its own (the library's definition);
+    1 / "fma": nvcc's default -fmad=true reading (see pcl_oracle.c header).  Process-global."""
+    _lib().pclo_set_contract(1 if mode in (1, True, "fma") else 0)
+
+
+def get_contract():
+    return int(_lib().pclo_get_contract())
+
+
+class contract:
+    """``with oracle.contract("fma"): ...`` -- evaluate the oracle under the contracted reading."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = get_contract()
+        set_contract(self.mode)
+
+    def __exit__(self, *a):
+        set_contract(self.prev)
+
+
+def knn_point_matmul(nsample, xyz, new_xyz, fma_dot=True, return_dist=False):
+    """misc/pointconv_utils.py:120-131 in the reference's matmul-form arithmetic: xyz [B,N,3], new_xyz [B,S,3] ->
+    int32 [B,S,nsample] (stable ascending argsort of -2ab + a^2 + b^2)."""
+    xyz, px = _f(xyz)
+    new_xyz, pq = _f(new_xyz)
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    idx = np.empty((B, S, nsample), np.int32)
+    dist = np.empty((B, S, N), np.float32) if return_dist else None
+    _check(_lib().pclo_knn_point_matmul_f32(px, pq, B, N, S, int(nsample), int(bool(fma_dot)), idx.ctypes.data_as(c_int_p),
+                                            dist.ctypes.data_as(c_float_p) if return_dist else None), "knn_point_matmul")
+    return (idx, dist) if return_dist else idx
+
+
 def three_nn(xyz1, xyz2):
     xyz1, p1 = _f(xyz1)
     xyz2, p2 = _f(xyz2)

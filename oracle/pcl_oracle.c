@@ -16,6 +16,19 @@
  * restatement (oracle/np_oracle.py) and hand-derived known answers
  * (tests/test_oracle_kat.py).
  *
+ * SECOND READING ("fma" mode, pclo_set_contract(1)): nvcc's default -fmad=true
+ * contracts a multiply feeding an add into one fused multiply-add.  For the
+ * three index-producing distance expressions that gives, in the left-to-right
+ * association C prescribes,
+ *     a*a + b*b + c*c   ->  fma(c, c, fma(b, b, a*a))          (:162, :165, :317-318)
+ *     ssd += tmp*tmp    ->  ssd = fma(tmp, tmp, ssd)            (:488-491)
+ * Mode 0 (default, the library's definition) rounds every operation on its
+ * own.  Mode 1 exists to MEASURE how many indices depend on that choice
+ * (tools/contraction_sensitivity.py -> profiles/r03_contraction_sensitivity.txt)
+ * and as the checker of the library's named second definition
+ * (PCL_KNN_CONTRACT=fma).  Neither reading is pinned by anything the
+ * reference holds.
+ *
  * All citations are into /root/reference/.
  */
 #include <stdint.h>
@@ -31,7 +44,19 @@
 #define PCLO_EINVAL -1
 #define PCLO_ENOMEM -2
 
-int pclo_version(void) { return 1; }
+int pclo_version(void) { return 2; }
+
+/* 0 = every operation rounded on its own (source reading); 1 = nvcc -fmad=true reading.
+ * Process-global, set between calls (never while one runs). */
+static int g_contract = 0;
+void pclo_set_contract(int mode) { g_contract = mode ? 1 : 0; }
+int pclo_get_contract(void) { return g_contract; }
+
+/* a*a + b*b + c*c in the active reading */
+static inline float sumsq3(float a, float b, float c, int contract) {
+    if (contract) return fmaf(c, c, fmaf(b, b, a * a));
+    return (a * a) + (b * b) + (c * c);
+}
 
 int pclo_num_threads(void) {
 #ifdef _OPENMP
@@ -77,6 +102,7 @@ int pclo_fps_f32(const float* xyz, int B, int N, int m, int block_size, int skip
         int* dists_i = (int*)malloc(sizeof(int) * (size_t)block_size);
         if (!temp || !dists || !dists_i) { rc = PCLO_ENOMEM; free(temp); free(dists); free(dists_i); continue; }
         const int stride = block_size;                          /* :141 */
+        const int contract = g_contract;
         int old = start_idx ? start_idx[b] : 0;                 /* :143 */
         idxs[0] = old;                                          /* :144 */
         for (int k = 0; k < N; ++k) temp[k] = 1e10f;            /* :147-148 */
@@ -92,11 +118,10 @@ int pclo_fps_f32(const float* xyz, int B, int N, int m, int block_size, int skip
                     const float y2 = dataset[k * 3 + 1];
                     const float z2 = dataset[k * 3 + 2];
                     if (skip_enabled) {
-                        const float mag = (x2 * x2) + (y2 * y2) + (z2 * z2);   /* :162 */
+                        const float mag = sumsq3(x2, y2, z2, contract);        /* :162 */
                         if ((double)mag <= 1e-3) continue;                     /* :163 */
                     }
-                    const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) +
-                                    (z2 - z1) * (z2 - z1);                     /* :165 */
+                    const float d = sumsq3(x2 - x1, y2 - y1, z2 - z1, contract); /* :165 */
                     const float d2 = fminf(d, temp[k]);                        /* :167 */
                     temp[k] = d2;
                     besti = d2 > best ? k : besti;                             /* :169 */
@@ -140,6 +165,7 @@ int pclo_ball_query_f32(const float* new_xyz, const float* xyz, int B, int m, in
                         int nsample, int32_t* idx, int32_t* cnt_out) {
     if (!new_xyz || !xyz || !idx || B < 0 || m < 0 || N < 1 || nsample < 1) return PCLO_EINVAL;
     const float radius2 = radius * radius;                                    /* :306 */
+    const int contract = g_contract;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < B; ++b) {
         const float* P = xyz + (size_t)b * N * 3;
@@ -151,8 +177,7 @@ int pclo_ball_query_f32(const float* new_xyz, const float* xyz, int B, int m, in
             for (int l = 0; l < nsample; ++l) I[j * nsample + l] = 0;         /* defined fill */
             for (int k = 0; k < N && cnt < nsample; ++k) {                    /* :313 */
                 const float x = P[k * 3 + 0], y = P[k * 3 + 1], z = P[k * 3 + 2];
-                const float d2 = (new_x - x) * (new_x - x) + (new_y - y) * (new_y - y) +
-                                 (new_z - z) * (new_z - z);                   /* :317-318 */
+                const float d2 = sumsq3(new_x - x, new_y - y, new_z - z, contract);   /* :317-318 */
                 if (d2 < radius2) {                                           /* :320 */
                     if (cnt == 0)
                         for (int l = 0; l < nsample; ++l) I[j * nsample + l] = k;   /* :321-324 */
@@ -239,6 +264,7 @@ int pclo_knn_f32(const float* ref, const float* qry, int B, int C, int Nr, int N
                  int32_t* idx, float* dist_scratch) {
     if (!ref || !qry || !idx || B < 0 || C < 1 || Nr < 1 || Nq < 1 || k < 1 || k > Nr) return PCLO_EINVAL;
     float* dist = dist_scratch;
+    const int contract = g_contract;
     if (!dist) {
         dist = (float*)malloc(sizeof(float) * (size_t)B * Nr * Nq);
         if (!dist) return PCLO_ENOMEM;
@@ -253,7 +279,7 @@ int pclo_knn_f32(const float* ref, const float* qry, int B, int C, int Nr, int N
                 float ssd = 0.f;                                              /* :456 */
                 for (int c = 0; c < C; ++c) {
                     const float tmp = R[(size_t)c * Nr + r] - Q[(size_t)c * Nq + q];   /* :489 */
-                    ssd += tmp * tmp;                                         /* :490 */
+                    ssd = contract ? fmaf(tmp, tmp, ssd) : ssd + tmp * tmp;   /* :490 */
                 }
                 D[(size_t)r * Nq + q] = ssd;                                  /* :500 */
             }
@@ -364,3 +390,61 @@ int pclo_density_f32(const float* xyz, int B, int N, float bandwidth, float* out
     }
     return PCLO_OK;
 }
+
+/* ------------------------------------------------------------------------- *
+ * PointConv knn_point in the reference's own arithmetic: misc/pointconv_utils.py:120-131
+ *   sqrdists = square_distance(new_xyz, xyz)            (:129)
+ *   square_distance (:34-53):  dist  = -2 * matmul(src, dst^T)       (:50)
+ *                              dist += sum(src**2, -1)[:, :, None]    (:51)
+ *                              dist += sum(dst**2, -1)[:, None, :]    (:52)
+ *   topk(largest=False) (:16-32) = the first k of a full ascending jt.argsort.
+ * Jittor's matmul / reduce / argsort are not in /root/reference (module `jittor`, unpinned).  DEFINED here
+ * as: dot product accumulated over c = 0,1,2 ascending -- `fma_dot` = 1: fma chain (what a BLAS sgemm micro-kernel
+ * does), 0: every product and sum rounded on its own; squares summed ascending, each rounded; the three terms added in
+ * the order the source adds them; argsort stable (ties -> lower index, what a radix / merge sort gives).
+ * This is the checker for how far the library's direct-form k-NN groups (pclo_knn_f32 on xyz) are from the
+ * reference's matmul-form ones.  src = new_xyz [B,S,3] (queries), dst = xyz [B,N,3]; out idx [B,S,k].
+ * `dist_out` (nullable) receives the [B,S,N] matrix.
+ * ------------------------------------------------------------------------- */
+typedef struct { float d; int32_t i; } pclo_di;
+static int pclo_di_cmp(const void* a, const void* b) {
+    const pclo_di* x = (const pclo_di*)a; const pclo_di* y = (const pclo_di*)b;
+    if (x->d < y->d) return -1;
+    if (x->d > y->d) return 1;
+    return (x->i > y->i) - (x->i < y->i);
+}
+int pclo_knn_point_matmul_f32(const float* xyz, const float* new_xyz, int B, int N, int S, int k, int fma_dot,
+                              int32_t* idx, float* dist_out) {
+    if (!xyz || !new_xyz || !idx || B < 0 || N < 1 || S < 0 || k < 1 || k > N) return PCLO_EINVAL;
+    int rc = PCLO_OK;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b) {
+        const float* P = xyz + (size_t)b * N * 3;
+        const float* Q = new_xyz + (size_t)b * S * 3;
+        float* dn = (float*)malloc(sizeof(float) * (size_t)N);
+        pclo_di* row = (pclo_di*)malloc(sizeof(pclo_di) * (size_t)N);
+        if (!dn || !row) { rc = PCLO_ENOMEM; free(dn); free(row); continue; }
+        for (int n = 0; n < N; ++n) dn[n] = ((P[3 * n] * P[3 * n]) + (P[3 * n + 1] * P[3 * n + 1])) + (P[3 * n + 2] * P[3 * n + 2]);   /* :52 */
+        for (int s = 0; s < S; ++s) {
+            const float qx = Q[3 * s], qy = Q[3 * s + 1], qz = Q[3 * s + 2];
+            const float sn = ((qx * qx) + (qy * qy)) + (qz * qz);                      /* :51 */
+            for (int n = 0; n < N; ++n) {
+                float dot;
+                if (fma_dot) dot = fmaf(qz, P[3 * n + 2], fmaf(qy, P[3 * n + 1], qx * P[3 * n]));
+                else dot = ((qx * P[3 * n]) + (qy * P[3 * n + 1])) + (qz * P[3 * n + 2]);
+                float d = -2.0f * dot;                                                 /* :50 */
+                d = d + sn;                                                            /* :51 */
+                d = d + dn[n];                                                         /* :52 */
+                row[n].d = d; row[n].i = n;
+                if (dist_out) dist_out[((size_t)b * S + s) * N + n] = d;
+            }
+            qsort(row, (size_t)N, sizeof(pclo_di), pclo_di_cmp);                       /* :26 argsort ascending, stable */
+            for (int j = 0; j < k; ++j) idx[((size_t)b * S + s) * k + j] = row[j].i;   /* :27 */
+        }
+        free(dn); free(row);
+    }
+    return rc;
+}
+
+/* a*a + b*b + c*c under reading `contract` -- exported for the known-answer test of the two readings only. */
+float pclo_sumsq3(float a, float b, float c, int contract) { return sumsq3(a, b, c, contract); }

@@ -48,12 +48,14 @@ def compute_density(xyz, bandwidth):
     return out
 
 
-def sample_and_group(npoint, nsample, xyz, points, density_scale=None, start_idx=None):
-    """(:133-170) -> new_xyz [B,S,3], new_points [B,S,ns,3+D], grouped_xyz_norm [B,S,ns,3], idx, grouped_density."""
+def sample_and_group(npoint, nsample, xyz, points, density_scale=None, start_idx=None, knn_idx=None):
+    """(:133-170) -> new_xyz [B,S,3], new_points [B,S,ns,3+D], grouped_xyz_norm [B,S,ns,3], idx, grouped_density.
+    ``knn_idx`` int32 [B,S,ns]: neighbour groups to use instead of ``knn_point``'s (parity tests feed the groups of the
+    reference's matmul-form arithmetic, :34-53, through here)."""
     B, N, C = xyz.shape
     fps_idx = farthest_point_sample(xyz, npoint, start_idx)
     new_xyz = index_points(xyz, fps_idx)
-    idx = knn_point(nsample, xyz, new_xyz)
+    idx = knn_point(nsample, xyz, new_xyz) if knn_idx is None else _dev(knn_idx, "knn_idx")
     grouped_xyz_norm = index_points(xyz, idx) - new_xyz.view(B, npoint, 1, C)
     if points is not None:
         new_points = torch.cat([grouped_xyz_norm, index_points(points, idx)], dim=-1)
@@ -146,7 +148,7 @@ class PointConvDensitySetAbstraction(nn.Module):
         self.group_all = group_all
         self.bandwidth = bandwidth
 
-    def forward(self, xyz, points, start_idx=None):
+    def forward(self, xyz, points, start_idx=None, knn_idx=None):
         B, _, N = xyz.shape
         xyz = xyz.permute(0, 2, 1).contiguous()
         if points is not None:
@@ -156,7 +158,7 @@ class PointConvDensitySetAbstraction(nn.Module):
             new_xyz, new_points, grouped_xyz_norm, grouped_density = sample_and_group_all(xyz, points, density_scale)
         else:
             new_xyz, new_points, grouped_xyz_norm, _, grouped_density = sample_and_group(
-                self.npoint, self.nsample, xyz, points, density_scale, start_idx)
+                self.npoint, self.nsample, xyz, points, density_scale, start_idx, knn_idx)
         new_points = self.mlp(new_points.contiguous())                                   # [B,S,ns,C]   :384-389
         weights = self.weightnet(grouped_xyz_norm.contiguous())                          # [B,S,ns,16]  :391-392
         new_points = pointconv_contract(new_points, grouped_density, weights)            # [B,S,C*16]   :393-394

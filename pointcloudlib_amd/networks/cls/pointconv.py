@@ -21,11 +21,13 @@ class PointConvDensityClsSsg(nn.Module):
         self.fc3 = nn.Linear(256, n_classes)
         self.relu = nn.ReLU()
 
-    def forward(self, xyz, start_idx=None):
-        """xyz [B,3,N] (the reference permutes from [B,N,3] at :26; callers here pass [B,3,N] directly)."""
+    def forward(self, xyz, start_idx=None, knn_lists=None):
+        """xyz [B,3,N] (the reference permutes from [B,N,3] at :26; callers here pass [B,3,N] directly).
+        ``knn_lists``: optional neighbour groups (int32 [B,512,32], [B,128,64]) replacing ``knn_point``'s."""
         B = xyz.shape[0]
-        l1_xyz, l1_points = self.sa1(xyz, None, None if start_idx is None else start_idx[0])
-        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, None if start_idx is None else start_idx[1])
+        k1, k2 = (None, None) if knn_lists is None else knn_lists
+        l1_xyz, l1_points = self.sa1(xyz, None, None if start_idx is None else start_idx[0], k1)
+        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, None if start_idx is None else start_idx[1], k2)
         _, l3_points = self.sa3(l2_xyz, l2_points)
         x = l3_points.reshape(B, 1024)
         x = self.drop1(head_layer(x, self.fc1, self.bn1, self.relu))       # fused head kernels (misc/head.py)

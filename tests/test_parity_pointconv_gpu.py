@@ -2,6 +2,11 @@
 at the stated size.  FPS indices (caller-supplied start index, no origin skip) and k-NN groups exact at both sampled levels,
 level outputs and logits within 1e-5 of the fp64 value, gradients of every parameter by the fp64 yardstick
 (oracle/parity.py).  Reference: misc/pointconv_utils.py:133-170,:361-400, networks/cls/pointconv.py:8-34.
+
+``knn_point``: the library groups by direct-form distances; the reference computes ``-2ab + a^2 + b^2`` and a full argsort
+(:34-53, :120-131).  ``test_pointconv_knn_point_matmul_form`` measures and BOUNDS the fraction of groups that differ between
+the HIP groups and the matmul-form restatement (``oracle.knn_point_matmul``) at B=32 N=1024, and runs the whole network,
+features and gradients, on the matmul-form groups as well.
 """
 import numpy as np
 import pytest
@@ -63,4 +68,60 @@ def test_pointconv_cls_b32_n1024(oracle, dev):
     assert all(v is not None for v in g_hip.values())
     report.grads(g_hip, {n: r32.grad(n) for n in g_hip}, {n: r64.grad(n) for n in g_hip})
     report.check(abs(loss.item() - soft_cross_entropy_loss(o64, torch.from_numpy(lab)).item()) <= 1e-5, 'loss differs from the fp64 restatement')
+    report.finish()
+
+
+def test_pointconv_knn_point_matmul_form(oracle, dev):
+    """SURVEY 8(a) row 9 against the reference's OWN arithmetic for knn_point (matmul-form distances + argsort)."""
+    from oracle.cpu_pointconv import PointConvClsCPU
+    from oracle.parity import Report
+    from pointcloudlib_amd.misc import pointconv_utils as pu
+    from pointcloudlib_amd.networks.cls.pointconv import PointConvDensityClsSsg
+    from pointcloudlib_amd.train_utils import soft_cross_entropy_loss
+    B, N = 32, 1024
+    torch.manual_seed(0)
+    pts, lab = synth.gauss_ball(B, N, 20245), synth.labels(B, 40, 21145)
+    rng = np.random.default_rng(9)
+    start = [rng.integers(0, N, B).astype(np.int32), rng.integers(0, 512, B).astype(np.int32)]
+    net = _no_dropout(PointConvDensityClsSsg().to(dev)).train()
+    state = net.state_dict()
+    r32, r64 = PointConvClsCPU(state), PointConvClsCPU(state, dtype=torch.float64)
+    r32.knn = r64.knn = "matmul"
+    xin_c = torch.from_numpy(pts).transpose(1, 2).contiguous()
+    o32, a32 = r32(xin_c, start, return_aux=True)
+    o64, a64 = r64(xin_c, start, return_aux=True)
+    soft_cross_entropy_loss(o32, torch.from_numpy(lab)).backward()
+    soft_cross_entropy_loss(o64, torch.from_numpy(lab)).backward()
+    xin, y = xin_c.to(dev), torch.from_numpy(lab).to(dev)
+    st = [torch.from_numpy(s).to(dev) for s in start]
+
+    # (1) how far are the library's direct-form groups from the matmul-form ones?  Measured on the HIP kernels' output.
+    report = Report(f"PointConv cls B={B} N={N}, knn_point in matmul form")
+    lists = []
+    with torch.no_grad():
+        cur_xyz, cur_p = xin, None
+        for i, sa in enumerate((net.sa1, net.sa2)):
+            xyz_cl = cur_xyz.permute(0, 2, 1).contiguous()
+            fidx = pu.farthest_point_sample(xyz_cl, sa.npoint, st[i])
+            assert np.array_equal(fidx.cpu().numpy(), a32[i]["fps_idx"]), f"sa{i + 1}: FPS indices differ"
+            hip = pu.knn_point(sa.nsample, xyz_cl, pu.index_points(xyz_cl, fidx)).cpu().numpy()
+            mm = a32[i]["knn_idx"]
+            ordered = float((hip != mm).any(-1).mean())
+            sets = float((np.sort(hip, -1) != np.sort(mm, -1)).any(-1).mean())
+            slots = float((hip != mm).mean())
+            print(f"\n    sa{i + 1}: HIP direct-form groups vs matmul-form restatement: ordered lists differ {ordered:.6f}, SETS differ {sets:.6f}, "
+                  f"index slots differ {slots:.7f}")
+            # bounds (measured on this input: sa1 2.4e-4 / 0 / 1.5e-5, sa2 7.3e-4 / 2.4e-4 / 1.9e-5; profiles/r03_contraction_sensitivity.txt)
+            report.check(sets <= 1e-3, f"sa{i + 1}: {sets:.2e} of the groups differ as SETS from the matmul-form restatement (bound 1e-3)")
+            report.check(ordered <= 3e-3, f"sa{i + 1}: {ordered:.2e} of the groups differ as ordered lists (bound 3e-3)")
+            lists.append(torch.from_numpy(np.ascontiguousarray(mm)).to(dev))
+            cur_xyz, cur_p = sa(cur_xyz, cur_p, st[i], lists[i])
+            report.feature(cur_p.permute(0, 2, 1), a32[i]["feat"], a64[i]["feat"], f"sa{i + 1} output (matmul-form groups)")
+    # (2) the whole network on the matmul-form groups, forward and backward
+    out = net(xin, st, knn_lists=lists)
+    report.feature(out, o32, o64, "logits (matmul-form groups)")
+    loss = soft_cross_entropy_loss(out, y)
+    loss.backward()
+    g_hip = {n: p.grad for n, p in net.named_parameters()}
+    report.grads(g_hip, {n: r32.grad(n) for n in g_hip}, {n: r64.grad(n) for n in g_hip})
     report.finish()
