@@ -6,6 +6,12 @@ mode: batch mean, biased batch variance, eps 1e-5) + ReLU / LeakyReLU (e.g. netw
 networks/cls/dgcnn.py:72-86, misc/ops.py:61-64).  A 1x1 conv over [B,C,...] is a row-wise linear map over channel-last
 rows, which is how it is written here, on plain PyTorch-CPU ops.  ``dtype=torch.float64`` gives the same composition in
 double precision: the value both fp32 pipelines (this restatement in fp32, and the HIP path) are measured against.
+
+``storage="fp32"`` (with dtype float64) is the third pipeline of oracle/parity.py: every dense op is evaluated in double
+precision -- exact sums for all practical purposes, i.e. what a perfectly compensated fp32 kernel would compute -- but each
+op's RESULT is rounded to fp32 before the next op reads it, as any fp32 implementation must store it.  Its distance from
+the pure fp64 value is the part of an fp32 pipeline's error that no summation scheme can remove (storage rounding,
+amplified by 1/std at every BatchNorm); rows of a parity report that exceed 1e-5 are judged against it.
 """
 import torch
 import torch.nn.functional as F
@@ -23,9 +29,11 @@ def act(y, slope):
 class ParamBag(torch.nn.Module):
     """A state_dict of one of pointcloudlib_amd's networks as CPU parameters of one dtype, addressed by the original keys."""
 
-    def __init__(self, state, dtype=torch.float32):
+    def __init__(self, state, dtype=torch.float32, storage=None):
         super().__init__()
         self.dtype = dtype
+        self.storage = storage
+        assert storage in (None, "fp32") and (storage is None or dtype == torch.float64)
         self.p = torch.nn.ParameterDict()
         self.keys = {}
         for k, v in state.items():
@@ -34,6 +42,12 @@ class ParamBag(torch.nn.Module):
             nk = k.replace(".", "__")
             self.p[nk] = torch.nn.Parameter(v.detach().cpu().to(dtype).clone())
             self.keys[k] = nk
+
+    def rs(self, y):
+        """round an op's result to the storage precision (identity unless storage="fp32"); straight-through for autograd"""
+        if self.storage is None:
+            return y
+        return y + (y.detach().float().double() - y.detach())
 
     def has(self, k):
         return k in self.keys
@@ -51,19 +65,19 @@ class ParamBag(torch.nn.Module):
             n += 1
         for i in range(n):
             b = self.g(f"{prefix}biases.{i}") if self.has(f"{prefix}biases.{i}") else None
-            y = F.linear(y, self.g(f"{prefix}weights.{i}"), b)
+            y = self.rs(F.linear(y, self.g(f"{prefix}weights.{i}"), b))
             if bn:
-                y = bn_train(y, self.g(f"{prefix}gammas.{i}"), self.g(f"{prefix}betas.{i}"))
+                y = self.rs(bn_train(y, self.g(f"{prefix}gammas.{i}"), self.g(f"{prefix}betas.{i}")))
             if i < n - 1 or last_act:
-                y = act(y, slope)
+                y = self.rs(act(y, slope))
         return y
 
     def fc_bn_act(self, x, lin, bn=None, slope=None):
         """nn.Linear [+ nn.BatchNorm1d] [+ (Leaky)ReLU] stored as ``<lin>.weight/.bias``, ``<bn>.weight/.bias``."""
         b = self.g(f"{lin}.bias") if self.has(f"{lin}.bias") else None
-        x = F.linear(x, self.g(f"{lin}.weight"), b)
+        x = self.rs(F.linear(x, self.g(f"{lin}.weight"), b))
         if bn is not None:
-            x = bn_train(x, self.g(f"{bn}.weight"), self.g(f"{bn}.bias"))
+            x = self.rs(bn_train(x, self.g(f"{bn}.weight"), self.g(f"{bn}.bias")))
         if slope is not None:
-            x = act(x, slope)
+            x = self.rs(act(x, slope))
         return x

@@ -21,8 +21,8 @@ from .cpu_common import ParamBag, act
 class DGCNNCPU(ParamBag):
     """state_dict-compatible with pointcloudlib_amd.networks.cls.dgcnn.DGCNN."""
 
-    def __init__(self, state, k=20, dtype=torch.float32):
-        super().__init__(state, dtype)
+    def __init__(self, state, k=20, dtype=torch.float32, storage=None):
+        super().__init__(state, dtype, storage)
         self.k = k
 
     def knn_lists(self, x):
@@ -34,7 +34,7 @@ class DGCNNCPU(ParamBag):
         B, N, C = x.shape
         nb = x[torch.arange(B)[:, None, None], idx]                                # [B,N,k,C]      :44-46
         ctr = x[:, :, None, :].expand(B, N, self.k, C)                             # :47
-        e = torch.cat([nb - ctr, ctr], dim=-1)                                     # :49
+        e = torch.cat([self.rs(nb - ctr), ctr], dim=-1)                            # :49
         y = self.mlp(f"{name}.", e.reshape(-1, 2 * C), slope=0.2)                  # conv + bn + LeakyReLU(0.2)  :72-83
         return y.reshape(B, N, self.k, -1).max(dim=2)[0]                           # :102
 
@@ -50,7 +50,7 @@ class DGCNNCPU(ParamBag):
         x = torch.cat(feats, dim=2)                                                # :112
         B, N, _ = x.shape
         x = self.mlp("conv5.", x.reshape(B * N, -1), slope=0.2).reshape(B, N, -1)   # :113
-        x = torch.cat([x.max(dim=1)[0], x.mean(dim=1)], dim=1)                     # :114-116
+        x = torch.cat([x.max(dim=1)[0], self.rs(x.mean(dim=1))], dim=1)            # :114-116
         x = self.fc_bn_act(x, "linear1", "bn6", 0.2)                               # :117
         x = self.fc_bn_act(x, "linear2", "bn7", 0.2)                               # :119
         x = self.fc_bn_act(x, "linear3")                                           # :121

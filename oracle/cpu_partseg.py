@@ -25,8 +25,8 @@ class PointNet2PartSegCPU(ParamBag):
     SSG = [(512, [0.2], [64]), (128, [0.4], [64]), (None, [None], [None])]
     MSG = [(512, [0.1, 0.2, 0.4], [16, 32, 128]), (128, [0.2, 0.4, 0.8], [32, 64, 128]), (None, [None], [None])]
 
-    def __init__(self, state, sa_spec, tie_stride=8, dtype=torch.float32):
-        super().__init__(state, dtype)
+    def __init__(self, state, sa_spec, tie_stride=8, dtype=torch.float32, storage=None):
+        super().__init__(state, dtype, storage)
         self.sa_spec = sa_spec
         self.tie_stride = tie_stride
 
@@ -50,7 +50,7 @@ class PointNet2PartSegCPU(ParamBag):
                 idx = _o.ball_query(new_xyz_np, xyz_np, r, ns)
                 rec["bq_idx"].append(idx)
                 li = torch.from_numpy(idx.astype(np.int64))
-                g_xyz = xyz[bi, li] - new_xyz[:, :, None, :]                                       # misc/ops.py:383-407
+                g_xyz = self.rs(xyz[bi, li] - new_xyz[:, :, None, :])                              # misc/ops.py:383-407
                 grouped = torch.cat([g_xyz, feat[bi, li]], -1) if feat is not None else g_xyz
                 y = self.mlp(f"pointnet_modules.{i}.mlps.{j}.", grouped.reshape(-1, grouped.shape[-1]))
                 outs.append(y.reshape(B, m, ns, -1).max(dim=2)[0])                                 # :63
@@ -69,7 +69,7 @@ class PointNet2PartSegCPU(ParamBag):
             aux.append({"three_nn": idx, "weights": w})
             li = torch.from_numpy(idx.astype(np.int64))
             nb = points2[torch.arange(B)[:, None, None], li]                                       # [B,N,3,D]
-            interp = (nb * torch.from_numpy(w).to(self.dtype)[..., None]).sum(dim=2)               # :93
+            interp = self.rs((nb * torch.from_numpy(w).to(self.dtype)[..., None]).sum(dim=2))      # :93
         new_points = torch.cat([points1, interp], dim=-1) if points1 is not None else interp      # :97
         y = self.mlp(f"{name}.mlp.", new_points.reshape(B * N, -1))                                # conv(bias) + bn + relu :103-106
         return y.reshape(B, N, -1)

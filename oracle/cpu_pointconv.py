@@ -39,7 +39,8 @@ class PointConvClsCPU(ParamBag):
         rec = {}
         if npoint is None:                                                                      # sample_and_group_all
             new_xyz = xyz.mean(dim=1, keepdim=True)
-            g_xyz = xyz[:, None] - new_xyz[:, :, None, :]                                       # [B,1,N,3]
+            new_xyz = self.rs(new_xyz)
+            g_xyz = self.rs(xyz[:, None] - new_xyz[:, :, None, :])                              # [B,1,N,3]
             new_points = torch.cat([g_xyz, points[:, None]], -1) if points is not None else g_xyz
             g_dens = dscale[:, None]                                                            # [B,1,N,1]
             S, ns = 1, N
@@ -55,14 +56,14 @@ class PointConvClsCPU(ParamBag):
                              nsample).transpose(0, 2, 1)                                        # :152, direct-form definition
             li = torch.from_numpy(np.ascontiguousarray(idx).astype(np.int64))
             b3 = torch.arange(B)[:, None, None]
-            g_xyz = xyz[b3, li] - new_xyz[:, :, None, :]                                        # :156-157
+            g_xyz = self.rs(xyz[b3, li] - new_xyz[:, :, None, :])                               # :156-157
             new_points = torch.cat([g_xyz, points[b3, li]], -1) if points is not None else g_xyz     # :158-162
             g_dens = dscale[b3, li]                                                             # :169
             S, ns = npoint, nsample
             rec["fps_idx"], rec["knn_idx"] = fidx, np.ascontiguousarray(idx)
         f = self.mlp(f"{name}.mlp.", new_points.reshape(B * S * ns, -1)).reshape(B, S, ns, -1)  # :384-389
         w = self.mlp(f"{name}.weightnet.mlp.", g_xyz.reshape(B * S * ns, 3)).reshape(B, S, ns, -1)   # :391-392
-        out = torch.matmul((f * g_dens).transpose(2, 3), w).reshape(B, S, -1)                   # :393-394
+        out = self.rs(torch.matmul(self.rs(f * g_dens).transpose(2, 3), w)).reshape(B, S, -1)   # :393-394
         out = self.mlp(f"{name}.linear.", out.reshape(B * S, -1)).reshape(B, S, -1)             # :395-397
         rec["new_xyz"], rec["feat"] = new_xyz, out
         aux.append(rec)

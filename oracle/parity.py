@@ -1,35 +1,75 @@
 """Comparison helpers shared by the GPU parity tests -- TEST INFRASTRUCTURE ONLY.
 
-Features (``Report.feature``): elementwise ``|got - want| <= ATOL + RTOL*|want|`` with ATOL = RTOL = 1e-5 (north_star:
-"within 1e-5 fp32 for features") against the restatement evaluated in fp64 -- the exact value of the reference's
-arithmetic, which every fp32 implementation of it (Jittor's, PyTorch-CPU's, the HIP path) only approximates.  Deep in a
-network an fp32 pipeline cannot hold 1e-5 (BatchNorm over few rows, or over channels with |mean| >> std, amplifies
-rounding by 1/std): there the row passes only if the HIP path is no further from the fp64 value than FEAT_SLACK x the
-fp32 restatement's own measured distance, and the report line is marked "fp32-limited" -- it never passes silently.
-Against the fp32 restatement the bound is 1e-5 plus both distances from the fp64 value.
+Three CPU evaluations of the restatement serve as yardsticks (oracle/cpu_common.py):
+  r64   every dense op in fp64 -- the exact value of the reference's arithmetic;
+  r32   the same composition in PyTorch-CPU fp32 -- a second, independent fp32 pipeline;
+  r64s  fp64 arithmetic with every op's result ROUNDED TO fp32 STORAGE -- what a perfectly compensated fp32
+        implementation would compute; |r64s - r64| is the error no summation scheme can remove (optional).
+
+Features (``Report.feature``): elementwise ``|got - r64| <= ATOL + RTOL*|r64|``, ATOL = RTOL = 1e-5 (north_star: "within
+1e-5 fp32 for features").  A row beyond that bound FAILS unless it carries a NAMED WAIVER (``WAIVERS``): waivers are
+listed below with their reason and their own hard cap, and a waived row must still be (i) within the waiver's cap, (ii) no
+further from fp64 than FEAT_SLACK x the fp32 restatement's own distance, and -- where the r64s pipeline is supplied --
+(iii) within STORAGE_SLACK x the storage-rounding floor.  Nothing passes by slack alone.
 
 Gradients (``Report.grads``): two fp32 pipelines cannot agree to 1e-5 (a max-pool winner that flips between two rows
 whose pre-BatchNorm outputs agree to an ulp moves a whole gradient row; BatchNorm backward divides by the batch std at
-every level), so the yardstick is the fp64 restatement: per tensor, the HIP gradient must be as close to it as the fp32
-restatement (PyTorch-CPU) is, within a factor GRAD_SLACK, or closer than GRAD_FLOOR -- in relative L2 and in max norm.
-There is no absolute cap: some tensors are ill-conditioned sums whose fp64 value is far below fp32 rounding of their terms
-(PointConv's one-channel DensityNet BatchNorm gamma: BOTH fp32 pipelines are >30 % off), and a cap would only measure
-that.  GRAD_SLACK = 10: two correct fp32 evaluations of one sum differ by the order of summation (sequential MFMA chains +
-fp64 partials here, blocked sgemm there), which moves the error constant by up to an order of magnitude; a wrong formula
-shows as 1e-2 .. O(1) on well-conditioned tensors, i.e. 1e2x .. 1e4x the restatement's error.  Measured worst ratios:
-6.7 (PointConv, the 8->1 layer of sa1's DensityNet: 0.7 % vs 0.1 %), 4.8 (DGCNN: the factorised EdgeConv forms
-U[nbr] + V, whose rounding scales with |U| instead of |Wa (x_nbr - x_i)|, so a few more max-pool winners flip), 3.7
-(part-seg MSG, max-norm); PointNet++ SSG cls: the HIP gradients are 4-15x CLOSER to fp64 than the restatement's.
-A tensor whose ABSOLUTE error is below ABS_FLOOR = 1e-6 of the largest gradient entry of the whole model passes as
-"noise-floor": its fp64 value is (near) zero by an exact invariance -- e.g. BatchNorm gamma in front of a ReLU whose
-output is renormalised downstream -- and relative error measures only rounding noise there.
-Every row is collected; ``finish`` prints the table and fails with the complete list.
+every level).  Per tensor, against r64, in relative L2 and relative max-norm:
+  * RELATIVE yardstick: error <= max(GRAD_SLACK x the fp32 restatement's own error, GRAD_FLOOR);
+  * ABSOLUTE CAP: relL2 <= GRAD_CAP_L2 and max-norm <= GRAD_CAP_MAX whatever the fp32 restatement does -- a shared
+    conditioning problem cannot hide behind a second fp32 pipeline that is just as wrong;
+  * "noise-floor": a tensor whose ABSOLUTE error is below ABS_FLOOR = 1e-6 of the model's largest gradient entry -- its
+    fp64 value is (near) zero and relative error measures only rounding noise;
+  * anything else needs a named waiver with its own cap on the absolute error, else FAIL.
+GRAD_SLACK = 10: two correct fp32 evaluations of one sum differ by the order of summation (sequential MFMA chains + fp64
+partials here, blocked sgemm there), which moves the error constant by up to an order of magnitude; a wrong formula
+shows as 1e-2 .. O(1) on well-conditioned tensors.
+Every row is collected; ``finish`` prints the table (waived rows with their waiver id) and fails with the complete list.
 """
+import fnmatch
+
 ATOL = RTOL = 1e-5
 FEAT_SLACK = 2.0
+STORAGE_SLACK = 4.0
 GRAD_SLACK = 10.0
 GRAD_FLOOR = 2e-5
+GRAD_CAP_L2 = 2e-2
+GRAD_CAP_MAX = 5e-2
 ABS_FLOOR = 1e-6
+
+# ---- named waivers -------------------------------------------------------------------------------------------------
+# (report-title pattern, row pattern) -> (id, cap, reason).  Feature caps are in units of the 1e-5 bound; gradient caps
+# are on max|error| relative to the model's largest gradient entry.  A waiver never switches a check off: the capped
+# quantity is still asserted.  DESIGN.md section 3.6c repeats this table with the measured values.
+FEATURE_WAIVERS = [
+    ("PointNet++ part-seg*", "fp? output",
+     ("W-F1 decoder depth", 12.0,
+      "feature propagation stacks 2-3 more BatchNorm'd layers on the encoder's output (up to 14 BatchNorms deep); each divides "
+      "the accumulated fp32 storage rounding by the batch std.  The fp64-arithmetic / fp32-storage pipeline is itself beyond "
+      "1e-5 here, so no fp32 implementation (Jittor's included) can hold the bound.")),
+    ("PointNet++ part-seg*", "logits*",
+     ("W-F1 decoder depth", 12.0, "same chain, two layers further")),
+    ("PointConv*", "sa? output*",
+     ("W-F2 density product", 12.0,
+      "PointConv multiplies the BatchNorm'd features by a learned inverse-density scale and sums 16 x ns products per output "
+      "before another BatchNorm: storage rounding of three BatchNorm'd factors, amplified by 1/std of a 16C-wide linear layer; "
+      "the PyTorch-CPU fp32 restatement is 12-20 x the bound on the same rows, the HIP path 3-7 x.")),
+]
+GRAD_WAIVERS = [
+    ("PointConv*", "sa?.densitynet.mlp.gammas.2",
+     ("W-G1 scale invariance", 2e-5,
+      "analytically ZERO: the last DensityNet layer is BatchNorm(1 channel) + ReLU with beta = 0 at initialisation, so the density "
+      "scale is gamma * relu(x^) and gamma multiplies every input of the PointConv Linear + BatchNorm that follows, which removes "
+      "it again (d loss / d gamma = 0).  The fp64 value is the rounding residue of a 32 768-term sum of O(1e-3) terms; relative "
+      "error against it is meaningless (both fp32 pipelines are > 100 % off).  Capped on the absolute error instead.")),
+]
+
+
+def _find(table, title, row):
+    for tp, rp, w in table:
+        if fnmatch.fnmatch(title, tp) and fnmatch.fnmatch(row, rp):
+            return w
+    return None
 
 
 def rel(a, b):
@@ -41,9 +81,9 @@ def rel(a, b):
 class Report:
     def __init__(self, title):
         self.title = title
-        self.frows, self.grows, self.failures = [], [], []
+        self.frows, self.grows, self.failures, self.waived = [], [], [], []
 
-    def feature(self, got, r32, r64, what):
+    def feature(self, got, r32, r64, what, r64s=None):
         got, r32, r64 = (t.detach().cpu().double() for t in (got, r32, r64))
         if got.shape != r64.shape:
             self.failures.append(f"{what}: shape {tuple(got.shape)} vs {tuple(r64.shape)}")
@@ -52,15 +92,27 @@ class Report:
         e64 = (got - r64).abs()
         own = (r32 - r64).abs()
         worst64, worst_own = (e64 / bound).max().item(), (own / bound).max().item()
+        worst_st = None if r64s is None else ((r64s.detach().cpu().double() - r64).abs() / bound).max().item()
         e32 = (got - r32).abs().max().item()
-        status = "ok"
+        status, why = "ok", ""
         if worst64 > 1.0:
-            status = "fp32-limited" if worst64 <= FEAT_SLACK * worst_own else "FAIL"
+            w = _find(FEATURE_WAIVERS, self.title, what)
+            if w is None:
+                status, why = "FAIL", "beyond 1e-5 and no named waiver"
+            elif worst64 > w[1]:
+                status, why = "FAIL", f"beyond the cap of waiver {w[0]} ({w[1]} x bound)"
+            elif worst64 > FEAT_SLACK * worst_own:
+                status, why = "FAIL", f"more than {FEAT_SLACK} x the fp32 restatement's own distance from fp64"
+            elif worst_st is not None and worst64 > STORAGE_SLACK * max(worst_st, 1.0):
+                status, why = "FAIL", f"more than {STORAGE_SLACK} x the fp32-storage floor"
+            else:
+                status = f"waived [{w[0]}]"
+                self.waived.append((what, w[0], worst64, w[1]))
         if e32 > (bound.max().item() + e64.max().item() + own.max().item()):
-            status = "FAIL"
-        self.frows.append((what, e64.max().item(), worst64, own.max().item(), worst_own, e32, status))
+            status, why = "FAIL", "inconsistent with the fp32 restatement"
+        self.frows.append((what, e64.max().item(), worst64, own.max().item(), worst_own, worst_st, e32, status))
         if status == "FAIL":
-            self.failures.append(f"{what}: max|hip-fp64| {e64.max().item():.3e} = {worst64:.2f} x bound; the fp32 restatement is "
+            self.failures.append(f"{what}: {why}: max|hip-fp64| {e64.max().item():.3e} = {worst64:.2f} x bound; the fp32 restatement is "
                                  f"{own.max().item():.3e} = {worst_own:.2f} x bound from fp64; max|hip-fp32 restatement| {e32:.3e}")
 
     def grads(self, g_hip, g32, g64, tag=""):
@@ -76,14 +128,24 @@ class Report:
                 continue
             e_hip, m_hip = rel(a, b64)
             e_cpu, m_cpu = rel(b32, b64)
-            ok = e_hip <= max(GRAD_SLACK * e_cpu, GRAD_FLOOR) and m_hip <= max(GRAD_SLACK * m_cpu, GRAD_FLOOR)
-            status = "ok" if ok else "FAIL"
             abs_err = (a - b64).abs().max().item()
-            if not ok and abs_err <= ABS_FLOOR * gscale:
+            rel_ok = e_hip <= max(GRAD_SLACK * e_cpu, GRAD_FLOOR) and m_hip <= max(GRAD_SLACK * m_cpu, GRAD_FLOOR)
+            cap_ok = e_hip <= GRAD_CAP_L2 and m_hip <= GRAD_CAP_MAX
+            if rel_ok and cap_ok:
+                status = "ok"
+            elif abs_err <= ABS_FLOOR * gscale:
                 status = "noise-floor"                     # |error| below 1e-6 of the model's largest gradient entry
-            self.grows.append((tag + name, e_hip, e_cpu, m_hip, m_cpu, status))
+            else:
+                w = _find(GRAD_WAIVERS, self.title, name)
+                if w is not None and abs_err <= w[1] * gscale:
+                    status = f"waived [{w[0]}]"
+                    self.waived.append((tag + name, w[0], abs_err / gscale, w[1]))
+                else:
+                    status = "FAIL"
+            self.grows.append((tag + name, e_hip, e_cpu, m_hip, m_cpu, status, abs_err, b64.abs().max().item()))
             if status == "FAIL":
-                self.failures.append(f"grad {tag}{name}: relL2 vs fp64 {e_hip:.3e} (fp32 restatement {e_cpu:.3e}), max-norm {m_hip:.3e} "
+                why = ("beyond the absolute cap" if rel_ok else "beyond the fp32 restatement's error x slack")
+                self.failures.append(f"grad {tag}{name}: {why}: relL2 vs fp64 {e_hip:.3e} (fp32 restatement {e_cpu:.3e}), max-norm {m_hip:.3e} "
                                      f"({m_cpu:.3e}); max|err| {abs_err:.2e}, max|g64| {b64.abs().max().item():.2e}, model max|g64| {gscale:.2e}")
 
     def check(self, cond, msg):
@@ -92,17 +154,21 @@ class Report:
 
     def finish(self, top=6):
         print(f"\n[parity {self.title}]")
-        for what, e64, w64, own, wown, e32, status in self.frows:
-            print(f"    {what:28s} max|hip-fp64| {e64:.2e} ({w64:5.2f} x bound)   max|fp32 restatement-fp64| {own:.2e} ({wown:5.2f} x bound)   "
+        for what, e64, w64, own, wown, wst, e32, status in self.frows:
+            st = "" if wst is None else f"   fp32-storage floor {wst:5.2f} x"
+            print(f"    {what:28s} max|hip-fp64| {e64:.2e} ({w64:5.2f} x bound)   max|fp32 restatement-fp64| {own:.2e} ({wown:5.2f} x bound){st}   "
                   f"max|hip-fp32 restatement| {e32:.2e}   {status}")
         rows = sorted(self.grows, key=lambda t: -t[1] / max(t[2], 1e-30))
         bad = [r for r in rows if r[5] != "ok"]
         self.n_noise = sum(1 for r in rows if r[5] == "noise-floor")
-        for name, e_hip, e_cpu, m_hip, m_cpu, status in (bad + [r for r in rows if r[5] == "ok"][:top]):
-            print(f"    grad {name:46s} relL2 hip {e_hip:.2e} / fp32-restatement {e_cpu:.2e}   max-norm {m_hip:.2e} / {m_cpu:.2e}   {status}")
+        for name, e_hip, e_cpu, m_hip, m_cpu, status, abs_err, gmax in (bad + [r for r in rows if r[5] == "ok"][:top]):
+            extra = "" if status == "ok" else f"   max|err| {abs_err:.2e} max|g64| {gmax:.2e}"
+            print(f"    grad {name:46s} relL2 hip {e_hip:.2e} / fp32-restatement {e_cpu:.2e}   max-norm {m_hip:.2e} / {m_cpu:.2e}   {status}{extra}")
         if self.grows:
-            worst = max(r[1] for r in self.grows)
+            worst = max(r[1] for r in self.grows if r[5] == "ok") if any(r[5] == "ok" for r in self.grows) else 0.0
             better = sum(1 for r in self.grows if r[1] <= r[2])
-            print(f"    gradients: {len(self.grows)} tensors, worst relL2 vs fp64 {worst:.2e}; the HIP path is closer to fp64 than the fp32 "
-                  f"restatement on {better} of them")
+            print(f"    gradients: {len(self.grows)} tensors, worst relL2 vs fp64 among the un-waived {worst:.2e} (cap {GRAD_CAP_L2:.0e}); the HIP "
+                  f"path is closer to fp64 than the fp32 restatement on {better} of them")
+        for what, wid, val, cap in self.waived:
+            print(f"    WAIVER {wid}: {what}: {val:.3g} (cap {cap:g})")
         assert not self.failures, f"{len(self.failures)} parity failures:\n  " + "\n  ".join(self.failures)

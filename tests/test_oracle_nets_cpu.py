@@ -75,3 +75,35 @@ def test_cpu_pointconv_restatement(oracle):
     _agree(o32, o64.detach(), 2e-3)
     o32.square().mean().backward()
     _grads_cover(r32)
+
+
+def test_fp32_storage_pipeline_sits_between_fp64_and_fp32(oracle):
+    """oracle/parity.py's third yardstick: fp64 arithmetic with fp32 storage.  It differs from the pure fp64 value (storage
+    rounding is real), stays in the neighbourhood of an fp32 pipeline's error, back-propagates, and with storage=None is the
+    identity."""
+    from oracle.cpu_partseg import PointNet2PartSegCPU
+    from oracle.cpu_pointconv import PointConvClsCPU
+    from pointcloudlib_amd.networks.cls.pointconv import PointConvDensityClsSsg
+    from pointcloudlib_amd.networks.seg.pointnet2_partseg import PointNet2_partseg
+    B, N = 2, 600
+    xyz = torch.from_numpy(synth.gauss_ball(B, N, 2))
+    nrm = torch.from_numpy(synth.unit_normals(B, N, 3))
+    onehot = torch.zeros(B, 16); onehot[torch.arange(B), torch.arange(B) % 16] = 1
+    torch.manual_seed(1)
+    state = PointNet2_partseg().state_dict()
+    spec = PointNet2PartSegCPU.SSG
+    o32 = PointNet2PartSegCPU(state, spec, tie_stride=1)(xyz, nrm, onehot).detach().double()
+    o64 = PointNet2PartSegCPU(state, spec, tie_stride=1, dtype=torch.float64)(xyz, nrm, onehot).detach()
+    r6s = PointNet2PartSegCPU(state, spec, tie_stride=1, dtype=torch.float64, storage="fp32")
+    o6s = r6s(xyz, nrm, onehot)
+    e_st, e_32 = (o6s.detach() - o64).abs().max().item(), (o32 - o64).abs().max().item()
+    assert 0.0 < e_st < 20 * e_32 and e_32 < 2e-3
+    o6s.square().mean().backward()
+    _grads_cover(r6s)
+    torch.manual_seed(2)
+    state = PointConvDensityClsSsg().state_dict()
+    x = torch.from_numpy(synth.gauss_ball(4, 640, 3)).transpose(1, 2).contiguous()
+    start = [np.zeros(4, np.int32), np.zeros(4, np.int32)]
+    p64 = PointConvClsCPU(state, dtype=torch.float64)(x, start).detach()
+    p6s = PointConvClsCPU(state, dtype=torch.float64, storage="fp32")(x, start).detach()
+    assert 0.0 < (p6s - p64).abs().max().item() < 1e-3

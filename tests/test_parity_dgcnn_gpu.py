@@ -5,7 +5,9 @@
 (2) Whole network, forward and backward, against oracle/cpu_dgcnn.py (the reference's formulation WITH the edge tensor,
     networks/cls/dgcnn.py:29-50,:96-122) in fp32 and fp64, all three sharing the fp32 restatement's neighbour lists: stage
     outputs and logits elementwise within 1e-5 of the fp64 value, gradients of every parameter by the fp64 yardstick
-    (oracle/parity.py).  The fraction of lists that would differ without sharing is printed.
+    (oracle/parity.py).  The fraction of lists that would differ without sharing is printed AND bounded: the HIP network's
+    own feature-space lists (stages 2-4, computed from ITS stage outputs) may differ from the fp32 restatement's as SETS on at
+    most OWN_LIST_BOUND of the points -- sharing lists must not hide a k-NN that drifts with the features.
 """
 import numpy as np
 import pytest
@@ -57,6 +59,9 @@ def test_dgcnn_cls_b32_n1024(oracle, dev):
     soft_cross_entropy_loss(logits64, torch.from_numpy(lab)).backward()
     differ = [float((np.sort(own_lists[s], -1) != np.sort(lists[s].numpy(), -1)).any(-1).mean()) for s in range(4)]
     assert differ[0] == 0.0                                                # xyz-space lists: identical inputs, identical lists
+    OWN_LIST_BOUND = 1e-3        # measured 0.0000 on this input; a near-tie at rank k under ~1e-6 feature noise is a ~1e-4 event
+    for s in (1, 2, 3):
+        assert differ[s] <= OWN_LIST_BOUND, f"stage {s + 1}: {differ[s]:.2e} of the points have a different own-feature kNN SET than the fp32 restatement"
     dev_lists = [l.to(dev).int().contiguous() for l in lists]
     out, stages = net(xin, lists=dev_lists, return_stages=True)
     report = Report(f"DGCNN cls B={B} N={N} k={k}")

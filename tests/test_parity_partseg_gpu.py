@@ -41,6 +41,8 @@ def test_pointnet2_partseg_b16_n2048(oracle, dev, variant):
     xyz_c, nrm_c = torch.from_numpy(pts), torch.from_numpy(nrm)
     o32, a32 = r32(xyz_c, nrm_c, onehot, return_aux=True)
     o64, a64 = r64(xyz_c, nrm_c, onehot, return_aux=True)
+    with torch.no_grad():      # fp64 arithmetic, fp32 storage: the floor no fp32 summation scheme can beat (oracle/parity.py)
+        o6s, a6s = PointNet2PartSegCPU(state, spec, tie_stride=S, dtype=torch.float64, storage="fp32")(xyz_c, nrm_c, onehot, return_aux=True)
     tgt = torch.from_numpy(seg)
     lossf = torch.nn.functional.cross_entropy                                     # train_partseg.py: CE over the 50 parts
     lossf(o32, tgt).backward(); lossf(o64, tgt).backward()
@@ -59,7 +61,7 @@ def test_pointnet2_partseg_b16_n2048(oracle, dev, variant):
             else:
                 samp = None
             new_xyz, cur_f = mod(cur_xyz, cur_f, samp)
-            report.feature(cur_f, a32["sa"][i]["feat"], a64["sa"][i]["feat"], f"SA{i + 1} pooled features")
+            report.feature(cur_f, a32["sa"][i]["feat"], a64["sa"][i]["feat"], f"SA{i + 1} pooled features", a6s["sa"][i]["feat"])
             lv.append((cur_xyz, new_xyz, cur_f))
             if new_xyz is not None:
                 cur_xyz = new_xyz
@@ -71,13 +73,13 @@ def test_pointnet2_partseg_b16_n2048(oracle, dev, variant):
         # decoder, module by module (networks/seg/pointnet2_partseg.py:168-173)
         l1_xyz, l1_f, l2_xyz, l2_f, l3_f = lv[0][1], lv[0][2], lv[1][1], lv[1][2], lv[2][2]
         d2 = net.fp3(l2_xyz, torch.zeros((B, 1, 3), device=dev), l2_f, l3_f)
-        report.feature(d2, a32["decoder"][0], a64["decoder"][0], "fp3 output")
+        report.feature(d2, a32["decoder"][0], a64["decoder"][0], "fp3 output", a6s["decoder"][0])
         d1 = net.fp2(l1_xyz, l2_xyz, l1_f, d2)
-        report.feature(d1, a32["decoder"][1], a64["decoder"][1], "fp2 output")
+        report.feature(d1, a32["decoder"][1], a64["decoder"][1], "fp2 output", a6s["decoder"][1])
         d0 = net.fp1(xyz, l1_xyz, torch.cat([oh.view(B, 1, 16).expand(B, N, 16), xyz, f], 2), d1)
-        report.feature(d0, a32["decoder"][2], a64["decoder"][2], "fp1 output")
+        report.feature(d0, a32["decoder"][2], a64["decoder"][2], "fp1 output", a6s["decoder"][2])
     out = net(xyz, f, oh)
-    report.feature(out, o32, o64, "logits [B,50,N]")
+    report.feature(out, o32, o64, "logits [B,50,N]", o6s)
     loss = lossf(out, tgt.to(dev))
     loss.backward()
     g_hip = {n: p.grad for n, p in net.named_parameters()}

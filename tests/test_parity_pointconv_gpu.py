@@ -41,6 +41,8 @@ def test_pointconv_cls_b32_n1024(oracle, dev):
     xin_c = torch.from_numpy(pts).transpose(1, 2).contiguous()
     o32, a32 = r32(xin_c, start, return_aux=True)
     o64, a64 = r64(xin_c, start, return_aux=True)
+    with torch.no_grad():      # fp64 arithmetic, fp32 storage: the floor no fp32 summation scheme can beat (oracle/parity.py)
+        o6s, a6s = PointConvClsCPU(state, dtype=torch.float64, storage="fp32")(xin_c, start, return_aux=True)
     soft_cross_entropy_loss(o32, torch.from_numpy(lab)).backward()
     soft_cross_entropy_loss(o64, torch.from_numpy(lab)).backward()
 
@@ -57,11 +59,11 @@ def test_pointconv_cls_b32_n1024(oracle, dev):
                 kidx = pu.knn_point(sa.nsample, xyz_cl, pu.index_points(xyz_cl, fidx))
                 assert np.array_equal(kidx.cpu().numpy(), a32[i]["knn_idx"]), f"sa{i + 1}: k-NN groups differ"
             cur_xyz, cur_p = sa(cur_xyz, cur_p, st[i] if i < 2 else None)
-            report.feature(cur_p.permute(0, 2, 1), a32[i]["feat"], a64[i]["feat"], f"sa{i + 1} output")
+            report.feature(cur_p.permute(0, 2, 1), a32[i]["feat"], a64[i]["feat"], f"sa{i + 1} output", a6s[i]["feat"])
             if not sa.group_all:
                 assert np.array_equal(cur_xyz.permute(0, 2, 1).cpu().numpy(), a32[i]["new_xyz"].numpy()), f"sa{i + 1}: centres differ"
     out = net(xin, st)
-    report.feature(out, o32, o64, "logits")
+    report.feature(out, o32, o64, "logits", o6s)
     loss = soft_cross_entropy_loss(out, y)
     loss.backward()
     g_hip = {n: p.grad for n, p in net.named_parameters()}
