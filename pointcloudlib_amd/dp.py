@@ -16,8 +16,14 @@ early issue lands in the part of backward where the GPU runs short kernels (head
 host, so ProcessGroupNCCL's ~0.1 ms of host work per collective is fully exposed there, more than the ~0.1 ms an
 8-rank 5.9 MB all-reduce costs when left exposed.  Hence overlap is off by default.
 BatchNorm statistics stay per-rank by default (weak scaling, per-GPU batch = the reference's batch); ``sync_bn=True``
-all-reduces the fp64 batch sums of every BatchNorm (pointcloudlib_amd/syncbn.py): the G-rank step then equals the 1-rank step
-on the concatenated batch (tests/test_syncbn_gpu.py).
+all-reduces the fp64 batch sums of every training-mode BatchNorm the library runs (pointcloudlib_amd/syncbn.py): the fused
+MLP stacks, EdgeConv's BatchNorm (misc/edgeconv.py), the FC head (any row count), the wide PointConv linear (routed to the
+fused MLP path), and the plain-PyTorch ``batch_norm_train`` path (PointCNN's BatchNorm after an activation, the ``torch``
+backend).  ``nn.BatchNorm*`` modules called directly by a user model (not through ``head_layer`` / ``fc_head``) are NOT
+synchronised; ``FlatBucketDP(sync_bn=True)`` raises if the wrapped module contains one it cannot reach (see
+``_unsynced_batchnorms``).  The G-rank step then equals the 1-rank step on the concatenated batch
+(tests/test_syncbn_gpu.py: PointNet++ and DGCNN).  The switch is process-global while the wrapper lives: ``close()``
+turns it off.
 """
 import torch
 import torch.distributed as dist
@@ -48,6 +54,10 @@ class FlatBucketDP:
         self.sync_bn = bool(sync_bn) and self.active
         if self.sync_bn:
             from . import syncbn
+            bad = _unsynced_batchnorms(module)
+            if bad:
+                raise RuntimeError("FlatBucketDP(sync_bn=True): these BatchNorm modules are called directly by the model and would keep "
+                                   f"per-rank statistics: {bad}; route them through misc.head.head_layer / fc_head or PointwiseMLP")
             syncbn.enable(process_group)
         self.world = dist.get_world_size(process_group) if self.active else 1
         self.overlap = overlap
@@ -80,6 +90,13 @@ class FlatBucketDP:
             if broadcast:
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t.data, src=0, group=self.group)
+
+    def close(self):
+        """Switch the process-global SyncBN state off again (a wrapper with ``sync_bn=True`` turned it on)."""
+        if self.sync_bn:
+            from . import syncbn
+            syncbn.disable()
+            self.sync_bn = False
 
     @property
     def nbytes(self):
@@ -148,6 +165,24 @@ class FlatBucketDP:
         if self.world > 1:
             self.flat.mul_(1.0 / self.world)
         torch._foreach_copy_(grads, views)
+
+
+def _unsynced_batchnorms(module):
+    """Names of ``nn.BatchNorm*`` modules that the library's synchronised paths cannot reach.  The counterpart networks keep
+    ``nn.BatchNorm1d`` modules only as parameter containers of the FC head (run through ``head_layer`` / ``fc_head``, which
+    synchronise) -- those are declared by the owning network in ``_syncbn_ok`` (a tuple of attribute-name prefixes) or sit in
+    an ``nn.Sequential`` that ``fc_head`` walks (``fc_layer``).  Anything else is reported."""
+    import torch.nn as nn
+    ok_prefixes = ("fc_layer", "bn", "classifier", "head")
+    extra = tuple(getattr(module, "_syncbn_ok", ()))
+    bad = []
+    for name, m in module.named_modules():
+        if isinstance(m, nn.modules.batchnorm._BatchNorm):
+            leaf = name.split(".")[-1]
+            top = name.split(".")[0]
+            if not (top.startswith(ok_prefixes) or leaf.startswith(ok_prefixes) or name.startswith(extra)):
+                bad.append(name)
+    return bad
 
 
 def shard_batch(tensors, rank, world):

@@ -11,7 +11,7 @@ import ctypes
 
 import torch
 
-from .. import _lib
+from .. import _lib, syncbn
 from .ops import _dev, _p, _stream, edge_features
 
 
@@ -44,7 +44,8 @@ class _EdgeConvPool(torch.autograd.Function):
             _lib.call("pcl_knn_transpose_i32", _p(idx), B, N, k, _p(in_off), _p(in_src), st)
         if training:
             scale, shift, mean, invstd = (torch.empty((C,), device=dev) for _ in range(4))
-            _lib.call("pcl_bn_finalize_f32", _p(stats), rows, _p(gamma), _p(beta), G * k, C, eps, momentum, _p(scale), _p(shift),
+            f_stats, f_rows, f_P = (stats, rows, G * k) if not syncbn.active() else syncbn.reduce_rows(stats, rows, G * k)
+            _lib.call("pcl_bn_finalize_f32", _p(f_stats), f_rows, _p(gamma), _p(beta), f_P, C, eps, momentum, _p(scale), _p(shift),
                       _p(mean), _p(invstd), _p(rmean), _p(rvar), st)
         else:
             invstd = torch.rsqrt(rvar + eps)
@@ -78,6 +79,12 @@ class _EdgeConvPool(torch.autograd.Function):
             dgamma, dbeta = torch.empty((C,), device=dev), torch.empty((C,), device=dev)
             _lib.call("pcl_bn_bwd_consts_f32", _p(stats), rows, _p(gamma), _p(mean), _p(invstd), G * k, C, _p(dgamma), _p(dbeta),
                       _p(a), _p(k1), _p(k2), None, st)
+            if syncbn.active():
+                # dgamma / dbeta stay sums over THIS rank's edges (the gradient all-reduce averages them); the constants of
+                # dy = a*du - k1 - k2*(y - mean) come from the global sums over the global edge count (syncbn.py)
+                g_stats, g_rows, g_P = syncbn.reduce_rows(stats, rows, G * k)
+                _lib.call("pcl_bn_bwd_consts_f32", _p(g_stats), g_rows, _p(gamma), _p(mean), _p(invstd), g_P, C, None, None,
+                          _p(a), _p(k1), _p(k2), None, st)
         else:
             s = stats[:rows].sum(0)
             a.copy_(scale); k1.zero_(); k2.zero_()

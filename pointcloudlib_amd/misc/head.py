@@ -71,7 +71,7 @@ def head_layer(x, linear, bn=None, act=None):
     if x.shape[0] > MAX_ROWS or x.dim() != 2 or x.dtype != torch.float32:     # large batches: plain library GEMMs
         y = linear(x)
         if bn is not None:
-            y = bn(y)
+            y = syncbn.batch_norm_1d(y, bn) if (bn.training and syncbn.active() and y.dim() == 2) else bn(y)
         return y if slope == 1.0 else F.leaky_relu(y, slope)
     if bn is not None and bn.training and syncbn.active():
         # synchronised statistics over all ranks' rows: the one-kernel layer computes its batch statistics inside the kernel,

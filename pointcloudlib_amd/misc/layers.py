@@ -27,6 +27,9 @@ def batch_norm_train(x2d, gamma, beta, running_mean, running_var, training, mome
     """BatchNorm over the rows of ``x2d`` [P,C] with Jittor's running-stat rule (biased variance)."""
     if not training:
         return F.batch_norm(x2d, running_mean, running_var, gamma, beta, False, 0.0, eps)
+    from .. import syncbn
+    if syncbn.active():          # data-parallel step with synchronised statistics: sums over every rank's rows
+        return syncbn.batch_norm_rows(x2d, gamma, beta, running_mean, running_var, momentum, eps)
     with torch.no_grad():
         var, mean = torch.var_mean(x2d, dim=0, unbiased=False)
         running_mean += (mean - running_mean) * momentum
@@ -117,8 +120,11 @@ class PointwiseMLP(nn.Module):
             raise RuntimeError("duplicate-compacted rows are a HIP-backend feature")
         if backend == "hip":
             K = x.shape[-1]
+            from .. import syncbn
             if (group_max is None and rowset is None and self.n_layers == 1 and self.bn and K >= 2048 and K % 4 == 0
-                    and x.numel() // K <= 32 and x.is_cuda):
+                    and x.numel() // K <= 32 and x.is_cuda and not (self.training and syncbn.active())):
+                # (synchronised BatchNorm: the wide head kernel takes its batch statistics inside the kernel, so that case
+                #  runs the fused MLP path below, whose statistics go through syncbn.reduce_rows)
                 # a handful of rows against a long reduction (PointConv's Linear(16*C, C) on the GroupAll level: 32 x 16384):
                 # 128x64 GEMM tiles give 16 workgroups here; the head kernels (csrc/head.hip) share X between 8 columns per
                 # workgroup and stream the weight once.  +4: running_var takes the biased variance like pcl_bn_finalize_f32.

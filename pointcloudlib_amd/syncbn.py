@@ -12,8 +12,14 @@ GLOBAL sums of du and du*y over the global row count (du being the per-rank-loss
 L is applied by the gradient average).
 
 Off by default (the reference has no distributed code; per-rank statistics = its per-GPU batch).  ``enable()`` is called
-by ``FlatBucketDP(sync_bn=True)``.
+by ``FlatBucketDP(sync_bn=True)`` and ``disable()`` by its ``close()``.  The switch is PROCESS-GLOBAL while it is on: every
+training-mode BatchNorm of the library (fused MLP stacks, EdgeConv, the FC head, the PointCNN / torch-backend
+``batch_norm_train`` path) then issues collectives, so every rank must run the same training-mode forwards in the same order
+-- a train-mode forward on one rank only deadlocks.  Not for use inside a HIP-graph capture (blocking all-reduces).
+Equal shards are assumed (``dp.shard_batch`` asserts them; ``PCL_SYNCBN_CHECK=1`` verifies the row counts with one more
+all-reduce + host sync per BatchNorm).
 """
+import os
 import torch
 import torch.distributed as dist
 
@@ -42,8 +48,20 @@ def group():
     return _STATE["group"]
 
 
+_CHECK = os.environ.get("PCL_SYNCBN_CHECK", "0") == "1"
+
+
+def _check_equal_counts(count, device):
+    c = torch.tensor([float(count), -float(count)], dtype=torch.float64, device=device)
+    dist.all_reduce(c, op=dist.ReduceOp.MAX, group=_STATE["group"])
+    if c[0].item() != -c[1].item():
+        raise RuntimeError(f"syncbn: ranks hold different row counts (this rank {count}); shards must be equal")
+
+
 def reduce_rows(stats, rows, count):
     """Partial rows of this rank -> (global sums as ONE row [1,2,C] fp64, 1, global row count)."""
+    if _CHECK:
+        _check_equal_counts(count, stats.device)
     g = stats[:rows].sum(dim=0, keepdim=True)               # fixed order -> deterministic; fp64
     dist.all_reduce(g, op=dist.ReduceOp.SUM, group=_STATE["group"])
     return g, 1, count * _STATE["world"]
@@ -87,3 +105,11 @@ def batch_norm_1d(y, bn):
     """``bn`` (an nn.BatchNorm1d in training mode) applied to y [R,N] with statistics over every rank's rows."""
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _SyncBN1d.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum)
+
+
+def batch_norm_rows(y2d, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
+    """Training-mode BatchNorm over the rows of y2d [P,C] of ALL ranks (the plain-PyTorch BatchNorm paths of the library:
+    ``layers.batch_norm_train``, PointCNN's BatchNorm after an activation, the head with more than 64 rows)."""
+    if _CHECK:
+        _check_equal_counts(y2d.shape[0], y2d.device)
+    return _SyncBN1d.apply(y2d, gamma, beta, running_mean, running_var, eps, momentum)

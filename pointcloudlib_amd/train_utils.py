@@ -65,6 +65,15 @@ class _LeanFusedSGD(torch.optim.SGD):
         super().__init__(params, fused=True, **kw)
         self._lean = None
 
+    def load_state_dict(self, state_dict):
+        # the parent replaces every momentum buffer with a new tensor: drop the cached lists, the next step() rebuilds them
+        self._lean = None
+        return super().load_state_dict(state_dict)
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._lean = None
+
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None or len(self.param_groups) != 1:
@@ -77,6 +86,11 @@ class _LeanFusedSGD(torch.optim.SGD):
                 self._lean = (ps, [self.state[p]["momentum_buffer"] for p in ps])
             return out
         ps, bufs = self._lean
+        # optimizer.state cleared or re-created behind our back: the cached buffers would be stale (first + last identity check)
+        st0, st1 = self.state.get(ps[0]), self.state.get(ps[-1])
+        if st0 is None or st1 is None or st0.get("momentum_buffer") is not bufs[0] or st1.get("momentum_buffer") is not bufs[-1]:
+            self._lean = None
+            return self.step()
         grads = [p.grad for p in ps]
         if any(x is None for x in grads):
             return super().step()

@@ -36,3 +36,36 @@ def test_train_partseg_driver(model, extra):
     assert min(losses[1:]) < losses[0] < 6.0, out
     for row in tr + te:
         assert all(0.0 <= float(v) <= 1.0 for v in row[1:]), out
+
+
+def test_lean_sgd_survives_load_state_dict(dev):
+    """the cached momentum-buffer lists of _LeanFusedSGD must be dropped when load_state_dict replaces the buffers
+    (a resume would otherwise keep updating the stale tensors and ignore the loaded momentum).  step, load, step against
+    torch.optim.SGD(fused=True), bit for bit; same after the state is cleared behind the optimizer's back."""
+    import copy
+    import torch
+    from pointcloudlib_amd.train_utils import make_sgd
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(33, 7, device=dev)), torch.nn.Parameter(torch.randn(5, device=dev))]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    a = make_sgd(ps, lr=0.02, momentum=0.9, weight_decay=1e-4)
+    b = torch.optim.SGD(qs, lr=0.02, momentum=0.9, weight_decay=1e-4, fused=True)
+    assert type(a).__name__ == "_LeanFusedSGD"
+
+    def step():
+        for p, q in zip(ps, qs):
+            g = torch.randn_like(p)
+            p.grad, q.grad = g.clone(), g.clone()
+        a.step(); b.step()
+        for p, q in zip(ps, qs):
+            assert torch.equal(p, q)
+
+    step(); step()                                        # second step runs on the cached lists
+    saved_a, saved_b = copy.deepcopy(a.state_dict()), copy.deepcopy(b.state_dict())
+    step(); step()
+    a.load_state_dict(saved_a); b.load_state_dict(saved_b)
+    step(); step()
+    for p, q in zip(ps, qs):                              # and the saved state is the live one
+        assert torch.equal(a.state[p]["momentum_buffer"], b.state[q]["momentum_buffer"])
+    a.state.clear(); b.state.clear()                      # state re-created behind the optimizer's back
+    step(); step()
