@@ -35,6 +35,9 @@ extern "C" {
 #define PCL_EWS (-4)      /* workspace too small                                  */
 
 int pcl_version(void);
+/* As pcl_time_next_launch, for the next GEMM-family launch whose launch tag equals `tag` ("fb256x128", "fwd128x256", ...:
+ * the per-stack entry points launch many such kernels from one call).  No reference counterpart (measurement hook). */
+void pcl_time_tagged_launch(void* start_event, void* stop_event, const char* tag);
 /* Measurement hook: arm two hipEvent_t (created with timing enabled) for the NEXT GEMM-family kernel this thread launches
  * (linear forward / dX / dW / fused backward); they receive that kernel's own begin and end timestamps.  No reference
  * counterpart (bench.py's roofline leg). */
@@ -307,6 +310,72 @@ int pcl_linear_bwd_dw_f32(const float* dU, const float* Y, const float* a, const
                           const int32_t* arg, const float* gz, int ns, const float* Xprev,
                           const float* prev_scale, const float* prev_shift, float prev_slope, int P, int Cout,
                           int Cin, float* dW, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- per-stack entry points -------------------------------------------------------------------------------------------
+ * One call runs what the reference runs per module `execute` (networks/cls/pointnet2.py:33-62: group -> conv/bn/relu xL ->
+ * max; PointNetFeaturePropagation's mlp, misc/ops.py:100-106): a whole [1x1 conv -> BatchNorm(training) -> (Leaky)ReLU] x L
+ * stack, optionally with the ball-query grouping folded into its first layer (`grouped`, pcl_group_linear_f32 on
+ * duplicate-compacted rows) and the max over each group.  The kernels are the ones behind the per-kernel entry points
+ * above, launched in the same order; the caller passes ONE descriptor, one persistent buffer (`save`, forward -> backward:
+ * pre-BatchNorm outputs, per-layer scale/shift/mean/invstd, arg/ymax, row records) and one transient buffer (`tmp`), both
+ * carved here (pcl_mlp_stack_sizes).  Training-mode BatchNorm on every layer with process-local statistics only.
+ *   plain stack:   x [P, c[0]] -> out [P, c[L]] (pool = 0) or [P/pool, c[L]] (max over groups of `pool` consecutive rows)
+ *   grouped stack: (xyz [B,N,3], new_xyz [B,m,3], feature [B,N,Cf] | NULL, idx [B,m,ns], cnt [B,m], group_off [B*m+1]) ->
+ *                  out [B*m, c[L]]; c[0] = 3*use_xyz + Cf, P = B*m*ns (row capacity), pool = ns; layer[0].W is the stored
+ *                  first-layer weight [c[1], c[0]] (no bias); Wf_dense = a dense copy of its feature columns [c[1], Cf],
+ *                  needed when Cf > 4 or the features require a gradient.
+ * Backward: gout [as out]; writes layer[l].dW / dgamma / dbeta (/ dbias) and, with need_dx, dx = the input gradient
+ * ([P, c[0]], columns below x_grad_from unwritten) of a plain stack or dfeature [B*N, Cf] of a grouped one. */
+#define PCL_STACK_MAX_LAYERS 8
+typedef struct pcl_stack_layer_t {
+    const float* W;              /* [c[l+1], c[l]] */
+    const float* bias;           /* nullable */
+    const float* gamma;
+    const float* beta;
+    float* running_mean;         /* nullable, updated by the forward */
+    float* running_var;
+    float* dW;                   /* backward outputs */
+    float* dbias;                /* nullable (must be given when bias is): exactly zero under BatchNorm */
+    float* dgamma;
+    float* dbeta;
+} pcl_stack_layer_t;
+typedef struct pcl_mlp_stack_t {
+    int32_t struct_bytes;        /* sizeof(pcl_mlp_stack_t) as the caller sees it */
+    int32_t n_layers;
+    int32_t c[PCL_STACK_MAX_LAYERS + 1];
+    int32_t P;
+    int32_t pool;
+    int32_t grouped;
+    int32_t x_grad_from;
+    int32_t need_dx;
+    int32_t B, N, m, Cf, use_xyz;            /* grouped only */
+    float slope, out_slope, eps, momentum;
+    const float* x;                          /* plain only */
+    const float* xyz;                        /* grouped only ... */
+    const float* new_xyz;
+    const float* feature;
+    const float* Wf_dense;
+    const int32_t* idx;
+    const int32_t* cnt;
+    const int32_t* group_off;
+    pcl_stack_layer_t layer[PCL_STACK_MAX_LAYERS];
+    float* out;
+    void* save;
+    size_t save_bytes;
+    void* tmp;
+    size_t tmp_bytes;
+    const float* gout;                       /* backward only */
+    float* dx;
+    void* stream;
+} pcl_mlp_stack_t;
+/* reference: no counterpart (Jittor allocates); sizes of `save`, of the forward's `tmp` and of the backward's `tmp` */
+int pcl_mlp_stack_sizes(const pcl_mlp_stack_t* desc, size_t* save_bytes, size_t* fwd_tmp_bytes, size_t* bwd_tmp_bytes);
+/* reference: PointNetModuleBase.execute, networks/cls/pointnet2.py:33-62 (grouper :51, mlp :54, argmax :57) */
+int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* desc);
+/* reference: the autograd backward of the same module (Jittor derives it; networks/cls/pointnet2.py:33-62) */
+int pcl_mlp_stack_bwd_f32(const pcl_mlp_stack_t* desc);
+/* helper of the stack entry points: p[0..n_one) = 1, p[n_one..n_one+n_zero) = 0 */
+int pcl_fill_ones_zeros_f32(float* p, int n_one, int n_zero, void* stream);
 
 /* ---- duplicate-compacted ("ragged") groups --------------------------------------------------------------
  * query_ball_point pads each group with copies of its first hit (misc/ops.py:321-324).  Identical rows stay

@@ -45,6 +45,11 @@ _P = c_void_p
 _SIGS = {
     "pcl_version": (c_int, []),
     "pcl_time_next_launch": (None, [_P, _P]),
+    "pcl_time_tagged_launch": (None, [_P, _P, ctypes.c_char_p]),
+    "pcl_mlp_stack_sizes": (c_int, [_P, _P, _P, _P]),
+    "pcl_mlp_stack_fwd_f32": (c_int, [_P]),
+    "pcl_mlp_stack_bwd_f32": (c_int, [_P]),
+    "pcl_fill_ones_zeros_f32": (c_int, [_P, c_int, c_int, _P]),
     "pcl_xconv_core_supported": (c_int, [c_int, c_int, c_int]),
     "pcl_xconv_core_partials": (c_int, [c_int, c_int]),
     "pcl_xconv_core_fwd_f32": (c_int, [_P, _P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, _P, _P]),

@@ -42,12 +42,17 @@ static inline hipStream_t as_stream(void* s) {
 // Measurement hook (bench.py): pcl_time_next_launch(start, stop) arms two HIP events for the next GEMM-family kernel this
 // thread launches; they receive the kernel's own begin / end timestamps (the dispatch packet's, what rocprofv3 reports)
 // instead of the times two marker packets around the call would see.  Unarmed (normal operation) it is a plain launch.
-struct TimeHook { hipEvent_t start, stop; };
+// Inside a per-stack entry point (stack.hip) many such kernels are launched by ONE call: each carries a launch tag
+// ("fb256x128", "fwd128x256", ...; set_launch_tag) and pcl_time_tagged_launch arms the events for the next launch whose tag
+// matches (an empty wanted tag matches anything).
+struct TimeHook { hipEvent_t start, stop; char want[32]; char cur[32]; };
 TimeHook& time_hook();
+void set_launch_tag(const char* tag);
+bool time_hook_matches(const TimeHook& h);
 #define PCL_LAUNCH_TIMED(kernel, grid, blk, st, ...)                                                                   \
     do {                                                                                                                \
         ::pcl::TimeHook& h_ = ::pcl::time_hook();                                                                       \
-        if (h_.start) {                                                                                                 \
+        if (h_.start && ::pcl::time_hook_matches(h_)) {                                                                 \
             hipExtLaunchKernelGGL(kernel, grid, blk, 0, st, h_.start, h_.stop, 0, __VA_ARGS__);                         \
             h_.start = h_.stop = nullptr;                                                                               \
         } else hipLaunchKernelGGL(kernel, grid, blk, 0, st, __VA_ARGS__);                                               \

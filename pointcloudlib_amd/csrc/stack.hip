@@ -1,0 +1,365 @@
+// stack.hip -- per-stack entry points: one C-ABI call runs a whole [1x1 conv -> BatchNorm(train) -> (Leaky)ReLU] x L
+// stack (+ the ball-query grouping folded into its first layer, + the max over the group), forward or backward.
+//
+// The reference runs one `execute` per module (networks/cls/pointnet2.py:33-62: group -> mlp -> max): that is the unit
+// these entry points take.  Nothing new is computed here -- the kernels are the library's own (mlp.hip, compact.hip),
+// launched in the order misc/mlp_hip.py launches them one ctypes call at a time; what changes is the host side: one call,
+// one descriptor, one persistent + one transient buffer carved here instead of ~25 allocations and ~15 Python-level
+// calls per stack and direction (the host needed 1.4-1.7 ms to enqueue a 2.1 ms PointNet++ step).
+//
+// Supported (everything else stays on the per-kernel entry points, see misc/mlp_hip.py):
+//   training-mode BatchNorm on every layer, statistics local to this process; first layer either plain (x [P, c0] given)
+//   or folded into the grouping of a set-abstraction level (`grouped`: pcl_group_linear_f32, duplicate-compacted rows).
+#include "common.h"
+#include <string.h>
+
+namespace pcl {
+
+static inline size_t al256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+struct Carver {
+    char* base; size_t off;
+    explicit Carver(void* p) : base(static_cast<char*>(p)), off(0) {}
+    template <typename T> T* take(size_t count) {
+        T* r = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += al256(count * sizeof(T));
+        return r;
+    }
+};
+
+// ---- layout of the persistent buffer (`save`: lives from forward to backward) --------------------------------------
+struct SaveLayout {
+    float* Y[PCL_STACK_MAX_LAYERS];        // pre-BatchNorm outputs [P, c[l+1]]
+    float* vec[PCL_STACK_MAX_LAYERS];      // [4][cout]: scale, shift, mean, invstd
+    int32_t* arg; float* ymax;             // pooled stacks: [G, cL]
+    int32_t* row_meta; int32_t* row_src; float* row_loc; float* row_feat;     // grouped stacks
+    size_t bytes;
+};
+
+static inline bool grouped_inline(const pcl_mlp_stack_t& d) { return d.grouped && d.Cf > 0 && d.Cf <= 4 && !d.need_dx; }
+static inline bool grouped_wide(const pcl_mlp_stack_t& d) { return d.grouped && d.Cf > 0 && !grouped_inline(d); }
+static inline int pooled_groups(const pcl_mlp_stack_t& d) { return d.grouped ? d.B * d.m : (d.pool ? d.P / d.pool : 0); }
+
+static SaveLayout save_layout(const pcl_mlp_stack_t& d, void* base) {
+    SaveLayout s = {};
+    Carver c(base);
+    const int L = d.n_layers;
+    for (int l = 0; l < L; ++l) {
+        s.Y[l] = c.take<float>((size_t)d.P * d.c[l + 1]);
+        s.vec[l] = c.take<float>((size_t)4 * d.c[l + 1]);
+    }
+    const int G = pooled_groups(d);
+    if (G) { s.arg = c.take<int32_t>((size_t)G * d.c[L]); s.ymax = c.take<float>((size_t)G * d.c[L]); }
+    if (d.grouped) {
+        s.row_meta = c.take<int32_t>((size_t)d.P * 2);
+        s.row_src = c.take<int32_t>((size_t)d.P);
+        s.row_loc = c.take<float>((size_t)d.P * 4);
+        if (grouped_inline(d)) s.row_feat = c.take<float>((size_t)d.P * 4);
+    }
+    s.bytes = c.off;
+    return s;
+}
+
+static inline bool use_gmax(const pcl_mlp_stack_t& d) { return !d.grouped && (d.pool == 32 || d.pool == 64); }
+static inline bool fused_bwd_enabled() {
+    static const int on = [] { const char* e = getenv("PCL_FUSED_BWD"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
+
+// ---- transient buffer of the forward -------------------------------------------------------------------------------
+struct FwdTmp {
+    double* stats;                  // one region, reused layer after layer (stream order: finalize reads it before the next GEMM writes)
+    float* Uf; double* pt_stats;    // grouped, wide features: the per-point product feat Wf^T and its (unused) sums
+    float *gmax, *gmin; int32_t *gamax, *gamin;
+    size_t bytes;
+};
+static FwdTmp fwd_tmp(const pcl_mlp_stack_t& d, void* base) {
+    FwdTmp t = {};
+    Carver c(base);
+    const int L = d.n_layers;
+    size_t rows_max = 0;
+    for (int l = 0; l < L; ++l) {
+        size_t r;
+        if (l == 0 && d.grouped) r = (size_t)pcl_group_linear_stat_rows(d.B, d.m) * 2 * d.c[1];
+        else r = (size_t)pcl_mlp_stat_rows(d.P, d.c[l + 1], d.grouped ? 2 : 0) * 2 * d.c[l + 1];
+        if (r > rows_max) rows_max = r;
+    }
+    t.stats = c.take<double>(rows_max);
+    if (grouped_wide(d)) {
+        t.Uf = c.take<float>((size_t)d.B * d.N * d.c[1]);
+        t.pt_stats = c.take<double>((size_t)pcl_mlp_stat_rows(d.B * d.N, d.c[1], 0) * 2 * d.c[1]);
+    }
+    if (use_gmax(d)) {
+        const size_t n = (size_t)(d.P / d.pool) * d.c[L];
+        t.gmax = c.take<float>(n); t.gmin = c.take<float>(n); t.gamax = c.take<int32_t>(n); t.gamin = c.take<int32_t>(n);
+    }
+    t.bytes = c.off;
+    return t;
+}
+
+// ---- transient buffer of the backward ------------------------------------------------------------------------------
+struct BwdTmp {
+    float* gz;                      // [G, cL] sparse max gradient
+    double* stats[2];               // BatchNorm-backward sums, ping-pong
+    float* dU[2];                   // [P, max c] gradient w.r.t. a BatchNorm output, ping-pong
+    float* consts[2];               // [3][max c]: a, k1, k2 (ping-pong: the fused finish writes the next layer's while this one's is in use)
+    float* ws;                      // partial dW tiles (fused kernel / dW kernel)
+    size_t ws_bytes;
+    float* dUf; float* dWxp; float* dWfp;      // grouped
+    float* ptws; size_t ptws_bytes;            // grouped wide: workspace of the point dW GEMM
+    size_t bytes;
+};
+static BwdTmp bwd_tmp(const pcl_mlp_stack_t& d, void* base) {
+    BwdTmp t = {};
+    Carver c(base);
+    const int L = d.n_layers;
+    int cmax = 0;
+    for (int l = 1; l <= L; ++l) cmax = d.c[l] > cmax ? d.c[l] : cmax;
+    const int cin_max = d.c[0] > cmax ? d.c[0] : cmax;
+    const int G = pooled_groups(d);
+    if (G) t.gz = c.take<float>((size_t)G * d.c[L]);
+    for (int i = 0; i < 2; ++i) t.stats[i] = c.take<double>((size_t)1024 * 2 * cin_max);
+    // dU buffers: the widest gradient that is ever materialised: layers' outputs (not the last one when it is pooled) and,
+    // for a plain stack, nothing for the input (dx is the caller's)
+    int cdu = 0;
+    for (int l = 1; l <= L; ++l) if (!(l == L && G)) cdu = d.c[l] > cdu ? d.c[l] : cdu;
+    for (int i = 0; i < 2; ++i) t.dU[i] = c.take<float>((size_t)d.P * (cdu ? cdu : 1));
+    for (int i = 0; i < 2; ++i) t.consts[i] = c.take<float>((size_t)3 * cmax);
+    size_t wsb = 0;
+    for (int l = 0; l < L; ++l) {
+        if (l == 0 && d.grouped) continue;
+        const int cin = d.c[l], cout = d.c[l + 1];
+        size_t b = pcl_linear_bwd_dw_workspace_bytes(d.P, cout, cin);
+        if (l > 0 && pcl_linear_bwd_fused_supported(cout, cin)) {
+            const size_t f = pcl_linear_bwd_fused_workspace_bytes(d.P, cout, cin);
+            if (f > b) b = f;
+        }
+        if (b > wsb) wsb = b;
+    }
+    t.ws_bytes = wsb;
+    t.ws = c.take<float>((wsb + 3) / 4);
+    if (d.grouped) {
+        const int rows = pcl_group_linear_stat_rows(d.B, d.m), C1 = d.c[1];
+        if (grouped_wide(d)) {
+            t.dUf = c.take<float>((size_t)d.B * d.N * C1);
+            t.ptws_bytes = pcl_linear_bwd_dw_workspace_bytes(d.B * d.N, C1, d.Cf);
+            t.ptws = c.take<float>((t.ptws_bytes + 3) / 4);
+        }
+        if (d.use_xyz) t.dWxp = c.take<float>((size_t)rows * C1 * 3);
+        if (grouped_inline(d)) t.dWfp = c.take<float>((size_t)rows * C1 * d.Cf);
+    }
+    t.bytes = c.off;
+    return t;
+}
+
+static int validate(const pcl_mlp_stack_t* dp, const char* who) {
+    PCL_REQUIRE(dp, "%s: null descriptor", who);
+    const pcl_mlp_stack_t& d = *dp;
+    PCL_REQUIRE(d.struct_bytes == (int32_t)sizeof(pcl_mlp_stack_t), "%s: descriptor is %d bytes, this library expects %zu (header mismatch)",
+                who, d.struct_bytes, sizeof(pcl_mlp_stack_t));
+    PCL_REQUIRE(d.n_layers >= 1 && d.n_layers <= PCL_STACK_MAX_LAYERS, "%s: n_layers=%d (1..%d)", who, d.n_layers, PCL_STACK_MAX_LAYERS);
+    PCL_REQUIRE(d.P >= 1, "%s: P=%d", who, d.P);
+    for (int l = 0; l <= d.n_layers; ++l) PCL_REQUIRE(d.c[l] >= 1, "%s: c[%d]=%d", who, l, d.c[l]);
+    PCL_REQUIRE(d.pool >= 0 && (d.pool == 0 || d.grouped || d.P % d.pool == 0), "%s: pool=%d does not divide P=%d", who, d.pool, d.P);
+    if (d.grouped) {
+        PCL_REQUIRE(d.n_layers >= 2, "%s: a grouped stack needs >= 2 layers (the folded layer's gradient arrives dense from the second)", who);
+        PCL_REQUIRE(d.B >= 1 && d.N >= 1 && d.m >= 1 && d.pool >= 1 && d.P == d.B * d.m * d.pool, "%s: grouped: P=%d must be B*m*ns = %d*%d*%d", who, d.P, d.B, d.m, d.pool);
+        PCL_REQUIRE(d.idx && d.cnt && d.group_off && d.xyz && d.new_xyz, "%s: grouped: null index / coordinate pointer", who);
+        PCL_REQUIRE(d.Cf >= 0 && (d.Cf == 0 || d.feature), "%s: grouped: Cf=%d without features", who, d.Cf);
+        PCL_REQUIRE(d.use_xyz || d.Cf > 0, "%s: grouped: neither coordinates nor features", who);
+        PCL_REQUIRE(d.c[0] == (d.use_xyz ? 3 : 0) + d.Cf, "%s: grouped: c[0]=%d must be the first layer's fan-in %d", who, d.c[0], (d.use_xyz ? 3 : 0) + d.Cf);
+        PCL_REQUIRE(!grouped_wide(d) || d.Wf_dense, "%s: grouped: wide features need Wf_dense", who);
+        PCL_REQUIRE(!d.layer[0].bias, "%s: grouped: the folded first layer takes no conv bias", who);
+    } else {
+        PCL_REQUIRE(d.x, "%s: null input", who);
+    }
+    for (int l = 0; l < d.n_layers; ++l)
+        PCL_REQUIRE(d.layer[l].W && d.layer[l].gamma && d.layer[l].beta, "%s: layer %d: W / gamma / beta must be given (training-mode BatchNorm on every layer)", who, l);
+    return PCL_OK;
+}
+
+#define PCL_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+static void tagf(const char* fmt, int a, int b) {
+    char buf[32];
+    snprintf(buf, sizeof buf, fmt, a, b);
+    set_launch_tag(buf);
+}
+
+}  // namespace pcl
+using namespace pcl;
+
+extern "C" int pcl_mlp_stack_sizes(const pcl_mlp_stack_t* d, size_t* save_bytes, size_t* fwd_tmp_bytes, size_t* bwd_tmp_bytes) {
+    PCL_TRY(validate(d, "pcl_mlp_stack_sizes"));
+    if (save_bytes) *save_bytes = save_layout(*d, nullptr).bytes;
+    if (fwd_tmp_bytes) *fwd_tmp_bytes = fwd_tmp(*d, nullptr).bytes;
+    if (bwd_tmp_bytes) *bwd_tmp_bytes = bwd_tmp(*d, nullptr).bytes;
+    return PCL_OK;
+}
+
+extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
+    PCL_TRY(validate(dp, "pcl_mlp_stack_fwd_f32"));
+    const pcl_mlp_stack_t& d = *dp;
+    PCL_REQUIRE(d.out && d.save && d.tmp, "pcl_mlp_stack_fwd_f32: null out / save / tmp");
+    const SaveLayout s = save_layout(d, d.save);
+    const FwdTmp t = fwd_tmp(d, d.tmp);
+    if (d.save_bytes < s.bytes || d.tmp_bytes < t.bytes)
+        return fail(PCL_EWS, "pcl_mlp_stack_fwd_f32: save %zu < %zu or tmp %zu < %zu", d.save_bytes, s.bytes, d.tmp_bytes, t.bytes);
+    const int L = d.n_layers, P = d.P;
+    const int G = pooled_groups(d);
+    const int32_t* rmeta = d.grouped ? s.row_meta : nullptr;
+    const int32_t* nrows = d.grouped ? d.group_off + G : nullptr;
+    void* st = d.stream;
+    const float* cur = d.x;
+    const float *in_scale = nullptr, *in_shift = nullptr;
+    for (int l = 0; l < L; ++l) {
+        const pcl_stack_layer_t& ly = d.layer[l];
+        const int cin = d.c[l], cout = d.c[l + 1];
+        float* Y = s.Y[l];
+        int rows;
+        if (l == 0 && d.grouped) {
+            const int off = d.use_xyz ? 3 : 0, ldw = d.c[0];
+            const bool inl = grouped_inline(d), wide = grouped_wide(d);
+            if (wide) {
+                tagf("pt%dx%d", d.Cf, cout);
+                PCL_TRY(pcl_linear_fwd_rows_f32(d.feature, d.Wf_dense, nullptr, nullptr, nullptr, 0.f, d.B * d.N, d.Cf, cout, t.Uf,
+                                                t.pt_stats, nullptr, nullptr, st));
+            }
+            tagf("glin%d", cout, 0);
+            PCL_TRY(pcl_group_linear_f32(d.xyz, d.new_xyz, wide ? t.Uf : nullptr, d.use_xyz ? ly.W : nullptr, inl ? d.feature : nullptr,
+                                         inl ? ly.W + off : nullptr, inl ? d.Cf : 0, ldw, d.idx, d.cnt, d.group_off, d.B, d.N, d.m,
+                                         d.pool, cout, Y, s.row_meta, s.row_src, s.row_loc, s.row_feat, t.stats, st));
+            rows = pcl_group_linear_stat_rows(d.B, d.m);
+        } else if (l == L - 1 && use_gmax(d)) {
+            tagf("fwd%dx%d", cin, cout);
+            PCL_TRY(pcl_linear_fwd_gmax_f32(cur, ly.W, ly.bias, in_scale, in_shift, d.slope, P, cin, cout, d.pool, Y, t.stats, t.gmax,
+                                            t.gmin, t.gamax, t.gamin, st));
+            rows = pcl_mlp_stat_rows(P, cout, 0);
+        } else {
+            tagf("fwd%dx%d", cin, cout);
+            PCL_TRY(pcl_linear_fwd_rows_f32(cur, ly.W, ly.bias, in_scale, in_shift, d.slope, P, cin, cout, Y, t.stats, rmeta, nrows, st));
+            rows = pcl_mlp_stat_rows(P, cout, d.grouped ? 2 : 0);
+        }
+        float* v = s.vec[l];
+        PCL_TRY(pcl_bn_finalize_f32(t.stats, rows, ly.gamma, ly.beta, P, cout, d.eps, d.momentum, v, v + cout, v + 2 * cout, v + 3 * cout,
+                                    ly.running_mean, ly.running_var, st));
+        cur = Y; in_scale = v; in_shift = v + cout;
+    }
+    const int cl = d.c[L];
+    if (G) {
+        if (use_gmax(d)) PCL_TRY(pcl_group_minmax_finalize_f32(t.gmax, t.gmin, t.gamax, t.gamin, in_scale, in_shift, d.out_slope, G, cl, d.out, s.arg, s.ymax, st));
+        else if (d.grouped) { tagf("maxrows%d", cl, 0); PCL_TRY(pcl_bn_act_max_rows_f32(cur, d.group_off, in_scale, in_shift, d.out_slope, G, cl, d.out, s.arg, s.ymax, st)); }
+        else { tagf("max%d", cl, 0); PCL_TRY(pcl_bn_act_max_f32(cur, in_scale, in_shift, d.out_slope, G, d.pool, cl, d.out, s.arg, s.ymax, st)); }
+    } else {
+        PCL_TRY(pcl_bn_act_f32(cur, in_scale, in_shift, d.out_slope, P, cl, d.out, st));
+    }
+    set_launch_tag("");
+    return PCL_OK;
+}
+
+extern "C" int pcl_mlp_stack_bwd_f32(const pcl_mlp_stack_t* dp) {
+    PCL_TRY(validate(dp, "pcl_mlp_stack_bwd_f32"));
+    const pcl_mlp_stack_t& d = *dp;
+    PCL_REQUIRE(d.out && d.save && d.tmp && d.gout, "pcl_mlp_stack_bwd_f32: null out / save / tmp / gout");
+    const SaveLayout s = save_layout(d, d.save);
+    const BwdTmp t = bwd_tmp(d, d.tmp);
+    if (d.save_bytes < s.bytes || d.tmp_bytes < t.bytes)
+        return fail(PCL_EWS, "pcl_mlp_stack_bwd_f32: save %zu < %zu or tmp %zu < %zu", d.save_bytes, s.bytes, d.tmp_bytes, t.bytes);
+    const int L = d.n_layers, P = d.P;
+    const int G = pooled_groups(d);
+    const int ns = d.pool ? d.pool : 1;
+    for (int l = 0; l < L; ++l)
+        PCL_REQUIRE(d.layer[l].dW && d.layer[l].dgamma && d.layer[l].dbeta && (!d.layer[l].bias || d.layer[l].dbias),
+                    "pcl_mlp_stack_bwd_f32: layer %d: null gradient output", l);
+    const int32_t* rmeta = d.grouped ? s.row_meta : nullptr;
+    const int32_t* nrows = d.grouped ? d.group_off + G : nullptr;
+    void* st = d.stream;
+    const int cl = d.c[L];
+    int rows = 0, cur_stats = 0, cur_du = 0, cur_c = 0;
+    const float* dU = nullptr;          // dense gradient w.r.t. the current layer's BatchNorm output (null: sparse (arg, gz))
+    bool sparse;
+    const float* vL = s.vec[L - 1];
+    if (G) {
+        PCL_TRY(pcl_maxgrad_prep_f32(d.gout, d.out, s.ymax, d.out_slope, G, cl, t.gz, t.stats[0], &rows, st));
+        sparse = true;
+    } else {
+        PCL_TRY(pcl_bn_act_bwd_f32(d.gout, s.Y[L - 1], vL, vL + cl, d.out_slope, P, cl, t.dU[0], t.stats[0], &rows, st));
+        dU = t.dU[0]; cur_du = 1; sparse = false;
+    }
+    bool have_pre = false;              // constants of layer l already computed by the fused finish of layer l + 1
+    for (int l = L - 1; l >= 0; --l) {
+        const pcl_stack_layer_t& ly = d.layer[l];
+        const int cin = d.c[l], cout = d.c[l + 1];
+        const float* v = s.vec[l];
+        const float *mean = v + 2 * cout, *invstd = v + 3 * cout;
+        float* k = t.consts[cur_c];
+        float *a = k, *k1 = k + cout, *k2 = k + 2 * cout;
+        if (!have_pre)
+            PCL_TRY(pcl_bn_bwd_consts_f32(t.stats[cur_stats], rows, ly.gamma, mean, invstd, P, cout, ly.dgamma, ly.dbeta, a, k1, k2, ly.dbias, st));
+        have_pre = false;
+        if (l == 0 && d.grouped) {
+            // the folded first layer: dy = a*du - w*(k1 + k2*(y - mean)) per distinct row, scattered to the points / summed into dWx
+            const int off = d.use_xyz ? 3 : 0, fan_in = d.c[0], C1 = cout;
+            const bool inl = grouped_inline(d), wide = grouped_wide(d);
+            tagf("glinbwd%d", C1, 0);
+            PCL_TRY(pcl_group_linear_bwd_f32(s.row_loc, s.row_feat, inl ? d.Cf : 0, dU, s.Y[0], a, k1, k2, mean, s.row_src, nrows, d.B, d.N, C1,
+                                             t.dUf, t.dWxp, t.dWfp, (t.dWxp || t.dWfp) ? ly.dW : nullptr, fan_in, off, st));
+            if (wide) {
+                // plain GEMMs through the BatchNorm-backward entry points with a = 1, k1 = k2 = 0 (dy == dUf): constants in consts[1 - cur_c]
+                float* one = t.consts[1 - cur_c];
+                float* zero = one + C1;
+                PCL_TRY(pcl_fill_ones_zeros_f32(one, C1, C1, st));
+                const int Pp = d.B * d.N;
+                tagf("ptdw%dx%d", C1, d.Cf);
+                PCL_TRY(pcl_linear_bwd_dw_rows_f32(t.dUf, t.dUf, one, zero, zero, zero, nullptr, nullptr, 1, d.feature, nullptr, nullptr, 0.f, Pp,
+                                                   C1, d.Cf, ly.dW + off, t.ptws, t.ptws_bytes, nullptr, nullptr, fan_in, st));
+                if (d.need_dx) {
+                    PCL_REQUIRE(d.dx, "pcl_mlp_stack_bwd_f32: need_dx without dx");
+                    tagf("ptdx%dx%d", C1, d.Cf);
+                    PCL_TRY(pcl_linear_bwd_dx_rows_f32(t.dUf, t.dUf, one, zero, zero, zero, nullptr, nullptr, 1, d.Wf_dense, Pp, C1, d.Cf, nullptr,
+                                                       nullptr, nullptr, 0.f, d.dx, nullptr, nullptr, nullptr, 0, 0, st));
+                }
+            }
+            break;
+        }
+        const float* Xprev = l > 0 ? s.Y[l - 1] : d.x;
+        const float* psc = l > 0 ? s.vec[l - 1] : nullptr;
+        const float* psh = l > 0 ? s.vec[l - 1] + cin : nullptr;
+        const float* Yl = s.Y[l];
+        if (l > 0 && fused_bwd_enabled() && pcl_linear_bwd_fused_supported(cout, cin)) {
+            // one pass forms dy once and produces BOTH the layer below's du (+ its BatchNorm-backward sums) and dW; the second
+            // launch sums the partial tiles and turns those sums into the constants of layer l - 1
+            float* dUp = t.dU[cur_du];
+            double* stn = t.stats[1 - cur_stats];
+            tagf("fb%dx%d", cout, cin);
+            PCL_TRY(pcl_linear_bwd_fused_rows_f32(dU, Yl, a, k1, k2, mean, sparse ? s.arg : nullptr, sparse ? t.gz : nullptr, ns, ly.W, P, cout, cin,
+                                                  Xprev, psc, psh, d.slope, dUp, stn, t.ws, t.ws_bytes, rmeta, nrows, st));
+            const pcl_stack_layer_t& lp = d.layer[l - 1];
+            float* kp = t.consts[1 - cur_c];
+            const float* vp = s.vec[l - 1];
+            PCL_TRY(pcl_linear_bwd_fused_finish_f32(t.ws, t.ws_bytes, P, cout, cin, ly.dW, stn, lp.gamma, vp + 2 * cin, vp + 3 * cin, P, lp.dgamma,
+                                                    lp.dbeta, kp, kp + cin, kp + 2 * cin, lp.dbias, st));
+            have_pre = true;
+            dU = dUp; sparse = false; cur_du = 1 - cur_du; cur_stats = 1 - cur_stats; cur_c = 1 - cur_c;
+            rows = pcl_linear_bwd_fused_stat_rows(P, cin);
+            continue;
+        }
+        tagf("dw%dx%d", cout, cin);
+        PCL_TRY(pcl_linear_bwd_dw_rows_f32(dU, Yl, a, k1, k2, mean, sparse ? s.arg : nullptr, sparse ? t.gz : nullptr, ns, Xprev, psc, psh, d.slope,
+                                           P, cout, cin, ly.dW, t.ws, t.ws_bytes, rmeta, nrows, 0, st));
+        if (l > 0 || d.need_dx) {
+            float* dUp = l > 0 ? t.dU[cur_du] : d.dx;
+            PCL_REQUIRE(dUp, "pcl_mlp_stack_bwd_f32: need_dx without dx");
+            double* stn = l > 0 ? t.stats[1 - cur_stats] : nullptr;
+            tagf("dx%dx%d", cout, cin);
+            PCL_TRY(pcl_linear_bwd_dx_rows_f32(dU, Yl, a, k1, k2, mean, sparse ? s.arg : nullptr, sparse ? t.gz : nullptr, ns, ly.W, P, cout, cin,
+                                               l > 0 ? Xprev : nullptr, psc, psh, d.slope, dUp, stn, rmeta, nrows, l == 0 ? d.x_grad_from : 0, 0, st));
+            if (l > 0) {
+                rows = pcl_mlp_stat_rows(P, cin, 1 | (rmeta ? 2 : 0));
+                dU = dUp; sparse = false; cur_du = 1 - cur_du; cur_stats = 1 - cur_stats; cur_c = 1 - cur_c;
+            }
+        }
+    }
+    set_launch_tag("");
+    return PCL_OK;
+}

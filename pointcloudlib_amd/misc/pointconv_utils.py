@@ -55,7 +55,7 @@ def sample_and_group(npoint, nsample, xyz, points, density_scale=None, start_idx
     B, N, C = xyz.shape
     fps_idx = farthest_point_sample(xyz, npoint, start_idx)
     new_xyz = index_points(xyz, fps_idx)
-    idx = knn_point(nsample, xyz, new_xyz) if knn_idx is None else _dev(knn_idx, "knn_idx")
+    idx = knn_point(nsample, xyz, new_xyz) if knn_idx is None else _dev(knn_idx, "knn_idx", torch.int32)
     grouped_xyz_norm = index_points(xyz, idx) - new_xyz.view(B, npoint, 1, C)
     if points is not None:
         new_points = torch.cat([grouped_xyz_norm, index_points(points, idx)], dim=-1)

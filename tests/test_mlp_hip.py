@@ -361,3 +361,79 @@ def test_wide_single_layer_takes_head_kernels(dev, R, K, N, bias):
         assert (p.grad.double().cpu() - q.grad).abs().max().item() <= tol(q.grad), n
     for b in ("running_mean_0", "running_var_0"):
         assert torch.allclose(getattr(m, b).double().cpu(), getattr(m64, b), rtol=1e-5, atol=1e-6), b
+
+
+# ---- per-stack entry points (csrc/stack.hip): one C call per stack and direction, the same kernels in the same order ----
+def _with_stack(flag, fn):
+    from pointcloudlib_amd.misc import mlp_hip
+    old = mlp_hip.USE_STACK
+    mlp_hip.USE_STACK = flag
+    try:
+        return fn()
+    finally:
+        mlp_hip.USE_STACK = old
+
+
+@pytest.mark.parametrize("spec,lead,ns,bias,slope", CASES + FB_CASES)
+def test_stack_entry_points_equal_per_kernel_path_plain(dev, spec, lead, ns, bias, slope):
+    """pcl_mlp_stack_fwd/bwd_f32 launch the kernels the per-kernel path launches, in the same order, on the same operands:
+    outputs, input gradient, every parameter gradient and the running statistics must be BIT-identical."""
+    torch.manual_seed(3)
+    mlp = PointwiseMLP(spec, bias=bias, slope=slope).to(dev).train()
+    with torch.no_grad():
+        for g in mlp.gammas:
+            g.uniform_(0.5, 1.5); g[::3] *= -1.0
+    x = torch.randn(*lead, spec[0], device=dev)
+    gshape = (lead[:-1] if ns else lead) + (spec[-1],)
+    gout = torch.randn(*gshape, device=dev)
+    a = _with_stack(False, lambda: run(copy.deepcopy(mlp), x, ns, gout, "auto"))
+    b = _with_stack(True, lambda: run(copy.deepcopy(mlp), x, ns, gout, "auto"))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for n in a[2]:
+        assert torch.equal(a[2][n], b[2][n]), n
+    for n in a[3]:
+        assert torch.equal(a[3][n], b[3][n]), n
+
+
+@pytest.mark.parametrize("C,feat_grad,use_xyz,spec_tail", [(3, False, True, [64, 64, 128]), (13, True, True, [32, 32, 64]),
+                                                          (128, True, True, [128, 128, 256]), (3, True, True, [64, 128]),
+                                                          (16, False, False, [64, 64]), (0, False, True, [32, 64, 64])])
+def test_stack_entry_points_equal_per_kernel_path_grouped(dev, C, feat_grad, use_xyz, spec_tail):
+    """The grouped stack (ball-query grouping folded into the first layer, duplicate-compacted rows, max over the group) as
+    one call forward and one backward against the two-node per-kernel path: identical forward; gradients identical where
+    no atomics are involved (everything but the scatter to the points), else to fp32 summation order."""
+    from pointcloudlib_amd import synth
+    from pointcloudlib_amd.misc import ops
+    torch.manual_seed(7)
+    B, N, m, ns = 4, 512, 96, 32
+    x = torch.from_numpy(synth.gauss_ball(B, N, 31)).to(dev)
+    feat0 = torch.randn(B, N, C, device=dev) if C else None
+    _, new_xyz = ops.furthest_point_sample(x, m)
+    idx, cnt = ops.ball_query(new_xyz, x, 0.25, ns, return_cnt=True)
+    goff = ops.group_offsets(cnt)
+    mlp = PointwiseMLP([(3 if use_xyz else 0) + C] + spec_tail).to(dev).train()
+    with torch.no_grad():
+        for g in mlp.gammas:
+            g.uniform_(0.5, 1.5); g[::4] *= -1.0
+    gout = torch.randn(B, m, spec_tail[-1], device=dev)
+
+    def go():
+        mm = copy.deepcopy(mlp)
+        f = None if feat0 is None else feat0.clone().requires_grad_(feat_grad)
+        out = mm.forward_grouped(x, new_xyz, f, idx, cnt, goff, use_xyz)
+        out.backward(gout)
+        return (out.detach(), None if (f is None or not feat_grad) else f.grad.detach(), {n: p.grad.detach() for n, p in mm.named_parameters()},
+                {n: b.detach().clone() for n, b in mm.named_buffers()})
+
+    a, b = _with_stack(False, go), _with_stack(True, go)
+    assert torch.equal(a[0], b[0])
+    for n in a[3]:
+        assert torch.equal(a[3][n], b[3][n]), n
+    atomics = C > 4 or feat_grad                      # the wide-feature path scatters dy to the points with fp32 atomics
+    for n in a[2]:
+        if atomics and n == "weights.0":
+            assert (a[2][n] - b[2][n]).abs().max().item() <= 1e-5 * max(1e-6, a[2][n].abs().max().item()), n
+        else:
+            assert torch.equal(a[2][n], b[2][n]), n
+    if a[1] is not None:
+        assert (a[1] - b[1]).abs().max().item() <= 1e-5 * max(1e-6, a[1].abs().max().item())
