@@ -175,6 +175,52 @@ int pcl_head_layer_bwd_f32(const float* X, const float* W, const float* dOUT, co
                            float slope, float* dY_ws, float* dW, float* dbias, float* dgamma, float* dbeta, float* dX,
                            void* stream);
 
+/* The whole FC head behind one entry point per direction: up to PCL_HEAD_MAX_LAYERS x [Linear (+bias) -> BatchNorm1d ->
+ * (Leaky)ReLU -> Dropout(drop_p)] on R <= 64 rows (networks/cls/pointnet2.py:138-147 + :157-158; dgcnn.py:87-93,:117-121;
+ * pointnet.py:22-38; pointconv.py:14-33).  Per layer: the kernels of pcl_head_layer_*_f32 with the same bn_mode / slope meaning;
+ * drop_p > 0 applies inverted dropout to the layer's OUTPUT (keep decision = counter-based hash of (seed, layer, element), the
+ * same in forward and backward -- no mask is stored; pass drop_p = 0 in evaluation mode).  `save` (forward -> backward) and the
+ * backward's `tmp` are carved here (pcl_fc_head_sizes).  out [R, N_last]; backward: gout [R, N_last] -> layer[l].dW / dbias /
+ * dgamma / dbeta and dx [R, K_0] (nullable). */
+#define PCL_HEAD_MAX_LAYERS 4
+typedef struct pcl_head_layer_t {
+    const float* W;              /* [N, K] (nn.Linear layout) */
+    const float* bias;           /* nullable */
+    const float* gamma;          /* nullable (no affine) */
+    const float* beta;
+    float* running_mean;         /* nullable */
+    float* running_var;
+    float* dW;                   /* backward outputs */
+    float* dbias;
+    float* dgamma;
+    float* dbeta;
+    int32_t K, N, bn_mode;       /* bn_mode as pcl_head_layer_fwd_f32 */
+    float eps, momentum, slope, drop_p;
+    int32_t pad_;
+} pcl_head_layer_t;
+typedef struct pcl_fc_head_t {
+    int32_t struct_bytes;
+    int32_t n_layers;
+    int32_t R;
+    int32_t pad_;
+    uint64_t seed;               /* dropout */
+    const float* x;              /* [R, K_0] */
+    pcl_head_layer_t layer[PCL_HEAD_MAX_LAYERS];
+    float* out;
+    void* save;
+    size_t save_bytes;
+    void* tmp;                   /* backward only */
+    size_t tmp_bytes;
+    const float* gout;
+    float* dx;
+    void* stream;
+} pcl_fc_head_t;
+int pcl_fc_head_sizes(const pcl_fc_head_t* desc, size_t* save_bytes, size_t* bwd_tmp_bytes);
+/* reference: the fc_layer of PointNet2_cls.execute, networks/cls/pointnet2.py:157-158 (dgcnn.py:117-121, pointnet.py:37-39) */
+int pcl_fc_head_fwd_f32(const pcl_fc_head_t* desc);
+/* reference: its autograd backward */
+int pcl_fc_head_bwd_f32(const pcl_fc_head_t* desc);
+
 /* Label-smoothed cross entropy of the classification drivers, soft_cross_entropy_loss of train_cls.py:31-51:
  *   w = one_hot*(1-eps) + (1-one_hot)*eps/(C-1);  *loss = -mean_r sum_c w[r,c] log_softmax(logits)[r,c]
  * logits [R,C], target [R] int64 class ids; dlogits [R,C] (nullable) = d loss / d logits = (softmax - w)/R.  One launch

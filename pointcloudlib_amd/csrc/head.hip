@@ -17,6 +17,19 @@ namespace pcl {
 
 constexpr int HD_KC = 256;       // k per wave pass: 64 lanes x 4
 
+// Dropout of the head (nn.Dropout between the FC layers, networks/cls/pointnet2.py:146, dgcnn.py:118-120): element idx of a
+// layer's output is kept with probability 1 - p and scaled by 1/(1-p).  The keep decision is a counter-based hash of
+// (seed, idx) -- recomputed in backward, no mask is stored.  p = 0: identity.
+struct Drop { float p; unsigned lo, hi; };
+__device__ __forceinline__ float drop_scale(const Drop d, unsigned idx) {
+    if (d.p <= 0.f) return 1.f;
+    unsigned h = (idx + d.hi) * 0x9E3779B1u ^ d.lo;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    h += d.hi; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    return u >= d.p ? 1.0f / (1.0f - d.p) : 0.f;
+}
+
 // One workgroup per output column n, its 4 waves split K in 256-wide chunks; X rows are read straight from global
 // memory (L2-resident, 16-byte pieces), so a lane has RMAX + 1 independent loads in flight per chunk and no barrier
 // until the four partial sums meet in LDS.
@@ -60,7 +73,7 @@ __device__ __forceinline__ void head_epilogue(float y, int lane, int n, const fl
                                               const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                               int R, int N, int bn_mode_full, float eps, float momentum, float slope,
                                               float* __restrict__ Ypre, float* __restrict__ OUT, float* __restrict__ mean_out,
-                                              float* __restrict__ invstd_out) {
+                                              float* __restrict__ invstd_out, const Drop drop = Drop{0.f, 0u, 0u}) {
     const int bn_mode = bn_mode_full & 3;
     const bool biased = (bn_mode_full & 4) != 0;
     const bool in = lane < R;
@@ -91,6 +104,7 @@ __device__ __forceinline__ void head_epilogue(float y, int lane, int n, const fl
         out = fmaf((y - mean) * invstd, gamma ? gamma[n] : 1.f, beta ? beta[n] : 0.f);
     }
     out = out > 0.f ? out : out * slope;
+    out *= drop_scale(drop, (unsigned)(lane * N + n));
     if (in) { Ypre[(size_t)lane * N + n] = y; OUT[(size_t)lane * N + n] = out; }
 }
 
@@ -102,7 +116,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                                                        float* __restrict__ rvar, int R, int K, int N, int bn_mode /*0 none,1 train,2 eval*/,
                                                        float eps, float momentum, float slope, float* __restrict__ Ypre,
                                                        float* __restrict__ OUT, float* __restrict__ mean_out,
-                                                       float* __restrict__ invstd_out) {
+                                                       float* __restrict__ invstd_out, const Drop drop) {
     __shared__ float part[4][RMAX];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x;
@@ -120,7 +134,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     if (wave != 0) return;
     float y = 0.f;
     if (lane < RMAX) y = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    head_epilogue(y, lane, n, bias, gamma, beta, rmean, rvar, R, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out);
+    head_epilogue(y, lane, n, bias, gamma, beta, rmean, rvar, R, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out, drop);
 }
 
 // Wide layers (K >= 4096: PointConv's per-point Linear on the GroupAll level is 32 x 16384 -> 1024): with one column per
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(256) void head_fwd_wide_kernel(const float* __restr
                                                             float* __restrict__ rvar, int R, int K, int N, int bn_mode, float eps,
                                                             float momentum, float slope, float* __restrict__ Ypre,
                                                             float* __restrict__ OUT, float* __restrict__ mean_out,
-                                                            float* __restrict__ invstd_out) {
+                                                            float* __restrict__ invstd_out, const Drop drop) {
     constexpr int RMAX = 32;
     __shared__ __attribute__((aligned(16))) float sX[RMAX][HW_KC + 4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -180,8 +194,8 @@ __global__ __launch_bounds__(256) void head_fwd_wide_kernel(const float* __restr
         for (int off = 32; off >= 1; off >>= 1) { u += __shfl_xor(u, off); v += __shfl_xor(v, off); }
         if (lane == r) { ya = u; yb = v; }
     }
-    if (n0 < N) head_epilogue(ya, lane, n0, bias, gamma, beta, rmean, rvar, R, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out);
-    if (n0 + 1 < N) head_epilogue(yb, lane, n0 + 1, bias, gamma, beta, rmean, rvar, R, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out);
+    if (n0 < N) head_epilogue(ya, lane, n0, bias, gamma, beta, rmean, rvar, R, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out, drop);
+    if (n0 + 1 < N) head_epilogue(yb, lane, n0 + 1, bias, gamma, beta, rmean, rvar, R, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out, drop);
 }
 
 // backward, column part: dy[:,n], dW[n,:], dbias[n], dgamma[n], dbeta[n].  One workgroup per column; every wave forms
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(256) void head_bwd_col_kernel(const float* __restri
                                                            const float* __restrict__ invstd, int R, int K, int N, int bn_mode,
                                                            float slope, float* __restrict__ dY, float* __restrict__ dW,
                                                            float* __restrict__ dbias, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, float* __restrict__ dX_zero) {
+                                                           float* __restrict__ dbeta, float* __restrict__ dX_zero, const Drop drop) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x;
     if (dX_zero) {                         // the dX kernel that follows accumulates with atomics: clear its target here
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(256) void head_bwd_col_kernel(const float* __restri
     }
     const bool in = lane < R;
     const size_t o = (size_t)min(lane, R - 1) * N + n;
-    float du = in ? dOUT[o] : 0.f;
+    float du = in ? dOUT[o] * drop_scale(drop, (unsigned)o) : 0.f;     // (a dropped element: OUT = 0 and du = 0)
     const float outv = OUT[o];
     du = outv > 0.f ? du : du * slope;                      // act'(.) from the sign of the activation's output (slope >= 0)
     float dy = du;
@@ -253,10 +267,10 @@ __device__ __forceinline__ float head_col_dy(int lane, int n, const float* __res
                                              const float* __restrict__ Ypre, const float* __restrict__ gamma,
                                              const float* __restrict__ mean, const float* __restrict__ invstd, int R, int N,
                                              int bn_mode, float slope, float* __restrict__ dY, float* __restrict__ dbias,
-                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                             float* __restrict__ dgamma, float* __restrict__ dbeta, const Drop drop) {
     const bool in = lane < R;
     const size_t o = (size_t)min(lane, R - 1) * N + n;
-    float du = in ? dOUT[o] : 0.f;
+    float du = in ? dOUT[o] * drop_scale(drop, (unsigned)o) : 0.f;
     du = OUT[o] > 0.f ? du : du * slope;
     float dy = du;
     if (bn_mode != 0) {
@@ -285,7 +299,7 @@ __global__ __launch_bounds__(256) void head_bwd_col_wide_kernel(const float* __r
                                                                 const float* __restrict__ invstd, int R, int K, int N, int bn_mode,
                                                                 float slope, float* __restrict__ dY, float* __restrict__ dW,
                                                                 float* __restrict__ dbias, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta, float* __restrict__ dX_zero) {
+                                                                float* __restrict__ dbeta, float* __restrict__ dX_zero, const Drop drop) {
     constexpr int RMAX = 32;
     __shared__ __attribute__((aligned(16))) float sX[RMAX][HW_KC + 4];
     __shared__ float sdy[HW_CB][RMAX];
@@ -299,7 +313,7 @@ __global__ __launch_bounds__(256) void head_bwd_col_wide_kernel(const float* __r
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         float dy = 0.f;
-        if (n0 + c < N) dy = head_col_dy(lane, n0 + c, dOUT, OUT, Ypre, gamma, mean, invstd, R, N, bn_mode & 3, slope, dY, dbias, dgamma, dbeta);
+        if (n0 + c < N) dy = head_col_dy(lane, n0 + c, dOUT, OUT, Ypre, gamma, mean, invstd, R, N, bn_mode & 3, slope, dY, dbias, dgamma, dbeta, drop);
         if (lane < RMAX) sdy[wave * 2 + c][lane] = dy;
     }
     const int xr = tid >> 6, xk = (tid & 63) * 4;
@@ -412,10 +426,10 @@ static bool head_wide(int R, int K, const float* X, const float* W) {
 }  // namespace pcl
 using namespace pcl;
 
-extern "C" int pcl_head_layer_fwd_f32(const float* X, const float* W, const float* bias, const float* gamma, const float* beta,
+static int head_layer_fwd_impl(const float* X, const float* W, const float* bias, const float* gamma, const float* beta,
                                       float* running_mean, float* running_var, int R, int K, int N, int bn_mode, float eps,
                                       float momentum, float slope, float* Ypre, float* OUT, float* mean_out, float* invstd_out,
-                                      void* stream) {
+                                      void* stream, const Drop drop) {
     PCL_REQUIRE(X && W && Ypre && OUT, "pcl_head_layer_fwd_f32: null pointer");
     PCL_REQUIRE(R >= 1 && R <= 64 && K >= 1 && N >= 1, "pcl_head_layer_fwd_f32: bad sizes R=%d K=%d N=%d (R <= 64)", R, K, N);
     PCL_REQUIRE((bn_mode & ~7) == 0 && (bn_mode & 3) <= 2 && ((bn_mode & 3) == 0 || (mean_out && invstd_out)) &&
@@ -424,20 +438,28 @@ extern "C" int pcl_head_layer_fwd_f32(const float* X, const float* W, const floa
     const dim3 grid(N), block(256);
     if (head_wide(R, K, X, W))
         hipLaunchKernelGGL(head_fwd_wide_kernel, dim3((N + HW_CB - 1) / HW_CB), block, 0, st, X, W, bias, gamma, beta, running_mean, running_var,
-                           R, K, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out);
+                           R, K, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out, drop);
     else if (R <= 32)
         hipLaunchKernelGGL(head_fwd_kernel<32>, grid, block, 0, st, X, W, bias, gamma, beta, running_mean, running_var, R, K, N, bn_mode, eps,
-                           momentum, slope, Ypre, OUT, mean_out, invstd_out);
+                           momentum, slope, Ypre, OUT, mean_out, invstd_out, drop);
     else
         hipLaunchKernelGGL(head_fwd_kernel<64>, grid, block, 0, st, X, W, bias, gamma, beta, running_mean, running_var, R, K, N, bn_mode, eps,
-                           momentum, slope, Ypre, OUT, mean_out, invstd_out);
+                           momentum, slope, Ypre, OUT, mean_out, invstd_out, drop);
     return check_launch("pcl_head_layer_fwd_f32");
 }
 
-extern "C" int pcl_head_layer_bwd_f32(const float* X, const float* W, const float* dOUT, const float* OUT, const float* Ypre,
+extern "C" int pcl_head_layer_fwd_f32(const float* X, const float* W, const float* bias, const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, int R, int K, int N, int bn_mode, float eps,
+                                      float momentum, float slope, float* Ypre, float* OUT, float* mean_out, float* invstd_out,
+                                      void* stream) {
+    return head_layer_fwd_impl(X, W, bias, gamma, beta, running_mean, running_var, R, K, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out,
+                               invstd_out, stream, Drop{0.f, 0u, 0u});
+}
+
+static int head_layer_bwd_impl(const float* X, const float* W, const float* dOUT, const float* OUT, const float* Ypre,
                                       const float* gamma, const float* mean, const float* invstd, int R, int K, int N, int bn_mode,
                                       float slope, float* dY_ws, float* dW, float* dbias, float* dgamma, float* dbeta, float* dX,
-                                      void* stream) {
+                                      void* stream, const Drop drop) {
     PCL_REQUIRE(X && W && dOUT && OUT && Ypre && dY_ws && dW, "pcl_head_layer_bwd_f32: null pointer");
     PCL_REQUIRE(R >= 1 && R <= 64 && K >= 1 && N >= 1, "pcl_head_layer_bwd_f32: bad sizes R=%d K=%d N=%d (R <= 64)", R, K, N);
     PCL_REQUIRE((bn_mode & 3) == 0 || (mean && invstd), "pcl_head_layer_bwd_f32: BatchNorm needs mean / invstd");
@@ -445,13 +467,13 @@ extern "C" int pcl_head_layer_bwd_f32(const float* X, const float* W, const floa
     const dim3 grid(N), block(256);
     if (head_wide(R, K, X, W) && (reinterpret_cast<uintptr_t>(dW) & 15) == 0)
         hipLaunchKernelGGL(head_bwd_col_wide_kernel, dim3((N + HW_CB - 1) / HW_CB), block, 0, st, X, dOUT, OUT, Ypre, gamma, mean, invstd, R, K,
-                           N, bn_mode, slope, dY_ws, dW, dbias, dgamma, dbeta, dX);
+                           N, bn_mode, slope, dY_ws, dW, dbias, dgamma, dbeta, dX, drop);
     else if (R <= 32)
         hipLaunchKernelGGL(head_bwd_col_kernel<32>, grid, block, 0, st, X, dOUT, OUT, Ypre, gamma, mean, invstd, R, K, N, bn_mode & 3, slope, dY_ws,
-                           dW, dbias, dgamma, dbeta, dX);
+                           dW, dbias, dgamma, dbeta, dX, drop);
     else
         hipLaunchKernelGGL(head_bwd_col_kernel<64>, grid, block, 0, st, X, dOUT, OUT, Ypre, gamma, mean, invstd, R, K, N, bn_mode & 3, slope, dY_ws,
-                           dW, dbias, dgamma, dbeta, dX);
+                           dW, dbias, dgamma, dbeta, dX, drop);
     int rc = check_launch("pcl_head_layer_bwd_f32(col)");
     if (rc || !dX) return rc;
     const dim3 g2((K + 63) / 64, (N + 4 * HD_NS - 1) / (4 * HD_NS));
@@ -459,6 +481,114 @@ extern "C" int pcl_head_layer_bwd_f32(const float* X, const float* W, const floa
     else if (R <= 32) hipLaunchKernelGGL(head_bwd_dx_kernel<32>, g2, block, 0, st, dY_ws, W, R, K, N, dX);
     else hipLaunchKernelGGL(head_bwd_dx_kernel<64>, g2, block, 0, st, dY_ws, W, R, K, N, dX);
     return check_launch("pcl_head_layer_bwd_f32(dx)");
+}
+
+extern "C" int pcl_head_layer_bwd_f32(const float* X, const float* W, const float* dOUT, const float* OUT, const float* Ypre,
+                                      const float* gamma, const float* mean, const float* invstd, int R, int K, int N, int bn_mode,
+                                      float slope, float* dY_ws, float* dW, float* dbias, float* dgamma, float* dbeta, float* dX,
+                                      void* stream) {
+    return head_layer_bwd_impl(X, W, dOUT, OUT, Ypre, gamma, mean, invstd, R, K, N, bn_mode, slope, dY_ws, dW, dbias, dgamma, dbeta, dX, stream,
+                               Drop{0.f, 0u, 0u});
+}
+
+// ---- the whole FC head behind one entry point (networks/cls/pointnet2.py:138-147,:157-158; dgcnn.py:87-93,:117-121) --------
+// Up to PCL_HEAD_MAX_LAYERS x [Linear (+bias) -> BatchNorm1d -> (Leaky)ReLU -> Dropout] on R <= 64 rows: the per-layer kernels
+// above, launched from ONE call per direction with the buffers carved here.  Backward start is where a training step is
+// host-bound (a dozen 5-10 us kernels, each behind its own autograd node): one node + one call instead.
+namespace pcl {
+struct HeadSave { float* Ypre[PCL_HEAD_MAX_LAYERS]; float* OUT[PCL_HEAD_MAX_LAYERS]; float* mean[PCL_HEAD_MAX_LAYERS]; float* invstd[PCL_HEAD_MAX_LAYERS]; size_t bytes; };
+static inline size_t hal(size_t n) { return (n + 255) & ~(size_t)255; }
+static HeadSave head_save(const pcl_fc_head_t& d, void* base) {
+    HeadSave h = {};
+    char* b = static_cast<char*>(base);
+    size_t off = 0;
+    auto take = [&](size_t n) { float* r = b ? reinterpret_cast<float*>(b + off) : nullptr; off += hal(n * sizeof(float)); return r; };
+    for (int l = 0; l < d.n_layers; ++l) {
+        const size_t rn = (size_t)d.R * d.layer[l].N;
+        h.Ypre[l] = take(rn);
+        h.OUT[l] = l == d.n_layers - 1 ? nullptr : take(rn);        // the last layer's output is the caller's `out`
+        h.mean[l] = take(d.layer[l].N); h.invstd[l] = take(d.layer[l].N);
+    }
+    h.bytes = off;
+    return h;
+}
+static size_t head_bwd_tmp(const pcl_fc_head_t& d, float** dY, float** dX0, float** dX1, void* base) {
+    int nmax = 0, kmax = 0;
+    for (int l = 0; l < d.n_layers; ++l) { nmax = d.layer[l].N > nmax ? d.layer[l].N : nmax; if (l > 0) kmax = d.layer[l].K > kmax ? d.layer[l].K : kmax; }
+    char* b = static_cast<char*>(base);
+    size_t off = 0;
+    auto take = [&](size_t n) { float* r = b ? reinterpret_cast<float*>(b + off) : nullptr; off += hal(n * sizeof(float)); return r; };
+    float* a = take((size_t)d.R * nmax); float* x0 = take((size_t)d.R * (kmax ? kmax : 1)); float* x1 = take((size_t)d.R * (kmax ? kmax : 1));
+    if (dY) *dY = a; if (dX0) *dX0 = x0; if (dX1) *dX1 = x1;
+    return off;
+}
+static int head_validate(const pcl_fc_head_t* dp, const char* who) {
+    PCL_REQUIRE(dp, "%s: null descriptor", who);
+    const pcl_fc_head_t& d = *dp;
+    PCL_REQUIRE(d.struct_bytes == (int32_t)sizeof(pcl_fc_head_t), "%s: descriptor is %d bytes, this library expects %zu", who, d.struct_bytes, sizeof(pcl_fc_head_t));
+    PCL_REQUIRE(d.n_layers >= 1 && d.n_layers <= PCL_HEAD_MAX_LAYERS && d.R >= 1 && d.R <= 64, "%s: n_layers=%d R=%d", who, d.n_layers, d.R);
+    for (int l = 0; l < d.n_layers; ++l) {
+        const pcl_head_layer_t& y = d.layer[l];
+        PCL_REQUIRE(y.W && y.K >= 1 && y.N >= 1 && (l == 0 || y.K == d.layer[l - 1].N), "%s: layer %d: K=%d N=%d", who, l, y.K, y.N);
+        PCL_REQUIRE(y.drop_p >= 0.f && y.drop_p < 1.f, "%s: layer %d: drop_p=%g", who, l, (double)y.drop_p);
+    }
+    return PCL_OK;
+}
+static inline Drop head_drop(const pcl_fc_head_t& d, int l) {
+    const unsigned lo = (unsigned)(d.seed & 0xffffffffull) ^ (0x9E3779B9u * (unsigned)(l + 1)), hi = (unsigned)(d.seed >> 32) + 0x7F4A7C15u * (unsigned)(l + 1);
+    return Drop{d.layer[l].drop_p, lo, hi};
+}
+}  // namespace pcl
+
+extern "C" int pcl_fc_head_sizes(const pcl_fc_head_t* d, size_t* save_bytes, size_t* bwd_tmp_bytes) {
+    int rc = head_validate(d, "pcl_fc_head_sizes");
+    if (rc) return rc;
+    if (save_bytes) *save_bytes = head_save(*d, nullptr).bytes;
+    if (bwd_tmp_bytes) *bwd_tmp_bytes = head_bwd_tmp(*d, nullptr, nullptr, nullptr, nullptr);
+    return PCL_OK;
+}
+
+extern "C" int pcl_fc_head_fwd_f32(const pcl_fc_head_t* dp) {
+    int rc = head_validate(dp, "pcl_fc_head_fwd_f32");
+    if (rc) return rc;
+    const pcl_fc_head_t& d = *dp;
+    PCL_REQUIRE(d.x && d.out && d.save, "pcl_fc_head_fwd_f32: null x / out / save");
+    const HeadSave h = head_save(d, d.save);
+    if (d.save_bytes < h.bytes) return fail(PCL_EWS, "pcl_fc_head_fwd_f32: save %zu < %zu", d.save_bytes, h.bytes);
+    const float* cur = d.x;
+    for (int l = 0; l < d.n_layers; ++l) {
+        const pcl_head_layer_t& y = d.layer[l];
+        float* out = l == d.n_layers - 1 ? d.out : h.OUT[l];
+        rc = head_layer_fwd_impl(cur, y.W, y.bias, y.gamma, y.beta, y.running_mean, y.running_var, d.R, y.K, y.N, y.bn_mode, y.eps, y.momentum,
+                                 y.slope, h.Ypre[l], out, h.mean[l], h.invstd[l], d.stream, head_drop(d, l));
+        if (rc) return rc;
+        cur = out;
+    }
+    return PCL_OK;
+}
+
+extern "C" int pcl_fc_head_bwd_f32(const pcl_fc_head_t* dp) {
+    int rc = head_validate(dp, "pcl_fc_head_bwd_f32");
+    if (rc) return rc;
+    const pcl_fc_head_t& d = *dp;
+    PCL_REQUIRE(d.x && d.out && d.save && d.tmp && d.gout, "pcl_fc_head_bwd_f32: null x / out / save / tmp / gout");
+    const HeadSave h = head_save(d, d.save);
+    float *dY, *dXa, *dXb;
+    const size_t need = head_bwd_tmp(d, &dY, &dXa, &dXb, d.tmp);
+    if (d.save_bytes < h.bytes || d.tmp_bytes < need) return fail(PCL_EWS, "pcl_fc_head_bwd_f32: save %zu < %zu or tmp %zu < %zu", d.save_bytes, h.bytes, d.tmp_bytes, need);
+    const float* g = d.gout;
+    for (int l = d.n_layers - 1; l >= 0; --l) {
+        const pcl_head_layer_t& y = d.layer[l];
+        PCL_REQUIRE(y.dW && (!y.bias || y.dbias) && (!(y.bn_mode & 3) || !y.gamma || (y.dgamma && y.dbeta)), "pcl_fc_head_bwd_f32: layer %d: null gradient output", l);
+        const float* X = l == 0 ? d.x : h.OUT[l - 1];
+        const float* OUT = l == d.n_layers - 1 ? d.out : h.OUT[l];
+        float* dX = l == 0 ? d.dx : ((d.n_layers - 1 - l) & 1 ? dXb : dXa);
+        rc = head_layer_bwd_impl(X, y.W, g, OUT, h.Ypre[l], y.gamma, h.mean[l], h.invstd[l], d.R, y.K, y.N, y.bn_mode, y.slope, dY, y.dW, y.dbias,
+                                 y.dgamma, y.dbeta, dX, d.stream, head_drop(d, l));
+        if (rc) return rc;
+        g = dX;
+    }
+    return PCL_OK;
 }
 
 // ---- label-smoothed cross entropy of the classifier (train_cls.py:31-51) --------------------------------------------

@@ -660,10 +660,15 @@ class _StackFn(torch.autograd.Function):
 
 
 def _stack_params(module):
+    cached = module.__dict__.get("_stack_params_cache")
+    if (cached is not None and cached[0][0] is module.weights[0] and cached[1][0] is module._buffers.get("running_mean_0")
+            and cached[0][-1] is (module.biases[-1] if module.biases is not None else module.betas[-1]) and cached[1][-1] is module._buffers.get(f"running_var_{module.n_layers - 1}")):
+        return cached
     ps, running = [], []
     for i in range(module.n_layers):
         ps += [module.weights[i], module.gammas[i], module.betas[i]] + ([module.biases[i]] if module.biases is not None else [])
         running += [getattr(module, f"running_mean_{i}"), getattr(module, f"running_var_{i}")]
+    module.__dict__["_stack_params_cache"] = (ps, running)      # (.to() / load_state_dict keep the Parameter objects; the identity check above catches replaced ones)
     return ps, running
 
 

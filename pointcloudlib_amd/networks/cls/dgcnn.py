@@ -15,7 +15,7 @@ from torch import nn
 
 from ...misc.layers import PointwiseMLP
 from ...misc.edgeconv import edge_conv
-from ...misc.head import head_layer
+from ...misc.head import fc_head
 from ...misc.ops import KNN, edge_features
 
 
@@ -31,6 +31,9 @@ def get_graph_feature(x, knn=None, k=None, idx=None):
         xt = x.transpose(1, 2).contiguous()           # [B,C,N] as KNN expects (misc/ops.py:651)
         idx = knn(xt, xt).permute(0, 2, 1).contiguous()   # [B,k,N] -> [B,N,k]   dgcnn.py:34-35
     return edge_features(x, idx)
+
+
+_LRELU = nn.LeakyReLU(0.2)          # activation marker for fc_head (no parameters, not part of the state dict)
 
 
 class DGCNN(nn.Module):
@@ -66,11 +69,8 @@ class DGCNN(nn.Module):
         x = torch.cat((x1, x2, x3, x4), dim=2)                              # [B,N,512]   :112
         x = self.conv5(x)                                                   # [B,N,1024]  :113
         x = torch.cat((x.max(dim=1)[0], x.mean(dim=1)), dim=1)              # :114-116
-        x = head_layer(x, self.linear1, self.bn6, 0.2)           # fused head kernels (misc/head.py)
-        x = self.dp1(x)
-        x = head_layer(x, self.linear2, self.bn7, 0.2)
-        x = self.dp2(x)
-        x = head_layer(x, self.linear3)
+        # :117-121 -- the whole head as one call per direction (misc/head.py: fc_head -> pcl_fc_head_*_f32)
+        x = fc_head([self.linear1, self.bn6, _LRELU, self.dp1, self.linear2, self.bn7, _LRELU, self.dp2, self.linear3], x)
         return (x, stages) if return_stages else x
 
     def execute(self, *a, **k):

@@ -2,7 +2,7 @@
 sa3 uses ``group_all=True``, which upstream cannot run (missing ``sample_and_group_all``); see pointconv_utils."""
 from torch import nn
 
-from ...misc.head import head_layer
+from ...misc.head import fc_head
 from ...misc.pointconv_utils import PointConvDensitySetAbstraction
 
 
@@ -30,9 +30,8 @@ class PointConvDensityClsSsg(nn.Module):
         l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, None if start_idx is None else start_idx[1], k2)
         _, l3_points = self.sa3(l2_xyz, l2_points)
         x = l3_points.reshape(B, 1024)
-        x = self.drop1(head_layer(x, self.fc1, self.bn1, self.relu))       # fused head kernels (misc/head.py)
-        x = self.drop2(head_layer(x, self.fc2, self.bn2, self.relu))
-        return head_layer(x, self.fc3)
+        # one call per direction (misc/head.py: fc_head -> pcl_fc_head_*_f32)
+        return fc_head([self.fc1, self.bn1, self.relu, self.drop1, self.fc2, self.bn2, self.relu, self.drop2, self.fc3], x)
 
     def execute(self, *a, **k):
         return self(*a, **k)

@@ -2,7 +2,7 @@
 no sampling/grouping; exercises the conv1d/BN/max/FC plumbing).  Input [B,3,N] like the reference."""
 from torch import nn
 
-from ...misc.head import head_layer
+from ...misc.head import fc_head
 from ...misc.layers import PointwiseMLP
 
 
@@ -20,9 +20,7 @@ class PointNet(nn.Module):
         x = x.transpose(1, 2).contiguous()                # [B,N,3]
         x = self.convs(x[:, None], group_max=x.shape[1])  # conv stack + max over N   :30-35  -> [B,1,1024]
         x = x.reshape(x.shape[0], -1)
-        x = head_layer(x, self.linear1, self.bn6, self.relu)     # fused head kernels (misc/head.py)
-        x = self.dp1(x)
-        return head_layer(x, self.linear2)
+        return fc_head([self.linear1, self.bn6, self.relu, self.dp1, self.linear2], x)     # one call per direction (misc/head.py)
 
     def execute(self, *a, **k):
         return self(*a, **k)

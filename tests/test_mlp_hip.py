@@ -437,3 +437,92 @@ def test_stack_entry_points_equal_per_kernel_path_grouped(dev, C, feat_grad, use
             assert torch.equal(a[2][n], b[2][n]), n
     if a[1] is not None:
         assert (a[1] - b[1]).abs().max().item() <= 1e-5 * max(1e-6, a[1].abs().max().item())
+
+
+# ---- the whole FC head as one call per direction (pcl_fc_head_*_f32) ---------------------------------------------------
+def _head_mods(dev, spec, bn, bias, slope, p):
+    from torch import nn
+    mods = []
+    for i in range(len(spec) - 1):
+        last = i == len(spec) - 2
+        mods.append(nn.Linear(spec[i], spec[i + 1], bias=bias or last))
+        if not last:
+            if bn:
+                mods.append(nn.BatchNorm1d(spec[i + 1]))
+            mods.append(nn.ReLU() if slope == 0.0 else nn.LeakyReLU(slope))
+            if p is not None:
+                mods.append(nn.Dropout(p))
+    return nn.Sequential(*mods).to(dev)
+
+
+@pytest.mark.parametrize("spec,R,bn,bias,slope", [([1024, 512, 256, 40], 32, True, False, 0.0), ([2048, 512, 256, 40], 16, True, True, 0.2),
+                                                  ([64, 40], 5, False, True, 0.0), ([100, 30, 7], 64, True, True, 0.2),
+                                                  ([48, 96, 96, 24, 10], 33, True, False, 0.0)])
+@pytest.mark.parametrize("training", [True, False])
+def test_head_stack_equals_per_layer_path(dev, spec, R, bn, bias, slope, training):
+    """pcl_fc_head_*_f32 chains the kernels of pcl_head_layer_*_f32: with dropout off, the output, the running statistics and
+    the last layer's parameter gradients are BIT-identical to the per-layer path; what passes through a dX kernel (fp32
+    atomics over the column splits) agrees to summation order."""
+    from pointcloudlib_amd.misc import head
+    torch.manual_seed(5)
+    seq = _head_mods(dev, spec, bn, bias, slope, 0.0)
+    seq.train(training)
+    x0 = torch.randn(R, spec[0], device=dev)
+    gout = torch.randn(R, spec[-1], device=dev)
+    res = []
+    for flag in (False, True):
+        s2 = copy.deepcopy(seq)
+        old, head.USE_STACK = head.USE_STACK, flag
+        try:
+            x = x0.clone().requires_grad_(True)
+            out = head.fc_head(s2, x)
+            out.backward(gout)
+        finally:
+            head.USE_STACK = old
+        res.append((out.detach(), x.grad.detach(), [p.grad.detach() for p in s2.parameters()], [b.detach().clone() for b in s2.buffers()]))
+    a, b = res
+    assert torch.equal(a[0], b[0])
+    gs = max(u.abs().max().item() for u in a[2])               # (a conv bias under BatchNorm has an exactly-zero gradient: judge by the model's scale)
+    assert (a[1] - b[1]).abs().max().item() <= 1e-5 * max(1e-6, a[1].abs().max().item())
+    for u, v in zip(a[2], b[2]):
+        assert (u - v).abs().max().item() <= 1e-5 * max(1e-3 * gs, u.abs().max().item())
+    n_last = 2                                                 # the last Linear always carries a bias here: (W, b) are its parameters
+    for u, v in zip(a[2][-n_last:], b[2][-n_last:]):
+        assert torch.equal(u, v)
+    for u, v in zip(a[3], b[3]):
+        assert torch.equal(u.float(), v.float())
+
+
+@pytest.mark.parametrize("p", [0.5, 0.2])
+def test_head_stack_dropout(dev, p):
+    """Dropout inside the head kernels: inverted dropout on a layer's output with the keep decision recomputed in backward.
+    A linear probe layer (identity weight) behind the dropped layer makes the mask visible."""
+    from torch import nn
+    from pointcloudlib_amd.misc import head
+    torch.manual_seed(9)
+    R, K, N = 32, 96, 256
+    lin1, lin2 = nn.Linear(K, N).to(dev), nn.Linear(N, N, bias=False).to(dev)
+    with torch.no_grad():
+        lin2.weight.copy_(torch.eye(N))
+    mods = [lin1, nn.Dropout(p), lin2]
+    for m in mods:
+        m.train()
+    x = torch.randn(R, K, device=dev, requires_grad=True)
+    out = head.fc_head(mods, x)
+    y = torch.nn.functional.linear(x.detach(), lin1.weight, lin1.bias)
+    mask = out.detach() != 0
+    keep = mask.float().mean().item()
+    assert abs(keep - (1 - p)) < 0.03, keep
+    assert torch.allclose(out.detach()[mask], (y / (1 - p))[mask], rtol=1e-5, atol=1e-6)
+    gout = torch.randn(R, N, device=dev)
+    out.backward(gout)
+    want_dx = (gout * mask / (1 - p)) @ lin1.weight.detach()
+    assert torch.allclose(x.grad, want_dx, rtol=1e-4, atol=1e-5)
+    want_dw = (gout * mask / (1 - p)).t() @ x.detach()
+    assert torch.allclose(lin1.weight.grad, want_dw, rtol=1e-4, atol=1e-5)
+    out2 = head.fc_head(mods, x.detach())                # another call draws another mask
+    assert ((out2 != 0) != mask).float().mean().item() > 0.1
+    for m in mods:
+        m.eval()
+    out3 = head.fc_head(mods, x.detach())                # evaluation mode: identity
+    assert torch.allclose(out3, y, rtol=1e-5, atol=1e-6)
