@@ -26,6 +26,7 @@ CPU_AFFINITY = pin_to_gpu_node(int(os.environ.get("LOCAL_RANK", "0")))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+HOST_DELAY_US = float(os.environ.get("PCL_HOST_DELAY_US", "0"))
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_PEAK_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
 
@@ -158,6 +159,10 @@ def main():
         i+1 are produced on a side stream while batch i's backward runs (input-pipeline style); every step still
         executes exactly one full set of index ops, and batch i's own set was produced during step i-1."""
         x, f, y = batches[i % len(batches)]
+        if HOST_DELAY_US:                      # lab switch: is the host on the critical path?  (busy-wait, no GPU interaction)
+            t_end = time.perf_counter() + HOST_DELAY_US * 1e-6
+            while time.perf_counter() < t_end:
+                pass
         dp.zero_grad()
         samp = pending.pop(i, None)
         out = net(x, f, sampling=samp)
@@ -199,9 +204,10 @@ def main():
     # kernels through the per-kernel entry points (mlp_hip.USE_STACK = False: bit-identical results, tests/test_mlp_hip.py),
     # and the TIMED region runs the product path with the events armed for the chosen kernel's launch tag.
     from pointcloudlib_amd.misc import mlp_hip
-    stack_default = mlp_hip.USE_STACK
+    from pointcloudlib_amd.misc import head as _head
+    stack_default, head_default = mlp_hip.USE_STACK, _head.USE_STACK
     if args.profile_all:                                # every rank steps (collectives); rank 0 prints
-        mlp_hip.USE_STACK = False
+        mlp_hip.per_kernel_path().__enter__()
         _lib.PROFILER = _lib.KernelTimer()
         for _ in range(3):
             step(it); it += 1
@@ -216,28 +222,28 @@ def main():
                 tf = v["algo_flops"] / (v["avg_ms"] * 1e-3) / 1e12 if v["algo_flops"] else 0
                 print(f"{name:28s} {tag:14s} n/step={v['launches'] / 3:4.1f} avg={v['avg_ms']:8.4f} ms  {gbs:8.1f} GB/s {tf:7.2f} TF",
                       file=sys.stderr)
-        mlp_hip.USE_STACK = stack_default
+        mlp_hip.USE_STACK = stack_default; _head.USE_STACK = head_default
     if args.dump_launch_order:
-        mlp_hip.USE_STACK = False
+        mlp_hip.per_kernel_path().__enter__()
         _lib.PROFILER = _lib.KernelTimer()
         step(it); it += 1
         torch.cuda.synchronize()
         if rank == 0:
             json.dump({"step_launch_order": _lib.PROFILER.order}, open(args.dump_launch_order, "w"))
         _lib.PROFILER = None
-        mlp_hip.USE_STACK = stack_default
+        mlp_hip.USE_STACK = stack_default; _head.USE_STACK = head_default
     # pick the dominant own kernel (untimed 2-step pre-pass with every entry point bracketed by events)
     target = args.roofline_kernel
     target_algo = None
     if target == "auto":
-        mlp_hip.USE_STACK = False
+        mlp_hip.per_kernel_path().__enter__()
         _lib.PROFILER = _lib.KernelTimer()
         step(it); it += 1
         step(it); it += 1
         torch.cuda.synchronize()
         summ = _lib.PROFILER.summary()
         _lib.PROFILER = None
-        mlp_hip.USE_STACK = stack_default
+        mlp_hip.USE_STACK = stack_default; _head.USE_STACK = head_default
         for _ in range(2):                        # back on the product path before anything is timed
             step(it); it += 1
         torch.cuda.synchronize()

@@ -116,6 +116,14 @@ size_t pcl_knn_workspace_bytes(int B, int C, int Nr, int Nq, int k);
 /* reference: replaces compute_distances + modified_insertion_sort + the host glue, misc/ops.py:429-552, :562-663 */
 int pcl_knn_f32(const float* ref, const float* qry, int B, int C, int Nr, int Nq, int k,
                 int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream);
+/* The NAMED SECOND DEFINITION of the same search: distances accumulated as ssd = fma(tmp, tmp, ssd) -- what nvcc's default
+ * -fmad=true makes of `ssd += tmp*tmp` (misc/ops.py:488-491) -- instead of a separately rounded product and sum.  2 VALU
+ * operations per (query, reference, channel) instead of 3.  Bit-exact against the oracle's "fma" reading
+ * (oracle.contract("fma")); on the BASELINE inputs it changes no neighbour SET and 1.2e-4 of the ordered lists
+ * (profiles/r03_contraction_sensitivity.txt).  Opt-in (PCL_KNN_CONTRACT=fma on the Python side); workspace as pcl_knn_f32
+ * (0 bytes up to 4096 references). */
+int pcl_knn_fma_f32(const float* ref, const float* qry, int B, int C, int Nr, int Nq, int k,
+                    int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- 3-NN inverse-distance interpolation (PointNetFeaturePropagation, misc/ops.py:83-93) -----
  *   xyz1 [B,N,3] (targets), xyz2 [B,S,3] (sources) -> idx3 [B,N,3], w3 [B,N,3]

@@ -18,6 +18,10 @@ namespace pcl {
 
 constexpr int KD_T = 256, KD_TILE = 64, KD_CK = 32;
 
+// FMA = the library's NAMED SECOND DEFINITION of the distance (pcl_knn_fma_f32): `ssd = fma(tmp, tmp, ssd)`, what nvcc's default
+// -fmad=true makes of `ssd += tmp*tmp` (misc/ops.py:490) -- 2 VALU operations per (query, reference, channel) instead of 3.
+// The default (FMA = false) rounds the product and the sum separately, as the source text reads.
+template <bool FMA>
 __global__ __launch_bounds__(KD_T) void knn_dist_kernel(const float* __restrict__ ref, const float* __restrict__ qry,
                                                         int C, int Nr, int Nq, float* __restrict__ dist) {
     __shared__ float sR[KD_CK][KD_TILE];
@@ -52,7 +56,8 @@ __global__ __launch_bounds__(KD_T) void knn_dist_kernel(const float* __restrict_
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float t = __fsub_rn(bb[j], a[i]);               // ref - query, :489
-                    acc[i][j] = __fadd_rn(acc[i][j], __fmul_rn(t, t));    // ssd += tmp*tmp, :490
+                    if constexpr (FMA) acc[i][j] = __fmaf_rn(t, t, acc[i][j]);
+                    else acc[i][j] = __fadd_rn(acc[i][j], __fmul_rn(t, t));    // ssd += tmp*tmp, :490
                 }
         }
         __syncthreads();
@@ -185,7 +190,7 @@ struct KnnCfg {
     static constexpr int CK = 8192 / NRP > 32 ? 32 : 8192 / NRP; // channels per LDS stage (<= 32 KB of references)
 };
 
-template <int PPT>
+template <int PPT, bool FMA = false>
 __global__ __launch_bounds__(256) void knn_fused_kernel(const float* __restrict__ ref, const float* __restrict__ qry, int C, int Nr,
                                                         int Nq, int k, int32_t* __restrict__ idx_out,
                                                         const unsigned char* __restrict__ redo) {
@@ -281,13 +286,21 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(const float* __restrict_
                     t[i][0] = r01 - qq; t[i][1] = r23 - qq;                                       // ref - query, :489
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (FMA) {                                                              // ssd = fma(tmp, tmp, ssd): v_pk_fma_f32
 #pragma unroll
-                for (int i = 0; i < QW; ++i) { t[i][0] = t[i][0] * t[i][0]; t[i][1] = t[i][1] * t[i][1]; }
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < QW; ++i) {
+                        acc[i][2 * J] = __builtin_elementwise_fma(t[i][0], t[i][0], acc[i][2 * J]);
+                        acc[i][2 * J + 1] = __builtin_elementwise_fma(t[i][1], t[i][1], acc[i][2 * J + 1]);
+                    }
+                } else {
 #pragma unroll
-                for (int i = 0; i < QW; ++i) {                                                    // ssd += tmp*tmp, :490
-                    acc[i][2 * J] = acc[i][2 * J] + t[i][0];
-                    acc[i][2 * J + 1] = acc[i][2 * J + 1] + t[i][1];
+                    for (int i = 0; i < QW; ++i) { t[i][0] = t[i][0] * t[i][0]; t[i][1] = t[i][1] * t[i][1]; }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < QW; ++i) {                                                // ssd += tmp*tmp, :490
+                        acc[i][2 * J] = acc[i][2 * J] + t[i][0];
+                        acc[i][2 * J + 1] = acc[i][2 * J + 1] + t[i][1];
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -667,8 +680,9 @@ extern "C" size_t pcl_knn_workspace_bytes(int B, int C, int Nr, int Nq, int k) {
     return sizeof(float) * (size_t)B * Nr * Nq;
 }
 
-extern "C" int pcl_knn_f32(const float* ref, const float* qry, int B, int C, int Nr, int Nq, int k,
-                           int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream) {
+template <bool FMA>
+static int knn_impl(const float* ref, const float* qry, int B, int C, int Nr, int Nq, int k,
+                    int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream) {
     PCL_REQUIRE(ref && qry && idx_out, "pcl_knn_f32: null pointer");
     PCL_REQUIRE(B >= 0 && C >= 1 && Nr >= 1 && Nq >= 1, "pcl_knn_f32: bad sizes B=%d C=%d Nr=%d Nq=%d", B, C, Nr, Nq);
     PCL_REQUIRE(k >= 1 && k <= Nr, "pcl_knn_f32: need 1 <= k <= Nr (k=%d Nr=%d)", k, Nr);
@@ -678,7 +692,7 @@ extern "C" int pcl_knn_f32(const float* ref, const float* qry, int B, int C, int
         hipStream_t st = as_stream(stream);
         const int ppt4 = (Nr + 255) / 256 * 4;                    // multiples of 4 registers per lane
         const unsigned char* redo = nullptr;
-        if (knn_filtered(C, Nr, k)) {
+        if (!FMA && knn_filtered(C, Nr, k)) {
             const size_t need = pcl_knn_workspace_bytes(B, C, Nr, Nq, k);
             if (!workspace || workspace_bytes < need)
                 return fail(PCL_EWS, "pcl_knn_f32: workspace %zu bytes < required %zu", workspace_bytes, need);
@@ -690,17 +704,17 @@ extern "C" int pcl_knn_f32(const float* ref, const float* qry, int B, int C, int
             if (rc) return rc;
             redo = static_cast<const unsigned char*>(workspace);  // the exact kernel below redoes the flagged 32-query blocks only
         }
-#define PCL_KF(P) if (ppt4 <= P) { hipLaunchKernelGGL(knn_fused_kernel<P>, dim3((Nq + 4 * KnnCfg<P>::QW - 1) / (4 * KnnCfg<P>::QW), B), dim3(256), 0, st, ref, qry, C, Nr, Nq, k, idx_out, redo); return check_launch("pcl_knn_f32(fused)"); }
+#define PCL_KF(P) if (ppt4 <= P) { hipLaunchKernelGGL((knn_fused_kernel<P, FMA>), dim3((Nq + 4 * KnnCfg<P>::QW - 1) / (4 * KnnCfg<P>::QW), B), dim3(256), 0, st, ref, qry, C, Nr, Nq, k, idx_out, redo); return check_launch("pcl_knn_f32(fused)"); }
         PCL_KF(4) PCL_KF(8) PCL_KF(16) PCL_KF(32) PCL_KF(64)
 #undef PCL_KF
     }
-    const size_t need = pcl_knn_workspace_bytes(B, C, Nr, Nq, k);
-    if (!workspace || workspace_bytes < need)
+    const size_t need = Nr <= KNN_FUSED_MAX_NR ? 0 : sizeof(float) * (size_t)B * Nr * Nq;
+    if (need && (!workspace || workspace_bytes < need))
         return fail(PCL_EWS, "pcl_knn_f32: workspace %zu bytes < required %zu", workspace_bytes, need);
     hipStream_t st = as_stream(stream);
     float* dist = static_cast<float*>(workspace);
     dim3 g0((Nr + KD_TILE - 1) / KD_TILE, (Nq + KD_TILE - 1) / KD_TILE, B);
-    hipLaunchKernelGGL(knn_dist_kernel, g0, dim3(KD_T), 0, st, ref, qry, C, Nr, Nq, dist);
+    hipLaunchKernelGGL(knn_dist_kernel<FMA>, g0, dim3(KD_T), 0, st, ref, qry, C, Nr, Nq, dist);
     int rc = check_launch("pcl_knn_f32(dist)");
     if (rc) return rc;
     dim3 g1((Nq + 3) / 4, B);
@@ -710,4 +724,14 @@ extern "C" int pcl_knn_f32(const float* ref, const float* qry, int B, int C, int
 #undef PCL_KSEL
     hipLaunchKernelGGL(knn_select_generic_kernel, g1, dim3(256), 0, st, dist, Nr, Nq, k, idx_out);
     return check_launch("pcl_knn_f32(select-generic)");
+}
+
+extern "C" int pcl_knn_f32(const float* ref, const float* qry, int B, int C, int Nr, int Nq, int k,
+                           int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return knn_impl<false>(ref, qry, B, C, Nr, Nq, k, idx_out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcl_knn_fma_f32(const float* ref, const float* qry, int B, int C, int Nr, int Nq, int k,
+                               int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return knn_impl<true>(ref, qry, B, C, Nr, Nq, k, idx_out, workspace, workspace_bytes, stream);
 }

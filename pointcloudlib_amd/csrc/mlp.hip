@@ -662,11 +662,16 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
         // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
         // Full tiles take a branch-free path (a store or load under a per-element branch makes hipcc wait
         // vmcnt(0) at every join, serialising the 64 stores of a lane).
-        const bool full = (m0 + TBM <= p.M) && (n0 + TBN <= p.N);
+        // (decided per 32-column block of a wave, not per tile: N = 96 -- the MSG stacks' 64->96->128 layers -- leaves the last
+        //  block of the last column tile empty, and taking the whole tile down the per-element path cost 0.77 ms per launch)
+        const bool full_rows = m0 + TBM <= p.M;
         float tw_all = 0.f;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-            const int col = n0 + wc * 32 * TN + tn * 32 + lr;
+            const int cb0 = n0 + wc * 32 * TN + tn * 32;        // this wave's 32-column block (wave-uniform)
+            if (cb0 >= p.N) continue;                           // entirely past N: nothing to store, sums stay 0
+            const bool full = full_rows && (cb0 + 32 <= p.N);
+            const int col = cb0 + lr;
             const bool cin = col < p.N;
             const float bias = ep_bias[tn], esc = ep_sc[tn], esh = ep_sh[tn];
             float ts = 0.f, tq = 0.f, tw = 0.f, piv = 0.f;

@@ -568,6 +568,24 @@ def _stack_plan(module, P, c0, pool, grouped, geom, need_dx, x_grad_from):
     return plan
 
 
+class per_kernel_path:
+    """``with per_kernel_path(): ...`` -- run the stacks and the FC head through the per-kernel entry points (one C-ABI call per
+    kernel) instead of the per-stack ones: the same kernels in the same order, bit-identical results
+    (tests/test_mlp_hip.py).  For the profiling passes that bracket individual C-ABI calls with events
+    (``_lib.KernelTimer``: bench.py's choice of the dominant kernel, tools/bench_models.py, ``--profile-all``)."""
+
+    def __enter__(self):
+        global USE_STACK
+        from . import head
+        self.prev = (USE_STACK, head.USE_STACK)
+        USE_STACK = head.USE_STACK = False
+
+    def __exit__(self, *a):
+        global USE_STACK
+        from . import head
+        USE_STACK, head.USE_STACK = self.prev
+
+
 def _stack_eligible(module):
     return (USE_STACK and module.bn and module.training and module.n_layers <= _MAXL and not syncbn.active())
 

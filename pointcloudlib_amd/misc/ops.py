@@ -9,6 +9,8 @@ stream and autograd bookkeeping.  CPU tensors are rejected: there is no fallback
 """
 import math
 
+import os
+
 import torch
 from torch import nn
 
@@ -88,8 +90,18 @@ def ball_query(new_xyz, xyz, radius, n_samples, return_cnt=False):
     return (idx, cnt) if return_cnt else idx
 
 
-def knn_indices(x_q, x_r, k):
+# The k-NN distance has two definitions in this library: the default rounds `tmp*tmp` and the sum
+# separately, as the reference's source text reads (misc/ops.py:488-491); "fma" is the NAMED second definition -- what nvcc's
+# default -fmad=true makes of that line -- one VALU operation fewer per element.  Opt-in: PCL_KNN_CONTRACT=fma or
+# ``ops.KNN_CONTRACT = "fma"``; each is bit-exact against the oracle evaluated under the same reading.
+KNN_CONTRACT = os.environ.get("PCL_KNN_CONTRACT", "")
+
+
+def knn_indices(x_q, x_r, k, contract=None):
     """KNN(k).execute(x_q [B,C,Nq], x_r [B,C,Nr]) -> int32 [B,k,Nq].  misc/ops.py:651-663."""
+    contract = KNN_CONTRACT if contract is None else contract
+    if contract not in ("", "fma"):
+        raise ValueError(f"knn contract {contract!r}: '' (source reading) or 'fma'")
     x_q = _dev(x_q, "x_q")
     x_r = _dev(x_r, "x_r")
     if x_q.dim() != 3 or x_r.dim() != 3 or x_q.shape[:2] != x_r.shape[:2]:
@@ -99,8 +111,8 @@ def knn_indices(x_q, x_r, k):
     idx = torch.empty((B, k, Nq), dtype=torch.int32, device=x_q.device)
     nbytes = _lib.lib().pcl_knn_workspace_bytes(B, C, Nr, Nq, k)
     ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=x_q.device)   # the reference's tmp_dist
-    _lib.call("pcl_knn_f32", _p(x_r), _p(x_q), B, C, Nr, Nq, int(k), _p(idx), _p(ws), nbytes, _stream(),
-              algo_bytes=4 * B * C * (Nr + Nq) + 4 * B * k * Nq, algo_flops=3 * B * Nr * Nq * C)
+    _lib.call("pcl_knn_fma_f32" if contract == "fma" else "pcl_knn_f32", _p(x_r), _p(x_q), B, C, Nr, Nq, int(k), _p(idx), _p(ws), nbytes,
+              _stream(), algo_bytes=4 * B * C * (Nr + Nq) + 4 * B * k * Nq, algo_flops=3 * B * Nr * Nq * C)
     return idx
 
 

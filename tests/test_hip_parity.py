@@ -215,6 +215,38 @@ def test_knn_mfma_filter_path_is_exact(oracle, dev, monkeypatch, B, C, Nr, Nq, k
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("B,C,Nr,Nq,k", [(2, 3, 1024, 1024, 20), (2, 64, 1024, 1024, 20), (2, 128, 1024, 512, 20), (1, 64, 2048, 300, 40),
+                                         (1, 9, 5000, 77, 16), (1, 128, 256, 256, 200), (3, 7, 333, 100, 5)])
+def test_knn_fma_definition_matches_oracle_fma_reading(oracle, dev, B, C, Nr, Nq, k):
+    """pcl_knn_fma_f32 -- the named second definition (ssd = fma(tmp, tmp, ssd), nvcc's default contraction of misc/ops.py:490)
+    -- is bit-exact against the oracle evaluated under the same reading, fused and two-pass (> 4096 references) paths."""
+    rng = np.random.default_rng(Nr + C)
+    r = rng.standard_normal((B, C, Nr)).astype(np.float32)
+    q = r[:, :, :Nq].copy() if Nq <= Nr else rng.standard_normal((B, C, Nq)).astype(np.float32)
+    with oracle.contract("fma"):
+        want = oracle.knn(q, r, k)
+    got = ops.knn_indices(T(q, dev), T(r, dev), k, contract="fma")
+    assert np.array_equal(got.cpu().numpy(), want)
+    plain = ops.knn_indices(T(q, dev), T(r, dev), k)                     # and the default stays the source reading
+    assert np.array_equal(plain.cpu().numpy(), oracle.knn(q, r, k))
+
+
+def test_knn_fma_and_default_definitions_differ_on_a_constructed_near_tie(oracle, dev):
+    """the two definitions are different functions: a pair of references ordered one way under one, the other way under the other"""
+    rng = np.random.default_rng(1)
+    q = np.array([0.1, -0.2, 0.3], np.float32)
+    d = rng.standard_normal((4000, 3))
+    refs = (q + d / np.linalg.norm(d, axis=1, keepdims=True) * (1 + rng.uniform(-2e-7, 2e-7, (4000, 1)))).astype(np.float32)
+    x_r = np.ascontiguousarray(refs.T[None])
+    x_q = np.ascontiguousarray(q[None, :, None])
+    a = oracle.knn(x_q, x_r, 200)[0, :, 0]
+    with oracle.contract("fma"):
+        b = oracle.knn(x_q, x_r, 200)[0, :, 0]
+    assert not np.array_equal(a, b)                                     # (2 ulp spread over 4000 points at one distance: many near-ties)
+    assert np.array_equal(ops.knn_indices(T(x_q, dev), T(x_r, dev), 200).cpu().numpy()[0, :, 0], a)
+    assert np.array_equal(ops.knn_indices(T(x_q, dev), T(x_r, dev), 200, contract="fma").cpu().numpy()[0, :, 0], b)
+
+
 def test_knn_ties_by_index(oracle, dev):
     g = np.load(os.path.join(GOLD, "small_cases.npz"))
     for k in (1, 7, 33):

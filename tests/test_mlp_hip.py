@@ -38,6 +38,10 @@ CASES = [
     ([64, 64, 128], (13, 8, 16), 16, False, 0.0),           # 1664 rows = 26 row tiles: full groups of 8 AND a remainder in the
                                                             # XCD-aware block -> tile mapping, two column tiles
     ([32, 192], (11, 3, 32), None, False, 0.0),             # 1056 rows, three column tiles, no max
+    ([6, 64, 96, 128], (3, 40, 32), 32, False, 0.0),        # the MSG stacks' 64 -> 96 -> 128: N = 96 ends inside a column tile (per-block
+                                                            # epilogue decision), forward AND dX (Cin = 96)
+    ([20, 96, 32], (2, 300), None, True, 0.0),              # 96 wide without a max, bias
+    ([16, 160, 48], (5, 64), None, False, 0.2),             # 160 = 128 + 32: a second column tile with one live 32-column block
 ]
 
 
@@ -485,7 +489,7 @@ def test_head_stack_equals_per_layer_path(dev, spec, R, bn, bias, slope, trainin
     gs = max(u.abs().max().item() for u in a[2])               # (a conv bias under BatchNorm has an exactly-zero gradient: judge by the model's scale)
     assert (a[1] - b[1]).abs().max().item() <= 1e-5 * max(1e-6, a[1].abs().max().item())
     for u, v in zip(a[2], b[2]):
-        assert (u - v).abs().max().item() <= 1e-5 * max(1e-3 * gs, u.abs().max().item())
+        assert (u - v).abs().max().item() <= 1e-5 * u.abs().max().item() + 2e-7 * gs
     n_last = 2                                                 # the last Linear always carries a bias here: (W, b) are its parameters
     for u, v in zip(a[2][-n_last:], b[2][-n_last:]):
         assert torch.equal(u, v)

@@ -17,11 +17,13 @@ def roofline_of(step):
     """Dominant own kernel of the step (every C-ABI entry point event-timed for two untimed steps; GEMM-family kernels report
     their own begin / end timestamps) and its roofline, as bench.py does for the headline config."""
     from pointcloudlib_amd import _lib
-    _lib.PROFILER = _lib.KernelTimer()
-    step(); step()
-    torch.cuda.synchronize()
-    summ = _lib.PROFILER.summary()
-    _lib.PROFILER = None
+    from pointcloudlib_amd.misc.mlp_hip import per_kernel_path
+    with per_kernel_path():          # the event timer brackets C-ABI calls: one call per kernel for this untimed pass (same kernels)
+        _lib.PROFILER = _lib.KernelTimer()
+        step(); step()
+        torch.cuda.synchronize()
+        summ = _lib.PROFILER.summary()
+        _lib.PROFILER = None
     by_name = {}
     for (n, t), v in summ.items():
         if n != "pcl_fps_f32":                        # latency-bound chain, runs beside the GEMMs where sampling is prefetched
@@ -70,9 +72,9 @@ def cpu_baseline_of(kind, state, n_warm=1, n_steps=5):
         net = DGCNNCPU(state, 20)
         x, y = torch.from_numpy(synth.gauss_ball(B, N, 20242)).transpose(1, 2).contiguous(), lab(B)
         fwd = lambda: soft_cross_entropy_loss(net(x), y)
-    elif kind == "cfg4":
+    elif kind in ("cfg4", "cfg4_msg"):
         B, N = 16, 2048
-        net = PointNet2PartSegCPU(state, PointNet2PartSegCPU.SSG, tie_stride=oracle.optimal_block(B))
+        net = PointNet2PartSegCPU(state, PointNet2PartSegCPU.MSG if kind == "cfg4_msg" else PointNet2PartSegCPU.SSG, tie_stride=oracle.optimal_block(B))
         x = torch.from_numpy(synth.gauss_ball(B, N, 20244))
         oh = torch.zeros(B, 16); oh[torch.arange(B), torch.arange(B) % 16] = 1
         seg = torch.from_numpy(np.random.default_rng(5).integers(0, 50, (B, N)))
@@ -136,7 +138,7 @@ def run_prefetch(name, make, inputs, loss_fn, steps, warmup=3):
     return _run_prefetch(name, make, inputs, loss_fn, steps, warmup)
 
 
-def _run_prefetch(name, make, inputs, loss_fn, steps, warmup=3):
+def _run_prefetch(name, make, inputs, loss_fn, steps, warmup=30):     # (two streams: the allocator pools settle over ~20 steps)
     """Same, with the encoder's FPS / ball query of the next batch issued on a side stream beside the backward pass
     (networks with ``precompute_sampling``; the input is the same tensor every step, the work is not)."""
     torch.manual_seed(0)
@@ -193,13 +195,15 @@ def main():
     xs = cloud(16, 2048, 20244)
     oh = torch.zeros(16, 16, device=dev); oh[torch.arange(16), torch.arange(16) % 16] = 1
     seg = torch.randint(0, 50, (16, 2048), device=dev)
-    res.append(run("cfg4 PointNet++ SSG part-seg B=16 N=2048", PointNet2_partseg, (xs, xs, oh),
+    res.append(run("cfg4-ssg PointNet++ SSG part-seg B=16 N=2048 (the variant train_partseg.py wires)", PointNet2_partseg, (xs, xs, oh),
                    lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps, cpu_kind="cfg4"))
-    res.append(run_prefetch("cfg4 PointNet++ SSG part-seg B=16 N=2048, sampling of batch t+1 on a side stream", PointNet2_partseg, (xs, xs, oh),
+    res.append(run_prefetch("cfg4-ssg PointNet++ SSG part-seg B=16 N=2048, sampling of batch t+1 on a side stream", PointNet2_partseg, (xs, xs, oh),
                             lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps))
     from pointcloudlib_amd.networks.seg.pointnet2_partseg import PointNetMSG
-    res.append(run("cfg4' PointNet++ MSG part-seg B=16 N=2048 (FP widths corrected, see DESIGN 7)", PointNetMSG, (xs, xs, oh),
-                   lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps))
+    res.append(run("cfg4 PointNet++ MSG part-seg B=16 N=2048 (BASELINE configs[3]; FP widths corrected, see DESIGN 7)", PointNetMSG, (xs, xs, oh),
+                   lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps, cpu_kind="cfg4_msg"))
+    res.append(run_prefetch("cfg4 PointNet++ MSG part-seg B=16 N=2048, sampling of batch t+1 on a side stream", PointNetMSG, (xs, xs, oh),
+                            lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps))
     res.append(run("cfg5 PointConv cls B=32 N=1024", PointConvDensityClsSsg, (x.transpose(1, 2).contiguous(),), lambda o: soft_cross_entropy_loss(o, y32), a.steps, cpu_kind="cfg5"))
     from pointcloudlib_amd.networks.cls.pointcnn import PointCNNcls
     from pointcloudlib_amd.networks.seg.pointcnn_partseg import PointCNN_partseg
