@@ -112,9 +112,6 @@ def main():
     ap.add_argument("--no-prefetch-sampling", dest="prefetch_sampling", action="store_false",
                     help="run FPS/ball query inline at the head of each forward instead of one step ahead on a side stream")
     ap.add_argument("--profile-all", action="store_true", help="print a per-entry-point event-timed table to stderr")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the main stream's part of a step as ONE captured HIP graph instead of enqueueing it from Python "
-                         "(measured: 2.90 vs 2.86 ms/step eager on ROCm 7.2 -- the replay is not faster, so it is opt-in)")
     ap.add_argument("--dist", choices=["gauss_ball", "sphere_shell"], default="gauss_ball",
                     help="synthetic cloud distribution (SURVEY 8d): gauss_ball = the ModelNet40 loader's statistics (headline), "
                          "sphere_shell = never-saturating ball queries, ~80 %% padded duplicates")
@@ -262,27 +259,7 @@ def main():
         target = None
     else:
         target = (target, None)
-    # The main stream's part of a step as ONE HIP graph launch (pointcloudlib_amd/graph_step.py); the sampling of the next
-    # batch stays eager on the side stream.  Kernels inside a graph cannot be bracketed by events, so the first N_EAGER
-    # steps of the timed region run the same data flow from Python with the event timer on -- same work, slower host.
-    N_EAGER = 8
-    gs, launch = None, "eager"
-    if args.graph and args.prefetch_sampling:
-        try:
-            from pointcloudlib_amd.graph_step import GraphedStep
-            torch.cuda.synchronize()
-            pending.clear()
-            gs = GraphedStep(net, lambda out, y: soft_cross_entropy_loss(out, y), opt, dp, lambda b: b[0],
-                             batches[it % len(batches)], side, capture_optimizer=not distributed)
-            gs.capture()
-            for _ in range(5):                                   # untimed replays
-                gs.step(batches[it % len(batches)], batches[(it + 1) % len(batches)]); it += 1
-            torch.cuda.synchronize()
-            launch = f"hip graph of the main stream + eager sampling side stream (first {N_EAGER} timed steps eager, event-timed)"
-        except Exception as e:                                   # noqa: BLE001 -- any capture problem: plain eager steps
-            print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); running eager", file=sys.stderr)
-            gs = None
-            torch.cuda.synchronize()
+    launch = "eager"
     timer = None
     if target:
         # HIP events around the dominant kernel's dominant launch shape only, a few launches of the timed region
@@ -290,23 +267,18 @@ def main():
         in_stack = (stack_default and target_algo is not None and target[1] is not None
                     and target[0] in _lib.KERNEL_TIMED)        # a GEMM-family kernel that the product path launches from a stack call
         if in_stack:
-            timer = _lib.KernelTimer(max_records=N_EAGER if gs else 64, inner=(target[0], target[1], target_algo[0], target_algo[1]))
+            timer = _lib.KernelTimer(max_records=64, inner=(target[0], target[1], target_algo[0], target_algo[1]))
         else:
-            timer = _lib.KernelTimer([target[0]], tags=None if target[1] is None else [target[1]], max_records=N_EAGER if gs else 64)
+            timer = _lib.KernelTimer([target[0]], tags=None if target[1] is None else [target[1]], max_records=64)
 
     import gc
     gc.collect()
     gc.disable()                 # no collector pauses inside the timed region (a gen-2 pass over the autograd objects is ~ms)
     fence()
     t0 = time.perf_counter()
+    _lib.PROFILER = timer
     for j in range(args.steps):
-        if gs is None:
-            _lib.PROFILER = timer
-            step(it)
-        else:
-            eager = timer is not None and j < N_EAGER
-            _lib.PROFILER = timer if eager else None
-            gs.step(batches[it % len(batches)], batches[(it + 1) % len(batches)], eager=eager)
+        step(it)
         it += 1
     fence()
     dt = time.perf_counter() - t0
@@ -314,7 +286,7 @@ def main():
     # host side of a step (untimed extras): the time Python needs to ENQUEUE one step with the stream empty behind it (4
     # steps back to back without a sync; the launch queue is deeper than that), and the number of own C-ABI launches
     host_ms = own_launches = None
-    if gs is None:
+    if True:
         torch.cuda.synchronize()
         h0 = time.perf_counter()
         for _ in range(4):

@@ -428,8 +428,6 @@ int pcl_mlp_stack_sizes(const pcl_mlp_stack_t* desc, size_t* save_bytes, size_t*
 int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* desc);
 /* reference: the autograd backward of the same module (Jittor derives it; networks/cls/pointnet2.py:33-62) */
 int pcl_mlp_stack_bwd_f32(const pcl_mlp_stack_t* desc);
-/* helper of the stack entry points: p[0..n_one) = 1, p[n_one..n_one+n_zero) = 0 */
-int pcl_fill_ones_zeros_f32(float* p, int n_one, int n_zero, void* stream);
 
 /* ---- duplicate-compacted ("ragged") groups --------------------------------------------------------------
  * query_ball_point pads each group with copies of its first hit (misc/ops.py:321-324).  Identical rows stay

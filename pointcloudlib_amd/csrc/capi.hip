@@ -22,10 +22,6 @@ void set_launch_tag(const char* tag) {
 }
 bool time_hook_matches(const TimeHook& h) { return h.want[0] == 0 || strcmp(h.want, h.cur) == 0; }
 
-__global__ void fill_ones_zeros_kernel(float* p, int n_one, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = i < n_one ? 1.f : 0.f;
-}
 }  // namespace pcl
 
 extern "C" void pcl_time_next_launch(void* start_event, void* stop_event) {
@@ -41,15 +37,6 @@ extern "C" void pcl_time_tagged_launch(void* start_event, void* stop_event, cons
     h.stop = static_cast<hipEvent_t>(stop_event);
     strncpy(h.want, tag ? tag : "", sizeof h.want - 1);
     h.want[sizeof h.want - 1] = 0;
-}
-
-// p[0 .. n_one) = 1, p[n_one .. n_one + n_zero) = 0: the (a, k1, k2, mu) = (1, 0, 0, 0) constants that turn the
-// BatchNorm-backward GEMM entry points into plain GEMMs (the per-point product of a folded first layer, stack.hip)
-extern "C" int pcl_fill_ones_zeros_f32(float* p, int n_one, int n_zero, void* stream) {
-    PCL_REQUIRE(p && n_one >= 0 && n_zero >= 0 && n_one + n_zero >= 1, "pcl_fill_ones_zeros_f32: bad arguments");
-    const int n = n_one + n_zero;
-    hipLaunchKernelGGL(pcl::fill_ones_zeros_kernel, dim3((n + 255) / 256), dim3(256), 0, pcl::as_stream(stream), p, n_one, n);
-    return pcl::check_launch("pcl_fill_ones_zeros_f32");
 }
 
 extern "C" int pcl_version(void) { return 100; }   // 0.1.0

@@ -621,10 +621,23 @@ extern "C" int pcl_group_linear_f32(const float* xyz, const float* new_xyz, cons
     return check_launch("pcl_group_linear_f32");
 }
 
+namespace pcl {
+int group_linear_bwd_impl(const float* row_loc, const float* row_feat, int CF, const float* dU, const float* Y, const float* a,
+                          const float* k1, const float* k2, const float* mu, const int32_t* row_src, const int32_t* n_rows_dev, int B, int N,
+                          int C1, float* dUf, float* dWx_part, float* dWf_part, float* dW0, int ldw, int off, void* stream, bool duf_is_zero);
+}
 extern "C" int pcl_group_linear_bwd_f32(const float* row_loc, const float* row_feat, int CF, const float* dU, const float* Y,
                                         const float* a, const float* k1, const float* k2, const float* mu, const int32_t* row_src,
                                         const int32_t* n_rows_dev, int B, int N, int C1, float* dUf, float* dWx_part,
                                         float* dWf_part, float* dW0, int ldw, int off, void* stream) {
+    return group_linear_bwd_impl(row_loc, row_feat, CF, dU, Y, a, k1, k2, mu, row_src, n_rows_dev, B, N, C1, dUf, dWx_part, dWf_part, dW0, ldw,
+                                 off, stream, false);
+}
+// duf_is_zero: an earlier launch of the same stack call already cleared dUf (stack.hip: the max-gradient kernel's side job)
+int pcl::group_linear_bwd_impl(const float* row_loc, const float* row_feat, int CF, const float* dU, const float* Y, const float* a,
+                               const float* k1, const float* k2, const float* mu, const int32_t* row_src, const int32_t* n_rows_dev, int B,
+                               int N, int C1, float* dUf, float* dWx_part, float* dWf_part, float* dW0, int ldw, int off, void* stream,
+                               bool duf_is_zero) {
     PCL_REQUIRE(row_loc && dU && Y && a && k1 && k2 && mu && row_src && n_rows_dev, "pcl_group_linear_bwd_f32: null pointer");
     PCL_REQUIRE(dUf || dWx_part || dWf_part, "pcl_group_linear_bwd_f32: nothing to compute");
     PCL_REQUIRE(!dWf_part || (row_feat && CF >= 1 && CF <= GL_CF), "pcl_group_linear_bwd_f32: dWf needs row_feat, CF=%d", CF);
@@ -632,7 +645,7 @@ extern "C" int pcl_group_linear_bwd_f32(const float* row_loc, const float* row_f
     PCL_REQUIRE(!dW0 || ((dWx_part || dWf_part) && ldw >= (dWx_part ? 3 : 0) && off >= 0 && ldw >= off + (dWf_part ? CF : 0)),
                 "pcl_group_linear_bwd_f32: dW0 needs the partial buffers and ldw=%d >= off=%d + CF", ldw, off);
     hipStream_t st = as_stream(stream);
-    if (dUf) {
+    if (dUf && !duf_is_zero) {
         hipError_t e = hipMemsetAsync(dUf, 0, sizeof(float) * (size_t)B * N * C1, st);
         if (e != hipSuccess) return fail(PCL_EHIP, "pcl_group_linear_bwd_f32: memset: %s", hipGetErrorString(e));
     }

@@ -192,11 +192,9 @@ struct KnnCfg {
 
 template <int PPT, bool FMA = false>
 __global__ __launch_bounds__(256) void knn_fused_kernel(const float* __restrict__ ref, const float* __restrict__ qry, int C, int Nr,
-                                                        int Nq, int k, int32_t* __restrict__ idx_out,
-                                                        const unsigned char* __restrict__ redo) {
+                                                        int Nq, int k, int32_t* __restrict__ idx_out) {
     int b, qblk;
     knn_block(gridDim.x, gridDim.y, b, qblk);
-    if (redo && !redo[(size_t)b * gridDim.x + qblk]) return;                      // (second launch after the filter kernel)
     using Cfg = KnnCfg<PPT>;
     constexpr int QW = Cfg::QW, NRP = Cfg::NRP, CK = Cfg::CK, QB = 4 * QW, NJ = PPT / 4;
     constexpr int RV = CK * NRP / 4 / 256;                       // 16-byte reference pieces per thread and stage
@@ -400,282 +398,16 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(const float* __restrict_
     }
 }
 
-// ---- filter + verify: MFMA distances pick the candidates, exact arithmetic decides among them ---------------------------
-// The exact distance costs 3 VALU operations per (query, reference, channel) and fp32 VALU peaks at 64 Tops/s
-// (tools/ubench/pkrate.hip) -- 0.4 ms per DGCNN step for arithmetic alone.  Only the k winners and their ORDER have to be the
-// reference's, so for C >= 16:
-//   1. approximate distances d~ = |q|^2 + |r|^2 - 2 q.r for 32 queries x all references of a cloud, the dot products on
-//      v_mfma_f32_32x32x2_f32 (A = queries, B = references, both streamed channel-major through a small LDS stage);
-//      the rows go to LDS (32 x Nr x 4 bytes);
-//   2. per query: tau = an upper bound of the k-th smallest d~ (k-th smallest of the 64 lane-local minima); every reference
-//      with d~ <= tau + 2E is a candidate.  E bounds |d~ - D| + |d_ref - D| (D = the real-number distance of the fp32
-//      inputs, d_ref = the reference's fp32 result): any reference in the reference's top k has d~ <= tau + 2E, because the
-//      k references with the smallest d~ all have d_ref <= tau + E.  E = 32 (C+1) 2^-24 (|q| + max|r|)^2 -- the reference's
-//      own error is (C+2) 2^-24 D, the MFMA form's is below 16 C 2^-24 (|q|+|r|)^2 even if every internal operation
-//      truncated; norms are inflated by 1e-3 to cover their own rounding;
-//   3. a second pass over the channels computes, for the <= 64 candidates of each query (one per lane), the reference's exact
-//      t = ref - qry; ssd += t*t in ascending channel order, and the candidates are ranked by (ssd bits, r).
-// More than 64 candidates (mass ties, non-finite data), or fewer than k: the workgroup raises its flag in the workspace and
-// the exact fused kernel above redoes exactly those 32 queries (second launch, exits at once elsewhere).
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ unsigned sortable(float x) {            // order-preserving float -> unsigned (negatives included)
-    const unsigned b = __float_as_uint(x);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-
-template <int NRP>
-__global__ __launch_bounds__(256) void knn_filter_kernel(const float* __restrict__ ref, const float* __restrict__ qry, int C, int Nr,
-                                                         int Nq, int k, int32_t* __restrict__ idx_out, unsigned char* __restrict__ redo) {
-    constexpr int QB = 32, CK = 2, TPW = NRP / 128, PPT = NRP / 64, RV = CK * NRP / 4 / 256;
-    static_assert(RV >= 1, "staging map");
-    __shared__ __attribute__((aligned(16))) float sRow[QB][NRP];
-    __shared__ __attribute__((aligned(16))) float sR[2][CK][NRP];
-    __shared__ __attribute__((aligned(16))) float sQ[2][CK][QB];
-    __shared__ float sNr[NRP], sNq[QB], sRed[4];
-    __shared__ unsigned sCand[QB][64];
-    __shared__ int sCnt[QB];
-    int b, qblk;
-    knn_block(gridDim.x, gridDim.y, b, qblk);
-    const int q0 = qblk * QB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 31, lh = lane >> 5;
-    const float* R = ref + (size_t)b * C * Nr;
-    const float* Q = qry + (size_t)b * C * Nq;
-
-    // Channel pairs stream global -> registers -> LDS stage.  One workgroup per CU and one wave per SIMD: nothing hides an L2
-    // round trip (~1.5 us) but distance, so RING stages are in flight -- a stage's registers are refilled for stage + RING
-    // the moment they have been written to LDS.
-    constexpr int RING = 8;
-    float4 pr[RING][RV];
-    float pq[RING];
-    const __amdgpu_buffer_rsrc_t rsR = knn_rsrc(R, (size_t)C * Nr * 4), rsQ = knn_rsrc(Q, (size_t)C * Nq * 4);
-    auto fetch = [&](int slot, int c0) {
-#pragma unroll
-        for (int v = 0; v < RV; ++v) {
-            const int e = tid + 256 * v, cc = e / (NRP / 4), r = 4 * (e % (NRP / 4));
-            pr[slot][v] = knn_ld4(rsR, (unsigned)(((size_t)(c0 + cc) * Nr + r) * 4));
-        }
-        const int cc = (tid / QB) & (CK - 1), qi = tid % QB;       // (threads past CK*QB load a value nobody stores)
-        pq[slot] = knn_ld1(rsQ, (unsigned)(((size_t)(c0 + cc) * Nq + q0 + qi) * 4));
-    };
-    auto stash = [&](int slot, int buf) {
-#pragma unroll
-        for (int v = 0; v < RV; ++v) {
-            const int e = tid + 256 * v;
-            *reinterpret_cast<float4*>(&sR[buf][e / (NRP / 4)][4 * (e % (NRP / 4))]) = pr[slot][v];
-        }
-        if (tid < CK * QB) sQ[buf][tid / QB][tid % QB] = pq[slot];
-    };
-    const int stages = (C + CK - 1) / CK;
-    // stream(compute, on_stash): stage s is in LDS buffer s & 1 while compute(s) runs; on_stash(slot) sees a stage's registers once
-    auto stream = [&](auto&& compute, auto&& on_stash) {
-#pragma unroll
-        for (int j = 0; j < RING; ++j) fetch(j, j * CK);         // (channels past C read as zeros)
-        on_stash(0);
-        stash(0, 0);
-        fetch(0, RING * CK);
-        __syncthreads();
-        for (int s0 = 0; s0 < stages; s0 += RING) {
-#pragma unroll
-            for (int j = 0; j < RING; ++j) {
-                const int st = s0 + j;
-                if (st < stages) {                                // (uniform)
-                    compute(st & 1);
-                    if (st + 1 < stages) {
-                        const int slot = (j + 1) % RING;
-                        on_stash(slot);
-                        stash(slot, (st + 1) & 1);
-                        fetch(slot, (st + 1 + RING) * CK);
-                    }
-                    __syncthreads();
-                }
-            }
-        }
-    };
-
-#if PCL_EXP == 8
-    long long tk[6], tl = __builtin_readcyclecounter();
-#define KF_MARK(i) { const long long t_ = __builtin_readcyclecounter(); tk[i] = t_ - tl; tl = t_; }
-#else
-#define KF_MARK(i)
-#endif
-    // ---- pass 1: dot products on the matrix cores, squared norms on the side (each thread keeps the norms of the
-    // references / the query it stages: piece e = tid + 256 v is the same set of 4 references for every channel pair)
-    f32x16 acc[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    float4 nr4[RV];
-#pragma unroll
-    for (int v = 0; v < RV; ++v) nr4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float nq1 = 0.f;
-    stream([&](int buf) {
-        const float a = sQ[buf][lh][lr];
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-            const float bb = sR[buf][lh][(wave * TPW + t) * 32 + lr];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[t], 0, 0, 0);
-        }
-    }, [&](int slot) {
-#pragma unroll
-        for (int v = 0; v < RV; ++v) {
-            nr4[v].x = fmaf(pr[slot][v].x, pr[slot][v].x, nr4[v].x); nr4[v].y = fmaf(pr[slot][v].y, pr[slot][v].y, nr4[v].y);
-            nr4[v].z = fmaf(pr[slot][v].z, pr[slot][v].z, nr4[v].z); nr4[v].w = fmaf(pr[slot][v].w, pr[slot][v].w, nr4[v].w);
-        }
-        nq1 = fmaf(pq[slot], pq[slot], nq1);
-    });
-    KF_MARK(0)
-    // norms -> LDS (a thread's pieces of the two staged channels cover different references: sum the channel pair's halves)
-#pragma unroll
-    for (int v = 0; v < RV; ++v) {
-        const int e = tid + 256 * v, r = 4 * (e % (NRP / 4));
-        if (e / (NRP / 4) == 0) { sNr[r] = 0.f; sNr[r + 1] = 0.f; sNr[r + 2] = 0.f; sNr[r + 3] = 0.f; }
-    }
-    if (tid < QB) sNq[tid] = 0.f;
-    __syncthreads();
-    for (int cc = 0; cc < CK; ++cc) {
-#pragma unroll
-        for (int v = 0; v < RV; ++v) {
-            const int e = tid + 256 * v, r = 4 * (e % (NRP / 4));
-            if (e / (NRP / 4) == cc) { sNr[r] += nr4[v].x; sNr[r + 1] += nr4[v].y; sNr[r + 2] += nr4[v].z; sNr[r + 3] += nr4[v].w; }
-        }
-        if (tid < CK * QB && tid / QB == cc) sNq[tid % QB] += nq1;
-        __syncthreads();
-    }
-    // max |r|^2 of the cloud
-    float mx = 0.f;
-    for (int r = tid; r < NRP; r += 256) mx = fmaxf(mx, sNr[r]);
-    mx = __uint_as_float(wave_max_u32(__float_as_uint(mx)));       // (non-negative floats: bit-monotone)
-    if (lane == 0) sRed[wave] = mx;
-    // approximate distances -> rows
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int j = (wave * TPW + t) * 32 + lr;
-        const float nrj = sNr[j];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            sRow[i][j] = j < Nr ? (sNq[i] + nrj) - 2.f * acc[t][r] : INFINITY;
-        }
-    }
-    __syncthreads();
-    const float rmax = sqrtf(fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3])) * 1.001f);
-
-    KF_MARK(1)
-    // ---- pass 2: candidates of the wave's 8 queries
-    bool bad = false;
-    for (int i = 0; i < 8; ++i) {
-        const int qi = wave * 8 + i;
-        if (q0 + qi >= Nq) break;                                      // (wave-uniform)
-        unsigned key[PPT];
-#pragma unroll
-        for (int J = 0; J < PPT / 4; ++J) {
-            const float4 v = *reinterpret_cast<const float4*>(&sRow[qi][256 * J + 4 * lane]);
-            key[4 * J] = sortable(v.x); key[4 * J + 1] = sortable(v.y); key[4 * J + 2] = sortable(v.z); key[4 * J + 3] = sortable(v.w);
-        }
-        unsigned m = key[0];
-#pragma unroll
-        for (int j = 1; j < PPT; ++j) m = min(m, key[j]);
-        unsigned T = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-            const unsigned trial = T | (1u << bit);
-            if (__popcll(__ballot(m < trial)) < k) T = trial;
-        }
-        // T = k-th smallest lane minimum (sortable domain) -> tau; candidates: d~ <= tau + 2E (rounded up)
-        const unsigned tb = (T & 0x80000000u) ? (T & 0x7FFFFFFFu) : ~T;
-        const float tau = __uint_as_float(tb);
-        const float nrm = sqrtf(sNq[qi] * 1.001f) + rmax;
-        const float E = 32.f * (float)(C + 1) * 5.9604645e-8f * nrm * nrm * 1.01f;
-        const float lim = (tau + 2.f * E) + fabsf(tau + 2.f * E) * 1e-6f;
-        const unsigned Tc = sortable(lim);
-        int n = 0;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) n += __popcll(__ballot(key[j] <= Tc));
-        if (!(n >= k && n <= 64) || !(lim == lim)) { bad = true; if (lane == 0) sCnt[qi] = 0; continue; }
-        int base = 0;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const bool pred = key[j] <= Tc;
-            const unsigned long long mask = __ballot(pred);
-            if (mask) {
-                if (pred) sCand[qi][base + mbcnt(mask)] = 256u * (j >> 2) + 4u * lane + (j & 3u);
-                base += __popcll(mask);
-            }
-        }
-        if (lane == 0) sCnt[qi] = n;
-    }
-    if (__ballot(bad) && lane == 0) redo[(size_t)b * gridDim.x + qblk] = 1;
-    __syncthreads();
-
-    KF_MARK(2)
-    // ---- pass 3: the reference's arithmetic for the candidates (lane = candidate), channels ascending
-    unsigned cr[8];
-    int cn[8];
-    float ex[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        cn[i] = sCnt[wave * 8 + i];
-        cr[i] = lane < cn[i] ? sCand[wave * 8 + i][lane] : 0u;
-        ex[i] = 0.f;
-    }
-    // (a zero-filled channel past C adds (0 - 0)^2 = +0 to a sum >= +0: bit-identical)
-    stream([&](int buf) {
-#pragma unroll
-        for (int cc = 0; cc < CK; ++cc) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float t = sR[buf][cc][cr[i]] - sQ[buf][cc][wave * 8 + i];      // ref - query, :489
-                ex[i] = ex[i] + t * t;                                               // ssd += tmp*tmp, :490 (no contraction in this file)
-            }
-        }
-    }, [&](int) {});
-    KF_MARK(3)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int qi = wave * 8 + i, n = cn[i];
-        if (q0 + qi >= Nq || n == 0) continue;                          // (wave-uniform; n == 0: redone by the exact kernel)
-        // rank among the candidates by (exact distance bits, r): the list is reused as (key, r) pairs through LDS
-        __builtin_amdgcn_wave_barrier();
-        if (lane < n) { sRow[qi][2 * lane] = ex[i]; sRow[qi][2 * lane + 1] = __uint_as_float(cr[i]); }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const unsigned mk = __float_as_uint(ex[i]), mr = cr[i];
-        int rank = 0;
-        for (int c = 0; c < n; ++c) {
-            const unsigned ok = __float_as_uint(sRow[qi][2 * c]), orr = __float_as_uint(sRow[qi][2 * c + 1]);
-            rank += (ok < mk || (ok == mk && orr < mr)) ? 1 : 0;
-        }
-        if (lane < n && rank < k) idx_out[(size_t)b * k * Nq + (size_t)rank * Nq + q0 + qi] = (int32_t)mr;
-    }
-    KF_MARK(4)
-#if PCL_EXP == 8
-    if (blockIdx.x == 3 && blockIdx.y == 5 && (tid == 0 || tid == 192))
-        printf("knn_filter<%d> C=%d wave %d: pass1 %lld | rows %lld | select %lld | pass3 %lld | rank %lld cycles\n", NRP, C, wave, tk[0], tk[1], tk[2], tk[3], tk[4]);
-#endif
-}
-
 }  // namespace pcl
 using namespace pcl;
 
-// Nr <= 4096: the fused kernel, no workspace.  Beyond that a query's row no longer fits the registers of a wave and the
-// two-pass form (distance matrix in a caller-provided workspace, then select) is used.
+// up to 4096 references the fused kernel keeps a query's whole distance row in registers (no workspace); beyond: two passes
 constexpr int KNN_FUSED_MAX_NR = 4096;
-// MFMA filter + exact verification: enough channels for the matrix cores to pay, the candidate list of a wave (64), one
-// row of approximate distances per query in LDS (32 x 1024 floats)
-// MEASURED AND NOT THE DEFAULT (DGCNN cls, B = 32, N = 1024, k = 20): C = 64: 220 us against 200 us for the exact fused kernel,
-// C = 128: 311 against 320 us.  One workgroup per CU (128 KB of rows) with one wave per SIMD leaves every LDS / L2 latency
-// of the two streaming passes (~950 cycles per channel pair each) and of the per-query select / rank code exposed
-// (make EXP=8 prints the phase cycle counts).  PCL_KNN_FILTER=1 selects it (tests keep it exact); the default stays the
-// exact fused kernel.
-static bool knn_filtered(int C, int Nr, int k) {
-    const char* e = getenv("PCL_KNN_FILTER");
-    return e && e[0] == '1' && C >= 16 && k <= 64 && Nr > 256 && Nr <= 1024;
-}
+// (An MFMA-filter variant -- approximate distances on the matrix cores choosing <= 64 candidates per query for the exact
+// arithmetic to rank -- was built in round 2, exact but not faster (C = 64: 220 against 200 us), and removed in round 3;
+// DESIGN.md section 3.4 keeps the measurements, the code is in the history.)
 extern "C" size_t pcl_knn_workspace_bytes(int B, int C, int Nr, int Nq, int k) {
     if (B <= 0 || Nr <= 0 || Nq <= 0) return 0;
-    if (knn_filtered(C, Nr, k)) return ((size_t)B * ((Nq + 31) / 32) + 15) / 16 * 16;       // one "redo" flag per 32 queries
     if (Nr <= KNN_FUSED_MAX_NR) return 0;
     return sizeof(float) * (size_t)B * Nr * Nq;
 }
@@ -691,20 +423,7 @@ static int knn_impl(const float* ref, const float* qry, int B, int C, int Nr, in
     if (Nr <= KNN_FUSED_MAX_NR) {
         hipStream_t st = as_stream(stream);
         const int ppt4 = (Nr + 255) / 256 * 4;                    // multiples of 4 registers per lane
-        const unsigned char* redo = nullptr;
-        if (!FMA && knn_filtered(C, Nr, k)) {
-            const size_t need = pcl_knn_workspace_bytes(B, C, Nr, Nq, k);
-            if (!workspace || workspace_bytes < need)
-                return fail(PCL_EWS, "pcl_knn_f32: workspace %zu bytes < required %zu", workspace_bytes, need);
-            if (hipMemsetAsync(workspace, 0, need, st) != hipSuccess) return fail(PCL_EHIP, "pcl_knn_f32: memset failed");
-            const dim3 grid((Nq + 31) / 32, B);
-            if (Nr <= 512) hipLaunchKernelGGL(knn_filter_kernel<512>, grid, dim3(256), 0, st, ref, qry, C, Nr, Nq, k, idx_out, static_cast<unsigned char*>(workspace));
-            else hipLaunchKernelGGL(knn_filter_kernel<1024>, grid, dim3(256), 0, st, ref, qry, C, Nr, Nq, k, idx_out, static_cast<unsigned char*>(workspace));
-            const int rc = check_launch("pcl_knn_f32(filter)");
-            if (rc) return rc;
-            redo = static_cast<const unsigned char*>(workspace);  // the exact kernel below redoes the flagged 32-query blocks only
-        }
-#define PCL_KF(P) if (ppt4 <= P) { hipLaunchKernelGGL((knn_fused_kernel<P, FMA>), dim3((Nq + 4 * KnnCfg<P>::QW - 1) / (4 * KnnCfg<P>::QW), B), dim3(256), 0, st, ref, qry, C, Nr, Nq, k, idx_out, redo); return check_launch("pcl_knn_f32(fused)"); }
+#define PCL_KF(P) if (ppt4 <= P) { hipLaunchKernelGGL((knn_fused_kernel<P, FMA>), dim3((Nq + 4 * KnnCfg<P>::QW - 1) / (4 * KnnCfg<P>::QW), B), dim3(256), 0, st, ref, qry, C, Nr, Nq, k, idx_out); return check_launch("pcl_knn_f32(fused)"); }
         PCL_KF(4) PCL_KF(8) PCL_KF(16) PCL_KF(32) PCL_KF(64)
 #undef PCL_KF
     }

@@ -1758,11 +1758,21 @@ __device__ __forceinline__ void fold_row_lanes(double s1, double s2, int c, int 
     if (rsub == 0 && c < C) { dst[c] = s1; dst[C + c] = s2; }
 }
 
+// `aux`: side jobs of the stack's backward that would otherwise be launches of their own (every dependent launch costs ~9 us
+// of a 2 ms step): zero-fill [zero, zero + n_zero) -- the target of the folded first layer's atomics -- and write the
+// (a, k1, k2, mu) = (1, 0, 0, 0) constants of its plain point GEMMs to [ones, ones + n_one) / [ones + n_one, .. + n_one0).
+struct PrepAux { float4* zero; size_t n_zero4; float* ones; int n_one, n_one0; };
 __global__ __launch_bounds__(256) void maxgrad_prep_kernel(const float* __restrict__ gout, const float* __restrict__ out,
                                                            const float* __restrict__ ymax, float slope, int G, int C, int CW,
-                                                           float* __restrict__ gz, double* __restrict__ stats) {
+                                                           float* __restrict__ gz, double* __restrict__ stats, const PrepAux aux) {
     // grid.x = channel blocks of CW, grid.y = row slices (<= STAT_ROWS)
     __shared__ double red[2 * 256];
+    if (aux.zero || aux.ones) {
+        const size_t nb = (size_t)gridDim.x * gridDim.y, b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        for (size_t e = b * 256 + threadIdx.x; e < aux.n_zero4; e += nb * 256) aux.zero[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b == 0 && aux.ones)
+            for (int e = threadIdx.x; e < aux.n_one + aux.n_one0; e += 256) aux.ones[e] = e < aux.n_one ? 1.f : 0.f;
+    }
     const int RS = 256 / CW, rsub = threadIdx.x / CW;
     const int c = blockIdx.x * CW + threadIdx.x % CW;
     double s1 = 0.0, s2 = 0.0;
@@ -2146,9 +2156,19 @@ extern "C" int pcl_bn_act_max_f32(const float* Y, const float* scale, const floa
     return check_launch("pcl_bn_act_max_f32");
 }
 
+namespace pcl {
+int maxgrad_prep_impl(const float* gout, const float* out, const float* ymax, float slope, int G, int C, float* gz, double* stats_ws,
+                      int* stat_rows_out, void* stream, float* zero, size_t n_zero, float* ones, int n_one, int n_one0);
+}
 extern "C" int pcl_maxgrad_prep_f32(const float* gout, const float* out, const float* ymax, float slope, int G, int C,
                                     float* gz, double* stats_ws, int* stat_rows_out, void* stream) {
+    return maxgrad_prep_impl(gout, out, ymax, slope, G, C, gz, stats_ws, stat_rows_out, stream, nullptr, 0, nullptr, 0, 0);
+}
+int pcl::maxgrad_prep_impl(const float* gout, const float* out, const float* ymax, float slope, int G, int C, float* gz, double* stats_ws,
+                           int* stat_rows_out, void* stream, float* zero, size_t n_zero, float* ones, int n_one, int n_one0) {
     PCL_REQUIRE(gout && out && ymax && gz && stats_ws && stat_rows_out, "pcl_maxgrad_prep_f32: null pointer");
+    PCL_REQUIRE(!zero || ((reinterpret_cast<uintptr_t>(zero) & 15) == 0 && n_zero % 4 == 0), "pcl_maxgrad_prep_f32: the zero-fill region must be 16-byte aligned and a multiple of 4 floats");
+    const PrepAux aux = {reinterpret_cast<float4*>(zero), n_zero / 4, ones, n_one, n_one0};
     PCL_REQUIRE(G >= 1 && C >= 1, "pcl_maxgrad_prep_f32: bad sizes");
     int CW = 256;
     while (CW / 2 >= C && CW > 1) CW >>= 1;            // lanes over channels: next power of two >= C, at most 256
@@ -2156,7 +2176,7 @@ extern "C" int pcl_maxgrad_prep_f32(const float* gout, const float* out, const f
     int rows = (G + RS - 1) / RS < 512 ? (G + RS - 1) / RS : 512;
     *stat_rows_out = rows;
     hipLaunchKernelGGL(maxgrad_prep_kernel, dim3((C + CW - 1) / CW, rows), dim3(256), 0, as_stream(stream), gout, out, ymax,
-                       slope, G, C, CW, gz, stats_ws);
+                       slope, G, C, CW, gz, stats_ws, aux);
     return check_launch("pcl_maxgrad_prep_f32");
 }
 

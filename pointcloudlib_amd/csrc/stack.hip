@@ -106,6 +106,7 @@ struct BwdTmp {
     float* ws;                      // partial dW tiles (fused kernel / dW kernel)
     size_t ws_bytes;
     float* dUf; float* dWxp; float* dWfp;      // grouped
+    float* unit;                               // grouped wide: [C1] ones then [2*C1] zeros: (a, k1, k2, mu) of the plain point GEMMs
     float* ptws; size_t ptws_bytes;            // grouped wide: workspace of the point dW GEMM
     size_t bytes;
 };
@@ -141,7 +142,8 @@ static BwdTmp bwd_tmp(const pcl_mlp_stack_t& d, void* base) {
     if (d.grouped) {
         const int rows = pcl_group_linear_stat_rows(d.B, d.m), C1 = d.c[1];
         if (grouped_wide(d)) {
-            t.dUf = c.take<float>((size_t)d.B * d.N * C1);
+            t.dUf = c.take<float>(((size_t)d.B * d.N * C1 + 3) / 4 * 4);
+            t.unit = c.take<float>((size_t)3 * C1);
             t.ptws_bytes = pcl_linear_bwd_dw_workspace_bytes(d.B * d.N, C1, d.Cf);
             t.ptws = c.take<float>((t.ptws_bytes + 3) / 4);
         }
@@ -151,6 +153,12 @@ static BwdTmp bwd_tmp(const pcl_mlp_stack_t& d, void* base) {
     t.bytes = c.off;
     return t;
 }
+
+int maxgrad_prep_impl(const float* gout, const float* out, const float* ymax, float slope, int G, int C, float* gz, double* stats_ws,
+                      int* stat_rows_out, void* stream, float* zero, size_t n_zero, float* ones, int n_one, int n_one0);
+int group_linear_bwd_impl(const float* row_loc, const float* row_feat, int CF, const float* dU, const float* Y, const float* a,
+                          const float* k1, const float* k2, const float* mu, const int32_t* row_src, const int32_t* n_rows_dev, int B, int N,
+                          int C1, float* dUf, float* dWx_part, float* dWf_part, float* dW0, int ldw, int off, void* stream, bool duf_is_zero);
 
 static int validate(const pcl_mlp_stack_t* dp, const char* who) {
     PCL_REQUIRE(dp, "%s: null descriptor", who);
@@ -280,7 +288,11 @@ extern "C" int pcl_mlp_stack_bwd_f32(const pcl_mlp_stack_t* dp) {
     bool sparse;
     const float* vL = s.vec[L - 1];
     if (G) {
-        PCL_TRY(pcl_maxgrad_prep_f32(d.gout, d.out, s.ymax, d.out_slope, G, cl, t.gz, t.stats[0], &rows, st));
+        // side jobs of this first launch (grouped stacks with wide features): clear the target of the folded layer's atomics and
+        // write the unit constants of its point GEMMs -- a memset and a fill launch less
+        const size_t nz = t.dUf ? ((size_t)d.B * d.N * d.c[1] + 3) / 4 * 4 : 0;
+        PCL_TRY(maxgrad_prep_impl(d.gout, d.out, s.ymax, d.out_slope, G, cl, t.gz, t.stats[0], &rows, st, t.dUf, nz, t.unit, t.unit ? d.c[1] : 0,
+                                  t.unit ? 2 * d.c[1] : 0));
         sparse = true;
     } else {
         PCL_TRY(pcl_bn_act_bwd_f32(d.gout, s.Y[L - 1], vL, vL + cl, d.out_slope, P, cl, t.dU[0], t.stats[0], &rows, st));
@@ -302,13 +314,12 @@ extern "C" int pcl_mlp_stack_bwd_f32(const pcl_mlp_stack_t* dp) {
             const int off = d.use_xyz ? 3 : 0, fan_in = d.c[0], C1 = cout;
             const bool inl = grouped_inline(d), wide = grouped_wide(d);
             tagf("glinbwd%d", C1, 0);
-            PCL_TRY(pcl_group_linear_bwd_f32(s.row_loc, s.row_feat, inl ? d.Cf : 0, dU, s.Y[0], a, k1, k2, mean, s.row_src, nrows, d.B, d.N, C1,
-                                             t.dUf, t.dWxp, t.dWfp, (t.dWxp || t.dWfp) ? ly.dW : nullptr, fan_in, off, st));
+            PCL_TRY(group_linear_bwd_impl(s.row_loc, s.row_feat, inl ? d.Cf : 0, dU, s.Y[0], a, k1, k2, mean, s.row_src, nrows, d.B, d.N, C1,
+                                          t.dUf, t.dWxp, t.dWfp, (t.dWxp || t.dWfp) ? ly.dW : nullptr, fan_in, off, st, /*duf_is_zero=*/true));
             if (wide) {
                 // plain GEMMs through the BatchNorm-backward entry points with a = 1, k1 = k2 = 0 (dy == dUf): constants in consts[1 - cur_c]
-                float* one = t.consts[1 - cur_c];
+                float* one = t.unit;                 // written by the max-gradient kernel at the head of this call
                 float* zero = one + C1;
-                PCL_TRY(pcl_fill_ones_zeros_f32(one, C1, C1, st));
                 const int Pp = d.B * d.N;
                 tagf("ptdw%dx%d", C1, d.Cf);
                 PCL_TRY(pcl_linear_bwd_dw_rows_f32(t.dUf, t.dUf, one, zero, zero, zero, nullptr, nullptr, 1, d.feature, nullptr, nullptr, 0.f, Pp,

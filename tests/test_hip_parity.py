@@ -198,23 +198,6 @@ def test_knn_matches_oracle(oracle, dev, B, C, Nr, Nq, k):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("B,C,Nr,Nq,k,dup", [(2, 64, 1024, 1024, 20, False), (2, 128, 700, 333, 33, False), (1, 32, 1024, 100, 64, False),
-                                             (1, 16, 1024, 64, 8, True)])
-def test_knn_mfma_filter_path_is_exact(oracle, dev, monkeypatch, B, C, Nr, Nq, k, dup):
-    """PCL_KNN_FILTER=1: approximate distances on the matrix cores choose <= 64 candidates per query, the reference's arithmetic
-    ranks them (csrc/knn.hip, knn_filter_kernel).  Same indices as the oracle, including a cloud of exact duplicates
-    (hundreds of tied candidates: the workgroup hands its queries back to the exact kernel)."""
-    monkeypatch.setenv("PCL_KNN_FILTER", "1")
-    rng = np.random.default_rng(Nr + C)
-    r = rng.standard_normal((B, C, Nr)).astype(np.float32)
-    if dup:
-        r[:, :, 200:] = r[:, :, :1]                             # 824 copies of one point
-    q = r[:, :, :Nq].copy()
-    want = oracle.knn(q, r, k)
-    got = ops.KNN(k)(T(q, dev), T(r, dev))
-    assert np.array_equal(got.cpu().numpy(), want)
-
-
 @pytest.mark.parametrize("B,C,Nr,Nq,k", [(2, 3, 1024, 1024, 20), (2, 64, 1024, 1024, 20), (2, 128, 1024, 512, 20), (1, 64, 2048, 300, 40),
                                          (1, 9, 5000, 77, 16), (1, 128, 256, 256, 200), (3, 7, 333, 100, 5)])
 def test_knn_fma_definition_matches_oracle_fma_reading(oracle, dev, B, C, Nr, Nq, k):

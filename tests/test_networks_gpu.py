@@ -308,46 +308,6 @@ def test_edgeconv_backward_lists_match_per_edge_atomics(oracle, dev):
     assert (d_edges - d_lists).abs().max().item() <= 2e-5 * max(1.0, scale)
 
 
-def test_graphed_step_matches_eager_step(dev):
-    """graph_step.GraphedStep (main stream captured as a HIP graph, sampling of the next batch eager on a side stream)
-    trains like the plain eager loop: same losses for the first steps (later ones drift through fp32 atomics)."""
-    from pointcloudlib_amd.dp import FlatBucketDP
-    from pointcloudlib_amd.graph_step import GraphedStep
-    from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
-    from pointcloudlib_amd.train_utils import make_sgd, soft_cross_entropy_loss
-    B, N = 8, 512
-    batches = [(torch.from_numpy(synth.gauss_ball(B, N, 50 + i)).to(dev), torch.from_numpy(synth.unit_normals(B, N, 60 + i)).to(dev),
-                torch.from_numpy(synth.labels(B, 40, 70 + i)).to(dev)) for i in range(3)]
-
-    def make():
-        torch.manual_seed(0)
-        net = no_dropout(PointNet2_cls().to(dev)).train()
-        return net, make_sgd(net.parameters(), lr=0.02, momentum=0.9)
-
-    net, opt = make()
-    eager = []
-    for i in range(6):
-        x, f, y = batches[i % 3]
-        for p in net.parameters():
-            p.grad = None
-        loss = soft_cross_entropy_loss(net(x, f), y)
-        loss.backward(); opt.step()
-        eager.append(loss.item())
-    net, opt = make()
-    init = {k: v.clone() for k, v in net.state_dict().items()}
-    gs = GraphedStep(net, soft_cross_entropy_loss, opt, FlatBucketDP(net), lambda b: b[0], batches[0], torch.cuda.Stream(priority=-1))
-    gs.capture(warmup=2)                                   # warm-up steps train: restore the initial state afterwards
-    net.load_state_dict(init)
-    for st in opt.state.values():
-        st["momentum_buffer"].zero_()
-    got = []
-    for i in range(6):
-        got.append(gs.step(batches[i % 3], batches[(i + 1) % 3], eager=(i == 3)).item())
-    # step 0 sees identical weights; later steps drift (fp32 atomics in the gradient scatter + SGD on a tiny batch)
-    assert abs(got[0] - eager[0]) <= 1e-4 * abs(eager[0]), (got, eager)
-    assert all(abs(a - b) <= 0.15 * abs(b) for a, b in zip(got, eager)), (got, eager)
-
-
 def test_lean_sgd_is_torch_fused_sgd(dev):
     """train_utils.make_sgd on GPU parameters caches the parameter / momentum lists after the first step and then calls the
     same multi-tensor kernel torch.optim.SGD(fused=True) does: bit-identical parameters after several steps, with weight
