@@ -1,8 +1,8 @@
 #!/bin/bash
 # One GPU-box pass that regenerates the measured evidence of a round (run through gpurun; copies go to profiles/ by hand):
-#   bash tools/evidence.sh r02
+#   bash tools/evidence.sh r03
 # kernel trace + stats, FETCH_SIZE / WRITE_SIZE passes (separate runs, counters only), SQ wave-state pass, the bench line.
-R=${1:-r02}; O=gpurun_out/$R; mkdir -p $O; cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+R=${1:-r03}; O=gpurun_out/$R; mkdir -p $O; cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 B="python bench.py --steps 20 --warmup 3 --no-settle --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o b -- $B > $O/kt.log 2>&1
 S="python bench.py --steps 3 --warmup 1 --no-settle --no-cpu-baseline --roofline-kernel none"
@@ -15,6 +15,7 @@ python tools/pmc_traffic.py $F $W $O/order.json $O/${R}_pmc_hbm_traffic.csv $O/$
 python tools/pmc_sq.py $(find $O/sq -name '*counter_collection.csv' | head -1) $O/${R}_pmc_sq_wave_states.csv
 cp $(find $O/kt -name '*kernel_stats.csv' | head -1) $O/${R}_bench_kernel_stats.csv
 T=$(find $O/kt -name '*kernel_trace.csv' | head -1)
+python tools/timeline.py $T > $O/${R}_step_timeline.csv 2>&1
 python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<true, true, 4, 2>' 1 0=fb256x128 > $O/${R}_dominant_kernel_by_shape.csv 2>&1
 python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<true, true, 2, 1>' 1 0=fb128x64 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
 python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 2, 2>' 1 0=fb128x128 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
@@ -26,7 +27,7 @@ python bench.py --steps 20 --warmup 3 --profile-all --no-cpu-baseline --roofline
 python -m pytest tests/test_parity_pointnet2_gpu.py tests/test_parity_dgcnn_gpu.py tests/test_parity_partseg_gpu.py tests/test_parity_pointconv_gpu.py -m gpu -s -q 2>&1 | grep -v Warning > $O/${R}_parity_reports.txt
 # the other BASELINE configs: one line each with the roofline of its dominant kernel, and a kernel-stats CSV per config
 python tools/bench_models.py --steps 20 --cpu-baseline --out $O/${R}_other_configs.json > $O/other.log 2>&1
-for c in "cfg2'" cfg3 "cfg4 PointNet++ SSG part-seg B=16 N=2048" cfg5; do
+for c in "cfg2'" cfg3 "cfg4 PointNet++ MSG part-seg B=16 N=2048 (BASELINE" cfg5; do
   t=$(echo "$c" | cut -c1-5 | tr -d "' " | sed "s/cfg2/cfg2_n4096/")
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$t -o b -- python tools/bench_models.py --steps 10 --only "$c" > $O/kt_$t.log 2>&1
   cp $(find $O/kt_$t -name '*kernel_stats.csv' | head -1) $O/${R}_${t}_kernel_stats.csv; rm -rf $O/kt_$t
