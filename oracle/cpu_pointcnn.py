@@ -92,7 +92,7 @@ def rand_pointcnn(mod, pts, fts, tie_stride):
     """RandPointCNN.execute (misc/layers.py:318-336)."""
     if 0 < mod.P < pts.shape[1]:
         _, rep = _o.fps(pts.detach().numpy(), mod.P, block_size=tie_stride, return_xyz=True)
-        rep_pts = torch.from_numpy(rep)
+        rep_pts = torch.from_numpy(rep).to(pts.dtype)          # (fp64 evaluation: the coordinates are exact fp32 values)
     else:
         rep_pts = pts
     return rep_pts, pointcnn(mod.pointcnn, rep_pts, pts, fts)

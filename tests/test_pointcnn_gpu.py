@@ -77,6 +77,39 @@ def test_pointcnn_cls_network(oracle, dev):
     assert (out.detach().cpu() - want).abs().max().item() <= 1e-3 * max(1.0, want.abs().max().item())
 
 
+def test_pointcnn_cls_b32_n1024_parity(oracle, dev):
+    """PointCNN cls at the classification drivers' size (B=32, N=1024), forward AND backward, by the methodology of the four
+    BASELINE networks (oracle/parity.py): the NCHW restatement of misc/layers.py evaluated in fp32 and in fp64 on the CPU; logits
+    elementwise within 1e-5 of the fp64 value, every parameter gradient by the fp64 yardstick with its absolute caps.
+    (Sampling / region indices depend on the coordinates only: identical in all three pipelines, checked per stage above.)"""
+    from oracle import cpu_pointcnn as ref
+    from oracle.parity import Report
+    from pointcloudlib_amd.networks.cls.pointcnn import PointCNNcls
+    from pointcloudlib_amd.train_utils import soft_cross_entropy_loss
+    torch.manual_seed(5)
+    B, N = 32, 1024
+    pts, lab = synth.gauss_ball(B, N, 20246), torch.from_numpy(synth.labels(B, 40, 21146))
+    net = no_dropout(PointCNNcls().to(dev)).train()
+    r32, r64 = cpu_copy(net), cpu_copy(net).double()
+    x_c = torch.from_numpy(pts)
+    o32 = ref.pointcnn_cls(r32, x_c)
+    o64 = ref.pointcnn_cls(r64, x_c.double())
+    soft_cross_entropy_loss(o32, lab).backward()
+    soft_cross_entropy_loss(o64, lab).backward()
+    out = net(x_c.to(dev))
+    loss = soft_cross_entropy_loss(out, lab.to(dev))
+    loss.backward()
+    rep = Report(f"PointCNN cls B={B} N={N}")
+    rep.feature(out, o32, o64, "logits")
+    g_hip = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    g32 = {n: p.grad for n, p in r32.named_parameters() if p.grad is not None}
+    g64 = {n: p.grad for n, p in r64.named_parameters() if p.grad is not None}
+    assert set(g_hip) == set(g64) == set(g32)
+    rep.grads(g_hip, g32, g64)
+    rep.check(abs(loss.item() - soft_cross_entropy_loss(o64, lab).item()) <= 1e-5, "loss differs from the fp64 restatement")
+    rep.finish()
+
+
 def test_pointcnn_partseg_network(oracle, dev):
     from oracle import cpu_pointcnn as ref
     from pointcloudlib_amd.networks.seg.pointcnn_partseg import PointCNN_partseg
