@@ -317,6 +317,14 @@ int pcl_bn_act_f32(const float* Y, const float* scale, const float* shift, float
 /* reference: gradient of that BatchNorm + ReLU (misc/ops.py:100-105) */
 int pcl_bn_act_bwd_f32(const float* gz, const float* Y, const float* scale, const float* shift, float slope,
                        int P, int C, float* du, double* stats_ws, int* stat_rows_out, void* stream);
+/* Stand-alone training-mode BatchNorm over the rows of x [P,C] -- the BatchNorm AFTER an activation of PointCNN's Conv / SepConv /
+ * Dense blocks (misc/layers.py:151-169,:173-206).  pcl_bn_rows_stats_f32 leaves fp64 partial rows [*stat_rows_out <= 1024][2][C] of
+ * (sum x, sum x^2) (g == NULL: forward; then pcl_bn_finalize_f32 and pcl_bn_act_f32 with slope 1 apply it) or of (sum g, sum g*x)
+ * (backward; then pcl_bn_bwd_consts_f32 and pcl_bn_rows_bwd_apply_f32: dx = a*g - k1 - k2*(x - mean)). */
+int pcl_bn_rows_stats_f32(const float* x, const float* g, int P, int C, double* stats_ws, int* stat_rows_out, void* stream);
+/* reference: gradient of nn.BatchNorm (training mode) w.r.t. its input, misc/layers.py:156,:192 */
+int pcl_bn_rows_bwd_apply_f32(const float* g, const float* x, const float* a, const float* k1, const float* k2, const float* mean,
+                              int P, int C, float* dx, void* stream);
 /* backward of the max: gz[g,c] = gout*act'(out) plus partial (sum gz, sum gz*ymax). */
 /* reference: gradient of the max over nsample, networks/cls/pointnet2.py:57 */
 int pcl_maxgrad_prep_f32(const float* gout, const float* out, const float* ymax, float slope, int G, int C,

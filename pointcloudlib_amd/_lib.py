@@ -49,6 +49,8 @@ _SIGS = {
     "pcl_mlp_stack_sizes": (c_int, [_P, _P, _P, _P]),
     "pcl_mlp_stack_fwd_f32": (c_int, [_P]),
     "pcl_mlp_stack_bwd_f32": (c_int, [_P]),
+    "pcl_bn_rows_stats_f32": (c_int, [_P, _P, c_int, c_int, _P, ctypes.POINTER(c_int), _P]),
+    "pcl_bn_rows_bwd_apply_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "pcl_fc_head_sizes": (c_int, [_P, _P, _P]),
     "pcl_fc_head_fwd_f32": (c_int, [_P]),
     "pcl_fc_head_bwd_f32": (c_int, [_P]),

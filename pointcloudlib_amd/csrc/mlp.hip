@@ -1818,6 +1818,44 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
     fold_row_lanes(s1, s2, c, rsub, RS, CW, C, red, stats + (size_t)blockIdx.y * 2 * C);
 }
 
+// ---- stand-alone training-mode BatchNorm over the rows of x [P,C] (the BatchNorm AFTER an activation of PointCNN's Conv /
+// SepConv / Dense blocks, misc/layers.py:151-169,:173-206): column sums as fp64 partial rows, the same finalize / constants
+// kernels as the stacks, one apply pass each way.
+//   forward : (sum x, sum x^2)   -> pcl_bn_finalize_f32 -> out = scale*x + shift          (pcl_bn_act_f32 with slope 1)
+//   backward: (sum g, sum g*x)   -> pcl_bn_bwd_consts_f32 -> dx = a*g - k1 - k2*(x - mean)
+__global__ __launch_bounds__(256) void bn_rows_stats_kernel(const float* __restrict__ x, const float* __restrict__ g, int P, int C, int CW,
+                                                            double* __restrict__ stats) {
+    __shared__ double red[2 * 256];
+    const int RS = 256 / CW, rsub = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + threadIdx.x % CW;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        // four independent streams per thread: the fp64 adds are a dependent chain otherwise
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+        const int step = gridDim.y * RS;
+        int r = blockIdx.y * RS + rsub;
+        for (; r + step < P; r += 2 * step) {
+            const size_t e0 = (size_t)r * C + c, e1 = (size_t)(r + step) * C + c;
+            const float x0 = x[e0], x1 = x[e1];
+            const float u0 = g ? g[e0] : x0, u1 = g ? g[e1] : x1;
+            a0 += u0; b0 += (double)u0 * x0;
+            a1 += u1; b1 += (double)u1 * x1;
+        }
+        if (r < P) { const size_t e0 = (size_t)r * C + c; const float x0 = x[e0], u0 = g ? g[e0] : x0; a0 += u0; b0 += (double)u0 * x0; }
+        s1 = a0 + a1; s2 = b0 + b1;
+    }
+    fold_row_lanes(s1, s2, c, rsub, RS, CW, C, red, stats + (size_t)blockIdx.y * 2 * C);
+}
+__global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                                const float* __restrict__ a, const float* __restrict__ k1,
+                                                                const float* __restrict__ k2, const float* __restrict__ mean, int C,
+                                                                size_t total, float* __restrict__ dx) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        dx[e] = fmaf(a[c], g[e], -k1[c]) - k2[c] * (x[e] - mean[c]);
+    }
+}
+
 static void linear_grid(int M, int N, bool bwd, bool rag, int& gx, int& n_tiles, bool& narrow, bool& low) {
     // 128x64 block tile instead of 128x128 for narrow outputs -- and for the backward (dy-forming) loaders, whose
     // three operand streams + 128x128 accumulators do not fit 256 VGPRs at 2 waves/SIMD (47-97 spilled VGPRs
@@ -2201,4 +2239,30 @@ extern "C" int pcl_bn_act_bwd_f32(const float* gz, const float* Y, const float* 
     hipLaunchKernelGGL(bn_act_bwd_kernel, dim3((C + CW - 1) / CW, rows), dim3(256), 0, as_stream(stream), gz, Y, scale, shift,
                        slope, P, C, CW, du, stats_ws);
     return check_launch("pcl_bn_act_bwd_f32");
+}
+
+// Column sums of a stand-alone BatchNorm over rows (see bn_rows_stats_kernel): g == NULL: (sum x, sum x^2); else (sum g, sum g*x).
+extern "C" int pcl_bn_rows_stats_f32(const float* x, const float* g, int P, int C, double* stats_ws, int* stat_rows_out, void* stream) {
+    PCL_REQUIRE(x && stats_ws && stat_rows_out && P >= 1 && C >= 1, "pcl_bn_rows_stats_f32: bad arguments");
+    int CW = 256;
+    while (CW / 2 >= C && CW > 1) CW >>= 1;
+    const int RS = 256 / CW;
+    int rows = (P + RS - 1) / RS < STAT_ROWS ? (P + RS - 1) / RS : STAT_ROWS;
+    // enough workgroups to fill the chip, not more partial rows than that needs
+    const int cb = (C + CW - 1) / CW;
+    const int want = (2048 + cb - 1) / cb;
+    if (rows > want) rows = want;
+    *stat_rows_out = rows;
+    hipLaunchKernelGGL(bn_rows_stats_kernel, dim3(cb, rows), dim3(256), 0, as_stream(stream), x, g, P, C, CW, stats_ws);
+    return check_launch("pcl_bn_rows_stats_f32");
+}
+
+extern "C" int pcl_bn_rows_bwd_apply_f32(const float* g, const float* x, const float* a, const float* k1, const float* k2, const float* mean,
+                                         int P, int C, float* dx, void* stream) {
+    PCL_REQUIRE(g && x && a && k1 && k2 && mean && dx && P >= 1 && C >= 1, "pcl_bn_rows_bwd_apply_f32: bad arguments");
+    const size_t total = (size_t)P * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), g, x, a, k1, k2, mean, C, total, dx);
+    return check_launch("pcl_bn_rows_bwd_apply_f32");
 }

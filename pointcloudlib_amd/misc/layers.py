@@ -23,13 +23,66 @@ from torch import nn
 __all__ = ["PointwiseMLP", "batch_norm_train", "max_over_group"]
 
 
-def batch_norm_train(x2d, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5):
-    """BatchNorm over the rows of ``x2d`` [P,C] with Jittor's running-stat rule (biased variance)."""
+class _BNRows(torch.autograd.Function):
+    """Training-mode BatchNorm over the rows of x [P,C] on the library's kernels (csrc/mlp.hip: bn_rows_*): 3 launches forward,
+    3 backward -- fp64 column sums, the stacks' finalize / constants kernels (biased running variance, Jittor's rule), one apply
+    pass each way.  The plain-PyTorch composite below needed ~11 launches per BatchNorm."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps):
+        import ctypes
+        from .. import _lib
+        from .ops import _p, _stream
+        x = x.contiguous()
+        P, C = x.shape
+        dev = x.device
+        st = _stream()
+        stats = torch.empty((1024, 2, C), dtype=torch.float64, device=dev)
+        rows = ctypes.c_int(0)
+        _lib.call("pcl_bn_rows_stats_f32", _p(x), None, P, C, _p(stats), ctypes.byref(rows), st)
+        vec = torch.empty((4, C), dtype=torch.float32, device=dev)
+        scale, shift, mean, invstd = vec.unbind(0)
+        _lib.call("pcl_bn_finalize_f32", _p(stats), rows.value, _p(gamma), _p(beta), P, C, eps, momentum, _p(scale), _p(shift), _p(mean),
+                  _p(invstd), _p(running_mean), _p(running_var), st)
+        out = torch.empty_like(x)
+        _lib.call("pcl_bn_act_f32", _p(x), _p(scale), _p(shift), 1.0, P, C, _p(out), st)
+        ctx.save_for_backward(x, gamma, mean, invstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        from .. import _lib
+        from .ops import _p, _stream
+        x, gamma, mean, invstd = ctx.saved_tensors
+        P, C = x.shape
+        dev = x.device
+        st = _stream()
+        g = g.contiguous()
+        stats = torch.empty((1024, 2, C), dtype=torch.float64, device=dev)
+        rows = ctypes.c_int(0)
+        _lib.call("pcl_bn_rows_stats_f32", _p(x), _p(g), P, C, _p(stats), ctypes.byref(rows), st)
+        vec = torch.empty((5, C), dtype=torch.float32, device=dev)
+        a, k1, k2, dgamma, dbeta = vec.unbind(0)
+        _lib.call("pcl_bn_bwd_consts_f32", _p(stats), rows.value, _p(gamma), _p(mean), _p(invstd), P, C, _p(dgamma), _p(dbeta), _p(a), _p(k1),
+                  _p(k2), None, st)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.call("pcl_bn_rows_bwd_apply_f32", _p(g), _p(x), _p(a), _p(k1), _p(k2), _p(mean), P, C, _p(dx), st)
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+def batch_norm_train(x2d, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, native=True):
+    """BatchNorm over the rows of ``x2d`` [P,C] with Jittor's running-stat rule (biased variance).  ``native=False``: the plain
+    PyTorch composite even on the GPU (the ``torch`` backend of ``PointwiseMLP``: the tests' numerics reference)."""
     if not training:
         return F.batch_norm(x2d, running_mean, running_var, gamma, beta, False, 0.0, eps)
     from .. import syncbn
     if syncbn.active():          # data-parallel step with synchronised statistics: sums over every rank's rows
         return syncbn.batch_norm_rows(x2d, gamma, beta, running_mean, running_var, momentum, eps)
+    if native and x2d.is_cuda and x2d.dtype == torch.float32 and gamma is not None and running_mean is not None:
+        return _BNRows.apply(x2d, gamma, beta, running_mean, running_var, float(momentum), float(eps))
     with torch.no_grad():
         var, mean = torch.var_mean(x2d, dim=0, unbiased=False)
         running_mean += (mean - running_mean) * momentum
@@ -90,7 +143,7 @@ class PointwiseMLP(nn.Module):
             y = F.linear(y, self.weights[i], None if self.biases is None else self.biases[i])
             if self.bn:
                 y = batch_norm_train(y, self.gammas[i], self.betas[i], getattr(self, f"running_mean_{i}"),
-                                     getattr(self, f"running_var_{i}"), self.training, self.momentum, self.eps)
+                                     getattr(self, f"running_var_{i}"), self.training, self.momentum, self.eps, native=False)
             if i < self.n_layers - 1 or self.last_act:
                 y = self._act(y)
         return y.reshape(*lead, y.shape[-1])

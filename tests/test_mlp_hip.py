@@ -530,3 +530,29 @@ def test_head_stack_dropout(dev, p):
         m.eval()
     out3 = head.fc_head(mods, x.detach())                # evaluation mode: identity
     assert torch.allclose(out3, y, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("P,C,offset", [(4096, 48, 0.0), (100000, 96, 3.0), (33, 7, 0.0), (20000, 288, -2.0), (5, 512, 0.5)])
+def test_bn_rows_matches_fp64(dev, P, C, offset):
+    """The stand-alone BatchNorm over rows (PointCNN's BatchNorm after an activation; csrc/mlp.hip bn_rows_*) against fp64
+    PyTorch: output 1e-5 of its scale, input / gamma / beta gradients 1e-5 relative to their max-norm (+ the model scale for
+    analytically small ones), running statistics by Jittor's rule (biased variance, momentum as given)."""
+    from pointcloudlib_amd.misc.layers import batch_norm_train
+    torch.manual_seed(P + C)
+    x0 = (torch.randn(P, C, dtype=torch.float64) * torch.rand(C, dtype=torch.float64).add(0.2) + offset).relu()
+    g0, b0 = torch.rand(C, dtype=torch.float64) + 0.5, torch.randn(C, dtype=torch.float64)
+    gout = torch.randn(P, C, dtype=torch.float64)
+    x64, g64, b64 = x0.clone().requires_grad_(True), g0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    want = torch.nn.functional.batch_norm(x64, None, None, g64, b64, True, 0.0, 1e-5)
+    want.backward(gout)
+    x, g, b = (t.float().to(dev).requires_grad_(True) for t in (x0, g0, b0))
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    got = batch_norm_train(x, g, b, rm, rv, True, momentum=0.9, eps=1e-5)
+    got.backward(gout.float().to(dev))
+    assert (got.detach().cpu().double() - want.detach()).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    gs = max(t.grad.abs().max().item() for t in (x64, g64, b64))
+    for name, a, r in (("dx", x.grad, x64.grad), ("dgamma", g.grad, g64.grad), ("dbeta", b.grad, b64.grad)):
+        assert (a.cpu().double() - r).abs().max().item() <= 2e-5 * r.abs().max().item() + 1e-6 * gs, name
+    mean, var = x0.mean(0), x0.var(0, unbiased=False)
+    assert torch.allclose(rm.cpu().double(), 0.9 * mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rv.cpu().double(), 1.0 + 0.9 * (var - 1.0), rtol=1e-5, atol=1e-6)
