@@ -353,6 +353,8 @@ int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a, const
  * pcl_linear_bwd_fused_finish_f32 (second launch) sums the partial tiles into dW[Cout][Cin] and -- when stats_ws is given --
  * computes the BatchNorm-backward constants of the layer below from those sums (what pcl_bn_bwd_consts_f32 does). */
 /* reference: the autograd backward of nn.Conv 1x1 + nn.BatchNorm + nn.ReLU, networks/cls/pointnet2.py:25-29 */
+/* test / tuning hook: cap the persistent grid of the fused backward at n workgroups (0 = one per CU); process-wide, set between calls */
+void pcl_set_fb_max_blocks(int n);
 int pcl_linear_bwd_fused_supported(int Cout, int Cin);
 int pcl_linear_bwd_fused_stat_rows(int P, int Cin);
 size_t pcl_linear_bwd_fused_workspace_bytes(int P, int Cout, int Cin);

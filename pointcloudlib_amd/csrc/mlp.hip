@@ -24,6 +24,9 @@
 // statistics are reduced in registers across tiles.
 #include <cstdlib>
 #include "common.h"
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "mlp.hip is written for gfx950 (MI355X) only: its buffer addressing relies on the range check covering the scalar offset (tools/ubench/bufcheck.hip)"
+#endif
 
 // PCL_EXP: timing experiments only (csrc/Makefile EXP=n builds a separate library; the product build has PCL_EXP == 0)
 #ifndef PCL_EXP
@@ -1540,13 +1543,23 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
     }
 }
 
+// one persistent workgroup per CU (the device's CU count, asked once); pcl_set_fb_max_blocks caps it (tests: several row tiles
+// per workgroup at sizes small enough for an fp64 comparison free of ReLU-mask flips; tuning).  The cap is a process-wide
+// setting made BETWEEN calls: it sizes the statistics rows, the workspace and the finish reduction of every later call.
+static int g_fb_cap = 0;
+static int fb_cu_count() {
+    static const int n = [] {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 1) cu = 256;
+        (void)hipGetLastError();
+        return cu > 256 ? 256 : cu;          // (the partial-tile workspace and the 256-row statistics are sized for <= 256)
+    }();
+    return n;
+}
 static int fb_grid(int P, int Cin) {
     const int R = fb_rows(Cin), tiles = (P + R - 1) / R;
-    // one persistent workgroup per CU; PCL_FB_MAX_BLOCKS caps it (tests: several row tiles per workgroup at sizes small enough
-    // for an fp64 comparison free of ReLU-mask flips; tuning)
-    const char* e = getenv("PCL_FB_MAX_BLOCKS");
-    const int cap = e ? atoi(e) : 0;
-    int gx = cap >= 1 && cap < 256 ? cap : 256;
+    const int cus = fb_cu_count();
+    int gx = g_fb_cap >= 1 && g_fb_cap < cus ? g_fb_cap : cus;
     if (gx > tiles) gx = tiles;
     if (gx < 1) gx = 1;
     return gx;
@@ -2083,6 +2096,8 @@ extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(blocks), dim3(256), 0, st, d.part, gx, n, Cin, dw_ld ? dw_ld : Cin, dW);
     return check_launch("pcl_linear_bwd_dw_f32(reduce)");
 }
+
+extern "C" void pcl_set_fb_max_blocks(int n) { g_fb_cap = n; }
 
 extern "C" int pcl_linear_bwd_fused_supported(int Cout, int Cin) {
     return ((Cout == 64 || Cout == 128) && (Cin == 64 || Cin == 128)) || (Cout == 256 && Cin == 128);

@@ -55,8 +55,11 @@ class _Batches:
 
 
 class ModelNet40:
-    def __init__(self, n_points, train, batch_size=1, shuffle=False, root=None):
+    def __init__(self, n_points, train, batch_size=1, shuffle=False, root=None, cache_dir=None):
+        """``cache_dir``: where to keep ``.npy`` copies of the parsed text files (None: in memory only; nothing is ever written
+        into the dataset directory)."""
         self.n_points, self.train, self.batch_size, self.shuffle = n_points, train, batch_size, shuffle
+        self.cache_dir = cache_dir
         root = root or os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
         self.path = os.path.join(root, "modelnet40_normal_resampled")
         names = os.path.join(self.path, "modelnet40_shape_names.txt")
@@ -77,32 +80,37 @@ class ModelNet40:
 
     def load(self, idx):
         """One shape, parsed ONCE: the 10 000-line text file costs ~0.1 s in np.loadtxt, against a ~13k clouds/s training
-        step.  Parsed arrays are kept in memory and as ``<shape>.npy`` next to the text file (the reference caches the
-        parsed dataset in LMDB/msgpack, data_utils/modelnet40_loader.py:40-100); a read-only dataset directory just
-        skips the on-disk copy."""
+        step.  The rows an item uses (the first ``n_points``) are kept in memory; with ``cache_dir`` the parsed array is also
+        kept there as ``<shape>.npy`` (the reference caches the parsed dataset in LMDB/msgpack,
+        data_utils/modelnet40_loader.py:40-100)."""
         cache = self.__dict__.setdefault("_cache", {})
         hit = cache.get(idx)
         if hit is not None:
             return hit
         shape_name, shape_file = self.shapes[idx]
         txt = os.path.join(self.path, shape_name, shape_file)
-        npy = txt[:-4] + ".npy"
+        # on-disk copy of the parsed array: only when a cache directory was asked for (``cache_dir``), never inside the dataset
+        cdir = getattr(self, "cache_dir", None)
+        npy = os.path.join(cdir, os.path.splitext(shape_file)[0] + ".npy") if cdir else None
         pts = None
-        if os.path.exists(npy) and os.path.getmtime(npy) >= os.path.getmtime(txt):
+        if npy and os.path.exists(npy) and os.path.getmtime(npy) >= os.path.getmtime(txt):
             try:
                 pts = np.load(npy)
             except (OSError, ValueError):
                 pts = None
         if pts is None:
             pts = np.loadtxt(txt, delimiter=",", dtype=np.float32)
+        if pts is not None and npy and not os.path.exists(npy):
             try:
+                os.makedirs(cdir, exist_ok=True)
                 tmp = npy + f".{os.getpid()}.tmp"
                 with open(tmp, "wb") as fh:
                     np.save(fh, pts)
                 os.replace(tmp, npy)                      # atomic: concurrent loaders never see a partial file
             except OSError:
                 pass
-        cache[idx] = (pts, self.classes[shape_name])
+        # item() uses the first n_points rows only: keep those (24 KB per shape at 1024 points, not the 240 KB of all 10 000 rows)
+        cache[idx] = (np.ascontiguousarray(pts[:self.n_points]), self.classes[shape_name])
         return cache[idx]
 
     def item(self, idx):

@@ -68,13 +68,14 @@ def test_fused_backward_tiles_per_block(dev, monkeypatch, spec, lead, ns, bias, 
     the cyclic weight-chunk stage, the double-buffered row records), at a row count where an fp64 comparison is still free
     of ReLU-mask flips (a pre-activation within fp32 rounding of 0 turns up about once per 10^7 elements)."""
     from pointcloudlib_amd import _lib
-    monkeypatch.setenv("PCL_FB_MAX_BLOCKS", str(blocks))
-    _lib.size_query.cache_clear()
+    from pointcloudlib_amd.misc import mlp_hip
+    _lib.lib().pcl_set_fb_max_blocks(blocks)
+    _lib.size_query.cache_clear(); mlp_hip._PLANS.clear()          # sizes depend on the cap
     try:
         _check_against_fp64(dev, spec, lead, ns, bias, slope)
     finally:
-        monkeypatch.delenv("PCL_FB_MAX_BLOCKS")
-        _lib.size_query.cache_clear()
+        _lib.lib().pcl_set_fb_max_blocks(0)
+        _lib.size_query.cache_clear(); mlp_hip._PLANS.clear()
 
 
 @pytest.mark.parametrize("spec,lead,ns", [([16, 128, 64, 256], (8, 512, 32), 32), ([16, 64, 128, 64], (3, 44444), None),
