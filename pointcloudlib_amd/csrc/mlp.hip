@@ -1176,6 +1176,226 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     }
 }
 
+// ---- forward of a hidden layer with the weight RESIDENT in LDS (round 3) ---------------------------------------------------------
+// Y[R x NS] = lrelu(BN_prev(X))[R x CIN] . W[n0..n0+NS)[CIN]^T for the set-abstraction shapes (CIN in {64,128}, Cout in {64,128,256}):
+// the plan of the fused backward's dX phase.  A persistent workgroup of 8 waves (two per SIMD) keeps its NS-column slab of W in
+// LDS for the whole kernel and walks row tiles of R = 128 (CIN = 64) or 64 (CIN = 128) rows: the tile's rows are transformed
+// ONCE on their way into a double-buffered LDS image (the next tile is deposited behind this tile's MFMAs and its raw rows were
+// requested a tile earlier), the K loop is LDS reads and MFMAs only -- no B re-staging per row tile, no barrier inside, one
+// barrier per tile -- and the epilogue stores the C/D layout as dword buffer stores with the row in the scalar offset and sums
+// the BatchNorm statistics about a per-lane pivot.  Cout = 256 runs as two 128-column slabs in workgroups 8 ids apart (same
+// XCD: the second reads the rows from L2).  linear_nt_kernel re-stages the weight tile for every 128-row tile behind two
+// barriers per 32-wide k step.
+constexpr int FR_T = 512;
+struct FrArgs {
+    const float* X; const float* W; const float* bias; const float* sc; const float* sh; float slope;
+    float* Y; double* stats; const int2* rmeta; const int* m_dev;
+    int M, N, gx, nt, stat_rows;
+};
+template <int CI, int NS, bool RAG, bool PLAIN>
+__global__ __launch_bounds__(FR_T) void linear_fwd_res_kernel(const FrArgs p_in) {
+    FrArgs p = p_in;
+    if (p.m_dev) p.M = __builtin_amdgcn_readfirstlane(*p.m_dev);
+    constexpr int CIN = 64 * CI, R = CIN == 64 ? 128 : 64;
+    constexpr int ALD = CIN + 4, WLD = CIN + 4;
+    constexpr int RB = R / 32, CBK = NS / 32, TM = RB * CBK / 8;            // 32x32 tiles per wave (same column block)
+    static_assert(RB * CBK == 8 * TM && (TM == 1 || TM == 2), "wave tiling");
+    constexpr int CPR = CIN / 4, RP = FR_T / CPR, NI = R / RP;               // staging: thread -> 16-byte piece k4 of rows row0 + RP*i
+    constexpr int NWB = NS * CIN / 4 / FR_T;
+    __shared__ __attribute__((aligned(16))) float lds[NS * WLD + 2 * R * ALD + 2 * R];
+    float* const sW = lds;
+    float* const sA = sW + NS * WLD;
+    float* const sMult = sA + 2 * R * ALD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    int bx, by;
+    tile_of_block(blockIdx.x, p.gx, p.nt, bx, by);
+    const int n0 = by * NS;
+    const int tiles = (p.M + R - 1) / R;
+    const unsigned irow = CIN * 4u, orow = (unsigned)p.N * 4u;
+    const int k4 = (tid % CPR) * 4, row0 = tid / CPR;
+    float4 csc = make_float4(1.f, 1.f, 1.f, 1.f), csh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (!PLAIN) { csc = *reinterpret_cast<const float4*>(p.sc + k4); csh = *reinterpret_cast<const float4*>(p.sh + k4); }
+    const int cb = wave % CBK, rb0 = wave / CBK;                             // tiles (rb0 + (8 / CBK) * t, cb), t < TM
+    const int col = n0 + cb * 32 + lr;
+    const float bias = p.bias ? p.bias[col] : 0.f;
+
+    // weight slab -> LDS (once)
+    {
+        const rsrc_t rW = buf_rsrc(p.W, (size_t)n0 * irow, (size_t)p.N * irow);
+#pragma unroll
+        for (int i = 0; i < NWB; ++i) {
+            const int e = tid + FR_T * i, n = e / CPR, kk = (e % CPR) * 4;
+            const float4 w = buf_ld4(rW, (unsigned)n * irow + (unsigned)kk * 4, 0);
+            *reinterpret_cast<float4*>(&sW[n * WLD + kk]) = w;
+        }
+    }
+    float4 rX[NI];
+    float rMu = 0.f;
+    auto request = [&](int tile) {
+        const bool live = tile < tiles;
+        const int m0 = tile * R;
+        const rsrc_t rA = buf_rsrc(p.X, (size_t)m0 * irow, live ? (size_t)p.M * irow : 0);
+        const unsigned vo = (unsigned)row0 * irow + (unsigned)k4 * 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) rX[i] = buf_ld4(rA, vo, (unsigned)(RP * i) * irow);
+        const int row = m0 + tid;
+        if constexpr (RAG) {
+            const rsrc_t rR = buf_rsrc(p.rmeta, 0, live ? (size_t)p.M * 8 : 0);
+            const int2 rec = buf_ld2i(rR, (tid < R && row < p.M) ? (unsigned)row * 8u : BUF_OOB);
+            rMu = (float)(rec.y >> 16);
+        } else {
+            rMu = (live && tid < R && row < p.M) ? 1.f : 0.f;
+        }
+    };
+    auto deposit = [&](int buf) {
+        float* a = sA + buf * R * ALD;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float4 z = rX[i];
+            if constexpr (!PLAIN) {             // the layer below's folded BatchNorm + activation, applied once per element
+                float t;
+                t = fmaf(csc.x, rX[i].x, csh.x); z.x = fmaxf(t, t * p.slope);
+                t = fmaf(csc.y, rX[i].y, csh.y); z.y = fmaxf(t, t * p.slope);
+                t = fmaf(csc.z, rX[i].z, csh.z); z.z = fmaxf(t, t * p.slope);
+                t = fmaf(csc.w, rX[i].w, csh.w); z.w = fmaxf(t, t * p.slope);
+            }
+            *reinterpret_cast<float4*>(&a[(row0 + RP * i) * ALD + k4]) = z;
+        }
+        if (tid < R) sMult[buf * R + tid] = rMu;
+    };
+    int tile = bx;
+    request(tile);
+    deposit(0);
+    request(tile + p.gx);
+    __syncthreads();
+    double st_s = 0.0, st_q = 0.0;
+    for (int it = 0; tile < tiles; tile += p.gx, ++it) {
+        const int buf = it & 1;
+        const int m0 = tile * R;
+        const float* a = sA + buf * R * ALD;
+        f32x16 acc[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        // operands of step k+1 are read from LDS before the MFMAs of step k are issued (pinned: hipcc sinks loads to their use)
+        const float* pa = a + (rb0 * 32 + lr) * ALD + lh * 4;
+        const float* pb = sW + (cb * 32 + lr) * WLD + lh * 4;
+        struct Op { float4 a[TM]; float4 b; };
+        auto ld = [&](int k8) -> Op {
+            Op o;
+#pragma unroll
+            for (int t = 0; t < TM; ++t) o.a[t] = *reinterpret_cast<const float4*>(pa + t * (8 / CBK) * 32 * ALD + k8 * 8);
+            o.b = *reinterpret_cast<const float4*>(pb + k8 * 8);
+            return o;
+        };
+        Op cur = ld(0);
+#pragma unroll
+        for (int k8 = 0; k8 < CIN / 8; ++k8) {
+            Op nxt = cur;
+            if (k8 + 1 < CIN / 8) nxt = ld(k8 + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t].x, cur.b.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t].y, cur.b.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t].z, cur.b.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t].w, cur.b.w, acc[t], 0, 0, 0);
+            }
+            cur = nxt;
+        }
+        // ---- epilogue: store (rows past M are dropped by the range check), multiplicity-weighted sums about a pivot
+        {
+            const rsrc_t rY = buf_rsrc(p.Y, (size_t)m0 * orow, (size_t)p.M * orow);
+            const unsigned v0 = (unsigned)(4 * lh) * orow + (unsigned)col * 4;
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const int rbase = (rb0 + t * (8 / CBK)) * 32;
+                const float piv = acc[t][0] + bias;
+                float ts = 0.f, tq = 0.f, tw = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = rbase + (r & 3) + 8 * (r >> 2);               // + 4*lh
+                    const float c = acc[t][r] + bias;
+                    const float w = sMult[buf * R + rl + 4 * lh];
+                    const float dlt = c - piv;
+                    tw += w; ts = fmaf(w, dlt, ts); tq = fmaf(w * dlt, dlt, tq);
+                    buf_st1(rY, v0, (unsigned)rl * orow, c);
+                }
+                const double n = (double)tw, pv = (double)piv;
+                st_s += (double)ts + n * pv; st_q += (double)tq + 2.0 * pv * (double)ts + n * pv * pv;
+            }
+        }
+        // the next tile (requested a tile ago) goes into the other image: its readers finished before the last barrier
+        deposit(buf ^ 1);
+        request(tile + 2 * p.gx);
+        __syncthreads();
+    }
+    // ---- this workgroup's row of the BatchNorm sums (its NS columns); the rows the 4-wave kernel's grid would have written beyond
+    // gx are cleared so that the finalize sums the same workspace layout
+    {
+        double s = st_s, q = st_q;
+        s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+        double* red = reinterpret_cast<double*>(sA);             // [8 waves][32][2]
+        __syncthreads();
+        if (lh == 0) { red[(wave * 32 + lr) * 2] = s; red[(wave * 32 + lr) * 2 + 1] = q; }
+        __syncthreads();
+        if (tid < NS) {
+            const int cb_ = tid / 32, l = tid & 31;
+            double ss = 0.0, qq = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8 / CBK; ++w) { ss += red[((w * CBK + cb_) * 32 + l) * 2]; qq += red[((w * CBK + cb_) * 32 + l) * 2 + 1]; }
+            double* dst = p.stats + (size_t)bx * 2 * p.N;
+            dst[n0 + tid] = ss; dst[p.N + n0 + tid] = qq;
+            for (int r = bx + p.gx; r < p.stat_rows; r += p.gx) {
+                double* z = p.stats + (size_t)r * 2 * p.N;
+                z[n0 + tid] = 0.0; z[p.N + n0 + tid] = 0.0;
+            }
+        }
+    }
+}
+
+// which forward launches take the resident-weight kernel: a hidden layer (folded BatchNorm + activation on the input) of a
+// set-abstraction shape with enough rows to keep one workgroup per CU busy for several tiles
+static bool fwd_res_eligible(const LinArgs& a) {
+    static const int on = [] { const char* e = getenv("PCL_FWD_RES"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (!on || (a.a_mode != A_BNACT && a.a_mode != A_PLAIN) || a.e_mode != E_STORE_STATS || a.gmax || a.n_begin != 0 || a.ldc != a.N) return false;
+    if (!((a.K == 64 && (a.N == 64 || a.N == 128)) || (a.K == 128 && (a.N == 128 || a.N == 256)))) return false;
+    if (a.M < 32768 || (size_t)a.M * (size_t)(a.N > a.K ? a.N : a.K) * 4 >= 0xffffffffull) return false;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (a.a_mode == A_PLAIN) return al16(a.A) && al16(a.B);
+    return al16(a.A) && al16(a.B) && al16(a.sc) && al16(a.sh) && a.slope >= 0.f && a.slope <= 1.f;
+}
+template <int CI, int NS>
+static int launch_fwd_res_t(const FrArgs& f, bool rag, hipStream_t st) {
+    const dim3 grid(f.gx * f.nt), blk(FR_T);
+    const bool plain = f.sc == nullptr;
+    if (rag && plain) PCL_LAUNCH_TIMED((linear_fwd_res_kernel<CI, NS, true, true>), grid, blk, st, f);
+    else if (rag) PCL_LAUNCH_TIMED((linear_fwd_res_kernel<CI, NS, true, false>), grid, blk, st, f);
+    else if (plain) PCL_LAUNCH_TIMED((linear_fwd_res_kernel<CI, NS, false, true>), grid, blk, st, f);
+    else PCL_LAUNCH_TIMED((linear_fwd_res_kernel<CI, NS, false, false>), grid, blk, st, f);
+    return check_launch("pcl_linear_fwd(resident weight)");
+}
+static int fr_cu_count();
+static int launch_fwd_res(const LinArgs& a, int stat_rows, hipStream_t st) {
+    FrArgs f = {};
+    f.X = a.A; f.W = a.B; f.bias = a.bias; f.sc = a.a_mode == A_PLAIN ? nullptr : a.sc; f.sh = a.a_mode == A_PLAIN ? nullptr : a.sh; f.slope = a.slope; f.Y = a.C; f.stats = a.stats;
+    f.rmeta = a.rmeta; f.m_dev = a.m_dev; f.M = a.M; f.N = a.N; f.stat_rows = stat_rows;
+    const int NS = a.N == 64 ? 64 : 128, R = a.K == 64 ? 128 : 64;
+    f.nt = a.N / NS;
+    const int tiles = (a.M + R - 1) / R;
+    int gx = fr_cu_count() / f.nt;                       // one workgroup per CU in all
+    if (gx > tiles) gx = tiles;
+    if (gx > stat_rows) gx = stat_rows;
+    if (gx < 1) gx = 1;
+    f.gx = gx;
+    const bool rag = a.rmeta != nullptr;
+    if (a.K == 64 && NS == 64) return launch_fwd_res_t<1, 64>(f, rag, st);
+    if (a.K == 64) return launch_fwd_res_t<1, 128>(f, rag, st);
+    return launch_fwd_res_t<2, 128>(f, rag, st);
+}
+
 // ---- fused backward of one layer: dX and dW from ONE pass over (dU | arg,gz ; Y ; Yprev) ---------------------------------
 // The two backward GEMMs of a layer both need dy = a*du - w*(k1 + k2*(y - mean)): formed separately, dy costs its VALU twice
 // (VALU time IS matrix time on gfx950, see the vector-path header) and (dU, Y) are read from HBM twice -- 2 of the 7
@@ -1556,6 +1776,7 @@ static int fb_cu_count() {
     }();
     return n;
 }
+static int fr_cu_count() { return fb_cu_count(); }
 static int fb_grid(int P, int Cin) {
     const int R = fb_rows(Cin), tiles = (P + R - 1) / R;
     const int cus = fb_cu_count();
@@ -1920,6 +2141,7 @@ static int linear_stat_rows(int M, int N, bool bwd, bool rag) {
 }
 
 static int launch_linear(const LinArgs& a, hipStream_t st) {
+    if (fwd_res_eligible(a)) return launch_fwd_res(a, linear_stat_rows(a.M, a.N, false, a.rmeta != nullptr), st);
     if (a.rmeta) {                                     // duplicate-compacted rows
         if (a.a_mode == A_PLAIN && a.e_mode == E_STORE_STATS) return launch_linear_t<A_PLAIN, E_STORE_STATS, 0, true>(a, st);
         if (a.a_mode == A_BNACT && a.e_mode == E_STORE_STATS) return launch_linear_t<A_BNACT, E_STORE_STATS, 0, true>(a, st);

@@ -557,3 +557,25 @@ def test_bn_rows_matches_fp64(dev, P, C, offset):
     mean, var = x0.mean(0), x0.var(0, unbiased=False)
     assert torch.allclose(rm.cpu().double(), 0.9 * mean, rtol=1e-5, atol=1e-6)
     assert torch.allclose(rv.cpu().double(), 1.0 + 0.9 * (var - 1.0), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("spec,rows,bias,slope", [([8, 64, 64], 40001, False, 0.0), ([8, 64, 128], 33000, True, 0.2), ([12, 128, 128], 70007, False, 0.0),
+                                                  ([12, 128, 256], 36864, False, 0.0), ([8, 64, 64, 128], 50000, False, 0.0),
+                                                  ([64, 128], 33333, False, 0.2), ([128, 256, 64], 40000, True, 0.0)])      # first layer = plain input
+def test_resident_weight_forward_kernel_against_fp64(dev, spec, rows, bias, slope):
+    """linear_fwd_res_kernel (hidden layers of the set-abstraction shapes at >= 32768 rows: weight slab resident in LDS, 8 waves,
+    double-buffered row image): module output and running statistics against fp64 PyTorch, ragged last tile, bias, LeakyReLU,
+    Cout = 256 as two slabs."""
+    torch.manual_seed(rows)
+    mlp = PointwiseMLP(spec, bias=bias, slope=slope).to(dev).train()
+    with torch.no_grad():
+        for g in mlp.gammas:
+            g.uniform_(0.5, 1.5); g[::3] *= -1.0
+    x = torch.randn(rows, spec[0], device=dev)
+    ref = copy.deepcopy(mlp).cpu().double()
+    ref.backend = "torch"
+    want = ref(x.cpu().double())
+    got = mlp(x)
+    assert (got.detach().cpu().double() - want.detach()).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    for (n, b), (_, r) in zip(mlp.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(b.cpu().double(), r, rtol=1e-5, atol=1e-6), n
