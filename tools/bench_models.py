@@ -138,7 +138,7 @@ def run_prefetch(name, make, inputs, loss_fn, steps, warmup=3):
     return _run_prefetch(name, make, inputs, loss_fn, steps, warmup)
 
 
-def _run_prefetch(name, make, inputs, loss_fn, steps, warmup=30):     # (two streams: the allocator pools settle over ~20 steps)
+def _run_prefetch(name, make, inputs, loss_fn, steps, warmup=120):    # (two streams: the allocator pools settle over tens of steps)
     """Same, with the encoder's FPS / ball query of the next batch issued on a side stream beside the backward pass
     (networks with ``precompute_sampling``; the input is the same tensor every step, the work is not)."""
     torch.manual_seed(0)
