@@ -265,6 +265,16 @@ int pcl_knn_transpose_i32(const int32_t* idx, int B, int N, int k, int32_t* in_o
  * (WeightNet(3,16)).  The backward entry point returns all three input gradients. */
 int pcl_pointconv_contract_f32(const float* feat, const float* density, const float* weights, int G, int ns, int C, int M,
                                float* out, void* stream);
+/* The same contraction with the feature MLP's last BatchNorm + activation folded into the feature load (misc/pointconv_utils.py:384-389
+ * feeding :393-394): Y [G,ns,C] is that layer's PRE-BatchNorm output, z = lrelu(scale*y + shift, slope) is formed on the fly.  The
+ * backward returns du = d_feat * lrelu'(.) (the gradient w.r.t. the BatchNorm's output) and pcl_pointconv_contract_bn_stat_rows(G)
+ * fp64 partial rows [rows][2][C] of (sum du, sum du*y) for pcl_bn_bwd_consts_f32 / pcl_mlp_stack_bwd_f32 (defer_act). */
+int pcl_pointconv_contract_bn_f32(const float* Y, const float* scale, const float* shift, float slope, const float* density,
+                                  const float* weights, int G, int ns, int C, int M, float* out, void* stream);
+int pcl_pointconv_contract_bn_stat_rows(int G);
+int pcl_pointconv_contract_bn_bwd_f32(const float* dout, const float* Y, const float* scale, const float* shift, float slope,
+                                      const float* density, const float* weights, int G, int ns, int C, int M, float* du,
+                                      float* dweights, float* ddensity, double* stats_ws, void* stream);
 /* reference: gradient of misc/pointconv_utils.py:393-394 */
 int pcl_pointconv_contract_bwd_f32(const float* dout, const float* feat, const float* density, const float* weights, int G,
                                    int ns, int C, int M, float* dfeat, float* dweights, float* ddensity, void* stream);
@@ -431,7 +441,17 @@ typedef struct pcl_mlp_stack_t {
     const float* gout;                       /* backward only */
     float* dx;
     void* stream;
+    int32_t defer_act;                       /* 1 (pool == 0 only): the consumer applies the last layer's BatchNorm + activation itself while loading
+                                              * (PointConv's contraction, pcl_pointconv_contract_bn_f32): the forward stops at the last pre-BatchNorm
+                                              * output (in `save`, see pcl_mlp_stack_last) and writes no `out`; the backward takes gout = the gradient
+                                              * w.r.t. that BatchNorm's OUTPUT already masked by the activation, with its (sum du, sum du*y) partial
+                                              * rows in ext_stats [ext_stat_rows][2][c[L]] (pcl_pointconv_contract_bn_bwd_f32 leaves both) */
+    int32_t ext_stat_rows;
+    const double* ext_stats;
 } pcl_mlp_stack_t;
+/* where, inside `save`, the last layer's pre-BatchNorm output [P, c[L]] and its folded BatchNorm (scale [c[L]], shift [c[L]]) live (byte
+ * offsets): what a deferring consumer reads (defer_act) */
+int pcl_mlp_stack_last(const pcl_mlp_stack_t* desc, size_t* y_offset, size_t* scale_offset, size_t* shift_offset);
 /* reference: no counterpart (Jittor allocates); sizes of `save`, of the forward's `tmp` and of the backward's `tmp` */
 int pcl_mlp_stack_sizes(const pcl_mlp_stack_t* desc, size_t* save_bytes, size_t* fwd_tmp_bytes, size_t* bwd_tmp_bytes);
 /* reference: PointNetModuleBase.execute, networks/cls/pointnet2.py:33-62 (grouper :51, mlp :54, argmax :57) */

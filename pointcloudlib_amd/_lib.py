@@ -47,6 +47,10 @@ _SIGS = {
     "pcl_time_next_launch": (None, [_P, _P]),
     "pcl_time_tagged_launch": (None, [_P, _P, ctypes.c_char_p]),
     "pcl_mlp_stack_sizes": (c_int, [_P, _P, _P, _P]),
+    "pcl_mlp_stack_last": (c_int, [_P, _P, _P, _P]),
+    "pcl_pointconv_contract_bn_f32": (c_int, [_P, _P, _P, c_float, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcl_pointconv_contract_bn_stat_rows": (c_int, [c_int]),
+    "pcl_pointconv_contract_bn_bwd_f32": (c_int, [_P, _P, _P, _P, c_float, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "pcl_mlp_stack_fwd_f32": (c_int, [_P]),
     "pcl_mlp_stack_bwd_f32": (c_int, [_P]),
     "pcl_bn_rows_stats_f32": (c_int, [_P, _P, c_int, c_int, _P, ctypes.POINTER(c_int), _P]),

@@ -19,14 +19,21 @@ constexpr int PC_M = 16;         // WeightNet's output width (pointconv_utils.py
 constexpr int PC_SCH = 64;       // rows of a group staged per pass
 
 // out[g,c,:] ; grid = G, block = 64..256 lanes over channels
+// The feature operand may be given as the PRE-BatchNorm output of the feature MLP's last layer plus that layer's folded
+// BatchNorm (fsc, fsh) and activation slope: z = lrelu(fsc*y + fsh) is then formed while loading -- the [G,ns,C] activation
+// (268 MB at the first two levels) is never written or re-read (misc/pointconv_utils.py:384-389 feeding :393-394).
+struct FeatBN { const float* sc; const float* sh; float slope; };
+__device__ __forceinline__ float feat_act(float y, float a, float b, float slope) { const float t = fmaf(a, y, b); return fmaxf(t, t * slope); }
+
 __global__ __launch_bounds__(256) void pointconv_contract_kernel(const float* __restrict__ feat, const float* __restrict__ dens,
                                                                  const float* __restrict__ w, int ns, int C,
-                                                                 float* __restrict__ out) {
+                                                                 float* __restrict__ out, const FeatBN bn) {
     __shared__ __attribute__((aligned(16))) float swd[PC_SCH * PC_M];
     const int g = blockIdx.x, tid = threadIdx.x;
     const float* F = feat + (size_t)g * ns * C;
     for (int c0 = blockIdx.y * blockDim.x; c0 < C; c0 += gridDim.y * blockDim.x) {      // grid.y: channel blocks (few groups)
         const int c = c0 + tid;
+        const float ba = bn.sc ? bn.sc[min(c, C - 1)] : 1.f, bb = bn.sc ? bn.sh[min(c, C - 1)] : 0.f, bs = bn.sc ? bn.slope : 1.f;
         float acc[PC_M];
 #pragma unroll
         for (int m = 0; m < PC_M; ++m) acc[m] = 0.f;
@@ -40,7 +47,7 @@ __global__ __launch_bounds__(256) void pointconv_contract_kernel(const float* __
                 for (int sb = 0; sb < len; sb += 8) {           // eight rows of the group in flight per lane
                     float f[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) f[u] = F[(size_t)(s0 + min(sb + u, len - 1)) * C + c];
+                    for (int u = 0; u < 8; ++u) f[u] = feat_act(F[(size_t)(s0 + min(sb + u, len - 1)) * C + c], ba, bb, bs);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         if (sb + u >= len) break;
@@ -96,6 +103,80 @@ __global__ __launch_bounds__(256) void pointconv_contract_bwd_feat_kernel(const 
     }
 }
 
+// The same with the feature MLP's last BatchNorm + activation folded in (see FeatBN): what leaves is du = d_feat * lrelu'(fsc*y+fsh),
+// the gradient w.r.t. that BatchNorm's output, and this workgroup's partial row of (sum du, sum du*y) -- the separate
+// elementwise pass (read d_feat and y, write du: 805 MB at the first two levels) is gone.  Persistent over the groups
+// (workgroup bx takes g = bx, bx + gridDim.x, ...), so that a workgroup owns one partial row: no atomics.
+// Block = CB channel lanes x TG groups in flight (512 threads): a workgroup owns one partial row and enough waves to hide the
+// latency of a streaming kernel (one group per workgroup at a time measured 189 us per 268 MB level; this form: see DESIGN).
+constexpr int PCB_T = 512;
+__global__ __launch_bounds__(PCB_T) void pointconv_contract_bwd_feat_bn_kernel(const float* __restrict__ dout, const float* __restrict__ dens,
+                                                                               const float* __restrict__ w, const float* __restrict__ Y,
+                                                                               const FeatBN bn, int G, int ns, int C, int CB, float* __restrict__ du,
+                                                                               double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];                 // [TG][PC_SCH*PC_M] staged weights, then [2][TG][CB] doubles
+    const int TG = PCB_T / CB;
+    const int tid = threadIdx.x, cl = tid % CB, tg = tid / CB;
+    float* swd = dyn + tg * PC_SCH * PC_M;
+    const int gstep = gridDim.x * TG;
+    const int iters = (G + gstep - 1) / gstep;                                   // the same for every thread: block barriers inside
+    for (int c0 = blockIdx.y * CB; c0 < C; c0 += gridDim.y * CB) {
+        const int c = c0 + cl;
+        const bool cok = c < C;
+        const float ba = bn.sc[min(c, C - 1)], bb = bn.sh[min(c, C - 1)];
+        double s1 = 0.0, s2 = 0.0;
+        for (int it = 0; it < iters; ++it) {
+            const int g = blockIdx.x * TG + tg + it * gstep;
+            const bool gok = g < G;
+            const int gg = gok ? g : G - 1;
+            float d[PC_M];
+            {
+                const float4* q = reinterpret_cast<const float4*>(dout + ((size_t)gg * C + min(c, C - 1)) * PC_M);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float4 v = q[j]; d[4 * j] = v.x; d[4 * j + 1] = v.y; d[4 * j + 2] = v.z; d[4 * j + 3] = v.w; }
+            }
+            const size_t base = (size_t)gg * ns * C;
+            float t1 = 0.f, t2 = 0.f;
+            for (int s0 = 0; s0 < ns; s0 += PC_SCH) {
+                const int len = min(PC_SCH, ns - s0);
+                __syncthreads();
+                for (int e = cl; e < len * PC_M; e += CB)
+                    swd[e] = w[((size_t)gg * ns + s0) * PC_M + e] * dens[(size_t)gg * ns + s0 + e / PC_M];
+                __syncthreads();
+                if (cok && gok) {
+                    for (int sb = 0; sb < len; sb += 8) {
+                        float y[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) y[u] = Y[base + (size_t)(s0 + min(sb + u, len - 1)) * C + c];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (sb + u >= len) break;
+                            float a = 0.f;
+#pragma unroll
+                            for (int m = 0; m < PC_M; ++m) a = fmaf(d[m], swd[(sb + u) * PC_M + m], a);
+                            const float v = fmaf(ba, y[u], bb) > 0.f ? a : a * bn.slope;
+                            du[base + (size_t)(s0 + sb + u) * C + c] = v;
+                            t1 += v; t2 = fmaf(v, y[u], t2);
+                        }
+                    }
+                }
+            }
+            s1 += (double)t1; s2 += (double)t2;
+        }
+        // fold the TG group lanes of a channel (fixed order), one row per workgroup
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(dyn);
+        red[tg * CB + cl] = s1; red[(TG + tg) * CB + cl] = s2;
+        __syncthreads();
+        if (tg == 0 && cok) {
+            double a = 0.0, b = 0.0;
+            for (int k = 0; k < TG; ++k) { a += red[k * CB + cl]; b += red[(TG + k) * CB + cl]; }
+            stats[(size_t)blockIdx.x * 2 * C + c] = a; stats[(size_t)blockIdx.x * 2 * C + C + c] = b;
+        }
+        __syncthreads();
+    }
+}
+
 // t[s,m] = sum_c feat[g,s,c] * dout[g,c,m];  d_w = dens * t;  d_dens = sum_m w * t.
 // One wave per group (four groups per workgroup), lane = row s of the group (64 rows per pass), 16 accumulators per lane.
 // The group's feature rows are staged 32 channels at a time through the wave's own LDS slab (coalesced 16-byte loads in,
@@ -108,7 +189,7 @@ constexpr int PC_CCH = 32;
 __global__ __launch_bounds__(256) void pointconv_contract_bwd_w_kernel(const float* __restrict__ feat, const float* __restrict__ dout,
                                                                        const float* __restrict__ dens, const float* __restrict__ w,
                                                                        int G, int ns, int C, float* __restrict__ dw,
-                                                                       float* __restrict__ ddens) {
+                                                                       float* __restrict__ ddens, const FeatBN bn) {
     __shared__ float sf[4][64][PC_CCH + 1];
     __shared__ __attribute__((aligned(16))) float sd[4][PC_CCH * PC_M];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -132,6 +213,16 @@ __global__ __launch_bounds__(256) void pointconv_contract_bwd_w_kernel(const flo
         auto load_chunk = [&](int c0) {
             const int cl = min(PC_CCH, C - c0);
             const int cq = (lane & 7) * 4;
+            float4 ba4 = make_float4(1.f, 1.f, 1.f, 1.f), bb4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bn.sc) {                  // channels as the (clamped) loads below address them
+                if (vec) {
+                    const int cb0 = c0 + min(cq, cl - 4);
+                    ba4 = *reinterpret_cast<const float4*>(bn.sc + cb0); bb4 = *reinterpret_cast<const float4*>(bn.sh + cb0);
+                } else {
+                    ba4 = make_float4(bn.sc[c0 + min(cq, cl - 1)], bn.sc[c0 + min(cq + 1, cl - 1)], bn.sc[c0 + min(cq + 2, cl - 1)], bn.sc[c0 + min(cq + 3, cl - 1)]);
+                    bb4 = make_float4(bn.sh[c0 + min(cq, cl - 1)], bn.sh[c0 + min(cq + 1, cl - 1)], bn.sh[c0 + min(cq + 2, cl - 1)], bn.sh[c0 + min(cq + 3, cl - 1)]);
+                }
+            }
 #pragma unroll
             for (int pass = 0; pass < 8; ++pass) {
                 const int r = pass * 8 + (lane >> 3);
@@ -139,6 +230,10 @@ __global__ __launch_bounds__(256) void pointconv_contract_bwd_w_kernel(const flo
                 float4 v;
                 if (vec) v = *reinterpret_cast<const float4*>(src + min(cq, cl - 4));
                 else { v.x = src[min(cq, cl - 1)]; v.y = src[min(cq + 1, cl - 1)]; v.z = src[min(cq + 2, cl - 1)]; v.w = src[min(cq + 3, cl - 1)]; }
+                if (bn.sc) {              // the feature MLP's folded BatchNorm + activation (this lane's four channels, constants per chunk)
+                    v.x = feat_act(v.x, ba4.x, bb4.x, bn.slope); v.y = feat_act(v.y, ba4.y, bb4.y, bn.slope);
+                    v.z = feat_act(v.z, ba4.z, bb4.z, bn.slope); v.w = feat_act(v.w, ba4.w, bb4.w, bn.slope);
+                }
                 const bool okr = r < len;
                 v.x = okr && cq < cl ? v.x : 0.f; v.y = okr && cq + 1 < cl ? v.y : 0.f;
                 v.z = okr && cq + 2 < cl ? v.z : 0.f; v.w = okr && cq + 3 < cl ? v.w : 0.f;
@@ -219,8 +314,48 @@ extern "C" int pcl_pointconv_contract_f32(const float* feat, const float* densit
                                           int M, float* out, void* stream) {
     PCL_REQUIRE(feat && density && weights && out, "pcl_pointconv_contract_f32: null pointer");
     PCL_REQUIRE(G >= 1 && ns >= 1 && C >= 1 && M == PC_M, "pcl_pointconv_contract_f32: bad sizes G=%d ns=%d C=%d M=%d (M must be 16)", G, ns, C, M);
-    hipLaunchKernelGGL(pointconv_contract_kernel, dim3(G, pc_chan_blocks(G, C)), dim3(pc_block(C)), 0, as_stream(stream), feat, density, weights, ns, C, out);
+    hipLaunchKernelGGL(pointconv_contract_kernel, dim3(G, pc_chan_blocks(G, C)), dim3(pc_block(C)), 0, as_stream(stream), feat, density, weights, ns, C, out,
+                       FeatBN{nullptr, nullptr, 1.f});
     return check_launch("pcl_pointconv_contract_f32");
+}
+
+extern "C" int pcl_pointconv_contract_bn_f32(const float* Y, const float* scale, const float* shift, float slope, const float* density,
+                                             const float* weights, int G, int ns, int C, int M, float* out, void* stream) {
+    PCL_REQUIRE(Y && scale && shift && density && weights && out, "pcl_pointconv_contract_bn_f32: null pointer");
+    PCL_REQUIRE(G >= 1 && ns >= 1 && C >= 1 && M == PC_M && slope >= 0.f && slope <= 1.f, "pcl_pointconv_contract_bn_f32: bad sizes G=%d ns=%d C=%d M=%d slope=%g", G, ns, C, M, (double)slope);
+    hipLaunchKernelGGL(pointconv_contract_kernel, dim3(G, pc_chan_blocks(G, C)), dim3(pc_block(C)), 0, as_stream(stream), Y, density, weights, ns, C, out,
+                       FeatBN{scale, shift, slope});
+    return check_launch("pcl_pointconv_contract_bn_f32");
+}
+
+extern "C" int pcl_pointconv_contract_bn_stat_rows(int G) { return G < 1 ? 0 : (G < 1024 ? G : 1024); }      // (<= G: a workgroup takes >= 1 group)
+
+extern "C" int pcl_pointconv_contract_bn_bwd_f32(const float* dout, const float* Y, const float* scale, const float* shift, float slope,
+                                                 const float* density, const float* weights, int G, int ns, int C, int M, float* du,
+                                                 float* dweights, float* ddensity, double* stats_ws, void* stream) {
+    PCL_REQUIRE(dout && Y && scale && shift && density && weights && du && dweights && ddensity && stats_ws, "pcl_pointconv_contract_bn_bwd_f32: null pointer");
+    PCL_REQUIRE(G >= 1 && ns >= 1 && C >= 1 && M == PC_M && slope >= 0.f && slope <= 1.f, "pcl_pointconv_contract_bn_bwd_f32: bad sizes G=%d ns=%d C=%d M=%d", G, ns, C, M);
+    PCL_REQUIRE(C % 4 != 0 || ((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0, "pcl_pointconv_contract_bn_bwd_f32: scale / shift must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    const FeatBN bn = {scale, shift, slope};
+    const int rows = pcl_pointconv_contract_bn_stat_rows(G);
+    const int CB = pc_block(C) == 192 ? 256 : pc_block(C), TG = PCB_T / CB;          // CB divides 512
+    const size_t lds = (size_t)TG * PC_SCH * PC_M * sizeof(float) > (size_t)2 * TG * CB * sizeof(double) ? (size_t)TG * PC_SCH * PC_M * sizeof(float)
+                                                                                                           : (size_t)2 * TG * CB * sizeof(double);
+    hipLaunchKernelGGL(pointconv_contract_bwd_feat_bn_kernel, dim3(rows, pc_chan_blocks(rows, C)), dim3(PCB_T), lds, st, dout, density, weights, Y, bn,
+                       G, ns, C, CB, du, stats_ws);
+    int rc = check_launch("pcl_pointconv_contract_bn_bwd_f32(feat)");
+    if (rc) return rc;
+    const int wgs = (G + 3) / 4;
+    int slices = wgs >= 512 ? 1 : (512 + wgs - 1) / wgs;
+    if (slices > (C + PC_CCH - 1) / PC_CCH) slices = (C + PC_CCH - 1) / PC_CCH;
+    if (slices > 1) {
+        hipError_t e = hipMemsetAsync(dweights, 0, sizeof(float) * (size_t)G * ns * PC_M, st);
+        if (e == hipSuccess) e = hipMemsetAsync(ddensity, 0, sizeof(float) * (size_t)G * ns, st);
+        if (e != hipSuccess) return fail(PCL_EHIP, "pcl_pointconv_contract_bn_bwd_f32: memset: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(pointconv_contract_bwd_w_kernel, dim3(wgs, slices), dim3(256), 0, st, Y, dout, density, weights, G, ns, C, dweights, ddensity, bn);
+    return check_launch("pcl_pointconv_contract_bn_bwd_f32(w)");
 }
 
 extern "C" int pcl_pointconv_contract_bwd_f32(const float* dout, const float* feat, const float* density, const float* weights,
@@ -242,6 +377,7 @@ extern "C" int pcl_pointconv_contract_bwd_f32(const float* dout, const float* fe
         if (e == hipSuccess) e = hipMemsetAsync(ddensity, 0, sizeof(float) * (size_t)G * ns, st);
         if (e != hipSuccess) return fail(PCL_EHIP, "pcl_pointconv_contract_bwd_f32: memset: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(pointconv_contract_bwd_w_kernel, dim3(wgs, slices), dim3(256), 0, st, feat, dout, density, weights, G, ns, C, dweights, ddensity);
+    hipLaunchKernelGGL(pointconv_contract_bwd_w_kernel, dim3(wgs, slices), dim3(256), 0, st, feat, dout, density, weights, G, ns, C, dweights, ddensity,
+                       FeatBN{nullptr, nullptr, 1.f});
     return check_launch("pcl_pointconv_contract_bwd_f32(w)");
 }

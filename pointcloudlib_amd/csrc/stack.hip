@@ -169,6 +169,7 @@ static int validate(const pcl_mlp_stack_t* dp, const char* who) {
     PCL_REQUIRE(d.P >= 1, "%s: P=%d", who, d.P);
     for (int l = 0; l <= d.n_layers; ++l) PCL_REQUIRE(d.c[l] >= 1, "%s: c[%d]=%d", who, l, d.c[l]);
     PCL_REQUIRE(d.pool >= 0 && (d.pool == 0 || d.grouped || d.P % d.pool == 0), "%s: pool=%d does not divide P=%d", who, d.pool, d.P);
+    PCL_REQUIRE(!d.defer_act || (d.pool == 0 && !d.grouped), "%s: defer_act needs a plain stack without a max", who);
     if (d.grouped) {
         PCL_REQUIRE(d.n_layers >= 2, "%s: a grouped stack needs >= 2 layers (the folded layer's gradient arrives dense from the second)", who);
         PCL_REQUIRE(d.B >= 1 && d.N >= 1 && d.m >= 1 && d.pool >= 1 && d.P == d.B * d.m * d.pool, "%s: grouped: P=%d must be B*m*ns = %d*%d*%d", who, d.P, d.B, d.m, d.pool);
@@ -205,10 +206,21 @@ extern "C" int pcl_mlp_stack_sizes(const pcl_mlp_stack_t* d, size_t* save_bytes,
     return PCL_OK;
 }
 
+extern "C" int pcl_mlp_stack_last(const pcl_mlp_stack_t* d, size_t* y_offset, size_t* scale_offset, size_t* shift_offset) {
+    PCL_TRY(validate(d, "pcl_mlp_stack_last"));
+    char* const base = reinterpret_cast<char*>(uintptr_t(4096));          // any non-null base: only differences are used
+    const SaveLayout s = save_layout(*d, base);
+    const int L = d->n_layers;
+    if (y_offset) *y_offset = (size_t)(reinterpret_cast<char*>(s.Y[L - 1]) - base);
+    if (scale_offset) *scale_offset = (size_t)(reinterpret_cast<char*>(s.vec[L - 1]) - base);
+    if (shift_offset) *shift_offset = (size_t)(reinterpret_cast<char*>(s.vec[L - 1] + d->c[L]) - base);
+    return PCL_OK;
+}
+
 extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
     PCL_TRY(validate(dp, "pcl_mlp_stack_fwd_f32"));
     const pcl_mlp_stack_t& d = *dp;
-    PCL_REQUIRE(d.out && d.save && d.tmp, "pcl_mlp_stack_fwd_f32: null out / save / tmp");
+    PCL_REQUIRE((d.out || d.defer_act) && d.save && d.tmp, "pcl_mlp_stack_fwd_f32: null out / save / tmp");
     const SaveLayout s = save_layout(d, d.save);
     const FwdTmp t = fwd_tmp(d, d.tmp);
     if (d.save_bytes < s.bytes || d.tmp_bytes < t.bytes)
@@ -258,9 +270,9 @@ extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
         if (use_gmax(d)) PCL_TRY(pcl_group_minmax_finalize_f32(t.gmax, t.gmin, t.gamax, t.gamin, in_scale, in_shift, d.out_slope, G, cl, d.out, s.arg, s.ymax, st));
         else if (d.grouped) { tagf("maxrows%d", cl, 0); PCL_TRY(pcl_bn_act_max_rows_f32(cur, d.group_off, in_scale, in_shift, d.out_slope, G, cl, d.out, s.arg, s.ymax, st)); }
         else { tagf("max%d", cl, 0); PCL_TRY(pcl_bn_act_max_f32(cur, in_scale, in_shift, d.out_slope, G, d.pool, cl, d.out, s.arg, s.ymax, st)); }
-    } else {
+    } else if (!d.defer_act) {
         PCL_TRY(pcl_bn_act_f32(cur, in_scale, in_shift, d.out_slope, P, cl, d.out, st));
-    }
+    }                                   // defer_act: the consumer forms lrelu(scale*y + shift) itself while loading Y[L-1]
     set_launch_tag("");
     return PCL_OK;
 }
@@ -268,7 +280,8 @@ extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
 extern "C" int pcl_mlp_stack_bwd_f32(const pcl_mlp_stack_t* dp) {
     PCL_TRY(validate(dp, "pcl_mlp_stack_bwd_f32"));
     const pcl_mlp_stack_t& d = *dp;
-    PCL_REQUIRE(d.out && d.save && d.tmp && d.gout, "pcl_mlp_stack_bwd_f32: null out / save / tmp / gout");
+    PCL_REQUIRE((d.out || d.defer_act) && d.save && d.tmp && d.gout, "pcl_mlp_stack_bwd_f32: null out / save / tmp / gout");
+    PCL_REQUIRE(!d.defer_act || (d.ext_stats && d.ext_stat_rows >= 1), "pcl_mlp_stack_bwd_f32: defer_act needs ext_stats / ext_stat_rows");
     const SaveLayout s = save_layout(d, d.save);
     const BwdTmp t = bwd_tmp(d, d.tmp);
     if (d.save_bytes < s.bytes || d.tmp_bytes < t.bytes)
@@ -285,6 +298,7 @@ extern "C" int pcl_mlp_stack_bwd_f32(const pcl_mlp_stack_t* dp) {
     const int cl = d.c[L];
     int rows = 0, cur_stats = 0, cur_du = 0, cur_c = 0;
     const float* dU = nullptr;          // dense gradient w.r.t. the current layer's BatchNorm output (null: sparse (arg, gz))
+    const double* ext_stats = nullptr;  // defer_act: the first layer's sums come from the consumer
     bool sparse;
     const float* vL = s.vec[L - 1];
     if (G) {
@@ -294,6 +308,9 @@ extern "C" int pcl_mlp_stack_bwd_f32(const pcl_mlp_stack_t* dp) {
         PCL_TRY(maxgrad_prep_impl(d.gout, d.out, s.ymax, d.out_slope, G, cl, t.gz, t.stats[0], &rows, st, t.dUf, nz, t.unit, t.unit ? d.c[1] : 0,
                                   t.unit ? 2 * d.c[1] : 0));
         sparse = true;
+    } else if (d.defer_act) {
+        // the consumer already formed du (masked by the activation) and its two channel sums
+        dU = d.gout; ext_stats = d.ext_stats; rows = d.ext_stat_rows; cur_du = 0; sparse = false;
     } else {
         PCL_TRY(pcl_bn_act_bwd_f32(d.gout, s.Y[L - 1], vL, vL + cl, d.out_slope, P, cl, t.dU[0], t.stats[0], &rows, st));
         dU = t.dU[0]; cur_du = 1; sparse = false;
@@ -307,7 +324,9 @@ extern "C" int pcl_mlp_stack_bwd_f32(const pcl_mlp_stack_t* dp) {
         float* k = t.consts[cur_c];
         float *a = k, *k1 = k + cout, *k2 = k + 2 * cout;
         if (!have_pre)
-            PCL_TRY(pcl_bn_bwd_consts_f32(t.stats[cur_stats], rows, ly.gamma, mean, invstd, P, cout, ly.dgamma, ly.dbeta, a, k1, k2, ly.dbias, st));
+            PCL_TRY(pcl_bn_bwd_consts_f32(ext_stats ? ext_stats : t.stats[cur_stats], rows, ly.gamma, mean, invstd, P, cout, ly.dgamma, ly.dbeta, a, k1,
+                                          k2, ly.dbias, st));
+        if (ext_stats) { ext_stats = nullptr; cur_stats = 1 - cur_stats; }      // (the layer below writes stats[1 - cur_stats]: keep the ping-pong consistent)
         have_pre = false;
         if (l == 0 && d.grouped) {
             // the folded first layer: dy = a*du - w*(k1 + k2*(y - mean)) per distinct row, scattered to the points / summed into dWx

@@ -511,21 +511,22 @@ class _CStack(ctypes.Structure):
                 + [(n, ctypes.c_void_p) for n in ("x", "xyz", "new_xyz", "feature", "Wf_dense", "idx", "cnt", "group_off")]
                 + [("layer", _CLayer * _MAXL), ("out", ctypes.c_void_p), ("save", ctypes.c_void_p), ("save_bytes", ctypes.c_size_t),
                    ("tmp", ctypes.c_void_p), ("tmp_bytes", ctypes.c_size_t), ("gout", ctypes.c_void_p), ("dx", ctypes.c_void_p),
-                   ("stream", ctypes.c_void_p)])
+                   ("stream", ctypes.c_void_p), ("defer_act", ctypes.c_int32), ("ext_stat_rows", ctypes.c_int32),
+                   ("ext_stats", ctypes.c_void_p)])
 
 
 class _StackPlan:
     """Everything about one (module, input shape) that does not change from step to step: the filled-in descriptor (only
     pointers are patched per call), buffer sizes, the layout of the flat parameter-gradient buffer."""
     __slots__ = ("desc", "ref", "save_bytes", "fwd_tmp", "bwd_tmp", "G", "cl", "L", "has_bias", "gsizes", "gshapes", "gtotal",
-                 "spec", "grouped", "wide", "off", "P", "c0")
+                 "spec", "grouped", "wide", "off", "P", "c0", "defer", "last_off", "out_slope")
 
 
 _PLANS = {}
 
 
-def _stack_plan(module, P, c0, pool, grouped, geom, need_dx, x_grad_from):
-    key = (id(module), P, c0, pool, grouped, geom, need_dx, x_grad_from, module.slope, module.last_act)
+def _stack_plan(module, P, c0, pool, grouped, geom, need_dx, x_grad_from, defer=False):
+    key = (id(module), P, c0, pool, grouped, geom, need_dx, x_grad_from, module.slope, module.last_act, defer)
     plan = _PLANS.get(key)
     if plan is not None and plan.spec is module.spec:
         return plan
@@ -538,6 +539,7 @@ def _stack_plan(module, P, c0, pool, grouped, geom, need_dx, x_grad_from):
     for l in range(L):
         d.c[l + 1] = spec[l + 1]
     d.P, d.pool, d.grouped, d.x_grad_from, d.need_dx = P, pool, int(grouped), int(x_grad_from), int(need_dx)
+    d.defer_act = int(defer)
     if grouped:
         d.B, d.N, d.m, d.Cf, d.use_xyz = geom
     d.slope, d.out_slope, d.eps, d.momentum = module.slope, (module.slope if module.last_act else 1.0), module.eps, module.momentum
@@ -552,6 +554,11 @@ def _stack_plan(module, P, c0, pool, grouped, geom, need_dx, x_grad_from):
     plan = _StackPlan()
     plan.desc, plan.ref = d, ctypes.byref(d)
     plan.save_bytes, plan.fwd_tmp, plan.bwd_tmp = sv.value, ft.value, bt.value
+    plan.defer, plan.last_off, plan.out_slope = bool(defer), None, (module.slope if module.last_act else 1.0)
+    if defer:
+        yo, so, ho = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(_lib.lib().pcl_mlp_stack_last(ctypes.byref(d), ctypes.byref(yo), ctypes.byref(so), ctypes.byref(ho)), "pcl_mlp_stack_last")
+        plan.last_off = (yo.value, so.value, ho.value)
     plan.L, plan.cl, plan.spec, plan.grouped, plan.P, plan.c0 = L, spec[L], module.spec, grouped, P, c0
     plan.G = (geom[0] * geom[2]) if grouped else (P // pool if pool else 0)
     plan.has_bias = module.biases is not None
@@ -596,14 +603,24 @@ class _StackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, t_in, aux, *params):
-        plan, geo, running = aux
+        plan, geo, running = aux[0], aux[1], aux[2]
         d, L = plan.desc, plan.L
         dev = params[0].device
         npl = 4 if plan.has_bias else 3
         st = _stream()
         save = torch.empty((plan.save_bytes,), dtype=torch.uint8, device=dev)
         tmp = torch.empty((plan.fwd_tmp,), dtype=torch.uint8, device=dev)
-        out = torch.empty((plan.G if plan.G else plan.P, plan.cl), dtype=torch.float32, device=dev)
+        if plan.defer:
+            # the consumer applies the last BatchNorm + activation itself (PointConv's contraction): what this node returns is
+            # the last PRE-BatchNorm output, a view into `save`; scale / shift travel through the link
+            yo, so, ho = plan.last_off
+            out = save[yo:yo + 4 * plan.P * plan.cl].view(torch.float32).view(plan.P, plan.cl)
+            link = aux[3]
+            link.scale = save[so:so + 4 * plan.cl].view(torch.float32)
+            link.shift = save[ho:ho + 4 * plan.cl].view(torch.float32)
+            link.slope = plan.out_slope
+        else:
+            out = torch.empty((plan.G if plan.G else plan.P, plan.cl), dtype=torch.float32, device=dev)
         Wf = None
         if plan.grouped:
             xyz, new_xyz, idx, cnt, group_off = geo
@@ -620,9 +637,11 @@ class _StackFn(torch.autograd.Function):
             ly.W, ly.gamma, ly.beta = q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr()
             ly.bias = q[3].data_ptr() if plan.has_bias else None
             ly.running_mean, ly.running_var = running[2 * l].data_ptr(), running[2 * l + 1].data_ptr()
-        d.out, d.save, d.save_bytes, d.tmp, d.tmp_bytes, d.stream = out.data_ptr(), save.data_ptr(), plan.save_bytes, tmp.data_ptr(), plan.fwd_tmp, st
+        d.out = None if plan.defer else out.data_ptr()
+        d.save, d.save_bytes, d.tmp, d.tmp_bytes, d.stream = save.data_ptr(), plan.save_bytes, tmp.data_ptr(), plan.fwd_tmp, st
         _lib.call("pcl_mlp_stack_fwd_f32", plan.ref, tag="stack_fwd")
         ctx.plan = plan
+        ctx.link = aux[3] if plan.defer else None
         ctx.save_for_backward(t_in, out, save, Wf, *(geo if plan.grouped else ()), *params)
         return out
 
@@ -671,8 +690,14 @@ class _StackFn(torch.autograd.Function):
                 grads.append(pieces[k + 3])
             else:
                 ly.dbias = None
-        d.out, d.save, d.save_bytes, d.tmp, d.tmp_bytes = out.data_ptr(), save.data_ptr(), plan.save_bytes, tmp.data_ptr(), plan.bwd_tmp
+        d.out = None if plan.defer else out.data_ptr()
+        d.save, d.save_bytes, d.tmp, d.tmp_bytes = save.data_ptr(), plan.save_bytes, tmp.data_ptr(), plan.bwd_tmp
         d.gout, d.dx, d.stream = gout.data_ptr(), (None if dx is None else dx.data_ptr()), _stream()
+        if plan.defer:
+            # gout IS du (the consumer masked it with the activation and left the BatchNorm-backward sums in the link)
+            link = ctx.link
+            d.ext_stats, d.ext_stat_rows = link.stats.data_ptr(), link.rows
+            link.stats = None
         _lib.call("pcl_mlp_stack_bwd_f32", plan.ref, tag="stack_bwd")
         return (dx, None) + tuple(grads)
 
@@ -697,6 +722,29 @@ def stack_plain(module, x2, ns, x_grad_from):
     plan = _stack_plan(module, P, c0, ns, False, None, need_dx, x_grad_from if need_dx else 0)
     ps, running = _stack_params(module)
     return _StackFn.apply(x2, (plan, None, running), *ps)
+
+
+class DeferLink:
+    """Side channel between a deferring stack (_StackFn, plan.defer) and the consumer that applies its last BatchNorm + activation
+    (pointconv_utils._PointConvContractBN): forward hands over scale / shift / slope, backward the (sum du, sum du*y) rows."""
+    __slots__ = ("scale", "shift", "slope", "stats", "rows")
+
+    def __init__(self):
+        self.scale = self.shift = self.stats = None
+        self.slope, self.rows = 0.0, 0
+
+
+def stack_plain_deferred(module, x2):
+    """Plain stack on rows x2 [P, C0] WITHOUT its last BatchNorm + activation: returns (Y_last [P, CL] pre-BatchNorm, link) for a
+    consumer that folds them into its own operand load; None when the stack path does not apply."""
+    if not (_stack_eligible(module) and module.weights[0].shape[1] == x2.shape[1]):
+        return None
+    P, c0 = x2.shape
+    need_dx = x2.requires_grad
+    plan = _stack_plan(module, P, c0, 0, False, None, need_dx, 0, defer=True)
+    ps, running = _stack_params(module)
+    link = DeferLink()
+    return _StackFn.apply(x2, (plan, None, running, link), *ps), link
 
 
 def stack_grouped(module, xyz, new_xyz, feature, idx, cnt, group_off, use_xyz):

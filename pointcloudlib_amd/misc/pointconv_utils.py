@@ -103,6 +103,53 @@ class _PointConvContract(torch.autograd.Function):
         return dfeat, dd, dw
 
 
+class _PointConvContractBN(torch.autograd.Function):
+    """The contraction with the feature MLP's last BatchNorm + activation folded into its feature load (csrc/pointconv.hip,
+    FeatBN): ``Y`` [B,S,ns,C] is that layer's pre-BatchNorm output (mlp_hip.stack_plain_deferred), z = lrelu(scale*y + shift) is
+    formed on the fly; the backward hands the deferring stack du (masked) and its BatchNorm-backward sums through ``link``.
+    Saves one write + one read of the [B,S,ns,C] activation forward and an 805 MB elementwise pass backward per level."""
+
+    @staticmethod
+    def forward(ctx, Y, link, density, weights):
+        B, S, ns, C = Y.shape
+        M = weights.shape[-1]
+        density, weights = _dev(density, "density"), _dev(weights, "weights")
+        out = torch.empty((B, S, C * M), dtype=torch.float32, device=Y.device)
+        _lib.call("pcl_pointconv_contract_bn_f32", _p(Y), _p(link.scale), _p(link.shift), float(link.slope), _p(density), _p(weights), B * S, ns, C,
+                  M, _p(out), _stream(), algo_bytes=4 * B * S * (ns * (C + 1 + M) + C * M), algo_flops=2 * B * S * ns * C * M)
+        ctx.link = link
+        ctx.save_for_backward(Y, density, weights, link.scale, link.shift)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        Y, density, weights, scale, shift = ctx.saved_tensors
+        link = ctx.link
+        B, S, ns, C = Y.shape
+        M = weights.shape[-1]
+        gout = _dev(gout, "grad")
+        du, dw, dd = torch.empty_like(Y), torch.empty_like(weights), torch.empty_like(density)
+        rows = _lib.size_query("pcl_pointconv_contract_bn_stat_rows", B * S)
+        stats = torch.empty((rows, 2, C), dtype=torch.float64, device=Y.device)
+        _lib.call("pcl_pointconv_contract_bn_bwd_f32", _p(gout), _p(Y), _p(scale), _p(shift), float(link.slope), _p(density), _p(weights), B * S,
+                  ns, C, M, _p(du), _p(dw), _p(dd), _p(stats), _stream())
+        link.stats, link.rows = stats, rows
+        return du, None, dd, dw
+
+
+def feature_mlp_contract(mlp, new_points, grouped_density, weights):
+    """``pointconv_contract(mlp(new_points), grouped_density, weights)`` (misc/pointconv_utils.py:384-394).  Where the feature MLP
+    runs on the per-stack entry points its last BatchNorm + activation are folded into the contraction's feature load."""
+    from . import mlp_hip
+    B, S, ns, _ = new_points.shape
+    if new_points.is_cuda and new_points.dtype == torch.float32 and mlp.last_act is not None:
+        r = mlp_hip.stack_plain_deferred(mlp, new_points.reshape(B * S * ns, new_points.shape[-1]).contiguous())
+        if r is not None:
+            Y, link = r
+            return _PointConvContractBN.apply(Y.view(B, S, ns, Y.shape[-1]), link, grouped_density.reshape(B, S, ns).contiguous(), weights)
+    return pointconv_contract(mlp(new_points.contiguous()), grouped_density, weights)
+
+
 def pointconv_contract(new_points, grouped_density, weights):
     """The density multiply + per-point (C x ns)(ns x 16) contraction of PointConv as one HIP kernel:
     new_points [B,S,ns,C], grouped_density [B,S,ns,1], weights [B,S,ns,16] -> [B,S,C*16]."""
@@ -159,9 +206,9 @@ class PointConvDensitySetAbstraction(nn.Module):
         else:
             new_xyz, new_points, grouped_xyz_norm, _, grouped_density = sample_and_group(
                 self.npoint, self.nsample, xyz, points, density_scale, start_idx, knn_idx)
-        new_points = self.mlp(new_points.contiguous())                                   # [B,S,ns,C]   :384-389
         weights = self.weightnet(grouped_xyz_norm.contiguous())                          # [B,S,ns,16]  :391-392
-        new_points = pointconv_contract(new_points, grouped_density, weights)            # [B,S,C*16]   :393-394
+        # feature MLP :384-389 + density multiply and per-point matmul :393-394 (the MLP's last BatchNorm + ReLU ride in the contraction)
+        new_points = feature_mlp_contract(self.mlp, new_points, grouped_density, weights)     # [B,S,C*16]
         new_points = self.linear(new_points)                                              # :395-397
         return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
 
@@ -198,9 +245,8 @@ class PointConvDensitySetInterpolation(nn.Module):
         density_scale = self.densitynet(compute_density(xyz1, self.bandwidth))            # :304-305
         _, new_points, grouped_xyz_norm, _, grouped_density = sample_and_group(
             N, self.nsample, xyz1, interpolated, density_scale, start_idx)                # :307
-        new_points = self.mlp(new_points.contiguous())                                    # :311-315
         weights = self.weightnet(grouped_xyz_norm.contiguous())                           # :317-318
-        new_points = pointconv_contract(new_points, grouped_density, weights)            # :319-320
+        new_points = feature_mlp_contract(self.mlp, new_points, grouped_density, weights)     # :311-315 + :319-320
         return self.linear(new_points).permute(0, 2, 1)                                   # :321-323
 
     def execute(self, *a, **k):

@@ -334,3 +334,41 @@ def test_lean_sgd_is_torch_fused_sgd(dev):
             assert torch.equal(p.data, q.data), step
     for p, q in zip(pa, pb):
         assert torch.equal(oa.state[p]["momentum_buffer"], ob.state[q]["momentum_buffer"])
+
+
+@pytest.mark.parametrize("B,S,ns,Cin,spec,slope", [(4, 96, 32, 19, [64, 64, 128], 0.0), (2, 1, 128, 35, [32, 96], 0.0), (3, 40, 24, 7, [16, 8], 0.2)])
+def test_pointconv_feature_mlp_folded_into_the_contraction(dev, B, S, ns, Cin, spec, slope):
+    """feature_mlp_contract: the feature MLP's last BatchNorm + activation applied inside the contraction kernels (forward and
+    backward, csrc/pointconv.hip FeatBN; the stack defers them, csrc/stack.hip defer_act) against the unfused composition
+    ``pointconv_contract(mlp(x), density, weights)`` on the per-kernel path: same outputs, same gradients (fp64 partial sums in
+    another order), same running statistics."""
+    import copy
+    from pointcloudlib_amd.misc import mlp_hip, pointconv_utils as pu
+    from pointcloudlib_amd.misc.layers import PointwiseMLP
+    torch.manual_seed(B * S + ns)
+    mlp = PointwiseMLP([Cin] + spec, bias=True, slope=slope).to(dev).train()
+    with torch.no_grad():
+        for g in mlp.gammas:
+            g.uniform_(0.5, 1.5); g[::3] *= -1.0
+    x0 = torch.randn(B, S, ns, Cin, device=dev)
+    dens0 = torch.rand(B, S, ns, 1, device=dev) + 0.5
+    w0 = torch.randn(B, S, ns, 16, device=dev)
+    gout = torch.randn(B, S, spec[-1] * 16, device=dev)
+    res = []
+    for fused in (False, True):
+        m = copy.deepcopy(mlp)
+        x, dn, w = (t.clone().requires_grad_(True) for t in (x0, dens0, w0))
+        if fused:
+            out = pu.feature_mlp_contract(m, x, dn, w)
+        else:
+            with mlp_hip.per_kernel_path():
+                out = pu.pointconv_contract(m(x), dn, w)
+        out.backward(gout)
+        res.append((out.detach(), [x.grad, dn.grad, w.grad] + [p.grad for p in m.parameters()], [b.clone() for b in m.buffers()]))
+    (o0, g0, b0), (o1, g1, b1) = res
+    assert (o0 - o1).abs().max().item() <= 1e-6 * max(1.0, o0.abs().max().item())
+    gs = max(t.abs().max().item() for t in g0)
+    for a, b in zip(g0, g1):
+        assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item() + 1e-7 * gs
+    for a, b in zip(b0, b1):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-6, atol=1e-7)
