@@ -160,6 +160,12 @@ int group_linear_bwd_impl(const float* row_loc, const float* row_feat, int CF, c
                           const float* k1, const float* k2, const float* mu, const int32_t* row_src, const int32_t* n_rows_dev, int B, int N,
                           int C1, float* dUf, float* dWx_part, float* dWf_part, float* dW0, int ldw, int off, void* stream, bool duf_is_zero);
 
+__global__ __launch_bounds__(256) void aux_fill_kernel(float4* zero, size_t n4, float* ones, int n_one, int n_zero) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (size_t)gridDim.x * 256) zero[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x == 0 && ones)
+        for (int e = threadIdx.x; e < n_one + n_zero; e += 256) ones[e] = e < n_one ? 1.f : 0.f;
+}
+
 static int validate(const pcl_mlp_stack_t* dp, const char* who) {
     PCL_REQUIRE(dp, "%s: null descriptor", who);
     const pcl_mlp_stack_t& d = *dp;
@@ -169,7 +175,7 @@ static int validate(const pcl_mlp_stack_t* dp, const char* who) {
     PCL_REQUIRE(d.P >= 1, "%s: P=%d", who, d.P);
     for (int l = 0; l <= d.n_layers; ++l) PCL_REQUIRE(d.c[l] >= 1, "%s: c[%d]=%d", who, l, d.c[l]);
     PCL_REQUIRE(d.pool >= 0 && (d.pool == 0 || d.grouped || d.P % d.pool == 0), "%s: pool=%d does not divide P=%d", who, d.pool, d.P);
-    PCL_REQUIRE(!d.defer_act || (d.pool == 0 && !d.grouped), "%s: defer_act needs a plain stack without a max", who);
+    PCL_REQUIRE(!d.defer_act || d.pool == 0 || d.grouped, "%s: defer_act: a plain stack must have no max (a grouped one keeps its rows: no pooling)", who);
     if (d.grouped) {
         PCL_REQUIRE(d.n_layers >= 2, "%s: a grouped stack needs >= 2 layers (the folded layer's gradient arrives dense from the second)", who);
         PCL_REQUIRE(d.B >= 1 && d.N >= 1 && d.m >= 1 && d.pool >= 1 && d.P == d.B * d.m * d.pool, "%s: grouped: P=%d must be B*m*ns = %d*%d*%d", who, d.P, d.B, d.m, d.pool);
@@ -178,7 +184,7 @@ static int validate(const pcl_mlp_stack_t* dp, const char* who) {
         PCL_REQUIRE(d.use_xyz || d.Cf > 0, "%s: grouped: neither coordinates nor features", who);
         PCL_REQUIRE(d.c[0] == (d.use_xyz ? 3 : 0) + d.Cf, "%s: grouped: c[0]=%d must be the first layer's fan-in %d", who, d.c[0], (d.use_xyz ? 3 : 0) + d.Cf);
         PCL_REQUIRE(!grouped_wide(d) || d.Wf_dense, "%s: grouped: wide features need Wf_dense", who);
-        PCL_REQUIRE(!d.layer[0].bias, "%s: grouped: the folded first layer takes no conv bias", who);
+        PCL_REQUIRE(!d.layer[0].bias || grouped_wide(d), "%s: grouped: a conv bias of the folded first layer rides in the per-point product (wide features only)", who);
     } else {
         PCL_REQUIRE(d.x, "%s: null input", who);
     }
@@ -242,7 +248,8 @@ extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
             const bool inl = grouped_inline(d), wide = grouped_wide(d);
             if (wide) {
                 tagf("pt%dx%d", d.Cf, cout);
-                PCL_TRY(pcl_linear_fwd_rows_f32(d.feature, d.Wf_dense, nullptr, nullptr, nullptr, 0.f, d.B * d.N, d.Cf, cout, t.Uf,
+                // (a conv bias of the folded layer is added here, once per point: every row gathers exactly one Uf row)
+                PCL_TRY(pcl_linear_fwd_rows_f32(d.feature, d.Wf_dense, ly.bias, nullptr, nullptr, 0.f, d.B * d.N, d.Cf, cout, t.Uf,
                                                 t.pt_stats, nullptr, nullptr, st));
             }
             tagf("glin%d", cout, 0);
@@ -266,7 +273,7 @@ extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
         cur = Y; in_scale = v; in_shift = v + cout;
     }
     const int cl = d.c[L];
-    if (G) {
+    if (G && !d.defer_act) {
         if (use_gmax(d)) PCL_TRY(pcl_group_minmax_finalize_f32(t.gmax, t.gmin, t.gamax, t.gamin, in_scale, in_shift, d.out_slope, G, cl, d.out, s.arg, s.ymax, st));
         else if (d.grouped) { tagf("maxrows%d", cl, 0); PCL_TRY(pcl_bn_act_max_rows_f32(cur, d.group_off, in_scale, in_shift, d.out_slope, G, cl, d.out, s.arg, s.ymax, st)); }
         else { tagf("max%d", cl, 0); PCL_TRY(pcl_bn_act_max_f32(cur, in_scale, in_shift, d.out_slope, G, d.pool, cl, d.out, s.arg, s.ymax, st)); }
@@ -301,16 +308,23 @@ extern "C" int pcl_mlp_stack_bwd_f32(const pcl_mlp_stack_t* dp) {
     const double* ext_stats = nullptr;  // defer_act: the first layer's sums come from the consumer
     bool sparse;
     const float* vL = s.vec[L - 1];
-    if (G) {
+    if (d.defer_act) {
+        // the consumer already formed du (masked by the activation) and its two channel sums
+        dU = d.gout; ext_stats = d.ext_stats; rows = d.ext_stat_rows; cur_du = 0; sparse = false;
+        if (t.dUf) {                    // (grouped, wide features: what the max-gradient launch does on the side in the pooled case)
+            const size_t nz4 = ((size_t)d.B * d.N * d.c[1] + 3) / 4;
+            int blocks = (int)((nz4 + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(aux_fill_kernel, dim3(blocks), dim3(256), 0, as_stream(st), reinterpret_cast<float4*>(t.dUf), nz4, t.unit, d.c[1], 2 * d.c[1]);
+            PCL_TRY(check_launch("pcl_mlp_stack_bwd_f32(aux)"));
+        }
+    } else if (G) {
         // side jobs of this first launch (grouped stacks with wide features): clear the target of the folded layer's atomics and
         // write the unit constants of its point GEMMs -- a memset and a fill launch less
         const size_t nz = t.dUf ? ((size_t)d.B * d.N * d.c[1] + 3) / 4 * 4 : 0;
         PCL_TRY(maxgrad_prep_impl(d.gout, d.out, s.ymax, d.out_slope, G, cl, t.gz, t.stats[0], &rows, st, t.dUf, nz, t.unit, t.unit ? d.c[1] : 0,
                                   t.unit ? 2 * d.c[1] : 0));
         sparse = true;
-    } else if (d.defer_act) {
-        // the consumer already formed du (masked by the activation) and its two channel sums
-        dU = d.gout; ext_stats = d.ext_stats; rows = d.ext_stat_rows; cur_du = 0; sparse = false;
     } else {
         PCL_TRY(pcl_bn_act_bwd_f32(d.gout, s.Y[L - 1], vL, vL + cl, d.out_slope, P, cl, t.dU[0], t.stats[0], &rows, st));
         dU = t.dU[0]; cur_du = 1; sparse = false;

@@ -747,6 +747,36 @@ def stack_plain_deferred(module, x2):
     return _StackFn.apply(x2, (plan, None, running, link), *ps), link
 
 
+_FULL = {}
+
+
+def stack_grouped_deferred(module, xyz, new_xyz, feature, idx, use_xyz=True):
+    """Grouping by FULL neighbour lists (k-NN groups: every slot a distinct point; PointConv's sample_and_group,
+    misc/pointconv_utils.py:133-170) + ``module`` WITHOUT its last BatchNorm + activation and without a max: the first conv is
+    folded into the grouping (pcl_group_linear_f32: the [B,S,ns,3+D] grouped tensor never exists, its K = 3+D first GEMM
+    runs over the N points instead of the S*ns rows), the consumer applies the last BatchNorm + activation while loading.
+    Returns (Y [B*S*ns, CL], link) or None when this path does not apply."""
+    if feature is None or feature.shape[-1] <= 4 or not use_xyz:
+        return None
+    if not (_stack_eligible(module) and module.n_layers >= 2 and module.spec[1] <= 256):
+        return None
+    B, m, ns = idx.shape
+    N = xyz.shape[1]
+    Cf = feature.shape[-1]
+    key = (xyz.device, B * m, ns)
+    full = _FULL.get(key)
+    if full is None:
+        full = _FULL[key] = (torch.full((B, m), ns, dtype=torch.int32, device=xyz.device),
+                             (torch.arange(B * m + 1, dtype=torch.int64, device=xyz.device) * ns).to(torch.int32))
+    cnt, group_off = full
+    need_dx = feature.requires_grad
+    plan = _stack_plan(module, B * m * ns, 3 + Cf, ns, True, (B, N, m, Cf, 1), need_dx, 0, defer=True)
+    ps, running = _stack_params(module)
+    link = DeferLink()
+    Y = _StackFn.apply(feature.contiguous(), (plan, (xyz.contiguous(), new_xyz.contiguous(), idx.contiguous(), cnt, group_off), running, link), *ps)
+    return Y, link
+
+
 def stack_grouped(module, xyz, new_xyz, feature, idx, cnt, group_off, use_xyz):
     B, m, ns = idx.shape
     N = xyz.shape[1]

@@ -137,6 +137,19 @@ class _PointConvContractBN(torch.autograd.Function):
         return du, None, dd, dw
 
 
+def grouped_feature_mlp_contract(mlp, xyz, new_xyz, points, idx, grouped_density, weights):
+    """``feature_mlp_contract(mlp, cat([xyz[idx] - new_xyz, points[idx]]), ...)`` without the grouped tensor: the feature MLP's first
+    conv is folded into the grouping (``W0 [dxyz | f] = W0[:, :3] dxyz + (points W0[:, 3:]^T)[idx]``: one GEMM over the N points),
+    its last BatchNorm + activation into the contraction.  None when that path does not apply (the caller builds the tensor)."""
+    from . import mlp_hip
+    r = mlp_hip.stack_grouped_deferred(mlp, xyz, new_xyz, points, idx)
+    if r is None:
+        return None
+    Y, link = r
+    B, S, ns = idx.shape
+    return _PointConvContractBN.apply(Y.view(B, S, ns, Y.shape[-1]), link, grouped_density.reshape(B, S, ns).contiguous(), weights)
+
+
 def feature_mlp_contract(mlp, new_points, grouped_density, weights):
     """``pointconv_contract(mlp(new_points), grouped_density, weights)`` (misc/pointconv_utils.py:384-394).  Where the feature MLP
     runs on the per-stack entry points its last BatchNorm + activation are folded into the contraction's feature load."""
@@ -201,6 +214,21 @@ class PointConvDensitySetAbstraction(nn.Module):
         if points is not None:
             points = points.permute(0, 2, 1).contiguous()
         density_scale = self.densitynet(compute_density(xyz, self.bandwidth))            # :376-377  [B,N,1]
+        if not self.group_all and points is not None and xyz.is_cuda:
+            # sample_and_group :133-170 WITHOUT the [B,S,ns,3+D] tensor: indices, centres, local coordinates and gathered density
+            # only; the feature MLP's first conv runs folded into the grouping (grouped_feature_mlp_contract)
+            fps_idx = farthest_point_sample(xyz, self.npoint, start_idx)
+            new_xyz = index_points(xyz, fps_idx)
+            idx = knn_point(self.nsample, xyz, new_xyz) if knn_idx is None else _dev(knn_idx, "knn_idx", torch.int32)
+            grouped_xyz_norm = index_points(xyz, idx) - new_xyz.view(B, self.npoint, 1, 3)
+            grouped_density = index_points(density_scale, idx)
+            weights = self.weightnet(grouped_xyz_norm.contiguous())                      # [B,S,ns,16]  :391-392
+            out = grouped_feature_mlp_contract(self.mlp, xyz, new_xyz, points, idx, grouped_density, weights)
+            if out is None:
+                new_points = torch.cat([grouped_xyz_norm, index_points(points, idx)], dim=-1)
+                out = feature_mlp_contract(self.mlp, new_points, grouped_density, weights)
+            new_points = self.linear(out)                                                 # :395-397
+            return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
         if self.group_all:
             new_xyz, new_points, grouped_xyz_norm, grouped_density = sample_and_group_all(xyz, points, density_scale)
         else:

@@ -372,3 +372,36 @@ def test_pointconv_feature_mlp_folded_into_the_contraction(dev, B, S, ns, Cin, s
         assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item() + 1e-7 * gs
     for a, b in zip(b0, b1):
         assert torch.allclose(a.float(), b.float(), rtol=1e-6, atol=1e-7)
+
+
+def test_pointconv_set_abstraction_folded_paths_equal_the_composition(dev):
+    """PointConvDensitySetAbstraction with points: the product path (first conv folded into the k-NN grouping, last BatchNorm + ReLU
+    folded into the contraction, per-stack entry points) against the plain composition on the per-kernel entry points
+    (cat([xyz[idx] - new_xyz, points[idx]]) -> MLP -> contraction): outputs, input-feature gradient and every parameter gradient."""
+    import copy
+    from pointcloudlib_amd import synth
+    from pointcloudlib_amd.misc import mlp_hip, pointconv_utils as pu
+    torch.manual_seed(3)
+    B, N, S, ns, D = 4, 512, 96, 24, 37
+    xyz = torch.from_numpy(synth.gauss_ball(B, N, 77)).to(dev).permute(0, 2, 1).contiguous()
+    pts0 = torch.randn(B, D, N, device=dev)
+    sa = pu.PointConvDensitySetAbstraction(npoint=S, nsample=ns, in_channel=D + 3, mlp=[48, 64], bandwidth=0.2, group_all=False).to(dev).train()
+    start = torch.zeros(B, dtype=torch.int32, device=dev)
+    gout = torch.randn(B, 64, S, device=dev)
+    res = []
+    for product in (False, True):
+        m = copy.deepcopy(sa)
+        p = pts0.clone().requires_grad_(True)
+        if product:
+            _, out = m(xyz, p, start)
+        else:
+            with mlp_hip.per_kernel_path():
+                _, out = m(xyz, p, start)
+        out.backward(gout)
+        res.append((out.detach(), p.grad.detach(), {n: q.grad.detach() for n, q in m.named_parameters()}))
+    (o0, f0, g0), (o1, f1, g1) = res
+    assert (o0 - o1).abs().max().item() <= 2e-5 * max(1.0, o0.abs().max().item())
+    gs = max(t.abs().max().item() for t in g0.values())
+    assert (f0 - f1).abs().max().item() <= 1e-4 * f0.abs().max().item() + 1e-7 * gs
+    for n in g0:
+        assert (g0[n] - g1[n]).abs().max().item() <= 1e-4 * g0[n].abs().max().item() + 1e-6 * gs, n
