@@ -11,6 +11,7 @@ pin_to_gpu_node(0)
 
 FP32_PEAK_TFLOPS, HBM_PEAK_GBS = 157.3, 8000.0        # MI355X_MICROARCH.md: dense fp32 MFMA, HBM3E
 ONLY = None                                            # --only: substring filter on the config names
+TABLE = 0                                              # --table N: print the N most expensive (entry point, shape) rows of each config
 
 
 def roofline_of(step):
@@ -24,6 +25,11 @@ def roofline_of(step):
         torch.cuda.synchronize()
         summ = _lib.PROFILER.summary()
         _lib.PROFILER = None
+    if TABLE:
+        for (n, t), v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:TABLE]:
+            gbs = v["algo_bytes"] / (v["avg_ms"] * 1e-3) / 1e9 if v["algo_bytes"] else 0
+            tf = v["algo_flops"] / (v["avg_ms"] * 1e-3) / 1e12 if v["algo_flops"] else 0
+            print(f"    {n:32s} {t:16s} n/step={v['launches'] / 2:4.1f} avg={v['avg_ms'] * 1e3:8.1f} us  {gbs:8.1f} GB/s {tf:7.2f} TF", file=sys.stderr)
     by_name = {}
     for (n, t), v in summ.items():
         if n != "pcl_fps_f32":                        # latency-bound chain, runs beside the GEMMs where sampling is prefetched
@@ -170,10 +176,11 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--out", default=None)
     ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU restatement of configs 2', 3, 4, 5 (tens of seconds each)")
+    ap.add_argument("--table", type=int, default=0, help="print the N most expensive (entry point, launch shape) rows per config to stderr")
     ap.add_argument("--only", default=None, help="run only the configs whose name contains this (one config under rocprofv3)")
     a = ap.parse_args()
-    global ONLY, CPU_BASELINE
-    ONLY, CPU_BASELINE = a.only, a.cpu_baseline
+    global ONLY, CPU_BASELINE, TABLE
+    ONLY, CPU_BASELINE, TABLE = a.only, a.cpu_baseline, a.table
     from pointcloudlib_amd.networks.cls.pointnet import PointNet
     from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
     from pointcloudlib_amd.networks.cls.dgcnn import DGCNN
