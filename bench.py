@@ -277,11 +277,16 @@ def main():
     fence()
     t0 = time.perf_counter()
     _lib.PROFILER = timer
+    host_trace = [] if os.environ.get("PCL_HOST_TRACE") else None      # lab switch: when does the HOST leave each step?
     for j in range(args.steps):
         step(it)
         it += 1
+        if host_trace is not None:
+            host_trace.append(time.perf_counter() - t0)
     fence()
     dt = time.perf_counter() - t0
+    if host_trace is not None and rank == 0:
+        print("host left step j at [ms]: " + " ".join(f"{t * 1e3:.2f}" for t in host_trace) + f" | fence at {dt * 1e3:.2f}", file=sys.stderr)
     _lib.PROFILER = None
     # host side of a step (untimed extras): the time Python needs to ENQUEUE one step with the stream empty behind it (4
     # steps back to back without a sync; the launch queue is deeper than that), and the number of own C-ABI launches

@@ -119,16 +119,25 @@ class SamplingPrefetch:
                     xyz = s[0]
             ev = torch.cuda.Event()
             ev.record(stream)
-        return {"levels": out, "event": ev, "stream": stream}
+        # "fed_from": every batch of work on `stream` starts by waiting for this consumer stream (the wait_stream above), so
+        # memory of this handle that the host frees after enqueueing its consumers can only be handed out again -- by the
+        # per-stream pools of the caching allocator, to a LATER call of this function -- behind those consumers.
+        return {"levels": out, "event": ev, "stream": stream, "fed_from": cur}
 
     @staticmethod
     def adopt_sampling(sampling):
-        """Make the current stream wait for a handle produced on another stream (and tell the allocator about the use)."""
+        """Make the current stream wait for a handle produced on another stream.  When the handle was produced by
+        ``precompute_sampling`` from this same consumer stream, reuse of its memory is already ordered (see there) and
+        nothing else is needed; for a handle of any other origin the allocator is told about the use (``record_stream``).
+        That fallback is not free: every recorded tensor costs an event record on the consumer stream when it dies -- ten
+        marker packets = 45 us of idle main stream at the head of each PointNet++ step (tools/dbg/section_times.py)."""
         if sampling is None:
             return
         cur = torch.cuda.current_stream()
         if sampling.get("event") is not None and sampling["stream"] != cur:
             cur.wait_event(sampling["event"])
+            if sampling.get("fed_from") == cur:
+                return
             for new_xyz, idxs in sampling["levels"]:              # allocator safety across streams
                 for t in [new_xyz] + [u for ic in idxs if ic is not None for u in ic]:
                     if t is not None:

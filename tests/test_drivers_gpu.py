@@ -69,3 +69,73 @@ def test_lean_sgd_survives_load_state_dict(dev):
         assert torch.equal(a.state[p]["momentum_buffer"], b.state[q]["momentum_buffer"])
     a.state.clear(); b.state.clear()                      # state re-created behind the optimizer's back
     step(); step()
+
+
+@pytest.mark.parametrize("model", ["cls", "partseg_msg"])
+def test_sampling_prefetch_equals_inline_sampling(dev, model):
+    """The bench / train drivers produce the FPS + ball-query indices of batch t+1 on a side stream under the backward of
+    batch t (SamplingPrefetch.precompute_sampling).  The handle's memory comes from the side stream's allocator pool and is
+    consumed on the main stream WITHOUT record_stream (reuse is ordered by the wait_stream at the head of every
+    precompute_sampling): 24 training steps over rotating batches must reproduce the inline-sampling run -- identical
+    indices every step (an early reuse of a live index buffer would corrupt them), the first losses to rounding and the
+    later ones to 2e-2 (the head's dX uses float atomics and max-pool winners flip on 1e-7 differences: two INLINE runs part
+    the same way, by 1e-3 after twenty steps even at this tiny learning rate)."""
+    import copy
+    import torch
+    from pointcloudlib_amd import synth
+    from pointcloudlib_amd.train_utils import make_sgd, soft_cross_entropy_loss
+    from pointcloudlib_amd.misc import head as _head
+    torch.manual_seed(0)
+    if model == "cls":
+        from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
+        B, N = 16, 1024
+        net_a = PointNet2_cls().to(dev).train()
+        ys = [torch.from_numpy(synth.labels(B, 40, 30 + i)).to(dev) for i in range(3)]
+        call = lambda net, x, f, y, s: soft_cross_entropy_loss(net(x, f, sampling=s), y)
+    else:
+        from pointcloudlib_amd.networks.seg.pointnet2_partseg import PointNetMSG
+        B, N = 4, 1024
+        net_a = PointNetMSG(part_num=50).to(dev).train()
+        ys = [torch.randint(0, 50, (B, N), device=dev) for i in range(3)]
+        cls = torch.zeros(B, 16, device=dev); cls[:, 3] = 1
+        call = lambda net, x, f, y, s: torch.nn.functional.cross_entropy(net(x, f, cls, sampling=s), y)
+    net_b = copy.deepcopy(net_a)
+    xs = [torch.from_numpy(synth.gauss_ball(B, N, 10 + i)).to(dev) for i in range(3)]
+    fs = [torch.from_numpy(synth.unit_normals(B, N, 20 + i)).to(dev) for i in range(3)]
+    side = torch.cuda.Stream(priority=-1)
+
+    def run(net, prefetch):
+        torch.manual_seed(1)                                  # the head's dropout masks: hash of (torch seed, call counter)
+        _head._DROP_CALLS[0] = 0
+        opt = make_sgd(net.parameters(), lr=1e-5, momentum=0.9)
+        losses, digests, pending = [], [], {}
+        for i in range(24):
+            opt.zero_grad(set_to_none=True)
+            s = pending.pop(i, None)
+            if not prefetch:
+                s = net.precompute_sampling(xs[i % 3])
+            elif s is None:
+                s = net.precompute_sampling(xs[i % 3], stream=side)
+            loss = call(net, xs[i % 3], fs[i % 3], ys[i % 3], s)
+            if prefetch:
+                pending[i + 1] = net.precompute_sampling(xs[(i + 1) % 3], stream=side)
+                assert pending[i + 1]["fed_from"] == torch.cuda.current_stream()
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+            # digest of every index tensor of the handle, taken on the consumer stream AFTER the whole step was enqueued
+            d = torch.zeros((), dtype=torch.int64, device=dev)
+            for new_xyz, idxs in s["levels"]:
+                for ic in idxs:
+                    for u in (ic or ()):
+                        if u is not None and not u.is_floating_point():
+                            d = d * 1000003 + u.to(torch.int64).sum()
+            digests.append(d)
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu(), torch.stack(digests).cpu()
+
+    la, da = run(net_a, False)
+    lb, db = run(net_b, True)
+    assert torch.equal(da, db), "sampling indices differ between the prefetched and the inline run"
+    assert torch.allclose(la[:3], lb[:3], rtol=1e-5, atol=1e-6), (la - lb).abs()[:3]
+    assert torch.allclose(la, lb, rtol=0, atol=2e-2), (la - lb).abs().max()
