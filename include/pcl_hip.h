@@ -396,8 +396,10 @@ int pcl_linear_bwd_dw_f32(const float* dU, const float* Y, const float* a, const
  *   plain stack:   x [P, c[0]] -> out [P, c[L]] (pool = 0) or [P/pool, c[L]] (max over groups of `pool` consecutive rows)
  *   grouped stack: (xyz [B,N,3], new_xyz [B,m,3], feature [B,N,Cf] | NULL, idx [B,m,ns], cnt [B,m], group_off [B*m+1]) ->
  *                  out [B*m, c[L]]; c[0] = 3*use_xyz + Cf, P = B*m*ns (row capacity), pool = ns; layer[0].W is the stored
- *                  first-layer weight [c[1], c[0]] (no bias); Wf_dense = a dense copy of its feature columns [c[1], Cf],
- *                  needed when Cf > 4 or the features require a gradient.
+ *                  first-layer weight [c[1], c[0]] (no bias); Wf_dense = a caller-owned BUFFER [c[1], Cf] that the
+ *                  forward call fills with the feature columns of that weight (dense: the point GEMM wants 16-byte aligned
+ *                  rows) and the backward call reads -- keep it with `save`; needed when Cf > 4 or the features require
+ *                  a gradient.
  * Backward: gout [as out]; writes layer[l].dW / dgamma / dbeta (/ dbias) and, with need_dx, dx = the input gradient
  * ([P, c[0]], columns below x_grad_from unwritten) of a plain stack or dfeature [B*N, Cf] of a grouped one. */
 #define PCL_STACK_MAX_LAYERS 8
@@ -428,7 +430,7 @@ typedef struct pcl_mlp_stack_t {
     const float* xyz;                        /* grouped only ... */
     const float* new_xyz;
     const float* feature;
-    const float* Wf_dense;
+    float* Wf_dense;
     const int32_t* idx;
     const int32_t* cnt;
     const int32_t* group_off;

@@ -181,6 +181,9 @@ constexpr int GL_MAXH = 4;       // channels per lane: C1 <= 256
 constexpr int GL_RPI = 4;        // rows in flight per wave
 constexpr int GL_CF = 4;         // features folded inline (e.g. the 3 normals of the first level), wider ones come as Uf
 
+// side job of the metadata kernel: the feature columns of the folded layer's weight as a dense matrix for the point GEMM
+struct DenseJob { const float* src; float* dst; int rows, cols, ldw, first, blocks; };
+
 // metadata of the distinct rows: one wave per group
 // Also per row: rloc = (xyz[nbr] - centre, multiplicity) and rfeat = the (<= 4) inline feature columns, so that the
 // streaming kernels below read one or two 16-byte records per row instead of a dozen scalars.
@@ -189,7 +192,15 @@ __global__ __launch_bounds__(256) void group_rows_meta_kernel(const float* __res
                                                               const int32_t* __restrict__ idx, const int32_t* __restrict__ cnt,
                                                               const int32_t* __restrict__ goff, int G, int N, int m, int ns,
                                                               int2* __restrict__ rmeta, int32_t* __restrict__ rsrc,
-                                                              float4* __restrict__ rloc, float4* __restrict__ rfeat) {
+                                                              float4* __restrict__ rloc, float4* __restrict__ rfeat, DenseJob dj) {
+    if ((int)blockIdx.x >= dj.first) {       // side job (stack.hip): columns [off, off + cols) of W[rows][ldw] -> dense [rows][cols]
+        const int n = dj.rows * dj.cols;
+        for (int i = ((int)blockIdx.x - dj.first) * 256 + (int)threadIdx.x; i < n; i += dj.blocks * 256) {
+            const int r = i / dj.cols;
+            dj.dst[i] = dj.src[(size_t)r * dj.ldw + (i - r * dj.cols)];
+        }
+        return;
+    }
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (g >= G) return;
     const int c = max(cnt[g], 1), base = goff[g], b = g / m;
@@ -586,13 +597,29 @@ constexpr int GL_BLOCKS = 1024;     // 4 workgroups of 4 waves per CU = one resi
 
 extern "C" int pcl_group_linear_stat_rows(int B, int m) { return (B < 1 || m < 1) ? 0 : GL_BLOCKS; }
 
+namespace pcl {
+int group_linear_fwd_impl(const float* xyz, const float* new_xyz, const float* Uf, const float* Wx, const float* feat_small,
+                          const float* Wf_small, int CF, int ldw, const int32_t* idx, const int32_t* cnt, const int32_t* group_off, int B,
+                          int N, int m, int ns, int C1, float* Y, int32_t* row_meta, int32_t* row_src, float* row_loc, float* row_feat,
+                          double* stats_ws, void* stream, int phase, const float* dense_src, float* dense_dst, int dense_cols);
+}
 extern "C" int pcl_group_linear_f32(const float* xyz, const float* new_xyz, const float* Uf, const float* Wx, const float* feat_small,
                                     const float* Wf_small, int CF, int ldw, const int32_t* idx, const int32_t* cnt,
                                     const int32_t* group_off, int B, int N, int m, int ns, int C1, float* Y, int32_t* row_meta,
                                     int32_t* row_src, float* row_loc, float* row_feat, double* stats_ws, void* stream) {
+    return group_linear_fwd_impl(xyz, new_xyz, Uf, Wx, feat_small, Wf_small, CF, ldw, idx, cnt, group_off, B, N, m, ns, C1, Y, row_meta, row_src,
+                                 row_loc, row_feat, stats_ws, stream, 3, nullptr, nullptr, 0);
+}
+// phase: 1 = the row metadata only (+ the densify side job: dense_dst[C1][dense_cols] = dense_src[C1][ldw] columns, stack.hip
+// runs the point GEMM that needs it between the two phases), 2 = the streaming kernel only, 3 = both
+int pcl::group_linear_fwd_impl(const float* xyz, const float* new_xyz, const float* Uf, const float* Wx, const float* feat_small,
+                               const float* Wf_small, int CF, int ldw, const int32_t* idx, const int32_t* cnt, const int32_t* group_off,
+                               int B, int N, int m, int ns, int C1, float* Y, int32_t* row_meta, int32_t* row_src, float* row_loc,
+                               float* row_feat, double* stats_ws, void* stream, int phase, const float* dense_src, float* dense_dst,
+                               int dense_cols) {
     PCL_REQUIRE(idx && cnt && group_off && Y && row_meta && row_src && row_loc && stats_ws, "pcl_group_linear_f32: null pointer");
     PCL_REQUIRE(CF == 0 || row_feat, "pcl_group_linear_f32: inline features need row_feat");
-    PCL_REQUIRE(Uf || Wx || CF > 0, "pcl_group_linear_f32: need features (Uf or feat_small) and/or coordinates (Wx)");
+    PCL_REQUIRE(phase == 1 || Uf || Wx || CF > 0, "pcl_group_linear_f32: need features (Uf or feat_small) and/or coordinates (Wx)");
     PCL_REQUIRE(CF >= 0 && CF <= GL_CF && (CF == 0 || (feat_small && Wf_small)), "pcl_group_linear_f32: CF=%d inline features (<= %d)", CF, GL_CF);
     PCL_REQUIRE(!Wx || (xyz && new_xyz), "pcl_group_linear_f32: Wx needs xyz and new_xyz");
     PCL_REQUIRE(ldw >= (Wx ? 3 : 0) && ldw >= CF, "pcl_group_linear_f32: ldw=%d", ldw);
@@ -600,11 +627,16 @@ extern "C" int pcl_group_linear_f32(const float* xyz, const float* new_xyz, cons
                 "pcl_group_linear_f32: bad sizes B=%d N=%d m=%d ns=%d C1=%d (C1 <= %d)", B, N, m, ns, C1, 64 * GL_MAXH);
     const int G = B * m;
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(group_rows_meta_kernel, dim3((G + 3) / 4), dim3(256), 0, st, Wx ? xyz : nullptr, new_xyz, feat_small, CF, idx, cnt,
-                       group_off, G, N, m, ns, reinterpret_cast<int2*>(row_meta), row_src, reinterpret_cast<float4*>(row_loc),
-                       reinterpret_cast<float4*>(CF ? row_feat : nullptr));
-    int rc = check_launch("pcl_group_linear_f32(meta)");
-    if (rc) return rc;
+    if (phase & 1) {
+        const int gb = (G + 3) / 4;
+        DenseJob dj = {dense_src, dense_dst, C1, dense_cols, ldw, gb, 0};
+        if (dense_dst) dj.blocks = (C1 * dense_cols + 1023) / 1024 < 64 ? (C1 * dense_cols + 1023) / 1024 : 64;
+        hipLaunchKernelGGL(group_rows_meta_kernel, dim3(gb + dj.blocks), dim3(256), 0, st, Wx ? xyz : nullptr, new_xyz, feat_small, CF, idx, cnt,
+                           group_off, G, N, m, ns, reinterpret_cast<int2*>(row_meta), row_src, reinterpret_cast<float4*>(row_loc),
+                           reinterpret_cast<float4*>(CF ? row_feat : nullptr), dj);
+        int rc = check_launch("pcl_group_linear_f32(meta)");
+        if (rc || phase == 1) return rc;
+    }
     const float4* rl = reinterpret_cast<const float4*>(row_loc);
     const float4* rf = reinterpret_cast<const float4*>(row_feat);
     const dim3 grid(GL_BLOCKS), block(256);

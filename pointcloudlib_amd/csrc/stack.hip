@@ -156,6 +156,10 @@ static BwdTmp bwd_tmp(const pcl_mlp_stack_t& d, void* base) {
 
 int maxgrad_prep_impl(const float* gout, const float* out, const float* ymax, float slope, int G, int C, float* gz, double* stats_ws,
                       int* stat_rows_out, void* stream, float* zero, size_t n_zero, float* ones, int n_one, int n_one0);
+int group_linear_fwd_impl(const float* xyz, const float* new_xyz, const float* Uf, const float* Wx, const float* feat_small,
+                          const float* Wf_small, int CF, int ldw, const int32_t* idx, const int32_t* cnt, const int32_t* group_off, int B,
+                          int N, int m, int ns, int C1, float* Y, int32_t* row_meta, int32_t* row_src, float* row_loc, float* row_feat,
+                          double* stats_ws, void* stream, int phase, const float* dense_src, float* dense_dst, int dense_cols);
 int group_linear_bwd_impl(const float* row_loc, const float* row_feat, int CF, const float* dU, const float* Y, const float* a,
                           const float* k1, const float* k2, const float* mu, const int32_t* row_src, const int32_t* n_rows_dev, int B, int N,
                           int C1, float* dUf, float* dWx_part, float* dWf_part, float* dW0, int ldw, int off, void* stream, bool duf_is_zero);
@@ -247,15 +251,21 @@ extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
             const int off = d.use_xyz ? 3 : 0, ldw = d.c[0];
             const bool inl = grouped_inline(d), wide = grouped_wide(d);
             if (wide) {
+                // row metadata first: its kernel also copies the feature columns of W (row stride c0, rows not 16-byte aligned)
+                // into the dense matrix the point GEMM reads -- no separate copy launch per step
+                PCL_TRY(group_linear_fwd_impl(d.xyz, d.new_xyz, nullptr, d.use_xyz ? ly.W : nullptr, nullptr, nullptr, 0, ldw, d.idx, d.cnt,
+                                              d.group_off, d.B, d.N, d.m, d.pool, cout, Y, s.row_meta, s.row_src, s.row_loc, s.row_feat, t.stats,
+                                              st, 1, ly.W + off, d.Wf_dense, d.Cf));
                 tagf("pt%dx%d", d.Cf, cout);
                 // (a conv bias of the folded layer is added here, once per point: every row gathers exactly one Uf row)
                 PCL_TRY(pcl_linear_fwd_rows_f32(d.feature, d.Wf_dense, ly.bias, nullptr, nullptr, 0.f, d.B * d.N, d.Cf, cout, t.Uf,
                                                 t.pt_stats, nullptr, nullptr, st));
             }
             tagf("glin%d", cout, 0);
-            PCL_TRY(pcl_group_linear_f32(d.xyz, d.new_xyz, wide ? t.Uf : nullptr, d.use_xyz ? ly.W : nullptr, inl ? d.feature : nullptr,
-                                         inl ? ly.W + off : nullptr, inl ? d.Cf : 0, ldw, d.idx, d.cnt, d.group_off, d.B, d.N, d.m,
-                                         d.pool, cout, Y, s.row_meta, s.row_src, s.row_loc, s.row_feat, t.stats, st));
+            PCL_TRY(group_linear_fwd_impl(d.xyz, d.new_xyz, wide ? t.Uf : nullptr, d.use_xyz ? ly.W : nullptr, inl ? d.feature : nullptr,
+                                          inl ? ly.W + off : nullptr, inl ? d.Cf : 0, ldw, d.idx, d.cnt, d.group_off, d.B, d.N, d.m,
+                                          d.pool, cout, Y, s.row_meta, s.row_src, s.row_loc, s.row_feat, t.stats, st, wide ? 2 : 3, nullptr,
+                                          nullptr, 0));
             rows = pcl_group_linear_stat_rows(d.B, d.m);
         } else if (l == L - 1 && use_gmax(d)) {
             tagf("fwd%dx%d", cin, cout);

@@ -627,7 +627,7 @@ class _StackFn(torch.autograd.Function):
             d.xyz, d.new_xyz, d.idx, d.cnt, d.group_off = xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), cnt.data_ptr(), group_off.data_ptr()
             d.feature = None if t_in is None else t_in.data_ptr()
             if plan.wide:
-                Wf = params[0][:, plan.off:].contiguous()          # the point GEMM wants its weight dense
+                Wf = torch.empty((params[0].shape[0], params[0].shape[1] - plan.off), dtype=torch.float32, device=dev)   # filled by the call (dense feature columns of W0)
             d.Wf_dense = None if Wf is None else Wf.data_ptr()
             d.x = None
         else:

@@ -8,6 +8,7 @@ channel-last tensors end to end: the reference's two NCHW transposes around ``nn
 Deliberate deviations from upstream bugs: ``PointnetModuleMSG`` iterates the
 ``mlps`` list directly (upstream :96 calls ``.layers.items()`` on a Python list and cannot be built).
 """
+import os
 from typing import List, Optional
 
 import torch
@@ -95,6 +96,9 @@ class PointnetModuleMSG(PointNetModuleBase):
             self.mlps.append(self.build_mlps(mlp, use_xyz, bn))
 
 
+_AB_RECORD_STREAM = bool(os.environ.get("PCL_AB_RECORD_STREAM"))        # lab switch for A/B timing on one box
+
+
 class SamplingPrefetch:
     """For networks with a ``pointnet_modules`` list: every index-producing op (FPS + ball query per level) depends on xyz
     only, so the set for a batch can be produced ahead of its forward pass, on another stream."""
@@ -136,7 +140,7 @@ class SamplingPrefetch:
         cur = torch.cuda.current_stream()
         if sampling.get("event") is not None and sampling["stream"] != cur:
             cur.wait_event(sampling["event"])
-            if sampling.get("fed_from") == cur:
+            if sampling.get("fed_from") == cur and not _AB_RECORD_STREAM:
                 return
             for new_xyz, idxs in sampling["levels"]:              # allocator safety across streams
                 for t in [new_xyz] + [u for ic in idxs if ic is not None for u in ic]:

@@ -139,3 +139,4 @@ def test_sampling_prefetch_equals_inline_sampling(dev, model):
     assert torch.equal(da, db), "sampling indices differ between the prefetched and the inline run"
     assert torch.allclose(la[:3], lb[:3], rtol=1e-5, atol=1e-6), (la - lb).abs()[:3]
     assert torch.allclose(la, lb, rtol=0, atol=2e-2), (la - lb).abs().max()
+
