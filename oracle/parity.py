@@ -64,7 +64,17 @@ FEATURE_WAIVERS = [
       "(either side of 1 depending on summation order), PyTorch-CPU 2.5 x")),
 ]
 GRAD_WAIVERS = [
-    # none in use.  (r2's 800 %-relative-error row, PointConv's sa?.densitynet.mlp.gammas.2, is analytically ZERO -- the last
+    ("PointConv*", "sa1.densitynet.mlp.*",
+     ("W-G1 density-branch gradient", 5e-4,
+      "DensityNet of the first level (1 -> 8 -> 8 -> 1 on 32 768 points): its weight gradients are residuals of two nested "
+      "cancellations -- BatchNorm backward of a ONE-channel output (dy = du - mean(du) - yhat mean(du yhat) removes most of du) "
+      "and a batch sum of 32 768 signed terms (|g| = 3e-2 against a model-wide 1.2) -- so fp32 summation-order noise of the "
+      "incoming gradient (the contraction's density branch: sum over C x 16 products per grouped point, then 16 atomic adds per "
+      "point) shows at 1e-3 in PyTorch-CPU fp32 and 4-9e-3 here (relL2; the 10x rule is missed by 10 % on max-norm for "
+      "weights.2).  Not the density input (same figures with the oracle's densities fed in, tools/dbg/pc_density_src.py), not "
+      "the DensityNet kernels (against fp64 on equal inputs they are closer than PyTorch fp32, tools/dbg/narrow_err.py).  Absolute "
+      "error 2.8e-4 = 2.3e-4 of the model's largest gradient entry; capped at 5e-4.")),
+    # (r2's 800 %-relative-error row, PointConv's sa?.densitynet.mlp.gammas.2, is analytically ZERO -- the last
     # DensityNet layer is BatchNorm(1 channel) + ReLU with beta = 0, so gamma scales every input of the Linear + BatchNorm that
     # follows, which removes it again -- and its absolute error, 1.6e-7 against a model-wide largest gradient entry of O(1), is
     # below ABS_FLOOR: it reports as "noise-floor" with max|err| and max|g64| printed beside it.)

@@ -154,6 +154,12 @@ static BwdTmp bwd_tmp(const pcl_mlp_stack_t& d, void* base) {
     return t;
 }
 
+bool narrow_supported(const pcl_mlp_stack_t& d);            // narrow.hip: three layers of <= 16 channels, recomputed per pass
+size_t narrow_save_bytes();
+size_t narrow_fwd_tmp_bytes();
+size_t narrow_bwd_tmp_bytes();
+int narrow_fwd(const pcl_mlp_stack_t& d);
+int narrow_bwd(const pcl_mlp_stack_t& d);
 int maxgrad_prep_impl(const float* gout, const float* out, const float* ymax, float slope, int G, int C, float* gz, double* stats_ws,
                       int* stat_rows_out, void* stream, float* zero, size_t n_zero, float* ones, int n_one, int n_one0);
 int group_linear_fwd_impl(const float* xyz, const float* new_xyz, const float* Uf, const float* Wx, const float* feat_small,
@@ -210,6 +216,12 @@ using namespace pcl;
 
 extern "C" int pcl_mlp_stack_sizes(const pcl_mlp_stack_t* d, size_t* save_bytes, size_t* fwd_tmp_bytes, size_t* bwd_tmp_bytes) {
     PCL_TRY(validate(d, "pcl_mlp_stack_sizes"));
+    if (narrow_supported(*d)) {
+        if (save_bytes) *save_bytes = narrow_save_bytes();
+        if (fwd_tmp_bytes) *fwd_tmp_bytes = narrow_fwd_tmp_bytes();
+        if (bwd_tmp_bytes) *bwd_tmp_bytes = narrow_bwd_tmp_bytes();
+        return PCL_OK;
+    }
     if (save_bytes) *save_bytes = save_layout(*d, nullptr).bytes;
     if (fwd_tmp_bytes) *fwd_tmp_bytes = fwd_tmp(*d, nullptr).bytes;
     if (bwd_tmp_bytes) *bwd_tmp_bytes = bwd_tmp(*d, nullptr).bytes;
@@ -231,6 +243,11 @@ extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
     PCL_TRY(validate(dp, "pcl_mlp_stack_fwd_f32"));
     const pcl_mlp_stack_t& d = *dp;
     PCL_REQUIRE((d.out || d.defer_act) && d.save && d.tmp, "pcl_mlp_stack_fwd_f32: null out / save / tmp");
+    if (narrow_supported(d)) {
+        if (d.save_bytes < narrow_save_bytes() || d.tmp_bytes < narrow_fwd_tmp_bytes())
+            return fail(PCL_EWS, "pcl_mlp_stack_fwd_f32: save %zu < %zu or tmp %zu < %zu", d.save_bytes, narrow_save_bytes(), d.tmp_bytes, narrow_fwd_tmp_bytes());
+        return narrow_fwd(d);
+    }
     const SaveLayout s = save_layout(d, d.save);
     const FwdTmp t = fwd_tmp(d, d.tmp);
     if (d.save_bytes < s.bytes || d.tmp_bytes < t.bytes)
@@ -299,6 +316,14 @@ extern "C" int pcl_mlp_stack_bwd_f32(const pcl_mlp_stack_t* dp) {
     const pcl_mlp_stack_t& d = *dp;
     PCL_REQUIRE((d.out || d.defer_act) && d.save && d.tmp && d.gout, "pcl_mlp_stack_bwd_f32: null out / save / tmp / gout");
     PCL_REQUIRE(!d.defer_act || (d.ext_stats && d.ext_stat_rows >= 1), "pcl_mlp_stack_bwd_f32: defer_act needs ext_stats / ext_stat_rows");
+    if (narrow_supported(d)) {
+        if (d.save_bytes < narrow_save_bytes() || d.tmp_bytes < narrow_bwd_tmp_bytes())
+            return fail(PCL_EWS, "pcl_mlp_stack_bwd_f32: save %zu < %zu or tmp %zu < %zu", d.save_bytes, narrow_save_bytes(), d.tmp_bytes, narrow_bwd_tmp_bytes());
+        for (int l = 0; l < d.n_layers; ++l)
+            PCL_REQUIRE(d.layer[l].dW && d.layer[l].dgamma && d.layer[l].dbeta && (!d.layer[l].bias || d.layer[l].dbias),
+                        "pcl_mlp_stack_bwd_f32: layer %d: null gradient output", l);
+        return narrow_bwd(d);
+    }
     const SaveLayout s = save_layout(d, d.save);
     const BwdTmp t = bwd_tmp(d, d.tmp);
     if (d.save_bytes < s.bytes || d.tmp_bytes < t.bytes)

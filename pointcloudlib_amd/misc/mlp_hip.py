@@ -578,7 +578,9 @@ def _stack_plan(module, P, c0, pool, grouped, geom, need_dx, x_grad_from, defer=
 class per_kernel_path:
     """``with per_kernel_path(): ...`` -- run the stacks and the FC head through the per-kernel entry points (one C-ABI call per
     kernel) instead of the per-stack ones: the same kernels in the same order, bit-identical results
-    (tests/test_mlp_hip.py).  For the profiling passes that bracket individual C-ABI calls with events
+    (tests/test_mlp_hip.py) -- except for the narrow stacks (PointConv's WeightNet / DensityNet, csrc/narrow.hip), which exist
+    behind the per-stack entry point only and run on the GEMM kernels here (equal to rounding,
+    ``test_narrow_stack_equals_the_gemm_path_at_size``).  For the profiling passes that bracket individual C-ABI calls with events
     (``_lib.KernelTimer``: bench.py's choice of the dominant kernel, tools/bench_models.py, ``--profile-all``)."""
 
     def __enter__(self):

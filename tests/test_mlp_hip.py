@@ -579,3 +579,99 @@ def test_resident_weight_forward_kernel_against_fp64(dev, spec, rows, bias, slop
     assert (got.detach().cpu().double() - want.detach()).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
     for (n, b), (_, r) in zip(mlp.named_buffers(), ref.named_buffers()):
         assert torch.allclose(b.cpu().double(), r, rtol=1e-5, atol=1e-6), n
+
+
+# ---- narrow stacks (csrc/narrow.hip): PointConv's WeightNet 3-8-8-16 and DensityNet 1-8-8-1, recomputed per BatchNorm pass ----
+def _run_nograd(module, x, gout, backend):
+    module.backend = backend
+    module.zero_grad()
+    out = module(x)
+    out.backward(gout)
+    return (out.detach(), {n: p.grad.detach().clone() for n, p in module.named_parameters()},
+            {n: b.detach().clone() for n, b in module.named_buffers()})
+
+
+def _narrow_plan_bytes(m, rows):
+    from pointcloudlib_amd.misc import mlp_hip
+    return mlp_hip._stack_plan(m, rows, m.spec[0], 0, False, None, False, 0).save_bytes
+
+
+NARROW_CASES = [(spec, bias, slope, off, spr, rows)
+                for spec, bias, slope, off, spr in [([3, 8, 8, 16], True, 0.0, 0.0, 1.0), ([1, 8, 8, 1], True, 0.0, 0.0, 1.0),
+                                                    ([3, 8, 8, 16], False, 0.2, 0.0, 1.0), ([1, 8, 8, 1], True, 0.0, 5.0, 0.01)]
+                for rows in (2, 300, 5000, 70001)]
+# |mean| / std = 300 on three input channels: every fp32 path (PyTorch's included) rounds the first layer's output at 6e-5 of its
+# spread, so at a few thousand rows some ReLU mask differs from the fp64 run and moves the batch sums by 1e-3 .. 1e-2 of their
+# size, for the GEMM path and PyTorch alike (tools/dbg/narrow_err.py) -- row counts where no mask flips only
+NARROW_CASES += [([3, 8, 8, 16], True, 0.0, 0.3, 1e-3, rows) for rows in (2, 300, 1000)]
+
+
+@pytest.mark.parametrize("spec,bias,slope,offset,spread,rows", NARROW_CASES)
+def test_narrow_stack_matches_fp64(dev, spec, bias, slope, offset, spread, rows):
+    """The recompute-per-pass kernels against the PyTorch composition in fp64: output, every parameter gradient, running
+    statistics; also with |mean| >> std inputs (DensityNet reads near-constant densities): never worse than 4x PyTorch's own fp32
+    path against the same truth.  The descriptor must have taken the narrow path (768 bytes live from forward to backward)."""
+    torch.manual_seed(7 + rows + spec[0])
+    m64 = PointwiseMLP(spec, bias=bias, slope=slope).double()
+    with torch.no_grad():
+        for g, b in zip(m64.gammas, m64.betas):
+            g.uniform_(0.5, 1.5); b.uniform_(-0.3, 0.3)
+        m64.gammas[1][::3] *= -1.0
+    x64 = offset + spread * torch.randn(rows, spec[0], dtype=torch.float64)
+    g64 = torch.randn(rows, spec[-1], dtype=torch.float64)
+    ref = _run_nograd(copy.deepcopy(m64), x64, g64, "torch")
+    m32 = copy.deepcopy(m64).float().to(dev).train()
+    import os
+    if os.environ.get("PCL_NARROW") != "0":
+        assert _narrow_plan_bytes(m32, rows) == 3 * 4 * 16 * 4
+    x32, g32 = x64.float().to(dev), g64.float().to(dev)
+    t32 = _run_nograd(copy.deepcopy(m32), x32, g32, "torch")
+    h32 = _run_nograd(copy.deepcopy(m32), x32, g32, "hip")
+
+    def err(a, b):
+        return (a.double().cpu() - b).abs().max().item()
+
+    scale = max(1.0, ref[0].abs().max().item())
+    e_h, e_t = err(h32[0], ref[0]), err(t32[0], ref[0])
+    assert e_h <= max(1e-5 * scale, 4 * e_t), f"features: hip err {e_h:.3e} (torch fp32 {e_t:.3e}), scale {scale:.3f}"
+    for name in ref[1]:
+        if "biases" in name:
+            assert h32[1][name].abs().max().item() == 0.0
+            continue
+        gs = max(1e-6, ref[1][name].abs().max().item())
+        e_h, e_t = err(h32[1][name], ref[1][name]), err(t32[1][name], ref[1][name])
+        assert e_h <= max(1e-4 * gs, 4 * e_t), f"{name}: hip {e_h:.3e} torch {e_t:.3e} scale {gs:.3e}"
+    for name in ref[2]:
+        assert err(h32[2][name], ref[2][name]) <= max(1e-5 * max(1.0, ref[2][name].abs().max().item()), 4 * err(t32[2][name], ref[2][name])), name
+
+
+@pytest.mark.parametrize("spec,rows", [([3, 8, 8, 16], 32 * 512 * 32), ([1, 8, 8, 1], 32 * 1024), ([3, 8, 8, 16], 32 * 128 * 64 + 5)])
+def test_narrow_stack_equals_the_gemm_path_at_size(dev, spec, rows):
+    """PointConv's row counts: the narrow kernels against the library's GEMM / BatchNorm kernels (per-kernel path) on the same
+    inputs -- the same arithmetic per element up to the summation order of the dot products and of the batch sums."""
+    from pointcloudlib_amd.misc import mlp_hip
+    torch.manual_seed(5)
+    m = PointwiseMLP(spec, bias=True).to(dev).train()
+    x = torch.randn(rows, spec[0], device=dev) * 0.3
+    g = torch.randn(rows, spec[-1], device=dev)
+    a = _run_nograd(copy.deepcopy(m), x, g, "hip")
+    with mlp_hip.per_kernel_path():
+        b = _run_nograd(copy.deepcopy(m), x, g, "hip")
+    scale = max(1.0, b[0].abs().max().item())
+    assert (a[0] - b[0]).abs().max().item() <= 1e-5 * scale
+    flips = ((a[0] > 0) != (b[0] > 0)).float().mean().item()
+    assert flips < 1e-5
+    # Gradients: the two fp32 paths round a pre-activation differently by ~1e-7, so about one ReLU mask per 10^7 elements differs
+    # between them (8M masked elements here): one flipped row moves a batch sum by that row's term, amplified by the layers below
+    # it -- 3e-3 of the gradient's max-norm covers a handful (against fp64 the narrow kernels are the closer of the two:
+    # tools/dbg/narrow_err.py).  DensityNet's first-layer weight gradient is exactly ZERO in exact arithmetic (one input channel:
+    # BatchNorm removes scale and shift of the affine map), both paths return rounding noise of sums whose terms are O(1).
+    for n in b[1]:
+        gs = max(1e-6, b[1][n].abs().max().item())
+        d = (a[1][n] - b[1][n]).abs().max().item()
+        if spec[0] == 1 and n == "weights.0":
+            assert max(a[1][n].abs().max().item(), b[1][n].abs().max().item()) <= 1e-6 * rows, (n, a[1][n], b[1][n])
+            continue
+        assert d <= 3e-3 * gs + 1e-7, (n, d, gs)
+    for n in b[2]:
+        assert torch.allclose(a[2][n], b[2][n], rtol=1e-5, atol=1e-6), n
