@@ -271,6 +271,20 @@ class PointConvDensitySetInterpolation(nn.Module):
         idx3, w3 = three_nn(xyz1, xyz2)                                                   # :293-299
         interpolated = three_interpolate(points2, idx3, w3)                               # :300
         density_scale = self.densitynet(compute_density(xyz1, self.bandwidth))            # :304-305
+        if xyz1.is_cuda:
+            # sample_and_group(N, nsample, ...) :307 without the [B,N,ns,3+D] tensor, as in PointConvDensitySetAbstraction.forward:
+            # the feature MLP's first conv runs folded into the grouping (K = 3+D GEMM over the N points, not over N*ns rows)
+            fps_idx = farthest_point_sample(xyz1, N, start_idx)
+            new_xyz = index_points(xyz1, fps_idx)
+            idx = knn_point(self.nsample, xyz1, new_xyz)
+            grouped_xyz_norm = index_points(xyz1, idx) - new_xyz.view(B, N, 1, 3)
+            grouped_density = index_points(density_scale, idx)
+            weights = self.weightnet(grouped_xyz_norm.contiguous())                       # :317-318
+            out = grouped_feature_mlp_contract(self.mlp, xyz1, new_xyz, interpolated, idx, grouped_density, weights)
+            if out is None:
+                new_points = torch.cat([grouped_xyz_norm, index_points(interpolated, idx)], dim=-1)
+                out = feature_mlp_contract(self.mlp, new_points, grouped_density, weights)
+            return self.linear(out).permute(0, 2, 1)                                      # :321-323
         _, new_points, grouped_xyz_norm, _, grouped_density = sample_and_group(
             N, self.nsample, xyz1, interpolated, density_scale, start_idx)                # :307
         weights = self.weightnet(grouped_xyz_norm.contiguous())                           # :317-318

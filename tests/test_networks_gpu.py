@@ -405,3 +405,40 @@ def test_pointconv_set_abstraction_folded_paths_equal_the_composition(dev):
     assert (f0 - f1).abs().max().item() <= 1e-4 * f0.abs().max().item() + 1e-7 * gs
     for n in g0:
         assert (g0[n] - g1[n]).abs().max().item() <= 1e-4 * g0[n].abs().max().item() + 1e-6 * gs, n
+
+
+def test_pointconv_interpolation_folded_paths_equal_the_composition(dev):
+    """PointConvDensitySetInterpolation (the part-seg decoder): the product path (first conv of the feature MLP folded into the k-NN
+    grouping over all N points, last BatchNorm + ReLU in the contraction, narrow-stack WeightNet / DensityNet) against the plain
+    composition on the per-kernel entry points: output, gradient of the coarse features and every parameter gradient."""
+    import copy
+    from pointcloudlib_amd import synth
+    from pointcloudlib_amd.misc import mlp_hip, pointconv_utils as pu
+    torch.manual_seed(4)
+    B, N, S, ns, D2 = 3, 384, 96, 16, 40
+    xyz1 = torch.from_numpy(synth.gauss_ball(B, N, 78)).to(dev).permute(0, 2, 1).contiguous()
+    xyz2 = xyz1[:, :, ::4].contiguous()
+    pts2 = torch.randn(B, D2, S, device=dev)
+    fp = pu.PointConvDensitySetInterpolation(nsample=ns, in_channel=D2 + 3, mlp=[48, 64], bandwidth=0.2).to(dev).train()
+    start = torch.zeros(B, dtype=torch.int32, device=dev)
+    gout = torch.randn(B, 64, N, device=dev)
+    res = []
+    for product in (False, True):
+        m = copy.deepcopy(fp)
+        p = pts2.clone().requires_grad_(True)
+        if product:
+            out = m(xyz1, xyz2, None, p, start)
+        else:
+            with mlp_hip.per_kernel_path():
+                out = m(xyz1, xyz2, None, p, start)
+        out.backward(gout)
+        res.append((out.detach(), p.grad.detach(), {n: q.grad.detach() for n, q in m.named_parameters()}))
+    (o0, f0, g0), (o1, f1, g1) = res
+    assert o0.shape == (B, 64, N)
+    assert (o0 - o1).abs().max().item() <= 2e-5 * max(1.0, o0.abs().max().item())
+    gs = max(t.abs().max().item() for t in g0.values())
+    assert (f0 - f1).abs().max().item() <= 1e-4 * f0.abs().max().item() + 1e-7 * gs
+    for n in g0:
+        if n.endswith("densitynet.mlp.weights.0"):          # analytically zero (one input channel under BatchNorm): rounding noise both ways
+            continue
+        assert (g0[n] - g1[n]).abs().max().item() <= 1e-4 * g0[n].abs().max().item() + 1e-6 * gs, n
