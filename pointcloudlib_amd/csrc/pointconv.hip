@@ -178,38 +178,49 @@ __global__ __launch_bounds__(PCB_T) void pointconv_contract_bwd_feat_bn_kernel(c
 }
 
 // t[s,m] = sum_c feat[g,s,c] * dout[g,c,m];  d_w = dens * t;  d_dens = sum_m w * t.
-// One wave per group (four groups per workgroup), lane = row s of the group (64 rows per pass), 16 accumulators per lane.
-// The group's feature rows are staged 32 channels at a time through the wave's own LDS slab (coalesced 16-byte loads in,
-// conflict-free scalar reads out); dout[g,c,:] sits beside it and is read as four broadcast 16-byte pieces per channel;
-// the next chunk's loads are in flight while the current one is consumed, and the waves (one group each, own LDS slabs)
-// never meet at a block barrier.  Measured per call (268 MB of features): first version (256 threads = 64 rows x 4
-// quarter-rows, both operands in LDS, block barriers) 230 us; this one 150 us; dout through scalar loads into SGPRs
-// instead of LDS 245 us (the scalar-load latency sits in every channel step).
-constexpr int PC_CCH = 32;
-__global__ __launch_bounds__(256) void pointconv_contract_bwd_w_kernel(const float* __restrict__ feat, const float* __restrict__ dout,
+// Per group a (ns x C)(C x 16) product: 16 output columns are exactly the N of v_mfma_f32_16x16x4_f32, so this one runs on the
+// matrix pipe (fp32 in, fp32 accumulate -- the arithmetic of the vector version, twice its rate, and a fifth of its LDS reads:
+// the vector form read every dout value once per lane-row, 4 broadcast 16-byte reads per 16 FMAs, and was LDS-issue-bound).
+// One wave per group (four groups per workgroup), 64 rows per pass = up to four 16-row M blocks.  The group's feature rows are
+// staged 32 channels at a time through the wave's own LDS slab, channel-major with a row stride of 80 dwords (A operand
+// feat[16mb + l%16][4kk + l/16]: the four k rows of a wave's read fall on two banks' worth of addresses = the 2-way minimum of a
+// 64-lane dword read), dout[g, c, :] beside it (B operand: 64 consecutive dwords per k step); the next chunk's loads are in
+// flight while the current one is consumed, and the waves (own slabs) never meet at a block barrier.  Results leave in the
+// C/D layout (lane = (4-row block q, column j)): d_w rows as 64-byte pieces, d_dens by a DPP sum over the 16 lanes of a row.
+// History per call (268 MB of features): 256 threads = 64 rows x 4 quarter-rows with block barriers 230 us; one wave per group
+// on the vector ALU 150 us (181 us with the feature BatchNorm folded in); dout through SGPRs 245 us.
+constexpr int PC_CCH = 32, PC_FLD = 80;
+typedef float pc_f32x4 __attribute__((ext_vector_type(4)));
+template <int CTRL>
+__device__ __forceinline__ float pc_dpp_add(float v) { return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }
+// NMB: 16-row blocks per 64-row pass; GPW: groups per wave -- groups of <= 32 rows go two to a wave (rows 0..31 | 32..63 of the
+// pass, each half with its own dout slab), so that the staging (64 rows per pass whatever the group size) is not half idle.
+template <int NMB, int GPW>
+__global__ __launch_bounds__(256, 2) void pointconv_contract_bwd_w_kernel(const float* __restrict__ feat, const float* __restrict__ dout,
                                                                        const float* __restrict__ dens, const float* __restrict__ w,
                                                                        int G, int ns, int C, float* __restrict__ dw,
                                                                        float* __restrict__ ddens, const FeatBN bn) {
-    __shared__ float sf[4][64][PC_CCH + 1];
-    __shared__ __attribute__((aligned(16))) float sd[4][PC_CCH * PC_M];
+    constexpr int RG = 64 / GPW, MBG = NMB / GPW;                 // rows and 16-row blocks of a pass per group
+    static_assert(MBG * GPW == NMB, "blocks per group");
+    // channel-major feature image sf[c][(row + 8*((c >> 2) & 3)) & 63], row stride 80 dwords: the A-operand reads (k rows 4kk..4kk+3
+    // x 16 rows) and the staging writes (lane = (row r, 4 channels 4*l7..)) both land on 32 distinct banks -- 2-way, the minimum
+    // for 64 lanes (without the rotation the writes are 8-way; with a stride of 66 instead the reads are 4-way: 137 vs 95 us)
+    __shared__ float sf[4][PC_CCH][PC_FLD];
+    __shared__ __attribute__((aligned(16))) float sd[4][GPW][PC_CCH * PC_M];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = __builtin_amdgcn_readfirstlane(min((int)blockIdx.x * 4 + wave, G - 1));   // uniform per wave
-    const bool live = (int)blockIdx.x * 4 + wave < G;
-    const float* F = feat + (size_t)g * ns * C;
-    const float* D = dout + (size_t)g * C * PC_M;
+    const int g0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * 4 + wave) * GPW);      // first group of this wave (uniform)
     const bool vec = (C & 3) == 0;
+    const int q = lane >> 4, j = lane & 15;
     // a wave owns its LDS slabs and LDS executes a wave's instructions in order: compiler fences instead of block barriers
     auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
     const int cstep = gridDim.y * PC_CCH;
-    for (int s0 = 0; s0 < ns; s0 += 64) {
-        const int len = min(64, ns - s0);
-        const bool split = len <= 32;
-        const int rowl = split ? (lane & 31) : lane, c_half = split ? (lane >> 5) * (PC_CCH / 2) : 0;
-        float t[PC_M];
+    for (int s0 = 0; s0 < ns; s0 += RG) {
+        const int len = min(RG, ns - s0);                 // rows of a group in this pass
+        pc_f32x4 acc[NMB];
 #pragma unroll
-        for (int m = 0; m < PC_M; ++m) t[m] = 0.f;
-        float4 pv[8], pd[2];                              // the next chunk, in flight while this one is consumed
-        // rows s0..s0+len, channels c0..c0+cl: 8 lanes x 16 B per row, 8 rows per pass; addresses clamped, no branches
+        for (int mb = 0; mb < NMB; ++mb) acc[mb] = pc_f32x4{0.f, 0.f, 0.f, 0.f};
+        float4 pv[8], pd[2 * GPW];                        // the next chunk, in flight while this one is consumed
+        // 64 rows of the pass, channels c0..c0+cl: 8 lanes x 16 B per row, 8 rows per load pass; addresses clamped, no branches
         auto load_chunk = [&](int c0) {
             const int cl = min(PC_CCH, C - c0);
             const int cq = (lane & 7) * 4;
@@ -226,7 +237,9 @@ __global__ __launch_bounds__(256) void pointconv_contract_bwd_w_kernel(const flo
 #pragma unroll
             for (int pass = 0; pass < 8; ++pass) {
                 const int r = pass * 8 + (lane >> 3);
-                const float* src = F + (size_t)(s0 + min(r, len - 1)) * C + c0;
+                const int grp = r / RG, rr = r % RG;
+                const int gg = min(g0 + grp, G - 1);
+                const float* src = feat + ((size_t)gg * ns + s0 + min(rr, len - 1)) * C + c0;
                 float4 v;
                 if (vec) v = *reinterpret_cast<const float4*>(src + min(cq, cl - 4));
                 else { v.x = src[min(cq, cl - 1)]; v.y = src[min(cq + 1, cl - 1)]; v.z = src[min(cq + 2, cl - 1)]; v.w = src[min(cq + 3, cl - 1)]; }
@@ -234,14 +247,15 @@ __global__ __launch_bounds__(256) void pointconv_contract_bwd_w_kernel(const flo
                     v.x = feat_act(v.x, ba4.x, bb4.x, bn.slope); v.y = feat_act(v.y, ba4.y, bb4.y, bn.slope);
                     v.z = feat_act(v.z, ba4.z, bb4.z, bn.slope); v.w = feat_act(v.w, ba4.w, bb4.w, bn.slope);
                 }
-                const bool okr = r < len;
+                const bool okr = rr < len;
                 v.x = okr && cq < cl ? v.x : 0.f; v.y = okr && cq + 1 < cl ? v.y : 0.f;
                 v.z = okr && cq + 2 < cl ? v.z : 0.f; v.w = okr && cq + 3 < cl ? v.w : 0.f;
                 pv[pass] = v;
             }
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {          // dout[g, c0..c0+cl, :] is cl*16 contiguous floats
-                const int e = (pass * 64 + lane) * 4;
+            for (int pass = 0; pass < 2 * GPW; ++pass) {    // dout[g, c0..c0+cl, :] is cl*16 contiguous floats per group
+                const int grp = pass >> 1, e = ((pass & 1) * 64 + lane) * 4;
+                const float* D = dout + (size_t)min(g0 + grp, G - 1) * C * PC_M;
                 const float4 v = *reinterpret_cast<const float4*>(D + (size_t)c0 * PC_M + min(e, cl * PC_M - 4));
                 pd[pass] = e < cl * PC_M ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -251,56 +265,62 @@ __global__ __launch_bounds__(256) void pointconv_contract_bwd_w_kernel(const flo
         for (; c0 < C; c0 += cstep) {
             wave_sync();
 #pragma unroll
-            for (int pass = 0; pass < 8; ++pass) {
-                const int r = pass * 8 + (lane >> 3), cq = (lane & 7) * 4;
-                sf[wave][r][cq] = pv[pass].x; sf[wave][r][cq + 1] = pv[pass].y; sf[wave][r][cq + 2] = pv[pass].z; sf[wave][r][cq + 3] = pv[pass].w;
+            for (int pass = 0; pass < 8; ++pass) {          // channel-major image: sf[c][row of the pass]
+                const int cq = (lane & 7) * 4, r = (pass * 8 + (lane >> 3) + 8 * (lane & 3)) & 63;      // ((cq + i) >> 2) & 3 = lane & 3
+                sf[wave][cq][r] = pv[pass].x; sf[wave][cq + 1][r] = pv[pass].y; sf[wave][cq + 2][r] = pv[pass].z; sf[wave][cq + 3][r] = pv[pass].w;
             }
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) *reinterpret_cast<float4*>(&sd[wave][(pass * 64 + lane) * 4]) = pd[pass];
+            for (int pass = 0; pass < 2 * GPW; ++pass) *reinterpret_cast<float4*>(&sd[wave][pass >> 1][((pass & 1) * 64 + lane) * 4]) = pd[pass];
             if (c0 + cstep < C) load_chunk(c0 + cstep);
             wave_sync();
-            // groups of <= 32 rows: the two half-waves take the two halves of the channel chunk for the same rows
-#pragma unroll 4
-            for (int cc = 0; cc < (split ? PC_CCH / 2 : PC_CCH); ++cc) {     // channels past cl are zeros in sd
-                const int c = cc + c_half;
-                const float f = sf[wave][rowl][c];
-                const float4* q = reinterpret_cast<const float4*>(&sd[wave][c * PC_M]);      // one address per half-wave: broadcast
+            // eight k steps of four channels (channels past cl are zeros on both sides); A = feat[16mb + j][4kk + q], B = dout[4kk + q][j]
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 v = q[j];
-                    t[4 * j] = fmaf(f, v.x, t[4 * j]); t[4 * j + 1] = fmaf(f, v.y, t[4 * j + 1]);
-                    t[4 * j + 2] = fmaf(f, v.z, t[4 * j + 2]); t[4 * j + 3] = fmaf(f, v.w, t[4 * j + 3]);
-                }
+            for (int kk = 0; kk < PC_CCH / 4; ++kk) {
+                float b[GPW];
+#pragma unroll
+                for (int gi = 0; gi < GPW; ++gi) b[gi] = sd[wave][gi][(4 * kk + q) * PC_M + j];
+                const float* arow = &sf[wave][4 * kk + q][0];
+#pragma unroll
+                for (int mb = 0; mb < NMB; ++mb)
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[((mb / MBG) * RG + (mb % MBG) * 16 + 8 * (kk & 3) + j) & 63], b[mb / MBG], acc[mb], 0, 0, 0);
             }
         }
-        if (split) {
+        // C/D layout: acc[mb][r] = t[group mb / MBG, row 16 (mb % MBG) + 4q + r][j]
 #pragma unroll
-            for (int m = 0; m < PC_M; ++m) t[m] += __shfl_xor(t[m], 32);
-        }
-        if (live && lane < len) {
-            const size_t row = (size_t)g * ns + s0 + lane;
-            const float de = dens[row];
-            const float4* wv = reinterpret_cast<const float4*>(w + row * PC_M);
-            float4* o = reinterpret_cast<float4*>(dw + row * PC_M);
-            float dd = 0.f;
+        for (int mb = 0; mb < NMB; ++mb) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 ww = wv[j];
-                dd += ww.x * t[4 * j] + ww.y * t[4 * j + 1] + ww.z * t[4 * j + 2] + ww.w * t[4 * j + 3];
-                if (gridDim.y == 1) o[j] = make_float4(de * t[4 * j], de * t[4 * j + 1], de * t[4 * j + 2], de * t[4 * j + 3]);
-                else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) unsafeAtomicAdd(dw + row * PC_M + 4 * j + q, de * t[4 * j + q]);
+            for (int r = 0; r < 4; ++r) {
+                const int grp = mb / MBG, rr = (mb % MBG) * 16 + 4 * q + r;
+                const bool ok = rr < len && g0 + grp < G;
+                const size_t row = ok ? (size_t)(g0 + grp) * ns + s0 + rr : 0;
+                const float tv = acc[mb][r];
+                float dd = ok ? w[row * PC_M + j] * tv : 0.f;
+                dd = pc_dpp_add<0xB1>(dd); dd = pc_dpp_add<0x4E>(dd); dd = pc_dpp_add<0x141>(dd); dd = pc_dpp_add<0x140>(dd);   // sum over the row's 16 lanes
+                if (ok) {
+                    const float de = dens[row];
+                    if (gridDim.y == 1) { dw[row * PC_M + j] = de * tv; if (j == 0) ddens[row] = dd; }
+                    else { unsafeAtomicAdd(dw + row * PC_M + j, de * tv); if (j == 0) unsafeAtomicAdd(ddens + row, dd); }
                 }
             }
-            if (gridDim.y == 1) ddens[row] = dd;
-            else unsafeAtomicAdd(ddens + row, dd);
         }
     }
 }
 
 }  // namespace pcl
 using namespace pcl;
+
+// groups per wave and 16-row blocks per pass of the weight-gradient kernel
+static int bwd_w_gpw(int ns) { return ns <= 32 ? 2 : 1; }
+static void launch_bwd_w(int slices, hipStream_t st, const float* feat, const float* dout, const float* dens, const float* w, int G, int ns, int C,
+                         float* dw, float* ddens, const FeatBN bn) {
+    const int gpw = bwd_w_gpw(ns);
+    const dim3 grid((G + 4 * gpw - 1) / (4 * gpw), slices), blk(256);
+    if (gpw == 2) {
+        if (ns <= 16) hipLaunchKernelGGL((pointconv_contract_bwd_w_kernel<2, 2>), grid, blk, 0, st, feat, dout, dens, w, G, ns, C, dw, ddens, bn);
+        else hipLaunchKernelGGL((pointconv_contract_bwd_w_kernel<4, 2>), grid, blk, 0, st, feat, dout, dens, w, G, ns, C, dw, ddens, bn);
+    } else if (ns <= 48) hipLaunchKernelGGL((pointconv_contract_bwd_w_kernel<3, 1>), grid, blk, 0, st, feat, dout, dens, w, G, ns, C, dw, ddens, bn);
+    else hipLaunchKernelGGL((pointconv_contract_bwd_w_kernel<4, 1>), grid, blk, 0, st, feat, dout, dens, w, G, ns, C, dw, ddens, bn);
+}
 
 static int pc_block(int C) { return C >= 256 ? 256 : (C + 63) / 64 * 64; }
 // channel blocks on grid.y when there are few groups (GroupAll level: G = batch size), so that >= ~512 workgroups exist
@@ -346,7 +366,7 @@ extern "C" int pcl_pointconv_contract_bn_bwd_f32(const float* dout, const float*
                        G, ns, C, CB, du, stats_ws);
     int rc = check_launch("pcl_pointconv_contract_bn_bwd_f32(feat)");
     if (rc) return rc;
-    const int wgs = (G + 3) / 4;
+    const int wgs = (G + 4 * bwd_w_gpw(ns) - 1) / (4 * bwd_w_gpw(ns));
     int slices = wgs >= 512 ? 1 : (512 + wgs - 1) / wgs;
     if (slices > (C + PC_CCH - 1) / PC_CCH) slices = (C + PC_CCH - 1) / PC_CCH;
     if (slices > 1) {
@@ -354,7 +374,7 @@ extern "C" int pcl_pointconv_contract_bn_bwd_f32(const float* dout, const float*
         if (e == hipSuccess) e = hipMemsetAsync(ddensity, 0, sizeof(float) * (size_t)G * ns, st);
         if (e != hipSuccess) return fail(PCL_EHIP, "pcl_pointconv_contract_bn_bwd_f32: memset: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(pointconv_contract_bwd_w_kernel, dim3(wgs, slices), dim3(256), 0, st, Y, dout, density, weights, G, ns, C, dweights, ddensity, bn);
+    launch_bwd_w(slices, st, Y, dout, density, weights, G, ns, C, dweights, ddensity, bn);
     return check_launch("pcl_pointconv_contract_bn_bwd_f32(w)");
 }
 
@@ -369,7 +389,7 @@ extern "C" int pcl_pointconv_contract_bwd_f32(const float* dout, const float* fe
     if (rc) return rc;
     // few groups (the GroupAll level: G = batch size): slice the channels over grid.y so that the chip is busy; the slices'
     // partial sums meet through atomics in zero-filled outputs
-    const int wgs = (G + 3) / 4;
+    const int wgs = (G + 4 * bwd_w_gpw(ns) - 1) / (4 * bwd_w_gpw(ns));
     int slices = wgs >= 512 ? 1 : (512 + wgs - 1) / wgs;
     if (slices > (C + PC_CCH - 1) / PC_CCH) slices = (C + PC_CCH - 1) / PC_CCH;
     if (slices > 1) {
@@ -377,7 +397,6 @@ extern "C" int pcl_pointconv_contract_bwd_f32(const float* dout, const float* fe
         if (e == hipSuccess) e = hipMemsetAsync(ddensity, 0, sizeof(float) * (size_t)G * ns, st);
         if (e != hipSuccess) return fail(PCL_EHIP, "pcl_pointconv_contract_bwd_f32: memset: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(pointconv_contract_bwd_w_kernel, dim3(wgs, slices), dim3(256), 0, st, feat, dout, density, weights, G, ns, C, dweights, ddensity,
-                       FeatBN{nullptr, nullptr, 1.f});
+    launch_bwd_w(slices, st, feat, dout, density, weights, G, ns, C, dweights, ddensity, FeatBN{nullptr, nullptr, 1.f});
     return check_launch("pcl_pointconv_contract_bwd_f32(w)");
 }

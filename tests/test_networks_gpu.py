@@ -203,7 +203,8 @@ def test_stn_identity_at_zero_weights(dev):
     assert STNkd(16).to(dev)(torch.randn(2, 64, 16, device=dev)).shape == (2, 16, 16)
 
 
-@pytest.mark.parametrize("B,S,ns,C", [(2, 5, 32, 128), (1, 3, 7, 20), (2, 1, 200, 64), (1, 4, 64, 300)])
+@pytest.mark.parametrize("B,S,ns,C", [(2, 5, 32, 128), (1, 3, 7, 20), (2, 1, 200, 64), (1, 4, 64, 300), (3, 7, 48, 33), (1, 5, 16, 64),
+                                      (2, 3, 24, 36), (1, 9, 33, 8)])
 def test_pointconv_contraction_kernel(dev, B, S, ns, C):
     """pcl_pointconv_contract_f32 (+bwd) against the reference formula (misc/pointconv_utils.py:393-394) in PyTorch."""
     from pointcloudlib_amd.misc.pointconv_utils import pointconv_contract
