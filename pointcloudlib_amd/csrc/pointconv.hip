@@ -208,101 +208,126 @@ __global__ __launch_bounds__(256, 2) void pointconv_contract_bwd_w_kernel(const 
     __shared__ float sf[4][PC_CCH][PC_FLD];
     __shared__ __attribute__((aligned(16))) float sd[4][GPW][PC_CCH * PC_M];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * 4 + wave) * GPW);      // first group of this wave (uniform)
     const bool vec = (C & 3) == 0;
     const int q = lane >> 4, j = lane & 15;
     // a wave owns its LDS slabs and LDS executes a wave's instructions in order: compiler fences instead of block barriers
     auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-    const int cstep = gridDim.y * PC_CCH;
-    for (int s0 = 0; s0 < ns; s0 += RG) {
-        const int len = min(RG, ns - s0);                 // rows of a group in this pass
-        pc_f32x4 acc[NMB];
+    // Persistent: a wave walks the units u = (GPW groups, one pass of RG rows) wave_id, wave_id + W, ... and inside a unit the
+    // channel chunks; the NEXT (unit, chunk) is always in flight while the current one is consumed -- also across units, so a
+    // wave pays the memory latency once, not once per group (one group per wave and exit: 176 us for the 268 MB level).
+    const int npass = (ns + RG - 1) / RG;
+    const int units = ((G + GPW - 1) / GPW) * npass;
+    const int W = gridDim.x * 4;
+    const int cfirst = blockIdx.y * PC_CCH, cstep = gridDim.y * PC_CCH;
+    float4 pv[8], pd[2 * GPW];                            // the next chunk, in flight while this one is consumed: RAW loads --
+    // masks and the folded BatchNorm are applied when the chunk is stored to LDS an iteration later (any arithmetic on the loaded
+    // values here makes the wave wait for them before this iteration's MFMAs: that was the case until round 3 and cost 2x)
+    // 64 rows of the pass, channels c0..c0+cl: 8 lanes x 16 B per row, 8 rows per load pass; addresses clamped, no branches
+    auto load_chunk = [&](int u, int c0) {
+        const int g0 = (u / npass) * GPW, s0 = (u % npass) * RG;
+        const int len = min(RG, ns - s0);
+        const int cl = min(PC_CCH, C - c0);
+        const int cq = (lane & 7) * 4;
 #pragma unroll
-        for (int mb = 0; mb < NMB; ++mb) acc[mb] = pc_f32x4{0.f, 0.f, 0.f, 0.f};
-        float4 pv[8], pd[2 * GPW];                        // the next chunk, in flight while this one is consumed
-        // 64 rows of the pass, channels c0..c0+cl: 8 lanes x 16 B per row, 8 rows per load pass; addresses clamped, no branches
-        auto load_chunk = [&](int c0) {
-            const int cl = min(PC_CCH, C - c0);
-            const int cq = (lane & 7) * 4;
-            float4 ba4 = make_float4(1.f, 1.f, 1.f, 1.f), bb4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bn.sc) {                  // channels as the (clamped) loads below address them
-                if (vec) {
-                    const int cb0 = c0 + min(cq, cl - 4);
-                    ba4 = *reinterpret_cast<const float4*>(bn.sc + cb0); bb4 = *reinterpret_cast<const float4*>(bn.sh + cb0);
-                } else {
-                    ba4 = make_float4(bn.sc[c0 + min(cq, cl - 1)], bn.sc[c0 + min(cq + 1, cl - 1)], bn.sc[c0 + min(cq + 2, cl - 1)], bn.sc[c0 + min(cq + 3, cl - 1)]);
-                    bb4 = make_float4(bn.sh[c0 + min(cq, cl - 1)], bn.sh[c0 + min(cq + 1, cl - 1)], bn.sh[c0 + min(cq + 2, cl - 1)], bn.sh[c0 + min(cq + 3, cl - 1)]);
-                }
-            }
+        for (int pass = 0; pass < 8; ++pass) {
+            const int r = pass * 8 + (lane >> 3);
+            const int grp = r / RG, rr = r % RG;
+            const int gg = min(g0 + grp, G - 1);
+            const float* src = feat + ((size_t)gg * ns + s0 + min(rr, len - 1)) * C + c0;
+            if (vec) pv[pass] = *reinterpret_cast<const float4*>(src + min(cq, cl - 4));
+            else { pv[pass].x = src[min(cq, cl - 1)]; pv[pass].y = src[min(cq + 1, cl - 1)]; pv[pass].z = src[min(cq + 2, cl - 1)]; pv[pass].w = src[min(cq + 3, cl - 1)]; }
+        }
 #pragma unroll
-            for (int pass = 0; pass < 8; ++pass) {
-                const int r = pass * 8 + (lane >> 3);
-                const int grp = r / RG, rr = r % RG;
-                const int gg = min(g0 + grp, G - 1);
-                const float* src = feat + ((size_t)gg * ns + s0 + min(rr, len - 1)) * C + c0;
-                float4 v;
-                if (vec) v = *reinterpret_cast<const float4*>(src + min(cq, cl - 4));
-                else { v.x = src[min(cq, cl - 1)]; v.y = src[min(cq + 1, cl - 1)]; v.z = src[min(cq + 2, cl - 1)]; v.w = src[min(cq + 3, cl - 1)]; }
-                if (bn.sc) {              // the feature MLP's folded BatchNorm + activation (this lane's four channels, constants per chunk)
-                    v.x = feat_act(v.x, ba4.x, bb4.x, bn.slope); v.y = feat_act(v.y, ba4.y, bb4.y, bn.slope);
-                    v.z = feat_act(v.z, ba4.z, bb4.z, bn.slope); v.w = feat_act(v.w, ba4.w, bb4.w, bn.slope);
-                }
-                const bool okr = rr < len;
-                v.x = okr && cq < cl ? v.x : 0.f; v.y = okr && cq + 1 < cl ? v.y : 0.f;
-                v.z = okr && cq + 2 < cl ? v.z : 0.f; v.w = okr && cq + 3 < cl ? v.w : 0.f;
-                pv[pass] = v;
-            }
-#pragma unroll
-            for (int pass = 0; pass < 2 * GPW; ++pass) {    // dout[g, c0..c0+cl, :] is cl*16 contiguous floats per group
-                const int grp = pass >> 1, e = ((pass & 1) * 64 + lane) * 4;
-                const float* D = dout + (size_t)min(g0 + grp, G - 1) * C * PC_M;
-                const float4 v = *reinterpret_cast<const float4*>(D + (size_t)c0 * PC_M + min(e, cl * PC_M - 4));
-                pd[pass] = e < cl * PC_M ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        };
-        int c0 = blockIdx.y * PC_CCH;
-        if (c0 < C) load_chunk(c0);
-        for (; c0 < C; c0 += cstep) {
-            wave_sync();
-#pragma unroll
-            for (int pass = 0; pass < 8; ++pass) {          // channel-major image: sf[c][row of the pass]
-                const int cq = (lane & 7) * 4, r = (pass * 8 + (lane >> 3) + 8 * (lane & 3)) & 63;      // ((cq + i) >> 2) & 3 = lane & 3
-                sf[wave][cq][r] = pv[pass].x; sf[wave][cq + 1][r] = pv[pass].y; sf[wave][cq + 2][r] = pv[pass].z; sf[wave][cq + 3][r] = pv[pass].w;
-            }
-#pragma unroll
-            for (int pass = 0; pass < 2 * GPW; ++pass) *reinterpret_cast<float4*>(&sd[wave][pass >> 1][((pass & 1) * 64 + lane) * 4]) = pd[pass];
-            if (c0 + cstep < C) load_chunk(c0 + cstep);
-            wave_sync();
-            // eight k steps of four channels (channels past cl are zeros on both sides); A = feat[16mb + j][4kk + q], B = dout[4kk + q][j]
-#pragma unroll
-            for (int kk = 0; kk < PC_CCH / 4; ++kk) {
-                float b[GPW];
-#pragma unroll
-                for (int gi = 0; gi < GPW; ++gi) b[gi] = sd[wave][gi][(4 * kk + q) * PC_M + j];
-                const float* arow = &sf[wave][4 * kk + q][0];
-#pragma unroll
-                for (int mb = 0; mb < NMB; ++mb)
-                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[((mb / MBG) * RG + (mb % MBG) * 16 + 8 * (kk & 3) + j) & 63], b[mb / MBG], acc[mb], 0, 0, 0);
+        for (int pass = 0; pass < 2 * GPW; ++pass) {    // dout[g, c0..c0+cl, :] is cl*16 contiguous floats per group
+            const int grp = pass >> 1, e = ((pass & 1) * 64 + lane) * 4;
+            const float* D = dout + (size_t)min(g0 + grp, G - 1) * C * PC_M;
+            pd[pass] = *reinterpret_cast<const float4*>(D + (size_t)c0 * PC_M + min(e, cl * PC_M - 4));
+        }
+    };
+    // chunk (u, c0) from the registers into the wave's LDS slabs: folded BatchNorm + activation, zeros outside the chunk / group
+    auto stash_chunk = [&](int u, int c0) {
+        const int s0 = (u % npass) * RG;
+        const int len = min(RG, ns - s0);
+        const int cl = min(PC_CCH, C - c0);
+        const int cq = (lane & 7) * 4;
+        float4 ba4 = make_float4(1.f, 1.f, 1.f, 1.f), bb4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bn.sc) {                  // channels as the (clamped) loads addressed them
+            if (vec) {
+                const int cb0 = c0 + min(cq, cl - 4);
+                ba4 = *reinterpret_cast<const float4*>(bn.sc + cb0); bb4 = *reinterpret_cast<const float4*>(bn.sh + cb0);
+            } else {
+                ba4 = make_float4(bn.sc[c0 + min(cq, cl - 1)], bn.sc[c0 + min(cq + 1, cl - 1)], bn.sc[c0 + min(cq + 2, cl - 1)], bn.sc[c0 + min(cq + 3, cl - 1)]);
+                bb4 = make_float4(bn.sh[c0 + min(cq, cl - 1)], bn.sh[c0 + min(cq + 1, cl - 1)], bn.sh[c0 + min(cq + 2, cl - 1)], bn.sh[c0 + min(cq + 3, cl - 1)]);
             }
         }
-        // C/D layout: acc[mb][r] = t[group mb / MBG, row 16 (mb % MBG) + 4q + r][j]
 #pragma unroll
-        for (int mb = 0; mb < NMB; ++mb) {
+        for (int pass = 0; pass < 8; ++pass) {            // channel-major image: sf[c][row of the pass, rotated]
+            const int r0 = pass * 8 + (lane >> 3);
+            float4 v = pv[pass];
+            if (bn.sc) {              // the feature MLP's folded BatchNorm + activation (this lane's four channels, constants per chunk)
+                v.x = feat_act(v.x, ba4.x, bb4.x, bn.slope); v.y = feat_act(v.y, ba4.y, bb4.y, bn.slope);
+                v.z = feat_act(v.z, ba4.z, bb4.z, bn.slope); v.w = feat_act(v.w, ba4.w, bb4.w, bn.slope);
+            }
+            const bool okr = r0 % RG < len;
+            v.x = okr && cq < cl ? v.x : 0.f; v.y = okr && cq + 1 < cl ? v.y : 0.f;
+            v.z = okr && cq + 2 < cl ? v.z : 0.f; v.w = okr && cq + 3 < cl ? v.w : 0.f;
+            const int r = (r0 + 8 * (lane & 3)) & 63;     // ((cq + i) >> 2) & 3 = lane & 3
+            sf[wave][cq][r] = v.x; sf[wave][cq + 1][r] = v.y; sf[wave][cq + 2][r] = v.z; sf[wave][cq + 3][r] = v.w;
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int grp = mb / MBG, rr = (mb % MBG) * 16 + 4 * q + r;
-                const bool ok = rr < len && g0 + grp < G;
-                const size_t row = ok ? (size_t)(g0 + grp) * ns + s0 + rr : 0;
-                const float tv = acc[mb][r];
-                float dd = ok ? w[row * PC_M + j] * tv : 0.f;
-                dd = pc_dpp_add<0xB1>(dd); dd = pc_dpp_add<0x4E>(dd); dd = pc_dpp_add<0x141>(dd); dd = pc_dpp_add<0x140>(dd);   // sum over the row's 16 lanes
-                if (ok) {
-                    const float de = dens[row];
-                    if (gridDim.y == 1) { dw[row * PC_M + j] = de * tv; if (j == 0) ddens[row] = dd; }
-                    else { unsafeAtomicAdd(dw + row * PC_M + j, de * tv); if (j == 0) unsafeAtomicAdd(ddens + row, dd); }
+        for (int pass = 0; pass < 2 * GPW; ++pass) {
+            const int e = ((pass & 1) * 64 + lane) * 4;
+            *reinterpret_cast<float4*>(&sd[wave][pass >> 1][e]) = e < cl * PC_M ? pd[pass] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    int u = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave), c0 = cfirst;
+    if (u >= units || cfirst >= C) return;
+    load_chunk(u, c0);
+    pc_f32x4 acc[NMB];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) acc[mb] = pc_f32x4{0.f, 0.f, 0.f, 0.f};
+    while (u < units) {                                   // one (unit, chunk) per iteration; a single prefetch site
+        wave_sync();
+        stash_chunk(u, c0);
+        const bool last = c0 + cstep >= C;                // last chunk of this unit
+        const int nu = last ? u + W : u, nc = last ? cfirst : c0 + cstep;
+        if (nu < units) load_chunk(nu, nc);
+        wave_sync();
+        // eight k steps of four channels (channels past cl are zeros on both sides); A = feat[16mb + j][4kk + q], B = dout[4kk + q][j]
+#pragma unroll
+        for (int kk = 0; kk < PC_CCH / 4; ++kk) {
+            float b[GPW];
+#pragma unroll
+            for (int gi = 0; gi < GPW; ++gi) b[gi] = sd[wave][gi][(4 * kk + q) * PC_M + j];
+            const float* arow = &sf[wave][4 * kk + q][0];
+#pragma unroll
+            for (int mb = 0; mb < NMB; ++mb)
+                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[((mb / MBG) * RG + (mb % MBG) * 16 + 8 * (kk & 3) + j) & 63], b[mb / MBG], acc[mb], 0, 0, 0);
+        }
+        if (last) {
+            // C/D layout: acc[mb][r] = t[group mb / MBG, row 16 (mb % MBG) + 4q + r][j]
+            const int g0 = (u / npass) * GPW, s0 = (u % npass) * RG;
+            const int len = min(RG, ns - s0);             // rows of a group in this pass
+#pragma unroll
+            for (int mb = 0; mb < NMB; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int grp = mb / MBG, rr = (mb % MBG) * 16 + 4 * q + r;
+                    const bool ok = rr < len && g0 + grp < G;
+                    const size_t row = ok ? (size_t)(g0 + grp) * ns + s0 + rr : 0;
+                    const float tv = acc[mb][r];
+                    float dd = ok ? w[row * PC_M + j] * tv : 0.f;
+                    dd = pc_dpp_add<0xB1>(dd); dd = pc_dpp_add<0x4E>(dd); dd = pc_dpp_add<0x141>(dd); dd = pc_dpp_add<0x140>(dd);   // sum over the row's 16 lanes
+                    if (ok) {
+                        const float de = dens[row];
+                        if (gridDim.y == 1) { dw[row * PC_M + j] = de * tv; if (j == 0) ddens[row] = dd; }
+                        else { unsafeAtomicAdd(dw + row * PC_M + j, de * tv); if (j == 0) unsafeAtomicAdd(ddens + row, dd); }
+                    }
                 }
+                acc[mb] = pc_f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+        u = nu; c0 = nc;
     }
 }
 
@@ -311,10 +336,24 @@ using namespace pcl;
 
 // groups per wave and 16-row blocks per pass of the weight-gradient kernel
 static int bwd_w_gpw(int ns) { return ns <= 32 ? 2 : 1; }
+static int bwd_w_max_wgs(int slices) {
+    static const int cus = [] {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 1) cu = 256;
+        (void)hipGetLastError();
+        return cu;
+    }();
+    const int n = 2 * cus / (slices < 1 ? 1 : slices);
+    return n < 1 ? 1 : n;
+}
 static void launch_bwd_w(int slices, hipStream_t st, const float* feat, const float* dout, const float* dens, const float* w, int G, int ns, int C,
                          float* dw, float* ddens, const FeatBN bn) {
     const int gpw = bwd_w_gpw(ns);
-    const dim3 grid((G + 4 * gpw - 1) / (4 * gpw), slices), blk(256);
+    const int RG = 64 / gpw, units = ((G + gpw - 1) / gpw) * ((ns + RG - 1) / RG);
+    int wgs = (units + 3) / 4;
+    const int cap = bwd_w_max_wgs(slices) * (gpw == 1 ? 3 : 2) / 2;      // persistent: as many workgroups as fit (LDS: 48 / 56 KB each)
+    if (wgs > cap) wgs = cap;
+    const dim3 grid(wgs, slices), blk(256);
     if (gpw == 2) {
         if (ns <= 16) hipLaunchKernelGGL((pointconv_contract_bwd_w_kernel<2, 2>), grid, blk, 0, st, feat, dout, dens, w, G, ns, C, dw, ddens, bn);
         else hipLaunchKernelGGL((pointconv_contract_bwd_w_kernel<4, 2>), grid, blk, 0, st, feat, dout, dens, w, G, ns, C, dw, ddens, bn);
