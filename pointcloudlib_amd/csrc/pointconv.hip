@@ -5,9 +5,11 @@
 //     out        = matmul(new_points^T [C x ns], weights [ns x 16])   -> [B,S,C*16]
 // i.e. out[g,c,m] = sum_s feat[g,s,c] * dens[g,s] * w[g,s,m] for every group g = (b, point).
 // The reference runs an elementwise multiply, a transpose copy and a batched GEMM of tiny (C x ns)(ns x 16) problems:
-// three round trips of the [G,ns,C] tensor.  This is an HBM-bound streaming op (2*C*ns*16 flops per group against
-// 4*ns*C + 64*C bytes), so it stays on the vector ALU: one workgroup per group, the density-scaled weights of the group
-// in LDS (broadcast reads), one lane per channel streaming the group's rows coalesced.
+// three round trips of the [G,ns,C] tensor.  Here: one streaming pass per direction.  The op is HBM-bound (2*C*ns*16 flops per
+// group against 4*ns*C + 64*C bytes), but 16 output columns are exactly the N of v_mfma_f32_16x16x4_f32, so the forward and the
+// weight-gradient kernels feed the matrix pipe (fp32 in, fp32 accumulate: the arithmetic of a vector-ALU version at twice its
+// rate and a fifth of its LDS reads -- the vector versions were LDS-issue-bound, not HBM-bound); the feature-gradient kernel
+// (K = 16) stays on the vector ALU.
 //   backward:  d_feat[g,s,c] = dens[g,s] * sum_m dout[g,c,m] * w[g,s,m]
 //              t[g,s,m]      = sum_c feat[g,s,c] * dout[g,c,m]
 //              d_w[g,s,m]    = dens[g,s] * t[g,s,m],   d_dens[g,s] = sum_m w[g,s,m] * t[g,s,m]
@@ -18,57 +20,11 @@ namespace pcl {
 constexpr int PC_M = 16;         // WeightNet's output width (pointconv_utils.py:236: WeightNet(3, 16))
 constexpr int PC_SCH = 64;       // rows of a group staged per pass
 
-// out[g,c,:] ; grid = G, block = 64..256 lanes over channels
 // The feature operand may be given as the PRE-BatchNorm output of the feature MLP's last layer plus that layer's folded
 // BatchNorm (fsc, fsh) and activation slope: z = lrelu(fsc*y + fsh) is then formed while loading -- the [G,ns,C] activation
 // (268 MB at the first two levels) is never written or re-read (misc/pointconv_utils.py:384-389 feeding :393-394).
 struct FeatBN { const float* sc; const float* sh; float slope; };
 __device__ __forceinline__ float feat_act(float y, float a, float b, float slope) { const float t = fmaf(a, y, b); return fmaxf(t, t * slope); }
-
-__global__ __launch_bounds__(256) void pointconv_contract_kernel(const float* __restrict__ feat, const float* __restrict__ dens,
-                                                                 const float* __restrict__ w, int ns, int C,
-                                                                 float* __restrict__ out, const FeatBN bn) {
-    __shared__ __attribute__((aligned(16))) float swd[PC_SCH * PC_M];
-    const int g = blockIdx.x, tid = threadIdx.x;
-    const float* F = feat + (size_t)g * ns * C;
-    for (int c0 = blockIdx.y * blockDim.x; c0 < C; c0 += gridDim.y * blockDim.x) {      // grid.y: channel blocks (few groups)
-        const int c = c0 + tid;
-        const float ba = bn.sc ? bn.sc[min(c, C - 1)] : 1.f, bb = bn.sc ? bn.sh[min(c, C - 1)] : 0.f, bs = bn.sc ? bn.slope : 1.f;
-        float acc[PC_M];
-#pragma unroll
-        for (int m = 0; m < PC_M; ++m) acc[m] = 0.f;
-        for (int s0 = 0; s0 < ns; s0 += PC_SCH) {
-            const int len = min(PC_SCH, ns - s0);
-            __syncthreads();
-            for (int e = tid; e < len * PC_M; e += blockDim.x)
-                swd[e] = w[((size_t)g * ns + s0) * PC_M + e] * dens[(size_t)g * ns + s0 + e / PC_M];
-            __syncthreads();
-            if (c < C) {
-                for (int sb = 0; sb < len; sb += 8) {           // eight rows of the group in flight per lane
-                    float f[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) f[u] = feat_act(F[(size_t)(s0 + min(sb + u, len - 1)) * C + c], ba, bb, bs);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        if (sb + u >= len) break;
-                        const float4* q = reinterpret_cast<const float4*>(&swd[(sb + u) * PC_M]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float4 v = q[j];
-                            acc[4 * j] = fmaf(f[u], v.x, acc[4 * j]); acc[4 * j + 1] = fmaf(f[u], v.y, acc[4 * j + 1]);
-                            acc[4 * j + 2] = fmaf(f[u], v.z, acc[4 * j + 2]); acc[4 * j + 3] = fmaf(f[u], v.w, acc[4 * j + 3]);
-                        }
-                    }
-                }
-            }
-        }
-        if (c < C) {
-            float4* o = reinterpret_cast<float4*>(out + ((size_t)g * C + c) * PC_M);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
-        }
-    }
-}
 
 // d_feat[g,s,c] = dens[g,s] * sum_m dout[g,c,m] * w[g,s,m]
 __global__ __launch_bounds__(256) void pointconv_contract_bwd_feat_kernel(const float* __restrict__ dout, const float* __restrict__ dens,
@@ -294,15 +250,27 @@ __global__ __launch_bounds__(256, 2) void pointconv_contract_bwd_w_kernel(const 
         if (nu < units) load_chunk(nu, nc);
         wave_sync();
         // eight k steps of four channels (channels past cl are zeros on both sides); A = feat[16mb + j][4kk + q], B = dout[4kk + q][j]
+        // (the operands of step k+1 are read from LDS before the MFMAs of step k are issued: left alone hipcc reads each step's
+        // operands right before its MFMAs and the LDS latency is exposed eight times per chunk)
+        struct WOps { float a[NMB], b[GPW]; };
+        auto w_ld = [&](int kk) -> WOps {
+            WOps o;
 #pragma unroll
-        for (int kk = 0; kk < PC_CCH / 4; ++kk) {
-            float b[GPW];
-#pragma unroll
-            for (int gi = 0; gi < GPW; ++gi) b[gi] = sd[wave][gi][(4 * kk + q) * PC_M + j];
+            for (int gi = 0; gi < GPW; ++gi) o.b[gi] = sd[wave][gi][(4 * kk + q) * PC_M + j];
             const float* arow = &sf[wave][4 * kk + q][0];
 #pragma unroll
-            for (int mb = 0; mb < NMB; ++mb)
-                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[((mb / MBG) * RG + (mb % MBG) * 16 + 8 * (kk & 3) + j) & 63], b[mb / MBG], acc[mb], 0, 0, 0);
+            for (int mb = 0; mb < NMB; ++mb) o.a[mb] = arow[((mb / MBG) * RG + (mb % MBG) * 16 + 8 * (kk & 3) + j) & 63];
+            return o;
+        };
+        WOps cur = w_ld(0);
+#pragma unroll
+        for (int kk = 0; kk < PC_CCH / 4; ++kk) {
+            WOps nxt = cur;
+            if (kk + 1 < PC_CCH / 4) nxt = w_ld(kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mb = 0; mb < NMB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[mb], cur.b[mb / MBG], acc[mb], 0, 0, 0);
+            cur = nxt;
         }
         if (last) {
             // C/D layout: acc[mb][r] = t[group mb / MBG, row 16 (mb % MBG) + 4q + r][j]
@@ -328,6 +296,146 @@ __global__ __launch_bounds__(256, 2) void pointconv_contract_bwd_w_kernel(const 
             }
         }
         u = nu; c0 = nc;
+    }
+}
+
+// ---- forward on the matrix pipe -----------------------------------------------------------------------------------------
+// out[g, c, m] = sum_s z[g,s,c] * (dens[g,s] * w[g,s,m]): per group a (C x ns)(ns x 16) product -- M = channels, N = 16 = the
+// MFMA's N, K = the group's rows.  Same skeleton as the weight-gradient kernel above: persistent waves, a unit = GPW groups x one
+// pass of 64 / GPW rows, 32-channel chunks of the feature rows staged ROW-major through the wave's LDS slab (A operand
+// z[4kk + q][16mb + j], row stride 48 dwords: 2-way), the density-scaled weights of the unit's rows beside it (B operand: 64
+// consecutive dwords per k step), the next (unit, chunk, pass) in flight while this one is consumed, loaded values untouched
+// until they are stored to LDS.  A chunk's 32 x 16 outputs per group are complete after the group's last pass and leave in the
+// C/D layout as 64-byte rows.  PointConv cls, first two levels (435 / 352 MB of features, weights and outputs): 114 / 97 us =
+// 3.8 / 3.6 TB/s inside a training step (the vector version -- one workgroup per group, a lane per channel, 16 accumulators, one
+// short-lived wave per group paying the memory latency -- 150 / 140 us); streaming reads of this pattern reach 5.8 TB/s from cold
+// HBM (tools/ubench/rowpattern.hip).
+constexpr int PC_RLD = 48;
+template <int GPW>
+__global__ __launch_bounds__(256) void pointconv_contract_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ dens,
+                                                                     const float* __restrict__ w, int G, int ns, int C,
+                                                                     float* __restrict__ out, const FeatBN bn) {
+    constexpr int RG = 64 / GPW;
+    __shared__ __attribute__((aligned(16))) float sfr[4][64][PC_RLD];
+    __shared__ __attribute__((aligned(16))) float swd[4][64 * PC_M];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool vec = (C & 3) == 0;
+    const int q = lane >> 4, j = lane & 15;
+    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    const int npass = (ns + RG - 1) / RG;
+    const int units = (G + GPW - 1) / GPW;
+    const int W = gridDim.x * 4;
+    const int cfirst = blockIdx.y * PC_CCH, cstep = gridDim.y * PC_CCH;
+    float4 pv[8], pw[4];
+    float pdn[4];
+    // position = (unit u, chunk c0, pass ps); order: passes innermost (a chunk's outputs accumulate over the passes of its groups)
+    auto load_pos = [&](int u, int c0, int ps) {
+        const int g0 = u * GPW, s0 = ps * RG;
+        const int len = min(RG, ns - s0);
+        const int cl = min(PC_CCH, C - c0);
+        const int cq = (lane & 7) * 4;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int r = pass * 8 + (lane >> 3);
+            const int grp = r / RG, rr = r % RG;
+            const int gg = min(g0 + grp, G - 1);
+            const float* src = feat + ((size_t)gg * ns + s0 + min(rr, len - 1)) * C + c0;
+            if (vec) pv[pass] = *reinterpret_cast<const float4*>(src + min(cq, cl - 4));
+            else { pv[pass].x = src[min(cq, cl - 1)]; pv[pass].y = src[min(cq + 1, cl - 1)]; pv[pass].z = src[min(cq + 2, cl - 1)]; pv[pass].w = src[min(cq + 3, cl - 1)]; }
+        }
+        if (npass > 1 || c0 == cfirst) {                  // the rows' weights and densities (once per unit when there is one pass)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = i * 16 + (lane >> 2);       // row of the pass, 4 lanes x 16 B per row
+                const int grp = r / RG, rr = r % RG;
+                const size_t row = (size_t)min(g0 + grp, G - 1) * ns + s0 + min(rr, len - 1);
+                pw[i] = *reinterpret_cast<const float4*>(w + row * PC_M + (lane & 3) * 4);
+                pdn[i] = dens[row];
+            }
+        }
+    };
+    auto stash_pos = [&](int u, int c0, int ps) {
+        const int g0 = u * GPW, s0 = ps * RG;
+        const int len = min(RG, ns - s0);
+        const int cl = min(PC_CCH, C - c0);
+        const int cq = (lane & 7) * 4;
+        float4 ba4 = make_float4(1.f, 1.f, 1.f, 1.f), bb4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bn.sc) {
+            if (vec) {
+                const int cb0 = c0 + min(cq, cl - 4);
+                ba4 = *reinterpret_cast<const float4*>(bn.sc + cb0); bb4 = *reinterpret_cast<const float4*>(bn.sh + cb0);
+            } else {
+                ba4 = make_float4(bn.sc[c0 + min(cq, cl - 1)], bn.sc[c0 + min(cq + 1, cl - 1)], bn.sc[c0 + min(cq + 2, cl - 1)], bn.sc[c0 + min(cq + 3, cl - 1)]);
+                bb4 = make_float4(bn.sh[c0 + min(cq, cl - 1)], bn.sh[c0 + min(cq + 1, cl - 1)], bn.sh[c0 + min(cq + 2, cl - 1)], bn.sh[c0 + min(cq + 3, cl - 1)]);
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int r = pass * 8 + (lane >> 3);
+            float4 v = pv[pass];
+            if (bn.sc) {
+                v.x = feat_act(v.x, ba4.x, bb4.x, bn.slope); v.y = feat_act(v.y, ba4.y, bb4.y, bn.slope);
+                v.z = feat_act(v.z, ba4.z, bb4.z, bn.slope); v.w = feat_act(v.w, ba4.w, bb4.w, bn.slope);
+            }
+            const bool okr = r % RG < len && g0 + r / RG < G;
+            v.x = okr && cq < cl ? v.x : 0.f; v.y = okr && cq + 1 < cl ? v.y : 0.f;
+            v.z = okr && cq + 2 < cl ? v.z : 0.f; v.w = okr && cq + 3 < cl ? v.w : 0.f;
+            *reinterpret_cast<float4*>(&sfr[wave][r][cq]) = v;
+        }
+        if (npass > 1 || c0 == cfirst) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = i * 16 + (lane >> 2);
+                const bool okr = r % RG < len && g0 + r / RG < G;
+                const float d = okr ? pdn[i] : 0.f;
+                *reinterpret_cast<float4*>(&swd[wave][r * PC_M + (lane & 3) * 4]) = make_float4(pw[i].x * d, pw[i].y * d, pw[i].z * d, pw[i].w * d);
+            }
+        }
+    };
+    int u = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave), c0 = cfirst, ps = 0;
+    if (u >= units || cfirst >= C) return;
+    load_pos(u, c0, ps);
+    pc_f32x4 acc[GPW][2];
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) { acc[gi][0] = pc_f32x4{0.f, 0.f, 0.f, 0.f}; acc[gi][1] = pc_f32x4{0.f, 0.f, 0.f, 0.f}; }
+    while (u < units) {
+        wave_sync();
+        stash_pos(u, c0, ps);
+        const bool lastp = ps + 1 >= npass, lastc = c0 + cstep >= C;
+        const int nps = lastp ? 0 : ps + 1, nc = !lastp ? c0 : (lastc ? cfirst : c0 + cstep), nu = (lastp && lastc) ? u + W : u;
+        if (nu < units) load_pos(nu, nc, nps);
+        wave_sync();
+        // sixteen k steps of four rows: A = z[4kk + q][16mb + j], B = wd[4kk + q][j]; the rows of group gi are k steps gi*RG/4 ..
+        struct FOps { float a0, a1, b; };
+        auto f_ld = [&](int kk) -> FOps {
+            const float* arow = &sfr[wave][4 * kk + q][j];
+            return FOps{arow[0], arow[16], swd[wave][(4 * kk + q) * PC_M + j]};
+        };
+        FOps cur = f_ld(0);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {                 // (operands of step k+1 read before the MFMAs of step k)
+            FOps nxt = cur;
+            if (kk + 1 < 16) nxt = f_ld(kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[(4 * kk) / RG][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a0, cur.b, acc[(4 * kk) / RG][0], 0, 0, 0);
+            acc[(4 * kk) / RG][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a1, cur.b, acc[(4 * kk) / RG][1], 0, 0, 0);
+            cur = nxt;
+        }
+        if (lastp) {                                      // C/D layout: acc[gi][mb][r] = out[g0 + gi][c0 + 16mb + 4q + r][j]
+#pragma unroll
+            for (int gi = 0; gi < GPW; ++gi) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = c0 + 16 * mb + 4 * q + r;
+                        if (c < C && u * GPW + gi < G) out[((size_t)(u * GPW + gi) * C + c) * PC_M + j] = acc[gi][mb][r];
+                    }
+                    acc[gi][mb] = pc_f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        u = nu; c0 = nc; ps = nps;
     }
 }
 
@@ -369,12 +477,26 @@ static int pc_chan_blocks(int G, int C) {
     return want < per ? want : per;
 }
 
+static void launch_contract_fwd(hipStream_t st, const float* feat, const float* dens, const float* w, int G, int ns, int C, float* out,
+                                const FeatBN bn) {
+    const int gpw = bwd_w_gpw(ns);
+    const int units = (G + gpw - 1) / gpw;
+    int wgs = (units + 3) / 4;
+    // few groups (the GroupAll level): the channel chunks spread over grid.y (a chunk's outputs belong to one workgroup: no atomics)
+    int slices = wgs >= 512 ? 1 : (512 + wgs - 1) / wgs;
+    if (slices > (C + PC_CCH - 1) / PC_CCH) slices = (C + PC_CCH - 1) / PC_CCH;
+    const int cap = bwd_w_max_wgs(slices);                // persistent: two workgroups per CU (64 KB of LDS each)
+    if (wgs > cap) wgs = cap;
+    const dim3 grid(wgs, slices), blk(256);
+    if (gpw == 2) hipLaunchKernelGGL(pointconv_contract_fwd_kernel<2>, grid, blk, 0, st, feat, dens, w, G, ns, C, out, bn);
+    else hipLaunchKernelGGL(pointconv_contract_fwd_kernel<1>, grid, blk, 0, st, feat, dens, w, G, ns, C, out, bn);
+}
+
 extern "C" int pcl_pointconv_contract_f32(const float* feat, const float* density, const float* weights, int G, int ns, int C,
                                           int M, float* out, void* stream) {
     PCL_REQUIRE(feat && density && weights && out, "pcl_pointconv_contract_f32: null pointer");
     PCL_REQUIRE(G >= 1 && ns >= 1 && C >= 1 && M == PC_M, "pcl_pointconv_contract_f32: bad sizes G=%d ns=%d C=%d M=%d (M must be 16)", G, ns, C, M);
-    hipLaunchKernelGGL(pointconv_contract_kernel, dim3(G, pc_chan_blocks(G, C)), dim3(pc_block(C)), 0, as_stream(stream), feat, density, weights, ns, C, out,
-                       FeatBN{nullptr, nullptr, 1.f});
+    launch_contract_fwd(as_stream(stream), feat, density, weights, G, ns, C, out, FeatBN{nullptr, nullptr, 1.f});
     return check_launch("pcl_pointconv_contract_f32");
 }
 
@@ -382,8 +504,7 @@ extern "C" int pcl_pointconv_contract_bn_f32(const float* Y, const float* scale,
                                              const float* weights, int G, int ns, int C, int M, float* out, void* stream) {
     PCL_REQUIRE(Y && scale && shift && density && weights && out, "pcl_pointconv_contract_bn_f32: null pointer");
     PCL_REQUIRE(G >= 1 && ns >= 1 && C >= 1 && M == PC_M && slope >= 0.f && slope <= 1.f, "pcl_pointconv_contract_bn_f32: bad sizes G=%d ns=%d C=%d M=%d slope=%g", G, ns, C, M, (double)slope);
-    hipLaunchKernelGGL(pointconv_contract_kernel, dim3(G, pc_chan_blocks(G, C)), dim3(pc_block(C)), 0, as_stream(stream), Y, density, weights, ns, C, out,
-                       FeatBN{scale, shift, slope});
+    launch_contract_fwd(as_stream(stream), Y, density, weights, G, ns, C, out, FeatBN{scale, shift, slope});
     return check_launch("pcl_pointconv_contract_bn_f32");
 }
 
