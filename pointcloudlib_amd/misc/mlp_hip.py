@@ -63,6 +63,18 @@ class _Pack:
         return out
 
 
+_UNIT_CONSTS = {}
+
+
+def _unit_consts(dev, c):
+    """(ones[c], zeros[c]) on ``dev``, cached: the identity scale / zero shift of a layer without BatchNorm (never written to)."""
+    key = (dev.type, dev.index, c)
+    v = _UNIT_CONSTS.get(key)
+    if v is None:
+        v = _UNIT_CONSTS[key] = (torch.ones(c, device=dev), torch.zeros(c, device=dev))
+    return v
+
+
 class _FusedMLP(torch.autograd.Function):
     """inputs: x [P,C0]; cfg = (group_ns|0, slope, eps, momentum, training, bn, last_act); then per layer
     (W, bias|None, gamma|None, beta|None, running_mean|None, running_var|None)."""
@@ -128,7 +140,7 @@ class _FusedMLP(torch.autograd.Function):
                 scale = gamma * invstd
                 shift = beta - scale * rmean
             else:
-                scale, shift = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+                scale, shift = _unit_consts(dev, cout)      # cached constants (read-only everywhere): no fill launches per call
                 mean, invstd = shift, scale
             Ys.append(Y); scales.append(scale); shifts.append(shift); means.append(mean); invstds.append(invstd)
             cur, in_scale, in_shift, cin = Y, scale, shift, cout
@@ -232,15 +244,24 @@ class _FusedMLP(torch.autograd.Function):
                     _lib.call("pcl_bn_bwd_consts_f32", _P(g_stats), g_rows, _P(gamma), _P(means[l]), _P(invstds[l]), g_P, cout,
                               None, None, _P(a), _P(k1), _P(k2), None, st)
                 grads[6 * l + 1], grads[6 * l + 2], grads[6 * l + 3] = dbias, dgamma, dbeta
-            else:
+            elif bn:     # eval-mode BatchNorm: affine with constant statistics
                 a, k1, k2 = _empty((3, cout), dev).unbind(0)
                 s = stats[:rows].sum(0)
                 a.copy_(scales[l]); k1.zero_(); k2.zero_()
-                if bn:   # eval-mode BatchNorm: affine with constant statistics
-                    grads[6 * l + 3] = s[0].float()
-                    grads[6 * l + 2] = ((s[1] - means[l].double() * s[0]) * invstds[l].double()).float()
+                grads[6 * l + 3] = s[0].float()
+                grads[6 * l + 2] = ((s[1] - means[l].double() * s[0]) * invstds[l].double()).float()
+            else:        # no BatchNorm: dy = du (a = 1, k1 = k2 = 0: the cached constants); the bias gradient is sum(du) = what
+                         # pcl_bn_bwd_consts_f32 returns as dbeta -- one launch instead of six torch kernels per layer
+                a, k1 = _unit_consts(dev, cout)
+                k2 = k1
+                if bias is not None:
+                    dbias = _empty((cout,), dev)
+                    scratch = _empty((3, cout), dev)
+                    _lib.call("pcl_bn_bwd_consts_f32", _P(stats), rows, None, _P(k1), _P(a), P, cout, None, _P(dbias),
+                              _P(scratch[0]), _P(scratch[1]), _P(scratch[2]), None, st)
+                    grads[6 * l + 1] = dbias
             if bias is not None and not (bn and training) and grads[6 * l + 1] is None:
-                grads[6 * l + 1] = stats[:rows, 0].sum(0).float() * a             # without BatchNorm statistics: sum(du)
+                grads[6 * l + 1] = stats[:rows, 0].sum(0).float() * a             # eval-mode BatchNorm: sum(du) * scale
             if l == 0 and ctx.link is not None:
                 # hand the BatchNorm-backward constants of the folded first layer to _GroupLinear.backward, which forms
                 # dy = a*du - w*(k1 + k2*(y - mean)) itself; what flows back as "the gradient of x" is du (protocol
