@@ -127,8 +127,8 @@ class _PointLinear(torch.autograd.Function):
         st = _stream()
         lib = _lib.lib()
         dUV = _dev(dUV, "grad")
-        one = torch.ones(C2, device=dev)
-        zero = torch.zeros(C2, device=dev)
+        from .mlp_hip import _unit_consts
+        one, zero = _unit_consts(dev, C2)                   # cached read-only constants: no fill launches per call
         dx = dW = None
         if ctx.needs_input_grad[1]:
             nbytes = _lib.size_query("pcl_linear_bwd_dw_workspace_bytes", P, C2, C)
