@@ -316,6 +316,17 @@ int pcl_group_minmax_finalize_f32(const float* gmax, const float* gmin, const in
 int pcl_bn_finalize_f32(const double* stats_ws, int stat_rows, const float* gamma, const float* beta, int P,
                         int C, float eps, float momentum, float* scale, float* shift, float* mean_out,
                         float* invstd_out, float* running_mean, float* running_var, void* stream);
+/* Global max AND mean pooling of z = lrelu(scale*Y + shift) over the ns rows of each of G groups, straight from the pre-BatchNorm
+ * rows Y [G*ns, C] (the activation is never materialised): out_max[g*ldo + c], out_mean[g*ldo + c] (ldo >= C: both may be halves
+ * of one [G, 2C] tensor), arg [G,C] = first row attaining the max.  Backward: du [G*ns, C] = act'(.) * ([s == arg] gmax + gmean / ns)
+ * (gmax / gmean rows ldg floats apart) and its BatchNorm-backward sums as fp64 partial rows [stat_rows][2][C] (<= 1024 rows;
+ * feed pcl_bn_bwd_consts_f32, or pcl_mlp_stack_bwd_f32 of a defer_act stack as ext_stats). */
+/* reference: replaces BatchNorm + LeakyReLU of conv5 and x.max(dim=-1) / x.mean(dim=-1) + concat, networks/cls/dgcnn.py:113-116 */
+int pcl_bn_act_max_mean_f32(const float* Y, const float* scale, const float* shift, float slope, int G, int ns, int C, int ldo,
+                            float* out_max, float* out_mean, int32_t* arg, void* stream);
+int pcl_bn_act_max_mean_bwd_f32(const float* gmax, const float* gmean, int ldg, const int32_t* arg, const float* Y, const float* scale,
+                                const float* shift, float slope, int G, int ns, int C, float* du, double* stats_ws,
+                                int* stat_rows_out, void* stream);
 /* out[g,c] = max_s lrelu(scale*Y[g*ns+s,c]+shift); arg = first s attaining it; ymax = Y there (nullable). */
 /* reference: replaces BatchNorm + ReLU + argmax over nsample, networks/cls/pointnet2.py:28-29, :57 */
 int pcl_bn_act_max_f32(const float* Y, const float* scale, const float* shift, float slope, int G, int ns,

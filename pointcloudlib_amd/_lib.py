@@ -101,6 +101,8 @@ _SIGS = {
     "pcl_bn_act_max_f32": (c_int, [_P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P]),
     "pcl_bn_act_f32": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P]),
     "pcl_bn_act_bwd_f32": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, ctypes.POINTER(c_int), _P]),
+    "pcl_bn_act_max_mean_f32": (c_int, [_P, _P, _P, c_float, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "pcl_bn_act_max_mean_bwd_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, ctypes.POINTER(c_int), _P]),
     "pcl_maxgrad_prep_f32": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P, ctypes.POINTER(c_int), _P]),
     "pcl_bn_bwd_consts_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "pcl_linear_bwd_dx_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_float,

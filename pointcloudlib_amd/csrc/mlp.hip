@@ -1958,6 +1958,47 @@ __global__ __launch_bounds__(64 * SL) void bn_act_max_sliced_kernel(const float*
     if (ymax) ymax[e] = by;
 }
 
+// DGCNN's global pooling (networks/cls/dgcnn.py:114-116): max AND mean over the N points of a cloud of z = lrelu(scale*y + shift),
+// straight from the pre-BatchNorm conv output -- the [B,N,C] activation (134 MB at B = 32, N = 1024, C = 1024) is never written,
+// and neither are the two reads, the zero-filled scatter target, the broadcast and the sum of the composite's backward.
+// out_max / out_mean rows are ldo floats apart (both halves of the concatenated [B, 2C] vector in one tensor).
+template <int SL>
+__global__ __launch_bounds__(64 * SL) void bn_act_maxmean_sliced_kernel(const float* __restrict__ Y, const float* __restrict__ scale,
+                                                                        const float* __restrict__ shift, float slope, int ns, int C, int ldo,
+                                                                        float* __restrict__ out_max, float* __restrict__ out_mean,
+                                                                        int32_t* __restrict__ arg) {
+    __shared__ float sz[SL][64];
+    __shared__ int ss[SL][64];
+    __shared__ double sm[SL][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, g = blockIdx.y;
+    float best = -INFINITY;
+    int bi = 0;
+    double sum = 0.0;
+    if (c < C) {
+        const float a = scale[c], b = shift[c];
+        const float* y = Y + (size_t)g * ns * C + c;
+        for (int s = sl; s < ns; s += SL) {
+            const float z = lrelu(fmaf(a, y[(size_t)s * C], b), slope);
+            if (z > best) { best = z; bi = s; }
+            sum += (double)z;
+        }
+    }
+    sz[sl][cl] = best; ss[sl][cl] = bi; sm[sl][cl] = sum;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+#pragma unroll
+    for (int j = 1; j < SL; ++j) {
+        const float z = sz[j][cl];
+        const int s = ss[j][cl];
+        if (z > best || (z == best && s < bi)) { best = z; bi = s; }
+        sum += sm[j][cl];
+    }
+    out_max[(size_t)g * ldo + c] = best;
+    out_mean[(size_t)g * ldo + c] = (float)(sum / ns);
+    arg[(size_t)g * C + c] = bi;
+}
+
 // fused max-pool finish: pick the extreme that maximises lrelu(scale*y+shift) (max for scale >= 0, min otherwise)
 __global__ __launch_bounds__(256) void group_minmax_finalize_kernel(const float* __restrict__ gmax, const float* __restrict__ gmin,
                                                                     const int32_t* __restrict__ gamax, const int32_t* __restrict__ gamin,
@@ -2045,6 +2086,35 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
             const size_t e = (size_t)r * C + c;
             const float y = Y[e];
             const float v = gz[e] * (fmaf(a, y, b) > 0.f ? 1.f : slope);
+            du[e] = v;
+            s1 += v; s2 += (double)v * y;
+        }
+    }
+    fold_row_lanes(s1, s2, c, rsub, RS, CW, C, red, stats + (size_t)blockIdx.y * 2 * C);
+}
+
+// backward of bn_act_maxmean_sliced_kernel (DGCNN's global max + mean pooling): du[g*ns + s, c] = act'(scale*y + shift) * ([s == arg[g,c]] gmax[g,c] + gmean[g,c] / ns) with the
+// BatchNorm-backward sums (sum du, sum du*y) as fp64 partial rows (the layout pcl_bn_bwd_consts_f32 reads)
+__global__ __launch_bounds__(256) void bn_act_maxmean_bwd_kernel(const float* __restrict__ gmax, const float* __restrict__ gmean, int ldg,
+                                                                 const int32_t* __restrict__ arg, const float* __restrict__ Y,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 float slope, int G, int ns, int C, int CW, float* __restrict__ du,
+                                                                 double* __restrict__ stats) {
+    __shared__ double red[2 * 256];
+    const int RS = 256 / CW, rsub = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + threadIdx.x % CW;
+    const int P = G * ns;
+    const float inv_ns = 1.f / (float)ns;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        const float a = scale[c], b = shift[c];
+        for (int r = blockIdx.y * RS + rsub; r < P; r += gridDim.y * RS) {
+            const int g = r / ns, srow = r - g * ns;
+            const size_t e = (size_t)r * C + c;
+            const float y = Y[e];
+            const float gm = gmean[(size_t)g * ldg + c] * inv_ns;
+            const float gz = arg[(size_t)g * C + c] == srow ? gmax[(size_t)g * ldg + c] + gm : gm;
+            const float v = gz * (fmaf(a, y, b) > 0.f ? 1.f : slope);
             du[e] = v;
             s1 += v; s2 += (double)v * y;
         }
@@ -2429,6 +2499,32 @@ extern "C" int pcl_bn_act_max_f32(const float* Y, const float* scale, const floa
     hipLaunchKernelGGL(bn_act_max_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), Y, scale, shift, slope, G, ns, C,
                        out, arg, ymax);
     return check_launch("pcl_bn_act_max_f32");
+}
+
+extern "C" int pcl_bn_act_max_mean_f32(const float* Y, const float* scale, const float* shift, float slope, int G, int ns, int C, int ldo,
+                                       float* out_max, float* out_mean, int32_t* arg, void* stream) {
+    PCL_REQUIRE(Y && scale && shift && out_max && out_mean && arg, "pcl_bn_act_max_mean_f32: null pointer");
+    PCL_REQUIRE(G >= 1 && G <= 65535 && ns >= 1 && C >= 1 && ldo >= C, "pcl_bn_act_max_mean_f32: bad sizes G=%d ns=%d C=%d ldo=%d", G, ns, C, ldo);
+    const dim3 grid((C + 63) / 64, G);
+    if (ns >= 256) hipLaunchKernelGGL(bn_act_maxmean_sliced_kernel<16>, grid, dim3(1024), 0, as_stream(stream), Y, scale, shift, slope, ns, C, ldo, out_max, out_mean, arg);
+    else hipLaunchKernelGGL(bn_act_maxmean_sliced_kernel<4>, grid, dim3(256), 0, as_stream(stream), Y, scale, shift, slope, ns, C, ldo, out_max, out_mean, arg);
+    return check_launch("pcl_bn_act_max_mean_f32");
+}
+
+extern "C" int pcl_bn_act_max_mean_bwd_f32(const float* gmax, const float* gmean, int ldg, const int32_t* arg, const float* Y, const float* scale,
+                                           const float* shift, float slope, int G, int ns, int C, float* du, double* stats_ws,
+                                           int* stat_rows_out, void* stream) {
+    PCL_REQUIRE(gmax && gmean && arg && Y && scale && shift && du && stats_ws && stat_rows_out, "pcl_bn_act_max_mean_bwd_f32: null pointer");
+    PCL_REQUIRE(G >= 1 && ns >= 1 && C >= 1 && ldg >= C && (size_t)G * ns < 0x7fffffffull, "pcl_bn_act_max_mean_bwd_f32: bad sizes G=%d ns=%d C=%d ldg=%d", G, ns, C, ldg);
+    const int P = G * ns;
+    int CW = 256;
+    while (CW / 2 >= C && CW > 1) CW >>= 1;
+    const int RS = 256 / CW;
+    const int rows = (P + RS - 1) / RS < STAT_ROWS ? (P + RS - 1) / RS : STAT_ROWS;
+    *stat_rows_out = rows;
+    hipLaunchKernelGGL(bn_act_maxmean_bwd_kernel, dim3((C + CW - 1) / CW, rows), dim3(256), 0, as_stream(stream), gmax, gmean, ldg, arg, Y, scale, shift,
+                       slope, G, ns, C, CW, du, stats_ws);
+    return check_launch("pcl_bn_act_max_mean_bwd_f32");
 }
 
 namespace pcl {

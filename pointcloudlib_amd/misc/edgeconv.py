@@ -154,3 +154,51 @@ def edge_conv(mlp, x, idx):
         cfg = (mlp.slope, mlp.eps, mlp.momentum, mlp.training)
         return _EdgeConvPool.apply(UV, idx, mlp.gammas[0], mlp.betas[0], mlp.running_mean_0, mlp.running_var_0, cfg)
     return mlp(edge_features(x, idx), group_max=k)
+
+
+class _MaxMeanPoolBN(torch.autograd.Function):
+    """Global max and mean pooling over the N points of each cloud with the producing conv's BatchNorm + LeakyReLU folded in
+    (csrc/mlp.hip: bn_act_maxmean_sliced_kernel): ``Y`` [B,N,C] is the PRE-BatchNorm conv output of a deferring stack
+    (mlp_hip.stack_plain_deferred), the result [B, 2C] = cat(max_n z, mean_n z), z = lrelu(scale*y + shift).  The backward hands
+    the stack du and its BatchNorm-backward sums through ``link`` (the protocol of pointconv_utils._PointConvContractBN)."""
+
+    @staticmethod
+    def forward(ctx, Y, link):
+        B, N, C = Y.shape
+        out = torch.empty((B, 2 * C), dtype=torch.float32, device=Y.device)
+        arg = torch.empty((B, C), dtype=torch.int32, device=Y.device)
+        _lib.call("pcl_bn_act_max_mean_f32", _p(Y), _p(link.scale), _p(link.shift), float(link.slope), B, N, C, 2 * C, _p(out),
+                  out.data_ptr() + 4 * C, _p(arg), _stream(), algo_bytes=4 * B * N * C)
+        ctx.link = link
+        ctx.save_for_backward(Y, arg, link.scale, link.shift)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        import ctypes
+        Y, arg, scale, shift = ctx.saved_tensors
+        link = ctx.link
+        B, N, C = Y.shape
+        gout = _dev(gout, "grad")
+        du = torch.empty_like(Y)
+        stats = torch.empty((1024, 2, C), dtype=torch.float64, device=Y.device)
+        rows = ctypes.c_int(0)
+        _lib.call("pcl_bn_act_max_mean_bwd_f32", _p(gout), gout.data_ptr() + 4 * C, 2 * C, _p(arg), _p(Y), _p(scale), _p(shift),
+                  float(link.slope), B, N, C, _p(du), _p(stats), ctypes.byref(rows), _stream(), algo_bytes=8 * B * N * C)
+        link.stats, link.rows = stats, rows.value
+        return du, None
+
+
+def conv_max_mean_pool(mlp, x):
+    """``y = mlp(x)`` (one conv + BatchNorm + LeakyReLU on [B,N,Cin]) followed by ``cat(y.max(1), y.mean(1))`` -> [B, 2*Cout]
+    (networks/cls/dgcnn.py:113-116).  On the HIP training path the activated [B,N,Cout] tensor is never formed: the conv's stack
+    stops at its pre-BatchNorm output and the pooling kernel applies BatchNorm + activation while it reduces."""
+    from . import mlp_hip
+    B, N, Cin = x.shape
+    if x.is_cuda and x.dtype == torch.float32 and mlp.resolved_backend(x) == "hip" and mlp.last_act and N <= 65535:
+        r = mlp_hip.stack_plain_deferred(mlp, x.reshape(B * N, Cin).contiguous())
+        if r is not None:
+            Y, link = r
+            return _MaxMeanPoolBN.apply(Y.view(B, N, Y.shape[-1]), link)
+    y = mlp(x)
+    return torch.cat((y.max(dim=1)[0], y.mean(dim=1)), dim=1)

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from ...misc.layers import PointwiseMLP
-from ...misc.edgeconv import edge_conv
+from ...misc.edgeconv import conv_max_mean_pool, edge_conv
 from ...misc.head import fc_head
 from ...misc.ops import KNN, edge_features
 
@@ -67,8 +67,7 @@ class DGCNN(nn.Module):
         x4 = edge_conv(self.conv4, x3, g(3, x3))                    # :109-111
         stages = (x1, x2, x3, x4)
         x = torch.cat((x1, x2, x3, x4), dim=2)                              # [B,N,512]   :112
-        x = self.conv5(x)                                                   # [B,N,1024]  :113
-        x = torch.cat((x.max(dim=1)[0], x.mean(dim=1)), dim=1)              # :114-116
+        x = conv_max_mean_pool(self.conv5, x)                               # conv5 + max / mean over the points + concat  :113-116
         # :117-121 -- the whole head as one call per direction (misc/head.py: fc_head -> pcl_fc_head_*_f32)
         x = fc_head([self.linear1, self.bn6, _LRELU, self.dp1, self.linear2, self.bn7, _LRELU, self.dp2, self.linear3], x)
         return (x, stages) if return_stages else x

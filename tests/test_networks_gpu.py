@@ -443,3 +443,45 @@ def test_pointconv_interpolation_folded_paths_equal_the_composition(dev):
         if n.endswith("densitynet.mlp.weights.0"):          # analytically zero (one input channel under BatchNorm): rounding noise both ways
             continue
         assert (g0[n] - g1[n]).abs().max().item() <= 1e-4 * g0[n].abs().max().item() + 1e-6 * gs, n
+
+
+@pytest.mark.parametrize("B,N,Cin,Cout", [(4, 1024, 512, 1024), (3, 100, 24, 40), (2, 300, 64, 70)])
+def test_conv_max_mean_pool_equals_the_composition(dev, B, N, Cin, Cout):
+    """DGCNN's conv5 + global max / mean pooling (networks/cls/dgcnn.py:113-116): the product path (deferring stack + the pooling
+    kernel that applies BatchNorm + LeakyReLU while it reduces: no [B,N,C] activation) against conv -> max / mean / cat on the
+    per-kernel path, and against PyTorch in fp64: output, input gradient and the conv's parameter gradients."""
+    import copy
+    from pointcloudlib_amd.misc import mlp_hip
+    from pointcloudlib_amd.misc.edgeconv import conv_max_mean_pool
+    from pointcloudlib_amd.misc.layers import PointwiseMLP
+    torch.manual_seed(11)
+    m = PointwiseMLP([Cin, Cout], slope=0.2).to(dev).train()
+    with torch.no_grad():
+        m.gammas[0].uniform_(0.5, 1.5); m.gammas[0][::3] *= -1.0; m.betas[0].uniform_(-0.3, 0.3)
+    x0 = torch.randn(B, N, Cin, device=dev)
+    gout = torch.randn(B, 2 * Cout, device=dev)
+    res = []
+    for mode in ("product", "per_kernel", "fp64"):
+        mm = copy.deepcopy(m)
+        x = x0.clone().requires_grad_(True)
+        if mode == "product":
+            out = conv_max_mean_pool(mm, x)
+        elif mode == "per_kernel":
+            with mlp_hip.per_kernel_path():
+                out = conv_max_mean_pool(mm, x)
+        else:
+            mm = mm.double(); mm.backend = "torch"
+            x = x0.double().clone().requires_grad_(True)
+            y = mm(x)
+            out = torch.cat((y.max(dim=1)[0], y.mean(dim=1)), dim=1)
+        out.backward(gout.to(out.dtype))
+        res.append((out.detach().double(), x.grad.detach().double(), {n: p.grad.detach().double() for n, p in mm.named_parameters()},
+                    {n: b.detach().double() for n, b in mm.named_buffers()}))
+    ref = res[2]
+    for got in res[:2]:
+        assert (got[0] - ref[0]).abs().max().item() <= 1e-5 * max(1.0, ref[0].abs().max().item())
+        assert (got[1] - ref[1]).abs().max().item() <= 1e-4 * ref[1].abs().max().item() + 1e-7
+        for n in ref[2]:
+            assert (got[2][n] - ref[2][n]).abs().max().item() <= 1e-4 * max(1e-6, ref[2][n].abs().max().item()), n
+        for n in ref[3]:
+            assert (got[3][n] - ref[3][n]).abs().max().item() <= 1e-5 * max(1.0, ref[3][n].abs().max().item()), n
