@@ -249,6 +249,10 @@ int pcl_soft_ce_f32(const float* logits, const int64_t* target, float eps, int R
  *   pcl_knn_transpose_i32: idx [B,N,k] -> in_off [B*N+1] (global offsets into in_src), in_src [B*N*k] (for every point the
  *     sources i, index within the cloud, of the edges i->n, ascending).  N <= 8192. */
 int pcl_edgeconv_stat_rows(int B, int N);
+/* backward = 0: W = [Wa | Wb] [Co][2C] -> Wcat = [Wa ; Wb - Wa] [2Co][C] (the weight of the per-point GEMM UV = x Wcat^T);
+ * backward = 1: dWcat [2Co][C] -> dW [Co][2C] (dWa = top - bottom, dWb = bottom). */
+/* reference: the 1x1 conv over [x_nbr - x_i, x_i] of get_graph_feature + conv, networks/cls/dgcnn.py:29-50,:100-111 */
+int pcl_edgeconv_wcat_f32(const float* src, int Co, int C, int backward, float* dst, void* stream);
 /* reference: replaces get_graph_feature + conv + max over k, networks/cls/dgcnn.py:29-50, :72-83, :100-111 */
 int pcl_edgeconv_gather_f32(const float* UV, const int32_t* idx, int B, int N, int k, int C, float* ymax, float* ymin,
                             int32_t* jmax, int32_t* jmin, double* stats_ws, float* sumU, void* stream);

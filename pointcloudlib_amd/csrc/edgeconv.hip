@@ -329,8 +329,33 @@ __global__ __launch_bounds__(256) void edgeconv_insum_kernel(const float* __rest
     }
 }
 
+// W = [Wa | Wb] [Co][2C] of the stage's conv -> the point GEMM's weight Wcat = [Wa ; Wb - Wa] [2Co][C] (back = 0), and the
+// gradient of Wcat -> the gradient of W: dWa = dWcat_top - dWcat_bottom, dWb = dWcat_bottom (back = 1).  One launch each
+// instead of a slice, a subtraction and a concatenation in PyTorch per stage and direction.
+__global__ __launch_bounds__(256) void edgeconv_wcat_kernel(const float* __restrict__ src, int Co, int C, int back, float* __restrict__ dst) {
+    const int n = Co * C;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int o = i / C, c = i - o * C;
+        if (!back) {
+            const float wa = src[(size_t)o * 2 * C + c], wb = src[(size_t)o * 2 * C + C + c];
+            dst[i] = wa; dst[(size_t)n + i] = wb - wa;
+        } else {
+            const float top = src[i], bot = src[(size_t)n + i];
+            dst[(size_t)o * 2 * C + c] = top - bot; dst[(size_t)o * 2 * C + C + c] = bot;
+        }
+    }
+}
+
 }  // namespace pcl
 using namespace pcl;
+
+extern "C" int pcl_edgeconv_wcat_f32(const float* src, int Co, int C, int backward, float* dst, void* stream) {
+    PCL_REQUIRE(src && dst && Co >= 1 && C >= 1, "pcl_edgeconv_wcat_f32: bad arguments");
+    int blocks = (Co * C + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(edgeconv_wcat_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, Co, C, backward ? 1 : 0, dst);
+    return check_launch("pcl_edgeconv_wcat_f32");
+}
 
 extern "C" int pcl_edgeconv_stat_rows(int B, int N) {
     if (B < 1 || N < 1) return 0;

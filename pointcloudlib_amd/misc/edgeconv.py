@@ -107,7 +107,8 @@ class _PointLinear(torch.autograd.Function):
         B, N, C = x.shape
         Co = W.shape[0]
         dev = x.device
-        Wcat = torch.cat([W[:, :C], W[:, C:] - W[:, :C]], dim=0).contiguous()       # [2*Cout, C]
+        Wcat = torch.empty((2 * Co, C), device=dev)                                  # [Wa ; Wb - Wa]
+        _lib.call("pcl_edgeconv_wcat_f32", _p(W.contiguous()), Co, C, 0, _p(Wcat), _stream())
         P = B * N
         UV = torch.empty((B, N, 2 * Co), device=dev)
         rows = _lib.size_query("pcl_mlp_stat_rows", P, 2 * Co, 0)
@@ -136,7 +137,8 @@ class _PointLinear(torch.autograd.Function):
             dWcat = torch.empty((C2, C), device=dev)
             _lib.call("pcl_linear_bwd_dw_rows_f32", _p(dUV), _p(dUV), _p(one), _p(zero), _p(zero), _p(zero), None, None, 1, _p(x),
                       None, None, 0.0, P, C2, C, _p(dWcat), _p(ws), nbytes, None, None, 0, st, tag=f"uvdw{C2}x{C}")
-            dW = torch.cat([dWcat[:Co] - dWcat[Co:], dWcat[Co:]], dim=1)           # Wcat = [Wa ; Wb - Wa]
+            dW = torch.empty((Co, 2 * C), device=dev)                              # Wcat = [Wa ; Wb - Wa]
+            _lib.call("pcl_edgeconv_wcat_f32", _p(dWcat), Co, C, 1, _p(dW), st)
         if ctx.needs_input_grad[0]:
             dx = torch.empty((B, N, C), device=dev)
             _lib.call("pcl_linear_bwd_dx_rows_f32", _p(dUV), _p(dUV), _p(one), _p(zero), _p(zero), _p(zero), None, None, 1, _p(Wcat),
