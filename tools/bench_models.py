@@ -68,7 +68,13 @@ def cpu_baseline_of(kind, state, n_warm=1, n_steps=5):
     from oracle.cpu_partseg import PointNet2PartSegCPU
     from oracle.cpu_pointconv import PointConvClsCPU
     lab = lambda B: torch.from_numpy(synth.labels(B, 40, 1))
-    if kind == "cfg2_n4096":
+    if kind == "cfg1":
+        from oracle.cpu_pointnet import PointNetClsCPU
+        B, N = 8, 1024
+        net = PointNetClsCPU(state).train()
+        x, y = torch.from_numpy(synth.gauss_ball(B, N, 20241)).transpose(1, 2).contiguous(), lab(B)
+        fwd = lambda: soft_cross_entropy_loss(net(x), y)
+    elif kind == "cfg2_n4096":
         B, N = 32, 4096
         net = PointNet2ClsCPU(state, tie_stride=oracle.optimal_block(B)).train()
         x, f, y = torch.from_numpy(synth.gauss_ball(B, N, 20242)), torch.from_numpy(synth.unit_normals(B, N, 7)), lab(B)
@@ -193,7 +199,7 @@ def main():
     res = []
     y8, y32 = lab(8, 1), lab(32, 1)
     x = cloud(8, 1024, 20241)
-    res.append(run("cfg1 PointNet cls B=8 N=1024", PointNet, (x.transpose(1, 2).contiguous(),), lambda o: soft_cross_entropy_loss(o, y8), a.steps))
+    res.append(run("cfg1 PointNet cls B=8 N=1024", PointNet, (x.transpose(1, 2).contiguous(),), lambda o: soft_cross_entropy_loss(o, y8), a.steps, cpu_kind="cfg1"))
     x = cloud(32, 1024, 20242)
     res.append(run("cfg2 PointNet++ SSG cls B=32 N=1024 (no sampling prefetch)", PointNet2_cls, (x, nrm(32, 1024, 7)), lambda o: soft_cross_entropy_loss(o, y32), a.steps))
     x4 = cloud(32, 4096, 20242)

@@ -24,7 +24,7 @@ rm -rf $O/kt/*/*.db $O/fetch $O/write $O/sq/*/*.db 2>/dev/null
 python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
 # every C-ABI entry point event-timed (GEMM kernels: their own begin/end timestamps), algorithmic GB/s and TF per launch shape
 python bench.py --steps 20 --warmup 3 --profile-all --no-cpu-baseline --roofline-kernel none 2>&1 >/dev/null | grep -E "n/step|entry" > $O/${R}_entry_point_roofline.txt
-python -m pytest tests/test_parity_pointnet2_gpu.py tests/test_parity_dgcnn_gpu.py tests/test_parity_partseg_gpu.py tests/test_parity_pointconv_gpu.py tests/test_pointcnn_gpu.py -k "not xconv and not stage and not partseg_network and not cls_network" -m gpu -s -q 2>&1 | grep -v Warning > $O/${R}_parity_reports.txt
+python -m pytest tests/test_parity_pointnet_gpu.py tests/test_parity_pointnet2_gpu.py tests/test_parity_dgcnn_gpu.py tests/test_parity_partseg_gpu.py tests/test_parity_pointconv_gpu.py tests/test_pointcnn_gpu.py -k "not xconv and not stage and not partseg_network and not cls_network" -m gpu -s -q 2>&1 | grep -v Warning > $O/${R}_parity_reports.txt
 # the other BASELINE configs: one line each with the roofline of its dominant kernel, and a kernel-stats CSV per config
 python tools/bench_models.py --steps 20 --cpu-baseline --out $O/${R}_other_configs.json > $O/other.log 2>&1
 for c in "cfg2'" cfg3 "cfg4 PointNet++ MSG part-seg B=16 N=2048 (BASELINE" cfg5; do
