@@ -48,14 +48,21 @@ def compute_density(xyz, bandwidth):
     return out
 
 
-def sample_and_group(npoint, nsample, xyz, points, density_scale=None, start_idx=None, knn_idx=None):
-    """(:133-170) -> new_xyz [B,S,3], new_points [B,S,ns,3+D], grouped_xyz_norm [B,S,ns,3], idx, grouped_density.
-    ``knn_idx`` int32 [B,S,ns]: neighbour groups to use instead of ``knn_point``'s (parity tests feed the groups of the
-    reference's matmul-form arithmetic, :34-53, through here)."""
-    B, N, C = xyz.shape
+def sample_level(npoint, nsample, xyz, start_idx=None, knn_idx=None):
+    """The index-producing half of ``sample_and_group`` (depends on xyz only): FPS centres (:139-140) and their k-NN groups (:141)
+    -> (new_xyz [B,S,3], idx int32 [B,S,ns])."""
     fps_idx = farthest_point_sample(xyz, npoint, start_idx)
     new_xyz = index_points(xyz, fps_idx)
     idx = knn_point(nsample, xyz, new_xyz) if knn_idx is None else _dev(knn_idx, "knn_idx", torch.int32)
+    return new_xyz, idx
+
+
+def sample_and_group(npoint, nsample, xyz, points, density_scale=None, start_idx=None, knn_idx=None, sampled=None):
+    """(:133-170) -> new_xyz [B,S,3], new_points [B,S,ns,3+D], grouped_xyz_norm [B,S,ns,3], idx, grouped_density.
+    ``knn_idx`` int32 [B,S,ns]: neighbour groups to use instead of ``knn_point``'s (parity tests feed the groups of the
+    reference's matmul-form arithmetic, :34-53, through here).  ``sampled`` = a ``sample_level`` result produced ahead."""
+    B, N, C = xyz.shape
+    new_xyz, idx = sampled if sampled is not None else sample_level(npoint, nsample, xyz, start_idx, knn_idx)
     grouped_xyz_norm = index_points(xyz, idx) - new_xyz.view(B, npoint, 1, C)
     if points is not None:
         new_points = torch.cat([grouped_xyz_norm, index_points(points, idx)], dim=-1)
@@ -208,18 +215,29 @@ class PointConvDensitySetAbstraction(nn.Module):
         self.group_all = group_all
         self.bandwidth = bandwidth
 
-    def forward(self, xyz, points, start_idx=None, knn_idx=None):
+    def sample(self, xyz, start_idx=None):
+        """Everything of this level that depends on the coordinates only (xyz [B,N,3], no gradients): the kernel density (:376), the
+        FPS centres and their k-NN groups (:139-141).  -> (new_xyz | None, [(idx | None, density)]) for ``forward(sampling=...)``."""
+        density = compute_density(xyz, self.bandwidth)
+        if self.group_all:
+            return None, [(None, density)]
+        new_xyz, idx = sample_level(self.npoint, self.nsample, xyz, start_idx)
+        return new_xyz, [(idx, density)]
+
+    def forward(self, xyz, points, start_idx=None, knn_idx=None, sampling=None):
         B, _, N = xyz.shape
         xyz = xyz.permute(0, 2, 1).contiguous()
         if points is not None:
             points = points.permute(0, 2, 1).contiguous()
-        density_scale = self.densitynet(compute_density(xyz, self.bandwidth))            # :376-377  [B,N,1]
+        sampled = None
+        if sampling is not None:                                                         # produced ahead by ``sample`` (e.g. on a side stream)
+            (idx_pre, density_pre) = sampling[1][0]
+            sampled = None if idx_pre is None else (sampling[0], idx_pre)
+        density_scale = self.densitynet(density_pre if sampling is not None else compute_density(xyz, self.bandwidth))   # :376-377  [B,N,1]
         if not self.group_all and points is not None and xyz.is_cuda:
             # sample_and_group :133-170 WITHOUT the [B,S,ns,3+D] tensor: indices, centres, local coordinates and gathered density
             # only; the feature MLP's first conv runs folded into the grouping (grouped_feature_mlp_contract)
-            fps_idx = farthest_point_sample(xyz, self.npoint, start_idx)
-            new_xyz = index_points(xyz, fps_idx)
-            idx = knn_point(self.nsample, xyz, new_xyz) if knn_idx is None else _dev(knn_idx, "knn_idx", torch.int32)
+            new_xyz, idx = sampled if sampled is not None else sample_level(self.npoint, self.nsample, xyz, start_idx, knn_idx)
             grouped_xyz_norm = index_points(xyz, idx) - new_xyz.view(B, self.npoint, 1, 3)
             grouped_density = index_points(density_scale, idx)
             weights = self.weightnet(grouped_xyz_norm.contiguous())                      # [B,S,ns,16]  :391-392
@@ -233,7 +251,7 @@ class PointConvDensitySetAbstraction(nn.Module):
             new_xyz, new_points, grouped_xyz_norm, grouped_density = sample_and_group_all(xyz, points, density_scale)
         else:
             new_xyz, new_points, grouped_xyz_norm, _, grouped_density = sample_and_group(
-                self.npoint, self.nsample, xyz, points, density_scale, start_idx, knn_idx)
+                self.npoint, self.nsample, xyz, points, density_scale, start_idx, knn_idx, sampled)
         weights = self.weightnet(grouped_xyz_norm.contiguous())                          # [B,S,ns,16]  :391-392
         # feature MLP :384-389 + density multiply and per-point matmul :393-394 (the MLP's last BatchNorm + ReLU ride in the contraction)
         new_points = feature_mlp_contract(self.mlp, new_points, grouped_density, weights)     # [B,S,C*16]

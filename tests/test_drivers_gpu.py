@@ -71,7 +71,7 @@ def test_lean_sgd_survives_load_state_dict(dev):
     step(); step()
 
 
-@pytest.mark.parametrize("model", ["cls", "partseg_msg"])
+@pytest.mark.parametrize("model", ["cls", "partseg_msg", "pointconv"])
 def test_sampling_prefetch_equals_inline_sampling(dev, model):
     """The bench / train drivers produce the FPS + ball-query indices of batch t+1 on a side stream under the backward of
     batch t (SamplingPrefetch.precompute_sampling).  The handle's memory comes from the side stream's allocator pool and is
@@ -92,6 +92,14 @@ def test_sampling_prefetch_equals_inline_sampling(dev, model):
         net_a = PointNet2_cls().to(dev).train()
         ys = [torch.from_numpy(synth.labels(B, 40, 30 + i)).to(dev) for i in range(3)]
         call = lambda net, x, f, y, s: soft_cross_entropy_loss(net(x, f, sampling=s), y)
+    elif model == "pointconv":
+        # (PointConv's handle also carries the kernel densities; FPS starts are random draws of torch's generator: both runs
+        # draw them in the same order)
+        from pointcloudlib_amd.networks.cls.pointconv import PointConvDensityClsSsg
+        B, N = 8, 1024
+        net_a = PointConvDensityClsSsg().to(dev).train()
+        ys = [torch.from_numpy(synth.labels(B, 40, 30 + i)).to(dev) for i in range(3)]
+        call = lambda net, x, f, y, s: soft_cross_entropy_loss(net(x.transpose(1, 2).contiguous(), sampling=s), y)
     else:
         from pointcloudlib_amd.networks.seg.pointnet2_partseg import PointNetMSG
         B, N = 4, 1024
@@ -103,6 +111,7 @@ def test_sampling_prefetch_equals_inline_sampling(dev, model):
     xs = [torch.from_numpy(synth.gauss_ball(B, N, 10 + i)).to(dev) for i in range(3)]
     fs = [torch.from_numpy(synth.unit_normals(B, N, 20 + i)).to(dev) for i in range(3)]
     side = torch.cuda.Stream(priority=-1)
+    layout = (lambda t: t.transpose(1, 2).contiguous()) if model == "pointconv" else (lambda t: t)
 
     def run(net, prefetch):
         torch.manual_seed(1)                                  # the head's dropout masks: hash of (torch seed, call counter)
@@ -113,12 +122,12 @@ def test_sampling_prefetch_equals_inline_sampling(dev, model):
             opt.zero_grad(set_to_none=True)
             s = pending.pop(i, None)
             if not prefetch:
-                s = net.precompute_sampling(xs[i % 3])
+                s = net.precompute_sampling(layout(xs[i % 3]))
             elif s is None:
-                s = net.precompute_sampling(xs[i % 3], stream=side)
+                s = net.precompute_sampling(layout(xs[i % 3]), stream=side)
             loss = call(net, xs[i % 3], fs[i % 3], ys[i % 3], s)
             if prefetch:
-                pending[i + 1] = net.precompute_sampling(xs[(i + 1) % 3], stream=side)
+                pending[i + 1] = net.precompute_sampling(layout(xs[(i + 1) % 3]), stream=side)
                 assert pending[i + 1]["fed_from"] == torch.cuda.current_stream()
             loss.backward()
             opt.step()
@@ -138,5 +147,6 @@ def test_sampling_prefetch_equals_inline_sampling(dev, model):
     lb, db = run(net_b, True)
     assert torch.equal(da, db), "sampling indices differ between the prefetched and the inline run"
     assert torch.allclose(la[:3], lb[:3], rtol=1e-5, atol=1e-6), (la - lb).abs()[:3]
-    assert torch.allclose(la, lb, rtol=0, atol=2e-2), (la - lb).abs().max()
+    n_close = 8 if model == "pointconv" else 24       # (PointConv's steps are larger: two INLINE runs are 1e-1 apart after 24 of them)
+    assert torch.allclose(la[:n_close], lb[:n_close], rtol=0, atol=2e-2), (la - lb).abs().max()
 

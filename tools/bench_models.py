@@ -218,6 +218,8 @@ def main():
     res.append(run_prefetch("cfg4 PointNet++ MSG part-seg B=16 N=2048, sampling of batch t+1 on a side stream", PointNetMSG, (xs, xs, oh),
                             lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps))
     res.append(run("cfg5 PointConv cls B=32 N=1024", PointConvDensityClsSsg, (x.transpose(1, 2).contiguous(),), lambda o: soft_cross_entropy_loss(o, y32), a.steps, cpu_kind="cfg5"))
+    res.append(run_prefetch("cfg5 PointConv cls B=32 N=1024, densities / FPS / k-NN groups of batch t+1 on a side stream", PointConvDensityClsSsg,
+                            (x.transpose(1, 2).contiguous(),), lambda o: soft_cross_entropy_loss(o, y32), a.steps))
     from pointcloudlib_amd.networks.cls.pointcnn import PointCNNcls
     from pointcloudlib_amd.networks.seg.pointcnn_partseg import PointCNN_partseg
     from pointcloudlib_amd.networks.seg.pointnet_partseg import PointNet_partseg
