@@ -361,9 +361,13 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(const float* __restrict_
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 const uint2 mine = cand[lane < n ? lane : 0];
                 int rank = 0;
-                for (int c = 0; c < n; ++c) {
-                    const uint2 o = cand[c];                                 // broadcast read
-                    rank += (o.x < mine.x || (o.x == mine.x && o.y < mine.y)) ? 1 : 0;
+                for (int c0 = 0; c0 < n; c0 += 8) {                          // eight broadcast reads in flight: one LDS latency per
+                    uint2 o[8];                                              // eight candidates, not per candidate
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) o[u] = cand[(c0 + u) & 63];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        rank += (c0 + u < n && (o[u].x < mine.x || (o[u].x == mine.x && o[u].y < mine.y))) ? 1 : 0;
                 }
                 if (lane < n && rank < k) out[(size_t)rank * Nq] = (int32_t)mine.y;
                 __builtin_amdgcn_wave_barrier();                             // (the next query reuses the list)
