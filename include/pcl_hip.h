@@ -415,6 +415,9 @@ int pcl_linear_bwd_dw_f32(const float* dU, const float* Y, const float* a, const
  *                  forward call fills with the feature columns of that weight (dense: the point GEMM wants 16-byte aligned
  *                  rows) and the backward call reads -- keep it with `save`; needed when Cf > 4 or the features require
  *                  a gradient.
+ * A plain three-layer stack of widths 3-8-8-16 or 1-8-8-1 without pooling or input gradient (PointConv's WeightNet / DensityNet,
+ * misc/pointconv_utils.py:186-250) runs on kernels that exist only behind these entry points (csrc/narrow.hip: every BatchNorm
+ * pass recomputes a row's chain from x, `save` is 768 bytes); same results to fp32 rounding, PCL_NARROW=0 keeps the GEMM kernels.
  * Backward: gout [as out]; writes layer[l].dW / dgamma / dbeta (/ dbias) and, with need_dx, dx = the input gradient
  * ([P, c[0]], columns below x_grad_from unwritten) of a plain stack or dfeature [B*N, Cf] of a grouped one. */
 #define PCL_STACK_MAX_LAYERS 8
