@@ -10,9 +10,11 @@ BatchNorm semantics (Jittor's ``nn.BatchNorm``): batch
 variance ``max(E[x^2]-E[x]^2, 0)``, eps 1e-5, running stats ``r += (batch - r) * momentum`` with
 momentum 0.1 and the biased variance; affine gamma=1, beta=0 at init.
 
-Two backends with identical parameters:
-  * ``hip`` (= ``auto``, the default) -- fused gfx950 kernels of libpcl_hip.so; CPU tensors raise;
-  * ``torch`` -- plain PyTorch fp32 ops, only when requested by name: the numerics reference of the tests.
+One implementation ships: ``backend="hip"`` (= ``"auto"``, the default) -- the fused gfx950 kernels of libpcl_hip.so; CPU
+tensors raise, there is no fallback.  Tests compare it with a plain-PyTorch composite of the same layers; that composite is
+test infrastructure and lives in ``oracle/torch_backend.py``, which registers itself here under the name ``"torch"``
+(``register_reference_backend``).  Nothing in this package imports it, and a module whose ``backend`` names an implementation
+that nobody registered raises.
 """
 import math
 
@@ -20,7 +22,25 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-__all__ = ["PointwiseMLP", "batch_norm_train", "max_over_group"]
+__all__ = ["PointwiseMLP", "batch_norm_train", "max_over_group", "register_reference_backend", "reference_backend"]
+
+# name -> object with ``mlp_forward(mlp, x, group_max)``, ``batch_norm_rows(x2d, gamma, beta, running_mean, running_var,
+# momentum, eps)`` and ``sepconv_forward_x(module, X, F1, F2)``.  Empty in the product; filled by test infrastructure.
+_REFERENCE_BACKENDS = {}
+
+
+def register_reference_backend(name, impl):
+    if name in ("hip", "auto"):
+        raise ValueError(f"{name!r} names the library's own kernels")
+    _REFERENCE_BACKENDS[name] = impl
+
+
+def reference_backend(name):
+    try:
+        return _REFERENCE_BACKENDS[name]
+    except KeyError:
+        raise RuntimeError(f"backend {name!r} is not part of pointcloudlib_amd: the library runs its HIP kernels only (no fallback).  The "
+                           "plain-PyTorch composite the tests compare against is registered by `import oracle.torch_backend`.") from None
 
 
 class _BNRows(torch.autograd.Function):
@@ -73,21 +93,17 @@ class _BNRows(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None
 
 
-def batch_norm_train(x2d, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, native=True):
-    """BatchNorm over the rows of ``x2d`` [P,C] with Jittor's running-stat rule (biased variance).  ``native=False``: the plain
-    PyTorch composite even on the GPU (the ``torch`` backend of ``PointwiseMLP``: the tests' numerics reference)."""
+def batch_norm_train(x2d, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5):
+    """BatchNorm over the rows of ``x2d`` [P,C] with Jittor's running-stat rule (biased variance) on the library's kernels
+    (``_BNRows``).  Tensors the kernels do not take (CPU, fp64: only tests have them) go to the registered reference composite."""
     if not training:
         return F.batch_norm(x2d, running_mean, running_var, gamma, beta, False, 0.0, eps)
     from .. import syncbn
     if syncbn.active():          # data-parallel step with synchronised statistics: sums over every rank's rows
         return syncbn.batch_norm_rows(x2d, gamma, beta, running_mean, running_var, momentum, eps)
-    if native and x2d.is_cuda and x2d.dtype == torch.float32 and gamma is not None and running_mean is not None:
+    if x2d.is_cuda and x2d.dtype == torch.float32 and gamma is not None and running_mean is not None:
         return _BNRows.apply(x2d, gamma, beta, running_mean, running_var, float(momentum), float(eps))
-    with torch.no_grad():
-        var, mean = torch.var_mean(x2d, dim=0, unbiased=False)
-        running_mean += (mean - running_mean) * momentum
-        running_var += (var - running_var) * momentum
-    return F.batch_norm(x2d, None, None, gamma, beta, True, 0.0, eps)
+    return reference_backend("torch").batch_norm_rows(x2d, gamma, beta, running_mean, running_var, momentum, eps)
 
 
 def max_over_group(x, dim):
@@ -133,24 +149,9 @@ class PointwiseMLP(nn.Module):
     def n_layers(self):
         return len(self.weights)
 
-    def _act(self, y):
-        return F.relu(y) if self.slope == 0.0 else F.leaky_relu(y, self.slope)
-
-    def forward_torch(self, x):
-        lead = x.shape[:-1]
-        y = x.reshape(-1, x.shape[-1])
-        for i in range(self.n_layers):
-            y = F.linear(y, self.weights[i], None if self.biases is None else self.biases[i])
-            if self.bn:
-                y = batch_norm_train(y, self.gammas[i], self.betas[i], getattr(self, f"running_mean_{i}"),
-                                     getattr(self, f"running_var_{i}"), self.training, self.momentum, self.eps, native=False)
-            if i < self.n_layers - 1 or self.last_act:
-                y = self._act(y)
-        return y.reshape(*lead, y.shape[-1])
-
     def resolved_backend(self, x):
-        # "auto" IS the HIP path: a CPU tensor is an error there (no silent fallback).  The PyTorch implementation
-        # runs only when a test asks for it by name (backend="torch").
+        # "auto" IS the HIP path: a CPU tensor is an error there (no silent fallback).  Any other name must have been registered
+        # by test infrastructure (register_reference_backend).
         return "hip" if self.backend == "auto" else self.backend
 
     def forward_grouped(self, xyz, new_xyz, feature, idx, cnt, group_off, use_xyz=True):
@@ -188,10 +189,4 @@ class PointwiseMLP(nn.Module):
                 return y.reshape(*x.shape[:-1], y.shape[-1])
             from . import mlp_hip
             return mlp_hip.pointwise_mlp(self, x, group_max, rowset, x_grad_from)
-        if backend != "torch":
-            raise ValueError(f"unknown backend {backend!r}")
-        y = self.forward_torch(x)
-        if group_max is not None:
-            assert x.shape[-2] == group_max
-            y = max_over_group(y, dim=-2)
-        return y
+        return reference_backend(backend).mlp_forward(self, x, group_max)

@@ -106,7 +106,7 @@ class SepConv(_Module):
         kh, K = kernel_size
         assert kh == 1
         self.K, self.dm = K, depth_multiplier
-        self.backend = "auto"                             # "auto" = the HIP kernels; "torch" only when a test names it
+        self.backend = "auto"                             # "auto" = the HIP kernels; any other name: a registered test reference
         bound = 1.0 / math.sqrt(K)                        # fan-in of a depthwise (1,K) filter
         self.depthwise = nn.Parameter(torch.empty(in_channels, depth_multiplier, K).uniform_(-bound, bound))
         self.depthwise_bias = nn.Parameter(torch.empty(in_channels * depth_multiplier).uniform_(-bound, bound))
@@ -114,21 +114,18 @@ class SepConv(_Module):
                                       last_act=activation is not None)
         self.bn = _BatchNormLast(out_channels, momentum=0.9) if with_bn else None
 
-    def depthwise_conv(self, x):
-        B, P, K, C = x.shape
-        y = torch.einsum("bpkc,cjk->bpcj", x, self.depthwise).reshape(B, P, C * self.dm)
-        return y + self.depthwise_bias
-
     def forward(self, x):
-        y = self.pointwise(self.depthwise_conv(x))
-        return self.bn(y) if self.bn is not None else y
+        """``SepConv.execute`` (:160-169) on a region tensor [B,P,K,C]: the X-conv core below with X = I."""
+        B, P, K, C = x.shape
+        X = torch.eye(K, device=x.device, dtype=x.dtype).expand(B, P, K, K).contiguous()
+        return self.forward_x(X, x, None)
 
     def forward_x(self, X, F1, F2):
         """``SepConv(X @ concat(F1, F2))`` with the matmul, the concat and the depthwise conv in one HIP kernel
         (csrc/xconv.hip); the pointwise conv runs on the MFMA GEMM as before."""
-        if self.backend == "torch":      # plain PyTorch composite: runs only when a test asks for it by name
-            F = F1 if F2 is None else torch.cat((F1, F2), dim=-1)
-            return self.forward(torch.matmul(X, F))
+        if self.backend != "auto":       # a reference composite registered by test infrastructure (oracle/torch_backend.py)
+            from .layers import reference_backend
+            return reference_backend(self.backend).sepconv_forward_x(self, X, F1, F2)
         y = self.pointwise(xconv_core(X, F1, F2, self.depthwise, self.depthwise_bias))
         return self.bn(y) if self.bn is not None else y
 

@@ -31,12 +31,16 @@ class DGCNN_partseg(nn.Module):
         self.conv10 = PointwiseMLP([256, 128], slope=0.2)             # :83-85
         self.conv11 = nn.Linear(128, part_num, bias=False)            # :86
 
-    def forward(self, x, l):
+    def forward(self, x, l, lists=None, return_stages=False):
+        """``lists``: optional neighbour lists [3] x int32 [B,N,k] used instead of the network's own kNN -- the reference's
+        ``get_graph_feature(..., idx=...)`` argument (:11,:15): whole-network comparisons between two fp32 pipelines share one
+        set of lists (a near-tie in a FEATURE-space kNN orders two neighbours differently for inputs that agree to 1e-6)."""
         B, _, N = x.shape
         x = x.transpose(1, 2).contiguous()                                         # channel-last [B,N,3]
-        x1 = self.conv12(get_graph_feature(x, self.knn), group_max=self.k)         # :95-98
-        x2 = self.conv34(get_graph_feature(x1, self.knn), group_max=self.k)        # :100-103
-        x3 = edge_conv(self.conv5, x2, knn_graph(x2, self.knn))                    # :105-107 (single conv: factorised)
+        g = (lambda i, t: knn_graph(t, self.knn)) if lists is None else (lambda i, t: lists[i])
+        x1 = self.conv12(get_graph_feature(x, idx=g(0, x)), group_max=self.k)      # :95-98
+        x2 = self.conv34(get_graph_feature(x1, idx=g(1, x1)), group_max=self.k)    # :100-103
+        x3 = edge_conv(self.conv5, x2, g(2, x2))                                   # :105-107 (single conv: factorised)
         x123 = torch.cat((x1, x2, x3), dim=2)                                      # [B,N,192]  :109
         g = self.conv6(x123[:, None].contiguous(), group_max=N).reshape(B, 1024)   # conv6 + max over N  :111-112
         lf = self.conv7(l.reshape(B, 16))                                          # :114-115
@@ -45,7 +49,8 @@ class DGCNN_partseg(nn.Module):
         y = self.dp1(self.conv8(y))
         y = self.dp2(self.conv9(y))
         y = self.conv10(y)
-        return self.conv11(y).permute(0, 2, 1)                                     # [B,part,N]
+        out = self.conv11(y).permute(0, 2, 1)                                      # [B,part,N]
+        return (out, (x1, x2, x3)) if return_stages else out
 
     def execute(self, *a, **k):
         return self(*a, **k)

@@ -17,6 +17,7 @@ def _free_port():
 
 
 def _make_model():
+    import oracle.torch_backend  # noqa: F401  (registers the plain-PyTorch composite: these workers run on CPU tensors)
     from pointcloudlib_amd.misc.layers import PointwiseMLP
     torch.manual_seed(7)
     m = PointwiseMLP([5, 16, 12, 8], bias=True, bn=False, backend="torch")     # no BatchNorm: grads are batch-additive

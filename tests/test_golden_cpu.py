@@ -93,10 +93,21 @@ def test_ops_reject_cpu_tensors():
 
 
 def test_mlp_has_no_silent_cpu_path():
-    """PointwiseMLP's default backend is the HIP path and must refuse CPU tensors; the PyTorch implementation runs
-    only when a test names it (backend="torch")."""
+    """PointwiseMLP's default backend is the HIP path and must refuse CPU tensors; the package ships NO other implementation --
+    a backend name nobody registered raises; the plain-PyTorch composite is test infrastructure (oracle/torch_backend.py) and
+    runs only when a test imports it AND names it."""
+    import subprocess
+    import sys
     import torch
     from pointcloudlib_amd.misc.layers import PointwiseMLP
+    code = ("import torch; from pointcloudlib_amd.misc.layers import PointwiseMLP, _REFERENCE_BACKENDS\n"
+            "assert not _REFERENCE_BACKENDS, 'the package registered a reference backend by itself'\n"
+            "m = PointwiseMLP([4, 8]); m.backend = 'torch'\n"
+            "try:\n    m(torch.randn(2, 5, 4))\nexcept RuntimeError as e:\n    assert 'not part of pointcloudlib_amd' in str(e)\n"
+            "else:\n    raise SystemExit('unregistered backend ran')\n")
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=root)
+    import oracle.torch_backend  # noqa: F401
     m = PointwiseMLP([4, 8])
     x = torch.randn(2, 5, 4)
     try:

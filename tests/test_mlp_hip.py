@@ -7,6 +7,8 @@ import copy
 import pytest
 import torch
 
+import oracle.torch_backend  # noqa: F401,E402  (registers the plain-PyTorch composite the tests compare against)
+
 from pointcloudlib_amd.misc.layers import PointwiseMLP
 
 pytestmark = pytest.mark.gpu

@@ -6,6 +6,8 @@ import copy
 import pytest
 import torch
 
+import oracle.torch_backend  # noqa: F401,E402  (registers the plain-PyTorch composite the tests compare against)
+
 
 def _torch_backend(model):
     for m in model.modules():

@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+import oracle.torch_backend  # noqa: F401,E402  (registers the plain-PyTorch composite the tests compare against)
+
 from pointcloudlib_amd import synth
 
 pytestmark = pytest.mark.gpu

@@ -12,6 +12,8 @@ import numpy as np
 import pytest
 import torch
 
+import oracle.torch_backend  # noqa: F401,E402  (registers the plain-PyTorch composite the tests compare against)
+
 pytestmark = pytest.mark.gpu
 
 B, N, TIE = 32, 1024, 8

@@ -1,6 +1,7 @@
 """Error of the narrow-stack kernels / the GEMM path / PyTorch fp32 against fp64, tensor by tensor (large-mean input)."""
 import copy, os, sys, torch
 sys.path.insert(0, os.getcwd())
+import oracle.torch_backend  # noqa: F401  (registers the plain-PyTorch composite)
 from pointcloudlib_amd.misc.layers import PointwiseMLP
 from pointcloudlib_amd.misc import mlp_hip
 spec, rows = [3, 8, 8, 16], int(sys.argv[1]) if len(sys.argv) > 1 else 5000
