@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU (BASELINE config 2: 32)")
     ap.add_argument("--npoints", type=int, default=1024, help="points per cloud (1024; 4096 is the north-star extra)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
+                    help="skip the short legs for N=4096 and BASELINE configs 3, 4, 5 that follow the timed region (N=1 only; ~20 s)")
     ap.add_argument("--roofline-kernel", default="auto")
     ap.add_argument("--no-prefetch-sampling", dest="prefetch_sampling", action="store_false",
                     help="run FPS/ball query inline at the head of each forward instead of one step ahead on a side stream")
@@ -148,7 +150,7 @@ def main():
     opt = make_sgd(net.parameters(), lr=0.02, momentum=0.9)   # train_cls.py:374-377,404
     batches = make_batches(B, N, 4, rank, dev, args.dist)
 
-    side = torch.cuda.Stream(priority=-1) if args.prefetch_sampling else None     # high priority: short latency-bound chain
+    side = "own" if args.prefetch_sampling else None     # the network's private high-priority producer stream (pointnet2.sampling_stream)
     pending = {}
 
     def step(i):
@@ -344,6 +346,16 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(state0, B, N)
+        others = None
+        if world == 1 and not distributed and args.other_configs and (B, N, args.dist) == (32, 1024, "gauss_ball"):
+            # after the headline's timed region and its CPU leg: the other BASELINE workloads, 20 train steps each on this GPU with the
+            # roofline of their own dominant kernel (tools/bench_models.py; builder-run copies with kernel-stat CSVs under profiles/)
+            del batches[:]
+            pending.clear()
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_models
+            others = bench_models.other_configs(steps=20)
         value = world * B * args.steps / dt
         line = {
             "metric": f"point-clouds/sec fwd+bwd, PointNet++ SSG B={B} N={N}", "value": round(value, 2),
@@ -361,7 +373,7 @@ def main():
                        "sync_bn": bool(getattr(dp, "sync_bn", False)),
                        "entry_points": "per-stack (pcl_mlp_stack_*_f32)" if stack_default else "per-kernel"},
             "own_launches_per_step": own_launches, "host_enqueue_ms": None if host_ms is None else round(host_ms, 3),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "other_configs": others,
         }
         print(json.dumps(line), flush=True)
     if distributed:

@@ -42,6 +42,10 @@ void pcl_time_tagged_launch(void* start_event, void* stop_event, const char* tag
  * (linear forward / dX / dW / fused backward); they receive that kernel's own begin and end timestamps.  No reference
  * counterpart (bench.py's roofline leg). */
 void pcl_time_next_launch(void* start_event, void* stop_event);
+/* Measurement hook: the source-level name of the GEMM-family / k-NN kernel this thread launched last ("(linear_nt_kernel<AM, EM,
+ * true, 2, GM, RAG>)", ...): lets the profiling tools match an entry point's launch with the kernel name a rocprofv3 trace
+ * shows (tools/pmc_traffic.py).  Static storage; "" before the first launch.  No reference counterpart. */
+const char* pcl_last_launch_kernel(void);
 /* reference: no reference counterpart: the reference has no error channel (CUDA errors surface at the next Jittor sync, misc/ops.py:269-271 are Python asserts) */
 const char* pcl_last_error(void);
 
@@ -324,7 +328,8 @@ int pcl_bn_finalize_f32(const double* stats_ws, int stat_rows, const float* gamm
  * rows Y [G*ns, C] (the activation is never materialised): out_max[g*ldo + c], out_mean[g*ldo + c] (ldo >= C: both may be halves
  * of one [G, 2C] tensor), arg [G,C] = first row attaining the max.  Backward: du [G*ns, C] = act'(.) * ([s == arg] gmax + gmean / ns)
  * (gmax / gmean rows ldg floats apart) and its BatchNorm-backward sums as fp64 partial rows [stat_rows][2][C] (<= 1024 rows;
- * feed pcl_bn_bwd_consts_f32, or pcl_mlp_stack_bwd_f32 of a defer_act stack as ext_stats). */
+ * feed pcl_bn_bwd_consts_f32, or pcl_mlp_stack_bwd_f32 of a defer_act stack as ext_stats).  Sizes: G <= 65535 (the groups are the
+ * launch grid's y axis; PCL_EINVAL beyond), ns and C any positive value. */
 /* reference: replaces BatchNorm + LeakyReLU of conv5 and x.max(dim=-1) / x.mean(dim=-1) + concat, networks/cls/dgcnn.py:113-116 */
 int pcl_bn_act_max_mean_f32(const float* Y, const float* scale, const float* shift, float slope, int G, int ns, int C, int ldo,
                             float* out_max, float* out_mean, int32_t* arg, void* stream);

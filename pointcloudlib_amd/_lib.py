@@ -46,6 +46,7 @@ _SIGS = {
     "pcl_version": (c_int, []),
     "pcl_time_next_launch": (None, [_P, _P]),
     "pcl_time_tagged_launch": (None, [_P, _P, ctypes.c_char_p]),
+    "pcl_last_launch_kernel": (ctypes.c_char_p, []),
     "pcl_mlp_stack_sizes": (c_int, [_P, _P, _P, _P]),
     "pcl_mlp_stack_last": (c_int, [_P, _P, _P, _P]),
     "pcl_pointconv_contract_bn_f32": (c_int, [_P, _P, _P, c_float, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
@@ -165,7 +166,8 @@ PROFILER = None   # set to a KernelTimer by bench.py; None in normal operation (
 
 # entry points that launch exactly one GEMM-family kernel (plus, for dW, small reductions that are not the kernel of interest)
 KERNEL_TIMED = {"pcl_linear_fwd_rows_f32", "pcl_linear_fwd_f32", "pcl_linear_bwd_dx_rows_f32", "pcl_linear_bwd_dx_f32",
-                "pcl_linear_bwd_dw_rows_f32", "pcl_linear_bwd_dw_f32", "pcl_linear_bwd_fused_rows_f32"}
+                "pcl_linear_bwd_dw_rows_f32", "pcl_linear_bwd_dw_f32", "pcl_linear_bwd_fused_rows_f32",
+                "pcl_knn_f32", "pcl_knn_fma_f32"}      # (k-NN: the fused kernel; the two-pass form arms nothing and is not recorded)
 _hip = None
 
 
@@ -260,7 +262,10 @@ class KernelTimer:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
         self.records.setdefault((name, tag), []).append((start, ev, algo_bytes, algo_flops))
-        self.order.append((name, tag))
+        fam = ""
+        if isinstance(start, _HipEventPair) and self.inner is None:      # which kernel the entry point chose (tools/pmc_traffic.py)
+            fam = (lib().pcl_last_launch_kernel() or b"").decode().strip("()").split("<")[0]
+        self.order.append((name, tag, fam))
 
     def summary(self):
         """{(name, tag): dict(launches, avg_ms, algo_bytes, algo_flops)} -- call after a device sync."""

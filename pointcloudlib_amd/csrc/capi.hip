@@ -12,7 +12,7 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 TimeHook& time_hook() {
-    static thread_local TimeHook h = {nullptr, nullptr, "", ""};
+    static thread_local TimeHook h = {nullptr, nullptr, "", "", ""};
     return h;
 }
 void set_launch_tag(const char* tag) {
@@ -37,6 +37,11 @@ extern "C" void pcl_time_tagged_launch(void* start_event, void* stop_event, cons
     h.stop = static_cast<hipEvent_t>(stop_event);
     strncpy(h.want, tag ? tag : "", sizeof h.want - 1);
     h.want[sizeof h.want - 1] = 0;
+}
+
+extern "C" const char* pcl_last_launch_kernel(void) {
+    const char* k = pcl::time_hook().last_kernel;
+    return k ? k : "";
 }
 
 extern "C" int pcl_version(void) { return 100; }   // 0.1.0

@@ -45,13 +45,14 @@ static inline hipStream_t as_stream(void* s) {
 // Inside a per-stack entry point (stack.hip) many such kernels are launched by ONE call: each carries a launch tag
 // ("fb256x128", "fwd128x256", ...; set_launch_tag) and pcl_time_tagged_launch arms the events for the next launch whose tag
 // matches (an empty wanted tag matches anything).
-struct TimeHook { hipEvent_t start, stop; char want[32]; char cur[32]; };
+struct TimeHook { hipEvent_t start, stop; char want[32]; char cur[32]; const char* last_kernel; };
 TimeHook& time_hook();
 void set_launch_tag(const char* tag);
 bool time_hook_matches(const TimeHook& h);
 #define PCL_LAUNCH_TIMED(kernel, grid, blk, st, ...)                                                                   \
     do {                                                                                                                \
         ::pcl::TimeHook& h_ = ::pcl::time_hook();                                                                       \
+        h_.last_kernel = #kernel;    /* pcl_last_launch_kernel(): which kernel an entry point chose (profiling tools) */ \
         if (h_.start && ::pcl::time_hook_matches(h_)) {                                                                 \
             hipExtLaunchKernelGGL(kernel, grid, blk, 0, st, h_.start, h_.stop, 0, __VA_ARGS__);                         \
             h_.start = h_.stop = nullptr;                                                                               \

@@ -427,7 +427,7 @@ static int knn_impl(const float* ref, const float* qry, int B, int C, int Nr, in
     if (Nr <= KNN_FUSED_MAX_NR) {
         hipStream_t st = as_stream(stream);
         const int ppt4 = (Nr + 255) / 256 * 4;                    // multiples of 4 registers per lane
-#define PCL_KF(P) if (ppt4 <= P) { hipLaunchKernelGGL((knn_fused_kernel<P, FMA>), dim3((Nq + 4 * KnnCfg<P>::QW - 1) / (4 * KnnCfg<P>::QW), B), dim3(256), 0, st, ref, qry, C, Nr, Nq, k, idx_out); return check_launch("pcl_knn_f32(fused)"); }
+#define PCL_KF(P) if (ppt4 <= P) { PCL_LAUNCH_TIMED((knn_fused_kernel<P, FMA>), dim3((Nq + 4 * KnnCfg<P>::QW - 1) / (4 * KnnCfg<P>::QW), B), dim3(256), st, ref, qry, C, Nr, Nq, k, idx_out); return check_launch("pcl_knn_f32(fused)"); }
         PCL_KF(4) PCL_KF(8) PCL_KF(16) PCL_KF(32) PCL_KF(64)
 #undef PCL_KF
     }

@@ -1401,18 +1401,27 @@ static int launch_fwd_res(const LinArgs& a, int stat_rows, hipStream_t st) {
 // (VALU time IS matrix time on gfx950, see the vector-path header) and (dU, Y) are read from HBM twice -- 2 of the 7
 // P-sized streams of a layer's backward.  Here a persistent workgroup (8 waves, two per SIMD so that one wave's LDS and
 // barrier waits are the other's issue slots) walks row tiles of R = 64 rows (128 when Cin = 64); per tile
-//   1. dy[R x Cout] is formed once into LDS (row-major, 4 dwords of padding) and Yprev[R x Cin] is staged raw;
+//   1. dy[R x Cout] is formed once into LDS (row-major, 4 dwords of padding) and Yprev[R x Cin] is staged raw.  Sparse mode (the
+//      layer under a max pool: du is gz[g][c] at ONE row per group and channel, the winner arg[g][c], and 0 elsewhere): the
+//      dense part -w (k1 + k2 (y - mean)) is deposited from Y alone and the winners are added in a second short pass, one
+//      (group, channel) pair per thread -- `dy[winner row][c] = fma(a, gz, dense)`, the same value the per-row form computes,
+//      bit for bit.  (Round 4.  Before, every row's thread gathered its group's (arg, gz) rows -- 2/3 of the 112 prefetch
+//      registers, 131 KB of L2 reads per tile for ~5 KB of information, and 8 compare / select per element.)
 //   2. dX = dy W: eight 32x32 output tiles, one per wave, K = Cout; the weight (as stored, [k][n]) is LDS-resident for the
-//      whole kernel when it fits (<= 64 KB) -- then this loop is LDS reads and MFMAs only, no VALU, no barrier -- and is
-//      otherwise (256 x 128) streamed in chunks of 32 rows through a double-buffered stage; the epilogue masks with
+//      whole kernel when it fits (<= 64 KB) -- then this loop is LDS reads and MFMAs only, no VALU, no barrier.  The one
+//      shape where it does not (256 x 128: 128 KB beside a 100 KB tile image) takes the B operand straight from L2 into
+//      registers: a lane's MFMA operand is W[k][its column], 32 consecutive floats of a weight row per half-wave, requested
+//      three 8-k steps ahead of the MFMAs that use them (round 4; before, 32-row chunks went through a double-buffered LDS
+//      stage with a block barrier per chunk, which kept all eight waves in lockstep: no wave's epilogue could run under
+//      another's MFMAs, and every chunk boundary drained the matrix pipe).  The epilogue masks with
 //      relu'(BN(Yprev)) read from LDS, sums (du, du*Yprev) for the BatchNorm below and stores dU_prev in the C/D layout;
 //   3. dW += dy^T z, z = lrelu(BN(Yprev)) applied while reading the staged Yprev: K = the tile's rows, A = dy columns, B = z
 //      columns, single-dword LDS reads of the same tiles; the [Cout x Cin] accumulators stay in registers for the whole
 //      kernel (1-4 32x32 tiles per wave; 64 x 64 has only four, so there two wave groups take half of the rows each) and
 //      leave once, as this workgroup's partial tile(s).
-// The next tile's raw operands are requested into registers as soon as nothing else is queued behind them in the wave's
-// in-order memory counter: right after the tile's LDS image is complete (resident weight), or after the dX loop (streamed
-// weight: a weight chunk waited for behind a row-tile prefetch would wait for all of it).
+// The next tile's raw operands are requested into registers where nothing that is waited for soon queues behind them in the
+// wave's in-order memory counter: under the dX loop (resident weight), or under the FIRST HALF of the dW loop (weight from L2:
+// a weight operand waited for behind a row-tile prefetch waits for all of it, so the prefetch has landed before dX starts).
 // Supported: (Cout, Cin) in {64,128} x {64,128} and 256 x 128, a masked (non-first) layer.
 constexpr int FB_T = 512;
 __host__ __device__ constexpr int fb_rows(int Cin) { return Cin == 64 ? 128 : 64; }
@@ -1439,11 +1448,11 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
     constexpr int COUT = 64 * CO, CIN = 64 * CI, R = fb_rows(CIN);
     constexpr bool WRES = fb_resident(COUT, CIN);
     constexpr int DLD = COUT + 4, YLD = CIN + 4, WLD = CIN + 4;          // LDS row strides (dwords)
-    constexpr int WROWS = WRES ? COUT : 64;                              // resident weight, or two stages of 32 rows
+    constexpr int WROWS = WRES ? COUT : 0;                               // resident weight (else: B operand from L2, no LDS copy)
     // staging maps: thread -> (16-byte column piece, rows row0 + RP*i)
     constexpr int CPR_O = COUT / 4, RP_O = FB_T / CPR_O, NI_O = R / RP_O;
     constexpr int CPR_I = CIN / 4, RP_I = FB_T / CPR_I, NI_I = R / RP_I;
-    constexpr int NWB = (WRES ? COUT : 32) * CIN / 4 / FB_T;             // 16-byte weight pieces per thread (all of it | one chunk)
+    constexpr int NWB = WRES ? COUT * CIN / 4 / FB_T : 1;                // 16-byte weight pieces per thread (resident weight)
     // dX: (R/32) x (CIN/32) = 8 output tiles, wave -> (rbx, cbx)
     constexpr int CB = CIN / 32;
     static_assert((R / 32) * CB == 8, "one dX tile per wave");
@@ -1453,11 +1462,16 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
     constexpr int WB = NTJ < WPG ? NTJ : WPG, WA = WPG / WB, TMW = NTI / WA, TNW = NTJ / WB;
     static_assert(WA * WB == WPG && TMW * WA == NTI && TNW * WB == NTJ, "dW tiling");
     constexpr int KR = R / KW;                                           // rows of a tile one wave group accumulates
-    __shared__ __attribute__((aligned(16))) float lds[R * DLD + R * YLD + WROWS * WLD + 2 * R * 2];
+    __shared__ __attribute__((aligned(16))) float lds[R * DLD + R * YLD + WROWS * WLD + 2 * R * 2 + 2 * 128 + 4 * COUT];
     float* const sDY = lds;
     float* const sY = sDY + R * DLD;
     float* const sWb = sY + R * YLD;
     int2* const sMeta = reinterpret_cast<int2*>(sWb + WROWS * WLD);      // [2][R] row records {group, row-in-group | mult << 16}
+    // [2][128] sparse mode: (tile row) - (row-in-group) of the rows of group g, at slot g & 127 (a tile's <= R groups are consecutive)
+    int* const sDelta = reinterpret_cast<int*>(sMeta + 2 * R);
+    // [4][COUT] the dy transform's constants (a, k1, k2, mean): read back once per tile by the deposit -- held in registers for the
+    // whole kernel they were 16 of the registers the 256 x 128 shape does not have
+    float* const sCst = reinterpret_cast<float*>(sDelta + 2 * 128);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
     const int bx = blockIdx.x;
@@ -1466,9 +1480,8 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
     // per-thread constants of the dy transform (this thread's 4 columns, fixed for the whole kernel)
     const int oc4 = (tid % CPR_O) * 4, orow0 = tid / CPR_O;
     const int ic4 = (tid % CPR_I) * 4, irow0 = tid / CPR_I;
-    const float4 ca = *reinterpret_cast<const float4*>(p.a + oc4), ck1 = *reinterpret_cast<const float4*>(p.k1 + oc4);
-    const float4 ck2 = *reinterpret_cast<const float4*>(p.k2 + oc4), cmu = *reinterpret_cast<const float4*>(p.mu + oc4);
-    const rsrc_t rArg = buf_rsrc(p.arg, 0, SPARSE ? 0xffffffffull : 0), rGz = buf_rsrc(p.gz, 0, SPARSE ? 0xffffffffull : 0);
+    for (int c = tid; c < COUT; c += FB_T) { sCst[c] = p.a[c]; sCst[COUT + c] = p.k1[c]; sCst[2 * COUT + c] = p.k2[c]; sCst[3 * COUT + c] = p.mu[c]; }
+    const rsrc_t rArg = buf_rsrc(p.arg, 0, SPARSE ? 0xfffffff0ull : 0), rGz = buf_rsrc(p.gz, 0, SPARSE ? 0xfffffff0ull : 0);      // (ends below BUF_OOB: the guard offset of a group past the tile must fail the range check)
     const rsrc_t rW = buf_rsrc(p.W, 0, (size_t)COUT * irow);
     // dX tile of this wave and the per-lane constants of its column (mask of the layer below); dW tiles and their z transform
     const int rbx = wave / CB, cbx = wave % CB;
@@ -1489,8 +1502,13 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
 
     // ---- raw operands of one tile in registers (256 x 128 sparse: 64 accumulator + 112 prefetch registers; they fit because the
     // requests are issued in slices through the dW loop -- all at once they spilled)
-    float4 rY[NI_O], rU[SPARSE ? 1 : NI_O], rG[SPARSE ? NI_O : 1], rP[NI_I];
-    int4 rA[SPARSE ? NI_O : 1];
+    float4 rY[NI_O], rU[SPARSE ? 1 : NI_O], rP[NI_I];
+    // sparse mode: (arg, gz) of the first NFX * GP groups of the tile at this thread's channel (thread -> channel tid % COUT of
+    // group tid / COUT of the round); further groups of a tile (rare: many groups of one or two rows) are read in the pass itself
+    constexpr int GP = FB_T / COUT, NFX = COUT >= 256 ? 2 : 4;        // (256 x 128 has no registers to spare: 4 groups per tile prefetched)
+    const int fxc = tid % COUT, fxg = tid / COUT;
+    int fxA[SPARSE ? NFX : 1]; float fxG[SPARSE ? NFX : 1];
+    const float fxa = SPARSE ? p.a[fxc] : 0.f;
     int2 rM = make_int2(0, 0);                       // row record of row tid (< R) of the tile after the requested one
     auto record_of = [&](int tile) -> int2 {         // row record of row tid of `tile`
         // a row past P gets multiplicity 0 and a row-in-group no `arg` entry can equal: du = 0 and dy = 0 exactly
@@ -1506,36 +1524,55 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
         }
         return in ? rec : make_int2(0, 0xffff);
     };
+    auto meta_store = [&](int mb, int2 rec) {        // row record of row tid -> LDS (+ the group's row offset, sparse mode)
+        if (tid < R) {
+            sMeta[mb * R + tid] = rec;
+            if constexpr (SPARSE) {
+                const int srow = rec.y & 0xffff;
+                if (srow != 0xffff && (tid == 0 || srow == 0)) sDelta[mb * 128 + (rec.x & 127)] = tid - srow;
+            }
+        }
+    };
     // The loads of a tile are a list of NREQ single requests (compile-time index n), issued a few at a time between the
     // MFMAs of the loop the prefetch flies under: a wave that issues 20-28 16-byte loads back to back sits in the memory
     // issue queue for thousands of cycles while the matrix pipe of its SIMD idles (both waves of a SIMD are in the same
     // phase).  Rows orow0 + RP*i: the row step goes into the scalar offset (one per-lane offset for all i, no VALU per load);
     // the hardware range check covers per-lane + scalar offset (measured: tools/ubench/bufcheck.hip), so rows past P --
     // and every row when there is no next tile (`len` = 0) -- read 0 without touching memory.
-    constexpr int PER_O = SPARSE ? 3 : 2, NREQ = NI_O * PER_O + NI_I;
-    struct ReqCtx { rsrc_t y, u, pr; const int2* mrow; unsigned vo, vi; };
+    constexpr int NREQ_O = NI_O * (SPARSE ? 1 : 2), NREQ = NREQ_O + NI_I + (SPARSE ? 2 * NFX : 0);
+    struct ReqCtx { rsrc_t y, u, pr; unsigned vo, vi; int gf, gl; };
+    auto tile_groups = [&](int tile, int mb, int& gf, int& gl) {      // first / last group of `tile` (its records are in sMeta[mb])
+        int nv = p.P - tile * R; nv = nv > R ? R : nv;
+        gf = 0; gl = -1;
+        if (nv > 0) { gf = sMeta[mb * R].x; gl = sMeta[mb * R + nv - 1].x; }
+    };
     auto req_open = [&](int tile, int mb, bool live) -> ReqCtx {
         const int m0 = tile * R;
         ReqCtx c;
         c.y = buf_rsrc(p.Y, (size_t)m0 * orow, live ? (size_t)p.P * orow : 0);
         c.u = buf_rsrc(p.dU, (size_t)m0 * orow, !SPARSE && live ? (size_t)p.P * orow : 0);
         c.pr = buf_rsrc(p.Yprev, (size_t)m0 * irow, live ? (size_t)p.P * irow : 0);
-        c.mrow = sMeta + mb * R + orow0;
         c.vo = (unsigned)orow0 * orow + (unsigned)oc4 * 4; c.vi = (unsigned)irow0 * irow + (unsigned)ic4 * 4;
+        c.gf = 0; c.gl = -1;
+        if constexpr (SPARSE) { if (live) tile_groups(tile, mb, c.gf, c.gl); }
         return c;
     };
     auto req_one = [&](const ReqCtx& c, int n) {     // n: compile-time after unrolling
-        if (n < NI_O * PER_O) {
-            const int i = n / PER_O, kind = n % PER_O;
-            if (kind == 0) rY[i] = buf_ld4(c.y, c.vo, (unsigned)(RP_O * i) * orow);
-            else if constexpr (SPARSE) {
-                const unsigned go = (unsigned)c.mrow[RP_O * i].x * orow + (unsigned)oc4 * 4;
-                if (kind == 1) rA[i] = buf_ld4i(rArg, go, 0);
-                else rG[i] = buf_ld4(rGz, go, 0);
-            } else rU[i] = buf_ld4(c.u, c.vo, (unsigned)(RP_O * i) * orow);
-        } else {
-            const int i = n - NI_O * PER_O;
+        if (n < NREQ_O) {
+            if constexpr (SPARSE) rY[n] = buf_ld4(c.y, c.vo, (unsigned)(RP_O * n) * orow);
+            else {
+                const int i = n / 2;
+                if (n % 2 == 0) rY[i] = buf_ld4(c.y, c.vo, (unsigned)(RP_O * i) * orow);
+                else rU[i] = buf_ld4(c.u, c.vo, (unsigned)(RP_O * i) * orow);
+            }
+        } else if (n < NREQ_O + NI_I) {
+            const int i = n - NREQ_O;
             rP[i] = buf_ld4(c.pr, c.vi, (unsigned)(RP_I * i) * irow);
+        } else if constexpr (SPARSE) {
+            const int j = (n - NREQ_O - NI_I) / 2, g = c.gf + j * GP + fxg;
+            const unsigned go = g <= c.gl ? ((unsigned)g * COUT + (unsigned)fxc) * 4u : BUF_OOB;
+            if ((n - NREQ_O - NI_I) % 2 == 0) fxA[j] = __builtin_bit_cast(int, buf_ld1(rArg, go, 0));
+            else fxG[j] = buf_ld1(rGz, go, 0);
         }
     };
     auto req_slice = [&](const ReqCtx& c, int j, int J) {        // slice j of J of the list
@@ -1548,20 +1585,22 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
         const int2* mrow = sMeta + mb * R + orow0;
         float* const dst = sDY + orow0 * DLD + oc4;
         float* const dsty = sY + irow0 * YLD + ic4;
+        const float4 ca = *reinterpret_cast<const float4*>(sCst + oc4), ck1 = *reinterpret_cast<const float4*>(sCst + COUT + oc4);
+        const float4 ck2 = *reinterpret_cast<const float4*>(sCst + 2 * COUT + oc4), cmu = *reinterpret_cast<const float4*>(sCst + 3 * COUT + oc4);
+        (void)ca;
 #pragma unroll
         for (int i = 0; i < NI_O; ++i) {
-            const int my = mrow[RP_O * i].y;
-            const float w = (float)(my >> 16);
-            float4 du;
-            if constexpr (SPARSE) {
-                const int srow = my & 0xffff;
-                du.x = rA[i].x == srow ? rG[i].x : 0.f; du.y = rA[i].y == srow ? rG[i].y : 0.f;
-                du.z = rA[i].z == srow ? rG[i].z : 0.f; du.w = rA[i].w == srow ? rG[i].w : 0.f;
-            } else du = rU[i];
+            const float w = (float)(mrow[RP_O * i].y >> 16);
             const float4 y = rY[i];
             float4 d;            // rows past P: du = y = 0 (range-checked loads) and w = 0 -> dy = 0 exactly
-            d.x = fmaf(ca.x, du.x, -w * fmaf(ck2.x, y.x - cmu.x, ck1.x)); d.y = fmaf(ca.y, du.y, -w * fmaf(ck2.y, y.y - cmu.y, ck1.y));
-            d.z = fmaf(ca.z, du.z, -w * fmaf(ck2.z, y.z - cmu.z, ck1.z)); d.w = fmaf(ca.w, du.w, -w * fmaf(ck2.w, y.w - cmu.w, ck1.w));
+            if constexpr (SPARSE) {      // the dense part; fma(a, du, this) with du = 0 is this value itself
+                d.x = -w * fmaf(ck2.x, y.x - cmu.x, ck1.x); d.y = -w * fmaf(ck2.y, y.y - cmu.y, ck1.y);
+                d.z = -w * fmaf(ck2.z, y.z - cmu.z, ck1.z); d.w = -w * fmaf(ck2.w, y.w - cmu.w, ck1.w);
+            } else {
+                const float4 du = rU[i];
+                d.x = fmaf(ca.x, du.x, -w * fmaf(ck2.x, y.x - cmu.x, ck1.x)); d.y = fmaf(ca.y, du.y, -w * fmaf(ck2.y, y.y - cmu.y, ck1.y));
+                d.z = fmaf(ca.z, du.z, -w * fmaf(ck2.z, y.z - cmu.z, ck1.z)); d.w = fmaf(ca.w, du.w, -w * fmaf(ck2.w, y.w - cmu.w, ck1.w));
+            }
             *reinterpret_cast<float4*>(dst + RP_O * i * DLD) = d;
         }
 #pragma unroll
@@ -1583,7 +1622,6 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
         }
     };
 
-    constexpr int NCH = COUT / 32;                   // 32-row weight chunks (even; streamed: the chunk sequence is cyclic over the tiles)
 #if PCL_EXP == 7                                     // lab build: cycles per phase of the tile loop, printed by two waves of one workgroup
     long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #define FB_MARK(i) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tlast; tlast = t_; }
@@ -1592,10 +1630,9 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
 #endif
     int tile = bx, it = 0;
     if (tile < tiles) {
-        if (tid < R) sMeta[tid] = record_of(tile);
+        meta_store(0, record_of(tile));
         rM = record_of(tile + p.gx);
-        w_request(0);
-        w_deposit(0);
+        if constexpr (WRES) { w_request(0); w_deposit(0); }
         __syncthreads();
         const ReqCtx c0 = req_open(tile, 0, true);
         req_slice(c0, 0, 1);
@@ -1605,9 +1642,31 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
         const bool more = tile + p.gx < tiles;
         // ---- LDS image of this tile, row records of the next one
         FB_MARK(6)
-        if (tid < R) sMeta[(mb ^ 1) * R + tid] = rM;                        // (its last readers passed barrier B of the tile before)
+        meta_store(mb ^ 1, rM);                                             // (its last readers passed barrier B of the tile before)
         deposit(mb);
         rM = record_of(tile + 2 * p.gx);
+        if constexpr (SPARSE) {
+            // ---- the winners: dy[row of slot arg[g][c] of group g][c] += a[c] gz[g][c], GP groups per round
+            __syncthreads();                                                // A0: the dense part is complete
+            int gf, gl;
+            tile_groups(tile, mb, gf, gl);
+            const int* dl = sDelta + mb * 128;
+            auto fix = [&](int g, int srow, float gzv) {
+                const int r = srow + dl[g & 127];
+                if (g <= gl && (unsigned)r < (unsigned)R) {
+                    float* q = sDY + r * DLD + fxc;
+                    *q = fmaf(fxa, gzv, *q);
+                }
+            };
+#pragma unroll
+            for (int j = 0; j < NFX; ++j)
+                if (gf + j * GP <= gl) fix(gf + j * GP + fxg, fxA[j], fxG[j]);
+            for (int g0 = gf + NFX * GP; g0 <= gl; g0 += GP) {              // (rare) groups beyond the prefetched rounds
+                const int g = g0 + fxg;
+                const unsigned go = g <= gl ? ((unsigned)g * COUT + (unsigned)fxc) * 4u : BUF_OOB;
+                fix(g, __builtin_bit_cast(int, buf_ld1(rArg, go, 0)), buf_ld1(rGz, go, 0));
+            }
+        }
         FB_MARK(0)
         __syncthreads();                                                    // A: sDY, sY, sMeta[next] complete
         FB_MARK(1)
@@ -1646,36 +1705,49 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
                 cur = nxt;
             }
         } else {
+            // B from L2: lane (lr, lh) of MFMA j of step k8 contracts k = 8*k8 + 4*lh + j, i.e. needs W[8*k8 + 4*lh + j][xcol]
+            // (the row goes into the scalar offset, one per-lane offset for the whole loop); ring of DB steps in flight
+            constexpr int DB = 3, NK8 = COUT / 8;
+            const unsigned vB = (unsigned)(lh * 4) * irow + (unsigned)xcol * 4u;
+            auto b_load = [&](int k8) -> float4 {
+                float4 b;
+                b.x = buf_ld1(rW, vB, (unsigned)(k8 * 8 + 0) * irow); b.y = buf_ld1(rW, vB, (unsigned)(k8 * 8 + 1) * irow);
+                b.z = buf_ld1(rW, vB, (unsigned)(k8 * 8 + 2) * irow); b.w = buf_ld1(rW, vB, (unsigned)(k8 * 8 + 3) * irow);
+                return b;
+            };
+            float4 bq[DB];
 #pragma unroll
-            for (int kc = 0; kc < NCH; ++kc) {
-                w_request(kc + 1 < NCH ? kc + 1 : 0);                       // (chunk 0 again: the next tile's first)
-                const float* sBx = sWb + ((kc & 1) * 32 + lh * 4) * WLD + xcol;
-                XOp cur = x_load(sAx + kc * 32, sBx);
+            for (int d = 0; d < DB; ++d) bq[d] = b_load(d);
+            float4 acur = *reinterpret_cast<const float4*>(sAx);
+#pragma unroll
+            for (int k8 = 0; k8 < NK8; ++k8) {
+                float4 anxt = acur;
+                if (k8 + 1 < NK8) anxt = *reinterpret_cast<const float4*>(sAx + (k8 + 1) * 8);
+                const float4 b = bq[k8 % DB];
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    XOp nxt = cur;
-                    if (kk + 1 < 4) nxt = x_load(sAx + kc * 32 + (kk + 1) * 8, sBx + (kk + 1) * 8 * WLD);
-                    __builtin_amdgcn_sched_barrier(0);
-                    x_mfma(cur);
-                    cur = nxt;
-                }
-                w_deposit((kc + 1) & 1);                                    // the other stage: its readers finished a chunk ago
-                __syncthreads();
+                accx = __builtin_amdgcn_mfma_f32_32x32x2f32(acur.x, b.x, accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_32x32x2f32(acur.y, b.y, accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_32x32x2f32(acur.z, b.z, accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_32x32x2f32(acur.w, b.w, accx, 0, 0, 0);
+                if (k8 + DB < NK8) bq[k8 % DB] = b_load(k8 + DB);
+                acur = anxt;
             }
         }
         FB_MARK(2)
         // ---- dX epilogue: mask with relu'(BN(Yprev)), sums for the BatchNorm below, store in the C/D layout
         {
-            // row rl of the tile goes into the scalar offset; rows past P are dropped by the range check
-            const rsrc_t rD = buf_rsrc(p.dUprev, (size_t)m0 * irow, (size_t)p.P * irow);
+            // row block rbx goes into the descriptor's base and the row within it into the scalar offset (compile-time); rows past P
+            // are dropped by the range check.  LDS: one base pointer + compile-time steps that fold into the DS offset field (sixteen
+            // addresses computed from rbx were hoisted out of the tile loop as 64-bit values and spilled).
+            const rsrc_t rD = buf_rsrc(p.dUprev, (size_t)(m0 + rbx * 32) * irow, (size_t)p.P * irow);
             float ts = 0.f, tq = 0.f;
-            const float piv = sY[(rbx * 32 + 4 * lh) * YLD + xcol];
+            const float* const yb = sY + (rbx * 32 + 4 * lh) * YLD + xcol;
+            const float piv = yb[0];
             const unsigned v0 = (unsigned)(4 * lh) * irow + (unsigned)xcol * 4;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rl = rbx * 32 + (r & 3) + 8 * (r >> 2);           // + 4*lh
-                const float y = sY[(rl + 4 * lh) * YLD + xcol];
+                const int rl = (r & 3) + 8 * (r >> 2);                      // + 4*lh + 32*rbx
+                const float y = yb[rl * YLD];
                 float c = accx[r];
                 c = fmaf(xsc, y, xsh) > 0.f ? c : c * p.pslope;
                 ts += c; tq = fmaf(c, y - piv, tq);
@@ -1705,7 +1777,8 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
             for (int ks = 0; ks < KR / 2; ++ks) {
                 WOp nxt = cur;
                 if (ks + 1 < KR / 2) nxt = w_load(ks + 1);
-                if constexpr (!WRES) req_slice(cn, ks, KR / 2);             // (streamed weight: no weight chunk may queue behind these)
+                if constexpr (!WRES && SPARSE) { if (ks < KR / 4) req_slice(cn, ks, KR / 4); }    // (weight from L2: first half of the loop, see header)
+                if constexpr (!WRES && !SPARSE) req_slice(cn, ks, KR / 2);
                 __builtin_amdgcn_sched_barrier(0);
                 float bv[TNW];
 #pragma unroll
@@ -1722,10 +1795,13 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
         }
         FB_MARK(4)
         };
-        // The two phases only read the tile's LDS image, in any order: with a resident weight (no barrier inside dX) waves 4-7
+        // The two phases only read the tile's LDS image, in any order (no barrier inside either): waves 4-7
         // -- the second wave of every SIMD -- take dW first, so that one wave's epilogue (VALU, LDS reads, stores; no MFMA)
         // runs under the other's MFMAs instead of both leaving the matrix pipe idle at the same time.
-        if (!WRES || wave < 4) { phase_dx(); phase_dw(); }
+        // (dense 256 x 128 -- no BASELINE network has it -- keeps one order: with dU its prefetch is 96 registers, which the second
+        //  order would hold across the dX loop; they do not exist)
+        constexpr bool STAGGER = WRES || SPARSE;
+        if (!STAGGER || wave < 4) { phase_dx(); phase_dw(); }
         else { phase_dw(); phase_dx(); }
         __syncthreads();                                                    // B: every wave is done with sDY / sY / sMeta[mb]
         FB_MARK(5)

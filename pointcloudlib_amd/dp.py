@@ -20,8 +20,8 @@ all-reduces the fp64 batch sums of every training-mode BatchNorm the library run
 MLP stacks, EdgeConv's BatchNorm (misc/edgeconv.py), the FC head (any row count), the wide PointConv linear (routed to the
 fused MLP path), and the plain-PyTorch ``batch_norm_train`` path (PointCNN's BatchNorm after an activation, the ``torch``
 backend).  ``nn.BatchNorm*`` modules called directly by a user model (not through ``head_layer`` / ``fc_head``) are NOT
-synchronised; ``FlatBucketDP(sync_bn=True)`` raises if the wrapped module contains one it cannot reach (see
-``_unsynced_batchnorms``).  The G-rank step then equals the 1-rank step on the concatenated batch
+synchronised; ``FlatBucketDP(sync_bn=True)`` raises at its first gradient exchange if a training-mode BatchNorm module of the
+wrapped model was not normalised by a synchronised path during that step (see ``_unsynced_batchnorms``).  The G-rank step then equals the 1-rank step on the concatenated batch
 (tests/test_syncbn_gpu.py: PointNet++ and DGCNN).  The switch is process-global while the wrapper lives: ``close()``
 turns it off.
 """
@@ -52,12 +52,9 @@ class FlatBucketDP:
         self.group = process_group
         self.active = dist.is_available() and dist.is_initialized()        # a 1-rank group still runs the collective
         self.sync_bn = bool(sync_bn) and self.active
+        self._bn_checked = not self.sync_bn
         if self.sync_bn:
             from . import syncbn
-            bad = _unsynced_batchnorms(module)
-            if bad:
-                raise RuntimeError("FlatBucketDP(sync_bn=True): these BatchNorm modules are called directly by the model and would keep "
-                                   f"per-rank statistics: {bad}; route them through misc.head.head_layer / fc_head or PointwiseMLP")
             syncbn.enable(process_group)
         self.world = dist.get_world_size(process_group) if self.active else 1
         self.overlap = overlap
@@ -139,6 +136,8 @@ class FlatBucketDP:
         """Average the gradients over ranks: finish the bucketed all-reduces (sum), then scale by 1/world."""
         if not self.active:
             return
+        if not self._bn_checked:
+            self._check_batchnorms()
         self._armed = False
         for b in self.buckets:
             if b.work is None:
@@ -151,12 +150,24 @@ class FlatBucketDP:
         for p, v in zip(self.params, self.views):
             p.grad = v
 
+    def _check_batchnorms(self):
+        """After the first forward + backward of a ``sync_bn=True`` wrapper: every training-mode BatchNorm module of the model must
+        have gone through a synchronised path (see ``_unsynced_batchnorms``)."""
+        self._bn_checked = True
+        bad = _unsynced_batchnorms(self.module)
+        if bad:
+            raise RuntimeError("FlatBucketDP(sync_bn=True): these BatchNorm modules were not normalised by a synchronised path in the first "
+                               f"step (called directly by the model, they keep per-rank statistics): {bad}; route them through "
+                               "misc.head.head_layer / fc_head or PointwiseMLP")
+
     def all_reduce_into_grads(self):
         """Same exchange for gradients that must stay where they are (``param.grad`` tensors written in place by a
         captured HIP graph): pack, one all-reduce of the whole flat buffer, scale, unpack.  Use with ``overlap=False``
         (hooks must not issue collectives inside a capture)."""
         if not self.active:
             return
+        if not self._bn_checked:
+            self._check_batchnorms()
         self._armed = False
         grads = [p.grad for p in self.params if p.grad is not None]
         views = [v for p, v in zip(self.params, self.views) if p.grad is not None]
@@ -168,21 +179,14 @@ class FlatBucketDP:
 
 
 def _unsynced_batchnorms(module):
-    """Names of ``nn.BatchNorm*`` modules that the library's synchronised paths cannot reach.  The counterpart networks keep
-    ``nn.BatchNorm1d`` modules only as parameter containers of the FC head (run through ``head_layer`` / ``fc_head``, which
-    synchronise) -- those are declared by the owning network in ``_syncbn_ok`` (a tuple of attribute-name prefixes) or sit in
-    an ``nn.Sequential`` that ``fc_head`` walks (``fc_layer``).  Anything else is reported."""
+    """Names of the ``nn.BatchNorm*`` modules in training mode that no synchronised path of the library has touched so far.  The
+    counterpart networks keep ``nn.BatchNorm1d`` modules only as parameter containers of the FC head; ``misc.head.head_layer``
+    (which ``fc_head`` and the stack path fall back to when synchronised statistics are on) marks every BatchNorm module it
+    normalises with ``_pcl_sync_routed``.  A module without the mark after a forward pass was called directly by the model
+    (``self.bn1(x)``) and kept per-rank statistics.  Decided by what ran, not by what a module is called."""
     import torch.nn as nn
-    ok_prefixes = ("fc_layer", "bn", "classifier", "head")
-    extra = tuple(getattr(module, "_syncbn_ok", ()))
-    bad = []
-    for name, m in module.named_modules():
-        if isinstance(m, nn.modules.batchnorm._BatchNorm):
-            leaf = name.split(".")[-1]
-            top = name.split(".")[0]
-            if not (top.startswith(ok_prefixes) or leaf.startswith(ok_prefixes) or name.startswith(extra)):
-                bad.append(name)
-    return bad
+    return [name for name, m in module.named_modules()
+            if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training and not getattr(m, "_pcl_sync_routed", False)]
 
 
 def shard_batch(tensors, rank, world):

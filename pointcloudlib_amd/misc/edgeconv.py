@@ -197,7 +197,7 @@ def conv_max_mean_pool(mlp, x):
     stops at its pre-BatchNorm output and the pooling kernel applies BatchNorm + activation while it reduces."""
     from . import mlp_hip
     B, N, Cin = x.shape
-    if x.is_cuda and x.dtype == torch.float32 and mlp.resolved_backend(x) == "hip" and mlp.last_act and N <= 65535:
+    if x.is_cuda and x.dtype == torch.float32 and mlp.resolved_backend(x) == "hip" and mlp.last_act and B <= 65535:      # (the clouds are the pooling kernels' grid.y)
         r = mlp_hip.stack_plain_deferred(mlp, x.reshape(B * N, Cin).contiguous())
         if r is not None:
             Y, link = r

@@ -73,6 +73,8 @@ def head_layer(x, linear, bn=None, act=None):
     slope = float(act) if isinstance(act, (int, float)) else _slope_of(act)
     if not x.is_cuda:
         raise RuntimeError("head_layer: expected a tensor on the GPU (libpcl_hip has no CPU path)")
+    if bn is not None and bn.training and syncbn.active():
+        bn._pcl_sync_routed = True               # dp.FlatBucketDP(sync_bn=True) checks that every BatchNorm module came through here
     if x.shape[0] > MAX_ROWS or x.dim() != 2 or x.dtype != torch.float32:     # large batches: plain library GEMMs
         y = linear(x)
         if bn is not None:
@@ -116,7 +118,8 @@ _DROP_CALLS = [0]
 
 def _head_plan(layers, R, training):
     """layers: [(linear, bn | None, slope, drop_p)]"""
-    key = (tuple(id(l[0]) for l in layers), R, training, tuple((l[2], l[3]) for l in layers))
+    key = (tuple(id(l[0]) for l in layers), R, training,
+           tuple((l[2], l[3], l[0].bias is not None, None if l[1] is None else (l[1].eps, l[1].momentum, l[1].weight is not None)) for l in layers))
     plan = _HEAD_PLANS.get(key)
     if plan is not None and all(a[0] is b[0] and a[1] is b[1] for a, b in zip(plan.layers, layers)):
         return plan
@@ -153,7 +156,7 @@ class _HeadStack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, aux, *params):
         plan, seed = aux
-        d = plan.desc
+        d = type(plan.desc).from_buffer_copy(plan.desc)      # private copy per call (see mlp_hip._stack_plan's callers)
         x = x.contiguous()
         dev = x.device
         save = torch.empty((plan.save_bytes,), dtype=torch.uint8, device=dev)
@@ -174,7 +177,7 @@ class _HeadStack(torch.autograd.Function):
                 ly.running_mean = None if bn.running_mean is None else bn.running_mean.data_ptr()
                 ly.running_var = None if bn.running_var is None else bn.running_var.data_ptr()
         d.seed, d.x, d.out, d.save, d.save_bytes, d.stream = seed, x.data_ptr(), out.data_ptr(), save.data_ptr(), plan.save_bytes, _stream()
-        _lib.call("pcl_fc_head_fwd_f32", plan.ref, tag="head_fwd")
+        _lib.call("pcl_fc_head_fwd_f32", ctypes.byref(d), tag="head_fwd")
         ctx.plan, ctx.seed = plan, seed
         ctx.save_for_backward(x, out, save, *params)
         return out
@@ -182,7 +185,7 @@ class _HeadStack(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         plan = ctx.plan
-        d = plan.desc
+        d = type(plan.desc).from_buffer_copy(plan.desc)      # private copy per call (see mlp_hip._stack_plan's callers)
         sv = ctx.saved_tensors
         x, out, save, params = sv[0], sv[1], sv[2], sv[3:]
         dev = x.device
@@ -214,7 +217,7 @@ class _HeadStack(torch.autograd.Function):
                 ly.dgamma = ly.dbeta = None
         d.seed, d.x, d.out, d.save, d.save_bytes = ctx.seed, x.data_ptr(), out.data_ptr(), save.data_ptr(), plan.save_bytes
         d.tmp, d.tmp_bytes, d.gout, d.dx, d.stream = tmp.data_ptr(), plan.bwd_tmp, gout.data_ptr(), (None if dx is None else dx.data_ptr()), _stream()
-        _lib.call("pcl_fc_head_bwd_f32", plan.ref, tag="head_bwd")
+        _lib.call("pcl_fc_head_bwd_f32", ctypes.byref(d), tag="head_bwd")
         return (dx, None) + tuple(grads)
 
 
@@ -236,6 +239,31 @@ def _head_layers(mods):
         out.append((m, bn, slope, p))
         i = j
     return out
+
+
+def _dropout_seed(device, n_draws):
+    """64-bit seed of one call's dropout masks (the kernels hash (seed, layer, element)), taken from torch's CUDA generator of the
+    device the way ``nn.Dropout`` takes its Philox (seed, offset) pair: ``torch.cuda.manual_seed`` / ``fork_rng`` reset and restore
+    the sequence, every call advances the generator's offset, and the rank of a data-parallel job is mixed in so that ranks that
+    were seeded alike draw different masks for their different clouds."""
+    rank = 0
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            rank = dist.get_rank()
+    except Exception:
+        pass
+    try:
+        gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+        base, off = gen.initial_seed(), gen.get_offset()
+        gen.set_offset(off + 4 * ((int(n_draws) + 3) // 4))
+    except Exception:                                # (a build without generator offsets: a process-wide call counter)
+        _DROP_CALLS[0] += 1
+        base, off = torch.initial_seed(), _DROP_CALLS[0]
+    m = 0xFFFFFFFFFFFFFFFF
+    z = (base * 0x9E3779B97F4A7C15 + off * 0xD1B54A32D192ED03 + (rank + 1) * 0x94D049BB133111EB) & m
+    z ^= z >> 31
+    return (z * 0xBF58476D1CE4E5B9) & m
 
 
 def head_stack(mods, x):
@@ -263,8 +291,7 @@ def head_stack(mods, x):
             params += [bn.weight, bn.bias]
     seed = 0
     if training and any(p > 0.0 for _, _, _, p in layers):
-        _DROP_CALLS[0] += 1
-        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _DROP_CALLS[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        seed = _dropout_seed(x.device, sum(l[0].out_features for l in layers) * x.shape[0])
     return _HeadStack.apply(x, (plan, seed), *params)
 
 

@@ -547,7 +547,8 @@ _PLANS = {}
 
 
 def _stack_plan(module, P, c0, pool, grouped, geom, need_dx, x_grad_from, defer=False):
-    key = (id(module), P, c0, pool, grouped, geom, need_dx, x_grad_from, module.slope, module.last_act, defer)
+    key = (id(module), P, c0, pool, grouped, geom, need_dx, x_grad_from, module.slope, module.last_act, defer,
+           module.eps, module.momentum, module.biases is not None)      # (everything the filled-in descriptor depends on)
     plan = _PLANS.get(key)
     if plan is not None and plan.spec is module.spec:
         return plan
@@ -627,7 +628,10 @@ class _StackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t_in, aux, *params):
         plan, geo, running = aux[0], aux[1], aux[2]
-        d, L = plan.desc, plan.L
+        # a private copy of the plan's descriptor per call (~1 KB): forward and autograd's backward thread, or two host threads,
+        # may be inside the same call site at once
+        d = type(plan.desc).from_buffer_copy(plan.desc)
+        L = plan.L
         dev = params[0].device
         npl = 4 if plan.has_bias else 3
         st = _stream()
@@ -662,7 +666,7 @@ class _StackFn(torch.autograd.Function):
             ly.running_mean, ly.running_var = running[2 * l].data_ptr(), running[2 * l + 1].data_ptr()
         d.out = None if plan.defer else out.data_ptr()
         d.save, d.save_bytes, d.tmp, d.tmp_bytes, d.stream = save.data_ptr(), plan.save_bytes, tmp.data_ptr(), plan.fwd_tmp, st
-        _lib.call("pcl_mlp_stack_fwd_f32", plan.ref, tag="stack_fwd")
+        _lib.call("pcl_mlp_stack_fwd_f32", ctypes.byref(d), tag="stack_fwd")
         ctx.plan = plan
         ctx.link = aux[3] if plan.defer else None
         ctx.save_for_backward(t_in, out, save, Wf, *(geo if plan.grouped else ()), *params)
@@ -671,7 +675,10 @@ class _StackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         plan = ctx.plan
-        d, L = plan.desc, plan.L
+        # a private copy of the plan's descriptor per call (~1 KB): forward and autograd's backward thread, or two host threads,
+        # may be inside the same call site at once
+        d = type(plan.desc).from_buffer_copy(plan.desc)
+        L = plan.L
         sv = ctx.saved_tensors
         t_in, out, save, Wf = sv[0], sv[1], sv[2], sv[3]
         n0 = 4
@@ -721,7 +728,7 @@ class _StackFn(torch.autograd.Function):
             link = ctx.link
             d.ext_stats, d.ext_stat_rows = link.stats.data_ptr(), link.rows
             link.stats = None
-        _lib.call("pcl_mlp_stack_bwd_f32", plan.ref, tag="stack_bwd")
+        _lib.call("pcl_mlp_stack_bwd_f32", ctypes.byref(d), tag="stack_bwd")
         return (dx, None) + tuple(grads)
 
 

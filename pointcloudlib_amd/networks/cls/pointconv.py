@@ -5,7 +5,7 @@ from torch import nn
 
 from ...misc.head import fc_head
 from ...misc.pointconv_utils import PointConvDensitySetAbstraction
-from .pointnet2 import SamplingPrefetch
+from .pointnet2 import SamplingPrefetch, sampling_stream
 
 
 class PointConvDensityClsSsg(nn.Module):
@@ -29,6 +29,7 @@ class PointConvDensityClsSsg(nn.Module):
         networks/cls/pointnet2.SamplingPrefetch: the producer stream waits for the consumer stream first, which also orders the
         reuse of the handle's memory).  xyz [B,3,N]; returns a handle for ``forward(xyz, sampling=handle)``."""
         cur = torch.cuda.current_stream()
+        stream, owned = sampling_stream(self, stream)          # "own": the network's private producer stream (pointnet2.sampling_stream)
         stream = cur if stream is None else stream
         if stream != cur:
             stream.wait_stream(cur)
@@ -42,7 +43,7 @@ class PointConvDensityClsSsg(nn.Module):
                     pts = lv[0]
             ev = torch.cuda.Event()
             ev.record(stream)
-        return {"levels": out, "event": ev, "stream": stream, "fed_from": cur}
+        return {"levels": out, "event": ev, "stream": stream, "fed_from": cur, "owned": owned}
 
     def forward(self, xyz, start_idx=None, knn_lists=None, sampling=None):
         """xyz [B,3,N] (the reference permutes from [B,N,3] at :26; callers here pass [B,3,N] directly).

@@ -99,6 +99,23 @@ class PointnetModuleMSG(PointNetModuleBase):
 _AB_RECORD_STREAM = bool(os.environ.get("PCL_AB_RECORD_STREAM"))        # lab switch for A/B timing on one box
 
 
+def sampling_stream(owner, stream):
+    """-> (stream, owned).  ``stream="own"`` selects the network's PRIVATE producer stream: created here on first use (high
+    priority: the work is a short latency-bound chain), stored on the network and never handed to anybody else, so the only
+    allocations and kernels it ever sees are those of ``precompute_sampling`` -- each call of which starts by waiting for the
+    consumer stream.  That ownership is what makes the handle's memory safe without ``Tensor.record_stream`` (``adopt_sampling``);
+    a stream the caller supplies may carry other work, and handles produced on it take the ``record_stream`` route."""
+    if isinstance(stream, str):
+        if stream != "own":
+            raise ValueError(f"stream={stream!r}: pass a torch.cuda.Stream, None or 'own'")
+        s = owner.__dict__.get("_own_sampling_stream")
+        if s is None:
+            s = torch.cuda.Stream(priority=-1)
+            owner.__dict__["_own_sampling_stream"] = s
+        return s, True
+    return stream, False
+
+
 class SamplingPrefetch:
     """For networks with a ``pointnet_modules`` list: every index-producing op (FPS + ball query per level) depends on xyz
     only, so the set for a batch can be produced ahead of its forward pass, on another stream."""
@@ -110,6 +127,7 @@ class SamplingPrefetch:
         ``forward(xyz, feature, sampling=handle)``.  The chain of m-1 dependent FPS steps occupies only B
         workgroups, so it costs nothing to run it beside the MFMA kernels."""
         cur = torch.cuda.current_stream()
+        stream, owned = sampling_stream(self, stream)
         if stream is None:
             stream = cur
         if stream != cur:
@@ -123,16 +141,17 @@ class SamplingPrefetch:
                     xyz = s[0]
             ev = torch.cuda.Event()
             ev.record(stream)
-        # "fed_from": every batch of work on `stream` starts by waiting for this consumer stream (the wait_stream above), so
-        # memory of this handle that the host frees after enqueueing its consumers can only be handed out again -- by the
-        # per-stream pools of the caching allocator, to a LATER call of this function -- behind those consumers.
-        return {"levels": out, "event": ev, "stream": stream, "fed_from": cur}
+        # "owned" + "fed_from": every batch of work on the network's private stream starts by waiting for this consumer stream (the
+        # wait_stream above), so memory of this handle that the host frees after enqueueing its consumers can only be handed out
+        # again -- by the per-stream pools of the caching allocator, to a LATER call of this function -- behind those consumers.
+        return {"levels": out, "event": ev, "stream": stream, "fed_from": cur, "owned": owned}
 
     @staticmethod
     def adopt_sampling(sampling):
         """Make the current stream wait for a handle produced on another stream.  When the handle was produced by
-        ``precompute_sampling`` from this same consumer stream, reuse of its memory is already ordered (see there) and
-        nothing else is needed; for a handle of any other origin the allocator is told about the use (``record_stream``).
+        ``precompute_sampling(..., stream="own")`` -- on the network's private stream -- from this same consumer stream, reuse of
+        its memory is already ordered (see there) and nothing else is needed; for a handle of any other origin (a stream the
+        caller supplied, another consumer stream) the allocator is told about the use (``record_stream``).
         That fallback is not free: every recorded tensor costs an event record on the consumer stream when it dies -- ten
         marker packets = 45 us of idle main stream at the head of each PointNet++ step (tools/dbg/section_times.py)."""
         if sampling is None:
@@ -140,7 +159,7 @@ class SamplingPrefetch:
         cur = torch.cuda.current_stream()
         if sampling.get("event") is not None and sampling["stream"] != cur:
             cur.wait_event(sampling["event"])
-            if sampling.get("fed_from") == cur and not _AB_RECORD_STREAM:
+            if sampling.get("owned") and sampling.get("fed_from") == cur and not _AB_RECORD_STREAM:
                 return
             for new_xyz, idxs in sampling["levels"]:              # allocator safety across streams
                 for t in [new_xyz] + [u for ic in idxs if ic is not None for u in ic]:

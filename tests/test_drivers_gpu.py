@@ -110,11 +110,11 @@ def test_sampling_prefetch_equals_inline_sampling(dev, model):
     net_b = copy.deepcopy(net_a)
     xs = [torch.from_numpy(synth.gauss_ball(B, N, 10 + i)).to(dev) for i in range(3)]
     fs = [torch.from_numpy(synth.unit_normals(B, N, 20 + i)).to(dev) for i in range(3)]
-    side = torch.cuda.Stream(priority=-1)
+    side = "own"           # the network's private producer stream: the route without record_stream (pointnet2.sampling_stream)
     layout = (lambda t: t.transpose(1, 2).contiguous()) if model == "pointconv" else (lambda t: t)
 
     def run(net, prefetch):
-        torch.manual_seed(1)                                  # the head's dropout masks: hash of (torch seed, call counter)
+        torch.manual_seed(1)                                  # the head's dropout masks: torch's CUDA generator (seed, offset), reset here
         _head._DROP_CALLS[0] = 0
         opt = make_sgd(net.parameters(), lr=1e-5, momentum=0.9)
         losses, digests, pending = [], [], {}
@@ -128,7 +128,7 @@ def test_sampling_prefetch_equals_inline_sampling(dev, model):
             loss = call(net, xs[i % 3], fs[i % 3], ys[i % 3], s)
             if prefetch:
                 pending[i + 1] = net.precompute_sampling(layout(xs[(i + 1) % 3]), stream=side)
-                assert pending[i + 1]["fed_from"] == torch.cuda.current_stream()
+                assert pending[i + 1]["fed_from"] == torch.cuda.current_stream() and pending[i + 1]["owned"]
             loss.backward()
             opt.step()
             losses.append(loss.detach())

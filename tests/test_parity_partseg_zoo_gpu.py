@@ -91,10 +91,12 @@ def test_pointnet_partseg_b16_n2048(oracle, dev):
     state = net.state_dict()
     r32, r64 = PointNetPartSegCPU(state), PointNetPartSegCPU(state, dtype=torch.float64)
     (o32, a32), (o64, a64) = r32(xt, onehot, return_aux=True), r64(xt, onehot, return_aux=True)
+    with torch.no_grad():      # fp64 arithmetic, fp32 storage: the floor no fp32 summation scheme can beat (oracle/parity.py)
+        o6s = PointNetPartSegCPU(state, dtype=torch.float64, storage="fp32")(xt, onehot)
     _ce(o32, seg).backward(); _ce(o64, seg).backward()
     out = net(xt.to(dev), onehot.to(dev))
     rep = Report(f"PointNet part-seg B={B} N={N}")
-    rep.feature(out, o32, o64, "logits [B,50,N]")
+    rep.feature(out, o32, o64, "logits [B,50,N]", o6s)
     loss = _ce(out, seg.to(dev))
     loss.backward()
     g_hip = {n: p.grad for n, p in net.named_parameters()}
@@ -129,13 +131,15 @@ def test_pointconv_partseg_b16_n2048(oracle, dev, monkeypatch):
     state = net.state_dict()
     r32, r64 = PointConvPartSegCPU(state), PointConvPartSegCPU(state, dtype=torch.float64)
     (o32, a32), (o64, a64) = r32(xyz, start, return_aux=True), r64(xyz, start, return_aux=True)
+    with torch.no_grad():
+        o6s = PointConvPartSegCPU(state, dtype=torch.float64, storage="fp32")(xyz, start)
     tgt = seg.reshape(-1)
     lossf = lambda o, t: _ce(o.reshape(-1, 50), t)
     lossf(o32, tgt).backward(); lossf(o64, tgt).backward()
     out = net(xyz.to(dev), onehot.to(dev))
     assert calls == list(range(8))
     rep = Report(f"PointConv part-seg B={B} N={N}")
-    rep.feature(out, o32, o64, "logits [B,N,50]")
+    rep.feature(out, o32, o64, "logits [B,N,50]", o6s)
     loss = lossf(out, tgt.to(dev))
     loss.backward()
     g_hip = {n: p.grad for n, p in net.named_parameters()}

@@ -12,6 +12,8 @@ pin_to_gpu_node(0)
 FP32_PEAK_TFLOPS, HBM_PEAK_GBS = 157.3, 8000.0        # MI355X_MICROARCH.md: dense fp32 MFMA, HBM3E
 ONLY = None                                            # --only: substring filter on the config names
 TABLE = 0                                              # --table N: print the N most expensive (entry point, shape) rows of each config
+ORDER_OUT = None                                       # --dump-launch-order FILE: the (entry point, shape, kernel) sequence of one step
+QUIET = False                                          # bench.py's other_configs leg: no per-config lines on stdout
 
 
 def roofline_of(step):
@@ -24,6 +26,13 @@ def roofline_of(step):
         step(); step()
         torch.cuda.synchronize()
         summ = _lib.PROFILER.summary()
+        _lib.PROFILER = None
+    if ORDER_OUT:
+        _lib.PROFILER = _lib.KernelTimer()
+        with per_kernel_path():
+            step()
+        torch.cuda.synchronize()
+        json.dump({"step_launch_order": _lib.PROFILER.order}, open(ORDER_OUT, "w"))
         _lib.PROFILER = None
     if TABLE:
         for (n, t), v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:TABLE]:
@@ -140,7 +149,8 @@ def run(name, make, inputs, loss_fn, steps, warmup=3, cpu_kind=None):
         # (timed after ALL GPU configs: the CPU legs spin up 32 OpenMP / PyTorch threads that would compete with the Python
         # launch thread of the host-bound configs that follow)
         CPU_JOBS.append((r, cpu_kind, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}))
-    print(json.dumps(r), flush=True)
+    if not QUIET:
+        print(json.dumps(r), flush=True)
     return r
 
 
@@ -156,7 +166,7 @@ def _run_prefetch(name, make, inputs, loss_fn, steps, warmup=120):    # (two str
     torch.manual_seed(0)
     net = make().cuda().train()
     opt = make_sgd(net.parameters(), lr=0.02, momentum=0.9)
-    side = torch.cuda.Stream(priority=-1)
+    side = "own"                      # the network's private producer stream
     pending = [None]
     def step():
         opt.zero_grad(set_to_none=True)
@@ -177,6 +187,62 @@ def _run_prefetch(name, make, inputs, loss_fn, steps, warmup=120):    # (two str
     return r
 
 
+def traffic_of(key, roofline):
+    """PMC HBM bytes per launch of the row's dominant kernel from profiles/r04_traffic_<key>.json (two separate rocprofv3 --pmc
+    passes of `tools/bench_models.py --only ...`, tools/prof_cfg.sh) -- only while the kernel sources still hash to what was measured."""
+    from pointcloudlib_amd.buildinfo import csrc_sha
+    try:
+        tj = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"r04_traffic_{key}.json")))
+        if tj.get("csrc_sha") == csrc_sha():
+            return tj["per_launch_hbm_bytes"].get(f"{roofline['kernel']}:{roofline['shape']}"), tj["source"]
+    except Exception:
+        pass
+    return None, None
+
+
+def other_configs(steps=20, keys=("cfg2_n4096", "cfg3", "cfg4", "cfg5")):
+    """bench.py's `other_configs` leg: the BASELINE workloads besides the headline (N = 4096 row of config 2, configs 3, 4 (MSG), 5), one
+    short train-step timing each on the same GPU with the roofline of its dominant kernel -- inline sampling, no prefetch."""
+    global QUIET
+    from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
+    from pointcloudlib_amd.networks.cls.dgcnn import DGCNN
+    from pointcloudlib_amd.networks.cls.pointconv import PointConvDensityClsSsg
+    from pointcloudlib_amd.networks.seg.pointnet2_partseg import PointNetMSG
+    dev = "cuda"
+    cloud = lambda B, N, seed: torch.from_numpy(synth.gauss_ball(B, N, seed)).to(dev)
+    y32 = torch.from_numpy(synth.labels(32, 40, 1)).to(dev)
+    ce = lambda o: soft_cross_entropy_loss(o, y32)
+    QUIET, out = True, []
+    try:
+        for key in keys:
+            if key == "cfg2_n4096":
+                x = cloud(32, 4096, 20242)
+                r = run("PointNet++ SSG cls B=32 N=4096 (north_star's second cloud size)", PointNet2_cls,
+                        (x, torch.from_numpy(synth.unit_normals(32, 4096, 7)).to(dev)), ce, steps)
+            elif key == "cfg3":
+                r = run("DGCNN cls B=32 N=1024 k=20 (BASELINE configs[2])", DGCNN, (cloud(32, 1024, 20242).transpose(1, 2).contiguous(),), ce, steps)
+            elif key == "cfg4":
+                xs = cloud(16, 2048, 20244)
+                oh = torch.zeros(16, 16, device=dev); oh[torch.arange(16), torch.arange(16) % 16] = 1
+                seg = torch.randint(0, 50, (16, 2048), device=dev)
+                r = run("PointNet++ MSG part-seg B=16 N=2048 (BASELINE configs[3])", PointNetMSG, (xs, xs, oh),
+                        lambda o: torch.nn.functional.cross_entropy(o, seg), steps)
+            elif key == "cfg5":
+                r = run("PointConv cls B=32 N=1024 (BASELINE configs[4])", PointConvDensityClsSsg,
+                        (cloud(32, 1024, 20242).transpose(1, 2).contiguous(),), ce, steps)
+            else:
+                continue
+            row = {"key": key, "workload": r["config"] + ", train step fwd+bwd+SGD, inline sampling", "ms_per_step": r["ms_per_step"],
+                   "value": r["clouds_per_s"], "unit": "point-clouds/s", "steps": steps, "roofline": r["roofline"]}
+            if row["roofline"]:
+                row["roofline"]["traffic"], row["roofline"]["traffic_source"] = traffic_of(key, row["roofline"])
+            out.append(row)
+            torch.cuda.empty_cache()
+    finally:
+        QUIET = False
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=40)
@@ -184,9 +250,10 @@ def main():
     ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU restatement of configs 2', 3, 4, 5 (tens of seconds each)")
     ap.add_argument("--table", type=int, default=0, help="print the N most expensive (entry point, launch shape) rows per config to stderr")
     ap.add_argument("--only", default=None, help="run only the configs whose name contains this (one config under rocprofv3)")
+    ap.add_argument("--dump-launch-order", default=None, help="with --only: write the (entry point, shape, kernel) sequence of one step as JSON (tools/pmc_traffic.py)")
     a = ap.parse_args()
-    global ONLY, CPU_BASELINE, TABLE
-    ONLY, CPU_BASELINE, TABLE = a.only, a.cpu_baseline, a.table
+    global ONLY, CPU_BASELINE, TABLE, ORDER_OUT
+    ONLY, CPU_BASELINE, TABLE, ORDER_OUT = a.only, a.cpu_baseline, a.table, a.dump_launch_order
     from pointcloudlib_amd.networks.cls.pointnet import PointNet
     from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
     from pointcloudlib_amd.networks.cls.dgcnn import DGCNN

@@ -12,7 +12,7 @@ opt = make_sgd(net.parameters(), lr=0.02, momentum=0.9)
 x = torch.from_numpy(synth.gauss_ball(32, 1024, 1)).cuda(); f = torch.from_numpy(synth.unit_normals(32, 1024, 2)).cuda()
 y = torch.from_numpy(synth.labels(32, 40, 3)).cuda()
 params = list(net.parameters())
-side = torch.cuda.Stream(priority=-1)
+side = "own"
 pending = {}
 def step(i, prefetch):
     for p in params: p.grad = None

@@ -25,7 +25,9 @@ FAMILY = {"linear_nt_kernel": ("pcl_linear_fwd_rows_f32", "pcl_linear_fwd_gmax_f
 RES_TAGS = {"fwd64x64", "fwd64x128", "fwd128x128", "fwd128x256"}
 
 
-def family_of(name, tag):
+def family_of(name, tag, fam=""):
+    if fam:                      # round 4: the launch order records the kernel each entry point chose (pcl_last_launch_kernel)
+        return fam
     if name.startswith("pcl_linear_fwd") and tag in RES_TAGS:
         return "linear_fwd_res_kernel"
     for fam, entries in FAMILY.items():
@@ -34,14 +36,14 @@ def family_of(name, tag):
     return None
 
 
-def family_series(path, counter):
+def family_series(path, counter, families=FAMILY):
     out = defaultdict(list)                                  # family -> [value per dispatch, in dispatch order]
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     for r in rows:
         if r["Counter_Name"] != counter:
             continue
-        for fam in FAMILY:
+        for fam in families:
             if f"pcl::{fam}<" in r["Kernel_Name"]:          # not group_linear_dw_kernel & co.
                 out[fam].append(float(r["Counter_Value"]))
     return out
@@ -49,14 +51,19 @@ def family_series(path, counter):
 
 def main():
     fetch_csv, write_csv, order_json, out_csv, out_json = sys.argv[1:6]
-    order = json.load(open(order_json))["step_launch_order"]
-    fetch, write = family_series(fetch_csv, "FETCH_SIZE"), family_series(write_csv, "WRITE_SIZE")
+    workload = sys.argv[6] if len(sys.argv) > 6 else "PointNet++ SSG cls B=32 N=1024, duplicate-compacted padded rows"
+    command = sys.argv[7] if len(sys.argv) > 7 else "python bench.py --steps 3 --warmup 1 --no-settle"
+    order = [tuple(o) + ("",) * (3 - len(o)) for o in json.load(open(order_json))["step_launch_order"]]
+    families = sorted({family_of(*o) for o in order} - {None, ""})
+    fetch, write = family_series(fetch_csv, "FETCH_SIZE", families), family_series(write_csv, "WRITE_SIZE", families)
     per_tag, lines = {}, []
-    for fam in FAMILY:
-        calls = [(n, t) for n, t in order if family_of(n, t) == fam]
+    for fam in families:
+        calls = [(n, t) for n, t, k in order if family_of(n, t, k) == fam]
         n = len(calls)
         f, w = fetch[fam], write[fam]
-        assert n and len(f) % n == 0 and len(w) % n == 0, (fam, n, len(f), len(w))
+        if not (n and f and w and len(f) % n == 0 and len(w) % n == 0):
+            print(f"# {fam}: {n} calls per step do not divide {len(f)} / {len(w)} dispatches -- skipped", file=sys.stderr)
+            continue
         for k, (name, tag) in enumerate(calls):
             fk = f[k::n]; wk = w[k::n]
             fm, wm = sum(fk) / len(fk), sum(wk) / len(wk)
@@ -64,12 +71,12 @@ def main():
             per_tag[f"{name}:{tag}"] = round(b)
             lines.append((name, tag, len(fk), fm, wm, b))
     with open(out_csv, "w") as fh:
-        fh.write("# two separate passes: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 3 --warmup 1 --no-settle\n")
+        fh.write(f"# {workload}\n# two separate passes: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- {command}\n")
         fh.write("# per-launch means; FETCH_SIZE/WRITE_SIZE in KiB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction, MI355X_MICROARCH.md HBM section)\n")
         fh.write("entry_point,shape,launches,FETCH_SIZE,WRITE_SIZE,hbm_bytes\n")
         for l in lines:
             fh.write(f"{l[0]},{l[1]},{l[2]},{l[3]:.1f},{l[4]:.1f},{l[5]:.0f}\n")
-    json.dump({"source": out_csv, "workload": "PointNet++ SSG cls B=32 N=1024, duplicate-compacted padded rows",
+    json.dump({"source": out_csv, "workload": workload,
                "csrc_sha": csrc_sha(),          # bench.py prints these numbers only for the same kernel sources
                "per_launch_hbm_bytes": per_tag}, open(out_json, "w"), indent=1)
     for l in lines:

@@ -120,7 +120,7 @@ def main():
     torch.manual_seed(a.seed)
     net = build_model(a.model).to(dev)
     opt = make_sgd(net.parameters(), lr=a.lr, momentum=a.momentum)
-    side = torch.cuda.Stream(priority=-1) if a.model == "pointnet2" else None     # sampling of batch t+1 beside batch t
+    side = "own" if a.model == "pointnet2" else None     # sampling of batch t+1 beside batch t, on the network's private stream
     best = 0.0
     for epoch in range(a.epochs):
         if a.lr_decay and epoch and epoch % 20 == 0:

@@ -140,7 +140,7 @@ def main():
     torch.manual_seed(a.seed)
     net = build_model(a.model).to(dev)
     opt = make_sgd(net.parameters(), lr=a.lr, momentum=a.momentum, weight_decay=1e-4)
-    side = torch.cuda.Stream(priority=-1) if (a.prefetch_sampling and a.model.startswith("pointnet2")) else None
+    side = "own" if (a.prefetch_sampling and a.model.startswith("pointnet2")) else None
     for epoch in range(a.epochs):
         loss, acc, bacc, iou, rate = run_epoch(net, a.model, train_set, dev, train_set.seg_num_all, opt, side)
         print(f"Train {epoch}, loss: {loss:.6f}, train acc: {acc:.6f}, train avg acc: {bacc:.6f}, train iou: {iou:.6f} ({rate:.0f} shapes/s)", flush=True)
