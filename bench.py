@@ -27,6 +27,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HOST_DELAY_US = float(os.environ.get("PCL_HOST_DELAY_US", "0"))
+PREFETCH_AT = os.environ.get("PCL_PREFETCH_AT", "fwd")     # where batch t+1's sampling is enqueued: beside step t's forward (default) or backward
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_PEAK_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
 
@@ -141,6 +142,8 @@ def main():
     from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
     from pointcloudlib_amd.train_utils import make_sgd, soft_cross_entropy_loss
     _lib.lib()                                                # fail loudly when the extension is missing
+    if os.environ.get("PCL_FPS_PRIO"):                        # lab switch (tools/ab.sh): issue priority of the FPS chain's waves
+        _lib.lib().pcl_set_fps_tuning(0, int(os.environ["PCL_FPS_PRIO"]))
 
     B, N = args.batch, args.npoints
     torch.manual_seed(0)
@@ -155,7 +158,7 @@ def main():
 
     def step(i):
         """One training step on batch i.  With --prefetch-sampling (default) the FPS/ball-query indices of batch
-        i+1 are produced on a side stream while batch i's backward runs (input-pipeline style); every step still
+        i+1 are produced on a side stream while step i runs (input-pipeline style; enqueued ahead of its forward); every step still
         executes exactly one full set of index ops, and batch i's own set was produced during step i-1."""
         x, f, y = batches[i % len(batches)]
         if HOST_DELAY_US:                      # lab switch: is the host on the critical path?  (busy-wait, no GPU interaction)
@@ -164,8 +167,10 @@ def main():
                 pass
         dp.zero_grad()
         samp = pending.pop(i, None)
+        if side is not None and PREFETCH_AT == "fwd":          # the next batch's sampling beside THIS step's forward (A/B: 1.900 vs 1.914 ms beside the backward)
+            pending[i + 1] = net.precompute_sampling(batches[(i + 1) % len(batches)][0], stream=side)
         out = net(x, f, sampling=samp)
-        if side is not None:
+        if side is not None and PREFETCH_AT != "fwd":
             pending[i + 1] = net.precompute_sampling(batches[(i + 1) % len(batches)][0], stream=side)
         loss = soft_cross_entropy_loss(out, y)
         loss.backward()
@@ -365,7 +370,7 @@ def main():
             "config": {"workload": f"PointNet++ SSG cls train step (fwd+bwd+SGD), B={B}/GPU, N={N} xyz+normal, "
                                    f"{args.dist} clouds (BASELINE configs[1])",
                        "global_batch": world * B, "n_points": N, "parallelism": f"dp{world}",
-                       "sampling": "indices of batch t+1 on a side stream during backward of batch t" if args.prefetch_sampling
+                       "sampling": ("indices of batch t+1 on a side stream during step t (enqueued before its " + ("forward" if PREFETCH_AT == "fwd" else "backward") + ")") if args.prefetch_sampling
                        else "inline",
                        "launch": launch, "grad_bucket_bytes": dp.bucket_nbytes, "grad_overlap": bool(dp.overlap and dp.active), "cpu_affinity": CPU_AFFINITY,
                        "world_size": dist.get_world_size() if distributed else 1, "backend": dist.get_backend() if distributed else None,

@@ -54,6 +54,11 @@ const char* pcl_last_error(void);
  * broken, so callers that want reference-identical sampling pass it as `tie_stride`. */
 int pcl_optimal_block(int batch_size);
 
+/* test / tuning hook (process-wide, set between calls; no reference counterpart): threads per cloud of pcl_fps_f32 (0 = chosen from N;
+ * one of 64, 128, 256, 512, 1024 -- any count gives the same indices) and the hardware issue priority of its waves (0..3, s_setprio;
+ * default 3: inline in a forward pass the serial chain is the critical path; 0 when the sampling of the NEXT batch runs on a side
+ * stream beside kernels the step waits for). */
+void pcl_set_fps_tuning(int threads_per_cloud, int issue_priority);
 /* ---- farthest point sampling -----------------------------------------------------------------
  * Replaces FurthestPointSampler's jt.code kernel, misc/ops.py:124-234 (launch :236-251), and the
  * gather of :280-284.

@@ -67,7 +67,7 @@ __device__ __forceinline__ unsigned long long wave_key_max(double v) {
 template <int T, int PPT>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int N, int m, int log2S,
                                                 double skip_thr, const int32_t* __restrict__ start_idx,
-                                                int32_t* __restrict__ idx_out, float* __restrict__ new_xyz_out) {
+                                                int32_t* __restrict__ idx_out, float* __restrict__ new_xyz_out, int prio) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = T / 64;
     unsigned long long* slots = reinterpret_cast<unsigned long long*>(smem);      // [2][NW] (NW > 1)
@@ -78,8 +78,12 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     const float* p = xyz + (size_t)b * N * 3;
     int32_t* out = idx_out + (size_t)b * m;
     float* oxyz = new_xyz_out ? new_xyz_out + (size_t)b * m * 3 : nullptr;
-    // latency-critical serial chain: when co-resident with throughput kernels (side stream), win issue arbitration
-    __builtin_amdgcn_s_setprio(3);
+    // a serial chain: `prio` (pcl_set_fps_tuning) decides who wins issue arbitration when it is co-resident with throughput kernels.
+    // Inline in a forward pass the chain IS the critical path (3); one batch ahead on a side stream it has a whole backward pass to
+    // finish in and every slot it takes is taken from a kernel the step waits for (0).
+    if (prio >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
 
     // stage the cloud: coalesced dword reads of the AoS xyz, scattered into float4 slots
     float* s_flat = reinterpret_cast<float*>(s_xyz);
@@ -219,6 +223,8 @@ __global__ __launch_bounds__(T) void fps_kernel_lds(const float* __restrict__ xy
     }
 }
 
+static int g_fps_threads = 0, g_fps_prio = 3;       // pcl_set_fps_tuning (process-wide, set between calls)
+
 template <int T, int PPT>
 static int launch_fps(const float* xyz, int B, int N, int m, int log2S, double thr, const int32_t* start,
                       int32_t* idx, float* nx, hipStream_t st) {
@@ -228,13 +234,18 @@ static int launch_fps(const float* xyz, int B, int N, int m, int log2S, double t
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(PCL_EHIP, "fps: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(T), lds, st, xyz, N, m, log2S, thr, start, idx, nx);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(T), lds, st, xyz, N, m, log2S, thr, start, idx, nx, g_fps_prio);
     return check_launch("pcl_fps_f32");
 }
 
 }  // namespace pcl
 
 using namespace pcl;
+
+extern "C" void pcl_set_fps_tuning(int threads_per_cloud, int issue_priority) {
+    g_fps_threads = threads_per_cloud > 0 ? threads_per_cloud : 0;
+    g_fps_prio = issue_priority < 0 ? 3 : issue_priority > 3 ? 3 : issue_priority;
+}
 
 extern "C" int pcl_fps_f32(const float* xyz, int B, int N, int m, int tie_stride, double skip_sqnorm_le,
                            const int32_t* start_idx, int32_t* idx_out, float* new_xyz_out, void* stream) {
@@ -246,10 +257,8 @@ extern "C" int pcl_fps_f32(const float* xyz, int B, int N, int m, int tie_stride
     int log2S = 0;
     while ((1 << log2S) < tie_stride) ++log2S;
     hipStream_t st = as_stream(stream);
-    static int env_t = -1;
-    if (env_t < 0) { const char* e = getenv("PCL_FPS_THREADS"); env_t = e ? atoi(e) : 0; }
     // threads per cloud: ~4-8 points per lane keeps the VALU part and the cross-wave part balanced
-    int T = env_t > 0 ? env_t : (N <= 256 ? 64 : N <= 1024 ? 256 : N <= 4096 ? 512 : 1024);
+    int T = g_fps_threads > 0 ? g_fps_threads : (N <= 256 ? 64 : N <= 1024 ? 256 : N <= 4096 ? 512 : 1024);
     const int ppt = (N + T - 1) / T;
 #define PCL_FPS_CASE(TT, PP) \
     if (T == TT && ppt <= PP) return launch_fps<TT, PP>(xyz, B, N, m, log2S, skip_sqnorm_le, start_idx, idx_out, new_xyz_out, st);

@@ -1,8 +1,10 @@
-"""Time pcl_fps_f32 (HIP events) for one shape; thread count via PCL_FPS_THREADS."""
+"""Time pcl_fps_f32 (HIP events) for one shape; thread count / issue priority via PCL_FPS_THREADS / PCL_FPS_PRIO (-> pcl_set_fps_tuning)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointcloudlib_amd import synth
 from pointcloudlib_amd.misc import ops
+from pointcloudlib_amd import _lib
+_lib.lib().pcl_set_fps_tuning(int(os.environ.get("PCL_FPS_THREADS", "0")), int(os.environ.get("PCL_FPS_PRIO", "3")))
 B, N, m = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 x = torch.from_numpy(synth.gauss_ball(B, N, 1)).cuda()
 for _ in range(3):
