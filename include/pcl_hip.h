@@ -133,6 +133,16 @@ int pcl_knn_f32(const float* ref, const float* qry, int B, int C, int Nr, int Nq
  * (0 bytes up to 4096 references). */
 int pcl_knn_fma_f32(const float* ref, const float* qry, int B, int C, int Nr, int Nq, int k,
                     int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream);
+/* PointConv's knn_point in the reference's own arithmetic, a NAMED SECOND DEFINITION like pcl_knn_fma_f32 (round 4): squared
+ * distances in matmul form, -2 (src . dst) + |src|^2 + |dst|^2 with the operation order of misc/pointconv_utils.py:50-52, dot product
+ * over c = 0, 1, 2 ascending (fma_dot = 1: fma chain; 0: every product and sum rounded), then the first k of a stable ascending
+ * order (distance, index) -- bit for bit oracle/pcl_oracle.c::pclo_knn_point_matmul_f32.  The library's own definition of these
+ * groups stays the direct form (pcl_knn_f32 on the coordinates); the two differ on 2.4e-4 / 7.3e-4 of PointConv's ordered lists.
+ *   xyz [B,N,3] (16-byte aligned, N a multiple of 4, N <= 4096), new_xyz [B,S,3] -> idx_out [B,S,k] int32.  Opt-in on the Python
+ *   side (PCL_KNN_POINT=matmul). */
+/* reference: misc/pointconv_utils.py:34-53, :120-131 */
+int pcl_knn_point_matmul_f32(const float* xyz, const float* new_xyz, int B, int N, int S, int k, int fma_dot, int32_t* idx_out,
+                             void* stream);
 
 /* ---- 3-NN inverse-distance interpolation (PointNetFeaturePropagation, misc/ops.py:83-93) -----
  *   xyz1 [B,N,3] (targets), xyz2 [B,S,3] (sources) -> idx3 [B,N,3], w3 [B,N,3]

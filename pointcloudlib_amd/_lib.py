@@ -78,6 +78,7 @@ _SIGS = {
     "pcl_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "pcl_knn_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     "pcl_knn_fma_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
+    "pcl_knn_point_matmul_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_three_nn_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "pcl_three_interp_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_three_interp_bwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),

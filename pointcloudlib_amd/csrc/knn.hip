@@ -402,6 +402,119 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(const float* __restrict_
     }
 }
 
+
+// ---- PointConv's knn_point in the reference's OWN arithmetic (named second definition, round 4) --------------------------------
+// /root/reference/misc/pointconv_utils.py:34-53 + :120-131: dist = -2 matmul(src, dst^T) + sum(src^2) + sum(dst^2), the first k of a
+// full ascending argsort.  The library's definition of these groups is the direct form (pcl_knn_f32 on the coordinates); this
+// kernel evaluates the matmul form exactly as oracle/pcl_oracle.c::pclo_knn_point_matmul_f32 defines it -- dot over c = 0, 1, 2
+// ascending (fma chain, or every product and sum rounded), squares summed ascending, the three terms added in source order,
+// stable order (distance, index) -- so the two agree bit for bit and a network can be run on the reference's own groups.
+// One wave per query row at a time (QW queries per wave), a lane owns PPT references (their coordinates and |p|^2 stay in
+// registers for all of the wave's queries); distances can be negative, so the select runs on order-preserving unsigned keys.
+template <int PPT>
+__device__ __forceinline__ void knn_select_keys(unsigned (&key)[PPT], int k, int32_t* out, uint2* cand, int lane) {
+    bool done = false;
+    if (k <= 64) {          // threshold T = the k-th smallest of the 64 lane minima, candidates <= T ranked by (key, r): see knn_fused_kernel
+        unsigned m = key[0];
+#pragma unroll
+        for (int j = 1; j < PPT; ++j) m = min(m, key[j]);
+        unsigned T = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned trial = T | (1u << bit);
+            if (__popcll(__ballot(m < trial)) < k) T = trial;
+        }
+        int n = 0;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) n += __popcll(__ballot(key[j] <= T));
+        if (n <= 64) {
+            int base = 0;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const bool pred = key[j] <= T;
+                const unsigned long long mask = __ballot(pred);
+                if (mask) {
+                    if (pred) cand[base + mbcnt(mask)] = make_uint2(key[j], 256u * (j >> 2) + 4u * lane + (j & 3u));
+                    base += __popcll(mask);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            const uint2 mine = cand[lane < n ? lane : 0];
+            int rank = 0;
+            for (int c = 0; c < n; ++c) {
+                const uint2 o = cand[c];
+                rank += (o.x < mine.x || (o.x == mine.x && o.y < mine.y)) ? 1 : 0;
+            }
+            if (lane < n && rank < k) out[rank] = (int32_t)mine.y;
+            __builtin_amdgcn_wave_barrier();
+            done = true;
+        }
+    }
+    for (int t = 0; t < k && !done; ++t) {
+        unsigned bk = 0xFFFFFFFFu, bj = 0;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const bool take = key[j] < bk;
+            bk = take ? key[j] : bk;
+            bj = take ? (unsigned)j : bj;
+        }
+        const unsigned br = 256u * (bj >> 2) + 4u * lane + (bj & 3u);
+        const unsigned wmin = wave_min_u32(bk);
+        const unsigned r = wave_min_u32(bk == wmin ? br : 0xFFFFFFFFu);
+        if (lane == 0) out[t] = (int32_t)r;
+        const unsigned rj = 4u * (r >> 8) + (r & 3u), rl = (r & 255u) >> 2;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j)
+            if ((unsigned)j == rj && (unsigned)lane == rl) key[j] = 0xFFFFFFFFu;
+    }
+}
+
+template <int PPT>
+__global__ __launch_bounds__(256) void knn_point_matmul_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz, int N, int S,
+                                                               int k, int fma_dot, int32_t* __restrict__ idx_out) {
+    constexpr int QW = 8, NJ = PPT / 4;
+    __shared__ uint2 sCand[4][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* P = xyz + (size_t)b * N * 3;
+    const float* Q = new_xyz + (size_t)b * S * 3;
+    const __amdgpu_buffer_rsrc_t rsP = knn_rsrc(P, (size_t)N * 12);
+    float px[PPT], py[PPT], pz[PPT], dn[PPT];
+#pragma unroll
+    for (int J = 0; J < NJ; ++J) {                   // references 256 J + 4 lane .. + 3: twelve consecutive floats
+        const unsigned off = (unsigned)(256 * J + 4 * lane) * 12u;
+        const float4 a = knn_ld4(rsP, off), c = knn_ld4(rsP, off + 16u), e = knn_ld4(rsP, off + 32u);
+        px[4 * J] = a.x; py[4 * J] = a.y; pz[4 * J] = a.z;
+        px[4 * J + 1] = a.w; py[4 * J + 1] = c.x; pz[4 * J + 1] = c.y;
+        px[4 * J + 2] = c.z; py[4 * J + 2] = c.w; pz[4 * J + 2] = e.x;
+        px[4 * J + 3] = e.y; py[4 * J + 3] = e.z; pz[4 * J + 3] = e.w;
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j)                    // sum(dst**2): squares summed ascending, each operation rounded (:52)
+        dn[j] = __fadd_rn(__fadd_rn(__fmul_rn(px[j], px[j]), __fmul_rn(py[j], py[j])), __fmul_rn(pz[j], pz[j]));
+    for (int i = 0; i < QW; ++i) {
+        const int q = (blockIdx.x * 4 + wave) * QW + i;
+        if (q >= S) break;                           // (wave-uniform)
+        const float qx = Q[3 * q], qy = Q[3 * q + 1], qz = Q[3 * q + 2];
+        const float sn = __fadd_rn(__fadd_rn(__fmul_rn(qx, qx), __fmul_rn(qy, qy)), __fmul_rn(qz, qz));          // :51
+        unsigned key[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int r = 256 * (j >> 2) + 4 * lane + (j & 3);
+            float dot;
+            if (fma_dot) dot = __fmaf_rn(qz, pz[j], __fmaf_rn(qy, py[j], __fmul_rn(qx, px[j])));
+            else dot = __fadd_rn(__fadd_rn(__fmul_rn(qx, px[j]), __fmul_rn(qy, py[j])), __fmul_rn(qz, pz[j]));
+            float d = __fmul_rn(-2.0f, dot);                                                                        // :50
+            d = __fadd_rn(d, sn);
+            d = __fadd_rn(d, dn[j]);
+            d = __fadd_rn(d, 0.0f);                  // -0 -> +0: the comparison sort treats them as equal (ties go by index)
+            unsigned u = __float_as_uint(d);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            key[j] = r < N ? u : 0xFFFFFFFFu;
+        }
+        knn_select_keys<PPT>(key, k, idx_out + ((size_t)b * S + q) * k, sCand[wave], lane);
+    }
+}
+
 }  // namespace pcl
 using namespace pcl;
 
@@ -457,4 +570,21 @@ extern "C" int pcl_knn_f32(const float* ref, const float* qry, int B, int C, int
 extern "C" int pcl_knn_fma_f32(const float* ref, const float* qry, int B, int C, int Nr, int Nq, int k,
                                int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream) {
     return knn_impl<true>(ref, qry, B, C, Nr, Nq, k, idx_out, workspace, workspace_bytes, stream);
+}
+
+// reference: misc/pointconv_utils.py:120-131 (knn_point) in the arithmetic of :34-53 (square_distance); see knn_point_matmul_kernel
+extern "C" int pcl_knn_point_matmul_f32(const float* xyz, const float* new_xyz, int B, int N, int S, int k, int fma_dot, int32_t* idx_out,
+                                        void* stream) {
+    PCL_REQUIRE(xyz && new_xyz && idx_out, "pcl_knn_point_matmul_f32: null pointer");
+    PCL_REQUIRE(B >= 0 && N >= 1 && S >= 1 && k >= 1 && k <= N, "pcl_knn_point_matmul_f32: bad sizes B=%d N=%d S=%d k=%d", B, N, S, k);
+    PCL_REQUIRE(B <= 65535 && N <= KNN_FUSED_MAX_NR, "pcl_knn_point_matmul_f32: B=%d (<= 65535), N=%d (<= %d: the references of a cloud live in one wave's registers)", B, N, KNN_FUSED_MAX_NR);
+    PCL_REQUIRE((reinterpret_cast<uintptr_t>(xyz) & 15) == 0 && ((size_t)N * 12) % 16 == 0, "pcl_knn_point_matmul_f32: xyz must be 16-byte aligned and N a multiple of 4");
+    if (B == 0) return PCL_OK;
+    hipStream_t st = as_stream(stream);
+    const int ppt4 = (N + 255) / 256 * 4;
+    const dim3 grid((S + 31) / 32, B), blk(256);
+#define PCL_KPM(P) if (ppt4 <= P) { hipLaunchKernelGGL(knn_point_matmul_kernel<P>, grid, blk, 0, st, xyz, new_xyz, N, S, k, fma_dot, idx_out); return check_launch("pcl_knn_point_matmul_f32"); }
+    PCL_KPM(4) PCL_KPM(8) PCL_KPM(16) PCL_KPM(32) PCL_KPM(64)
+#undef PCL_KPM
+    return fail(PCL_ENOSUP, "pcl_knn_point_matmul_f32: N=%d", N);
 }

@@ -16,6 +16,8 @@ implemented here with the original PointConv semantics (one group of all N point
 centroid, density reshaped [B,1,N,1]); ``DensityNet``'s sigmoid branch (:213) is unreachable upstream (``i == len``)
 so every layer is BN+ReLU, reproduced as such.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -33,8 +35,21 @@ def farthest_point_sample(xyz, npoint, start_idx=None):
     return idx
 
 
-def knn_point(nsample, xyz, new_xyz):
-    """k nearest points of xyz [B,N,3] for each new_xyz [B,S,3] -> int32 [B,S,nsample], ascending distance (:120-131)."""
+_KNN_POINT_FORM = os.environ.get("PCL_KNN_POINT", "direct")       # "matmul": the reference's own arithmetic (named second definition)
+
+
+def knn_point(nsample, xyz, new_xyz, form=None):
+    """k nearest points of xyz [B,N,3] for each new_xyz [B,S,3] -> int32 [B,S,nsample], ascending distance (:120-131).
+    ``form``: "direct" (the library's definition: direct-form squared distances, pcl_knn_f32) or "matmul" (the reference's
+    -2ab + a^2 + b^2 with its operation order, pcl_knn_point_matmul_f32, bit-exact against the oracle's restatement of it); default
+    from PCL_KNN_POINT."""
+    if (form or _KNN_POINT_FORM) == "matmul":
+        xyz, new_xyz = _dev(xyz, "xyz"), _dev(new_xyz, "new_xyz")
+        B, N, _ = xyz.shape
+        S = new_xyz.shape[1]
+        out = torch.empty((B, S, nsample), dtype=torch.int32, device=xyz.device)
+        _lib.call("pcl_knn_point_matmul_f32", _p(xyz), _p(new_xyz), B, N, S, int(nsample), 1, _p(out), _stream())
+        return out
     idx = knn_indices(new_xyz.transpose(1, 2).contiguous(), xyz.transpose(1, 2).contiguous(), nsample)   # [B,k,S]
     return idx.permute(0, 2, 1).contiguous()
 

@@ -99,19 +99,24 @@ class PointnetModuleMSG(PointNetModuleBase):
 _AB_RECORD_STREAM = bool(os.environ.get("PCL_AB_RECORD_STREAM"))        # lab switch for A/B timing on one box
 
 
+_OWN_SAMPLING_STREAM = {}          # device index -> the library's private producer stream
+
+
 def sampling_stream(owner, stream):
-    """-> (stream, owned).  ``stream="own"`` selects the network's PRIVATE producer stream: created here on first use (high
-    priority: the work is a short latency-bound chain), stored on the network and never handed to anybody else, so the only
-    allocations and kernels it ever sees are those of ``precompute_sampling`` -- each call of which starts by waiting for the
-    consumer stream.  That ownership is what makes the handle's memory safe without ``Tensor.record_stream`` (``adopt_sampling``);
-    a stream the caller supplies may carry other work, and handles produced on it take the ``record_stream`` route."""
+    """-> (stream, owned).  ``stream="own"`` selects the library's PRIVATE producer stream of the current device: created here on
+    first use (high priority: the work is a short latency-bound chain), never handed to anybody else, so the only allocations and
+    kernels it ever sees are those of ``precompute_sampling`` calls -- each of which starts by waiting for its consumer stream.  That
+    ownership is what makes a handle's memory safe without ``Tensor.record_stream`` (``adopt_sampling``); a stream the caller supplies
+    may carry other work, and handles produced on it take the ``record_stream`` route.  ONE stream per device, shared by
+    all networks: HIP multiplexes streams onto a handful of hardware queues, and a process that created a fresh side stream per
+    network found its fourth one on the main stream's queue -- the step went from 4.9 to 10 ms (round 4, bench.py's other_configs)."""
     if isinstance(stream, str):
         if stream != "own":
             raise ValueError(f"stream={stream!r}: pass a torch.cuda.Stream, None or 'own'")
-        s = owner.__dict__.get("_own_sampling_stream")
+        dev = torch.cuda.current_device()
+        s = _OWN_SAMPLING_STREAM.get(dev)
         if s is None:
-            s = torch.cuda.Stream(priority=-1)
-            owner.__dict__["_own_sampling_stream"] = s
+            s = _OWN_SAMPLING_STREAM[dev] = torch.cuda.Stream(priority=-1)
         return s, True
     return stream, False
 

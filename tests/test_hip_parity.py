@@ -325,3 +325,22 @@ def test_sa_level_matches_golden_fixture(dev):
         _, pooled = mod(xyz, feat)
         err = np.abs(pooled.detach().double().cpu().numpy() - g["pooled_f64"]).max()
         assert err <= 1e-5 * max(1.0, np.abs(g["pooled_f64"]).max()), (compact, err)
+
+
+@pytest.mark.parametrize("B,N,S,k", [(2, 512, 128, 64), (3, 1024, 512, 32), (2, 1024, 40, 100), (1, 2048, 33, 16), (2, 64, 64, 64), (1, 4096, 20, 8)])
+def test_knn_point_matmul_form_matches_oracle(oracle, dev, B, N, S, k):
+    """pcl_knn_point_matmul_f32 (PointConv's knn_point in the reference's own -2ab + a^2 + b^2 arithmetic, misc/pointconv_utils.py:34-53,
+    :120-131) against oracle.knn_point_matmul: exact [B,S,k] lists for both dot-product readings, incl. duplicate points (ties by
+    index), k > 64 (extraction rounds) and k = N."""
+    from pointcloudlib_amd import _lib
+    from pointcloudlib_amd.misc.ops import _p, _stream
+    pts = synth.gauss_ball(B, N, 300 + N + k)
+    pts[:, 5] = pts[:, 17]                                  # exact duplicates: distance ties, lower index first
+    pts[:, N // 2: N // 2 + 3] = pts[:, 1:2]
+    q = np.ascontiguousarray(pts[:, np.random.default_rng(k).permutation(N)[:S]])
+    x, qd = T(pts, dev), T(q, dev)
+    for fma_dot in (1, 0):
+        want = oracle.knn_point_matmul(k, pts, q, fma_dot=bool(fma_dot))
+        out = torch.empty((B, S, k), dtype=torch.int32, device=dev)
+        _lib.call("pcl_knn_point_matmul_f32", _p(x), _p(qd), B, N, S, k, fma_dot, _p(out), _stream())
+        assert np.array_equal(out.cpu().numpy(), want), (B, N, S, k, fma_dot)

@@ -106,8 +106,11 @@ def test_pointconv_knn_point_matmul_form(oracle, dev):
             xyz_cl = cur_xyz.permute(0, 2, 1).contiguous()
             fidx = pu.farthest_point_sample(xyz_cl, sa.npoint, st[i])
             assert np.array_equal(fidx.cpu().numpy(), a32[i]["fps_idx"]), f"sa{i + 1}: FPS indices differ"
-            hip = pu.knn_point(sa.nsample, xyz_cl, pu.index_points(xyz_cl, fidx)).cpu().numpy()
+            hip = pu.knn_point(sa.nsample, xyz_cl, pu.index_points(xyz_cl, fidx), form="direct").cpu().numpy()
             mm = a32[i]["knn_idx"]
+            # the named second definition (pcl_knn_point_matmul_f32, round 4): the matmul-form groups from the HIP kernel itself, exact
+            hip_mm = pu.knn_point(sa.nsample, xyz_cl, pu.index_points(xyz_cl, fidx), form="matmul")
+            assert np.array_equal(hip_mm.cpu().numpy(), mm), f"sa{i + 1}: HIP matmul-form groups differ from the oracle's restatement"
             ordered = float((hip != mm).any(-1).mean())
             sets = float((np.sort(hip, -1) != np.sort(mm, -1)).any(-1).mean())
             slots = float((hip != mm).mean())
@@ -116,7 +119,7 @@ def test_pointconv_knn_point_matmul_form(oracle, dev):
             # bounds (measured on this input: sa1 2.4e-4 / 0 / 1.5e-5, sa2 7.3e-4 / 2.4e-4 / 1.9e-5; profiles/r03_contraction_sensitivity.txt)
             report.check(sets <= 1e-3, f"sa{i + 1}: {sets:.2e} of the groups differ as SETS from the matmul-form restatement (bound 1e-3)")
             report.check(ordered <= 3e-3, f"sa{i + 1}: {ordered:.2e} of the groups differ as ordered lists (bound 3e-3)")
-            lists.append(torch.from_numpy(np.ascontiguousarray(mm)).to(dev))
+            lists.append(hip_mm.contiguous())                     # the network below runs on the HIP kernel's own matmul-form groups
             cur_xyz, cur_p = sa(cur_xyz, cur_p, st[i], lists[i])
             report.feature(cur_p.permute(0, 2, 1), a32[i]["feat"], a64[i]["feat"], f"sa{i + 1} output (matmul-form groups)")
     # (2) the whole network on the matmul-form groups, forward and backward

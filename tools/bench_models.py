@@ -126,8 +126,15 @@ def cpu_baseline_of(kind, state, n_warm=1, n_steps=5):
                       f"B={B} N={N}; CPU restatement of reference semantics (oracle/, Jittor not runnable), {threads} PyTorch threads"}
 
 
+def _selected(name):
+    """--only SUBSTRING, or --only 'NAME$' for an exact match (a config whose name is a prefix of its prefetch variant's)"""
+    if not ONLY:
+        return True
+    return name == ONLY[:-1] if ONLY.endswith("$") else ONLY in name
+
+
 def run(name, make, inputs, loss_fn, steps, warmup=3, cpu_kind=None):
-    if ONLY and ONLY not in name:
+    if not _selected(name):
         return None
     torch.manual_seed(0)
     net = make().cuda().train()
@@ -155,7 +162,7 @@ def run(name, make, inputs, loss_fn, steps, warmup=3, cpu_kind=None):
 
 
 def run_prefetch(name, make, inputs, loss_fn, steps, warmup=3):
-    if ONLY and ONLY not in name:
+    if not _selected(name):
         return None
     return _run_prefetch(name, make, inputs, loss_fn, steps, warmup)
 
@@ -170,8 +177,9 @@ def _run_prefetch(name, make, inputs, loss_fn, steps, warmup=120):    # (two str
     pending = [None]
     def step():
         opt.zero_grad(set_to_none=True)
-        out = net(*inputs, sampling=pending[0])
-        pending[0] = net.precompute_sampling(inputs[0], stream=side)
+        cur = pending[0]
+        pending[0] = net.precompute_sampling(inputs[0], stream=side)      # enqueued ahead of the forward (bench.py: 1.900 vs 1.914 ms behind it)
+        out = net(*inputs, sampling=cur)
         loss_fn(out).backward()
         opt.step()
     for _ in range(warmup):
@@ -183,7 +191,8 @@ def _run_prefetch(name, make, inputs, loss_fn, steps, warmup=120):    # (two str
     B = inputs[0].shape[0]
     r = {"config": name, "ms_per_step": round(dt * 1e3, 3), "clouds_per_s": round(B / dt, 1), "batch": B,
          "params": sum(p.numel() for p in net.parameters())}
-    print(json.dumps(r), flush=True)
+    if not QUIET:
+        print(json.dumps(r), flush=True)
     return r
 
 
@@ -202,7 +211,8 @@ def traffic_of(key, roofline):
 
 def other_configs(steps=20, keys=("cfg2_n4096", "cfg3", "cfg4", "cfg5")):
     """bench.py's `other_configs` leg: the BASELINE workloads besides the headline (N = 4096 row of config 2, configs 3, 4 (MSG), 5), one
-    short train-step timing each on the same GPU with the roofline of its dominant kernel -- inline sampling, no prefetch."""
+    short train-step timing each on the same GPU with the roofline of its dominant kernel; networks with a sampling front end are timed
+    both inline and with the headline's one-batch-ahead protocol."""
     global QUIET
     from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
     from pointcloudlib_amd.networks.cls.dgcnn import DGCNN
@@ -215,25 +225,36 @@ def other_configs(steps=20, keys=("cfg2_n4096", "cfg3", "cfg4", "cfg5")):
     QUIET, out = True, []
     try:
         for key in keys:
+            pre = None
             if key == "cfg2_n4096":
                 x = cloud(32, 4096, 20242)
-                r = run("PointNet++ SSG cls B=32 N=4096 (north_star's second cloud size)", PointNet2_cls,
-                        (x, torch.from_numpy(synth.unit_normals(32, 4096, 7)).to(dev)), ce, steps)
+                inp = (x, torch.from_numpy(synth.unit_normals(32, 4096, 7)).to(dev))
+                r = run("PointNet++ SSG cls B=32 N=4096 (north_star's second cloud size)", PointNet2_cls, inp, ce, steps)
+                pre = (PointNet2_cls, inp, ce)
             elif key == "cfg3":
                 r = run("DGCNN cls B=32 N=1024 k=20 (BASELINE configs[2])", DGCNN, (cloud(32, 1024, 20242).transpose(1, 2).contiguous(),), ce, steps)
             elif key == "cfg4":
                 xs = cloud(16, 2048, 20244)
                 oh = torch.zeros(16, 16, device=dev); oh[torch.arange(16), torch.arange(16) % 16] = 1
                 seg = torch.randint(0, 50, (16, 2048), device=dev)
-                r = run("PointNet++ MSG part-seg B=16 N=2048 (BASELINE configs[3])", PointNetMSG, (xs, xs, oh),
-                        lambda o: torch.nn.functional.cross_entropy(o, seg), steps)
+                lossf = lambda o: torch.nn.functional.cross_entropy(o, seg)
+                r = run("PointNet++ MSG part-seg B=16 N=2048 (BASELINE configs[3])", PointNetMSG, (xs, xs, oh), lossf, steps)
+                pre = (PointNetMSG, (xs, xs, oh), lossf)
             elif key == "cfg5":
-                r = run("PointConv cls B=32 N=1024 (BASELINE configs[4])", PointConvDensityClsSsg,
-                        (cloud(32, 1024, 20242).transpose(1, 2).contiguous(),), ce, steps)
+                inp = (cloud(32, 1024, 20242).transpose(1, 2).contiguous(),)
+                r = run("PointConv cls B=32 N=1024 (BASELINE configs[4])", PointConvDensityClsSsg, inp, ce, steps)
+                pre = (PointConvDensityClsSsg, inp, ce)
             else:
                 continue
-            row = {"key": key, "workload": r["config"] + ", train step fwd+bwd+SGD, inline sampling", "ms_per_step": r["ms_per_step"],
-                   "value": r["clouds_per_s"], "unit": "point-clouds/s", "steps": steps, "roofline": r["roofline"]}
+            row = {"key": key, "workload": r["config"] + ", train step fwd+bwd+SGD", "ms_per_step": r["ms_per_step"],
+                   "value": r["clouds_per_s"], "unit": "point-clouds/s", "steps": steps, "sampling": "inline", "roofline": r["roofline"]}
+            if pre is not None:
+                # the headline's protocol: the coordinate-only work of batch t+1 (FPS, ball query / k-NN groups, kernel densities) on the
+                # network's side stream during step t; the inline figure stays beside it
+                rp = _run_prefetch(r["config"], pre[0], pre[1], pre[2], steps, warmup=40)
+                row.update({"ms_per_step_inline": r["ms_per_step"], "ms_per_step": rp["ms_per_step"], "value": rp["clouds_per_s"],
+                            "sampling": "coordinate-only work of batch t+1 on a side stream during step t (the headline's protocol); "
+                                        "ms_per_step_inline = the same step with it inline"})
             if row["roofline"]:
                 row["roofline"]["traffic"], row["roofline"]["traffic_source"] = traffic_of(key, row["roofline"])
             out.append(row)

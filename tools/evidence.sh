@@ -1,11 +1,11 @@
 #!/bin/bash
 # One GPU-box pass that regenerates the measured evidence of a round (run through gpurun; copies go to profiles/ by hand):
-#   bash tools/evidence.sh r03
+#   bash tools/evidence.sh r04
 # kernel trace + stats, FETCH_SIZE / WRITE_SIZE passes (separate runs, counters only), SQ wave-state pass, the bench line.
-R=${1:-r03}; O=gpurun_out/$R; mkdir -p $O; cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-B="python bench.py --steps 20 --warmup 3 --no-settle --no-cpu-baseline"
+R=${1:-r04}; O=gpurun_out/$R; mkdir -p $O; cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+B="python bench.py --steps 20 --warmup 3 --no-settle --no-cpu-baseline --no-other-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o b -- $B > $O/kt.log 2>&1
-S="python bench.py --steps 3 --warmup 1 --no-settle --no-cpu-baseline --roofline-kernel none"
+S="python bench.py --steps 3 --warmup 1 --no-settle --no-cpu-baseline --no-other-configs --roofline-kernel none"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o b -- $S --dump-launch-order $O/order.json > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o b -- $S > $O/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
@@ -23,13 +23,16 @@ python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 1, 1>' 
 rm -rf $O/kt/*/*.db $O/fetch $O/write $O/sq/*/*.db 2>/dev/null
 python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
 # every C-ABI entry point event-timed (GEMM kernels: their own begin/end timestamps), algorithmic GB/s and TF per launch shape
-python bench.py --steps 20 --warmup 3 --profile-all --no-cpu-baseline --roofline-kernel none 2>&1 >/dev/null | grep -E "n/step|entry" > $O/${R}_entry_point_roofline.txt
-python -m pytest tests/test_parity_pointnet_gpu.py tests/test_parity_pointnet2_gpu.py tests/test_parity_dgcnn_gpu.py tests/test_parity_partseg_gpu.py tests/test_parity_pointconv_gpu.py tests/test_pointcnn_gpu.py -k "not xconv and not stage and not partseg_network and not cls_network" -m gpu -s -q 2>&1 | grep -v Warning > $O/${R}_parity_reports.txt
-# the other BASELINE configs: one line each with the roofline of its dominant kernel, and a kernel-stats CSV per config
+python bench.py --steps 20 --warmup 3 --profile-all --no-cpu-baseline --no-other-configs --roofline-kernel none 2>&1 >/dev/null | grep -E "n/step|entry" > $O/${R}_entry_point_roofline.txt
+python -m pytest tests/test_parity_pointnet_gpu.py tests/test_parity_pointnet2_gpu.py tests/test_parity_dgcnn_gpu.py tests/test_parity_partseg_gpu.py tests/test_parity_pointconv_gpu.py tests/test_pointcnn_gpu.py tests/test_parity_partseg_zoo_gpu.py -k "not xconv and not stage and not partseg_network and not cls_network" -m gpu -s -q 2>&1 | grep -v Warning > $O/${R}_parity_reports.txt
+# per-phase cycles of the fused backward's tile loop (lab build EXP=7: built beforehand with `make -C pointcloudlib_amd/csrc EXP=7`)
+if [ -f pointcloudlib_amd/libpcl_hip_exp7.so ]; then
+  PCL_HIP_SO=$PWD/pointcloudlib_amd/libpcl_hip_exp7.so python bench.py --steps 3 --warmup 2 --no-settle --no-cpu-baseline --no-other-configs --roofline-kernel none 2>&1 | grep "^fb<" | sort | uniq -c | sort -rn | awk '{$1=""; print}' | sort | awk 'NR%5==1' > $O/${R}_fused_backward_phase_cycles.txt
+fi
+# the other BASELINE configs: one line each with the roofline of its dominant kernel; per config kernel stats + PMC HBM traffic
 python tools/bench_models.py --steps 20 --cpu-baseline --out $O/${R}_other_configs.json > $O/other.log 2>&1
-for c in "cfg2'" cfg3 "cfg4 PointNet++ MSG part-seg B=16 N=2048 (BASELINE" cfg5; do
-  t=$(echo "$c" | cut -c1-5 | tr -d "' " | sed "s/cfg2/cfg2_n4096/")
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$t -o b -- python tools/bench_models.py --steps 10 --only "$c" > $O/kt_$t.log 2>&1
-  cp $(find $O/kt_$t -name '*kernel_stats.csv' | head -1) $O/${R}_${t}_kernel_stats.csv; rm -rf $O/kt_$t
-done
+bash tools/traffic_cfg.sh $R cfg2_n4096 "cfg2'" > $O/tc_cfg2.log 2>&1
+bash tools/traffic_cfg.sh $R cfg3 "cfg3" > $O/tc_cfg3.log 2>&1
+bash tools/traffic_cfg.sh $R cfg4 "cfg4 PointNet++ MSG part-seg B=16 N=2048 (BASELINE" > $O/tc_cfg4.log 2>&1
+bash tools/traffic_cfg.sh $R cfg5 "cfg5 PointConv cls B=32 N=1024$" > $O/tc_cfg5.log 2>&1
 tail -3 $O/kt.log; cat $O/traffic.txt | head -40; cat $O/${R}_dominant_kernel_by_shape.csv; tail -1 $O/${R}_bench_line.json
