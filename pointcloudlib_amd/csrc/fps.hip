@@ -258,7 +258,11 @@ extern "C" int pcl_fps_f32(const float* xyz, int B, int N, int m, int tie_stride
     while ((1 << log2S) < tie_stride) ++log2S;
     hipStream_t st = as_stream(stream);
     // threads per cloud: ~4-8 points per lane keeps the VALU part and the cross-wave part balanced
-    int T = g_fps_threads > 0 ? g_fps_threads : (N <= 256 ? 64 : N <= 1024 ? 256 : N <= 4096 ? 512 : 1024);
+    // (raced on MI355X, B = 32 / 16, round 4 -- ns per dependent step at T = 64 / 128 / 256 / 512 / 1024:
+    //  N = 512: 336 / 355 / 374 / - / -;  N = 1024: 479 / 410 / 381 / 416 / 736;  N = 2048: - / 550 / 450 / 475 / 766;  N = 4096: - / - / 589 / 611 / 869.
+    //  One wave per cloud -- no barrier, no LDS exchange, DPP only -- wins up to 512 points; beyond, four waves: the cross-wave
+    //  exchange costs less than the eight more distance evaluations per lane)
+    int T = g_fps_threads > 0 ? g_fps_threads : (N <= 512 ? 64 : N <= 4096 ? 256 : N <= 8192 ? 512 : 1024);
     const int ppt = (N + T - 1) / T;
 #define PCL_FPS_CASE(TT, PP) \
     if (T == TT && ppt <= PP) return launch_fps<TT, PP>(xyz, B, N, m, log2S, skip_sqnorm_le, start_idx, idx_out, new_xyz_out, st);
