@@ -144,6 +144,8 @@ def main():
     _lib.lib()                                                # fail loudly when the extension is missing
     if os.environ.get("PCL_FPS_PRIO"):                        # lab switch (tools/ab.sh): issue priority of the FPS chain's waves
         _lib.lib().pcl_set_fps_tuning(0, int(os.environ["PCL_FPS_PRIO"]))
+    if os.environ.get("PCL_MATRIX_FORM"):                     # lab switch (pcl_set_matrix_form): bit 0 resident forward, bit 1 staged GEMMs, min K << 8
+        _lib.lib().pcl_set_matrix_form(int(os.environ["PCL_MATRIX_FORM"], 0))
 
     B, N = args.batch, args.npoints
     torch.manual_seed(0)

@@ -400,6 +400,14 @@ int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a, const
 /* reference: the autograd backward of nn.Conv 1x1 + nn.BatchNorm + nn.ReLU, networks/cls/pointnet2.py:25-29 */
 /* test / tuning hook: cap the persistent grid of the fused backward at n workgroups (0 = one per CU); process-wide, set between calls */
 void pcl_set_fb_max_blocks(int n);
+/* Matrix-pipe form of the GEMM family (no reference counterpart: the reference calls cuDNN / cuBLAS fp32 through jittor's nn.Conv /
+ * nn.Linear, misc/layers.py:60-75).  Default 0: the fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere.  Opt-in, measured and not faster
+ * as a whole: every fp32 operand split EXACTLY into three bf16 values, an fp32 product = nine exact bf16 products
+ * accumulated in fp32 on v_mfma_f32_32x32x16_bf16.  form bit 0: the resident-operand forward (set-abstraction shapes); bit 1: the
+ * staged GEMMs (forward and dX through linear_nt_kernel) with K >= (form >> 8), 128 if that field is 0.  Process-wide; takes effect
+ * for launches enqueued after the call. */
+void pcl_set_matrix_form(int form);
+int pcl_get_matrix_form(void);
 int pcl_linear_bwd_fused_supported(int Cout, int Cin);
 int pcl_linear_bwd_fused_stat_rows(int P, int Cin);
 size_t pcl_linear_bwd_fused_workspace_bytes(int P, int Cout, int Cin);

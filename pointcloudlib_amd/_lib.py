@@ -121,6 +121,8 @@ _SIGS = {
     "pcl_scatter_rows_add_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_linear_bwd_dw_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "pcl_set_fb_max_blocks": (None, [c_int]),
+    "pcl_set_matrix_form": (None, [c_int]),
+    "pcl_get_matrix_form": (c_int, []),
     "pcl_set_fps_tuning": (None, [c_int, c_int]),
     "pcl_linear_bwd_fused_supported": (c_int, [c_int, c_int]),
     "pcl_linear_bwd_fused_stat_rows": (c_int, [c_int, c_int]),

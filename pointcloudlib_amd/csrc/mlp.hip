@@ -200,10 +200,55 @@ __device__ __forceinline__ float buf_ld1(rsrc_t r, unsigned voff, unsigned soff)
 __device__ __forceinline__ void buf_st1(rsrc_t r, unsigned voff, unsigned soff, float x) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0);
 }
+__device__ __forceinline__ void buf_st4(rsrc_t r, unsigned voff, unsigned soff, float4 x) {
+    const u32x4 v = {__float_as_uint(x.x), __float_as_uint(x.y), __float_as_uint(x.z), __float_as_uint(x.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
 __device__ __forceinline__ int2 buf_ld2i(rsrc_t r, unsigned voff) {
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
     return make_int2((int)v.x, (int)v.y);
 }
+
+// ---- fp32 operands as three bf16 planes (round 4; the method is described at linear_fwd_split_kernel) --------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16_pack(float x, float y) {          // v_cvt_pk_bf16_f32 (round to nearest even)
+    bf16x2 v = {(__bf16)x, (__bf16)y};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16_lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+// (x, y) -> three packed words, x in the low half: x = lo(p0) + lo(p1) + lo(p2) exactly
+__device__ __forceinline__ void split3(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+    p0 = bf16_pack(x, y);
+    const float rx = x - bf16_lo(p0), ry = y - bf16_hi(p0);
+    p1 = bf16_pack(rx, ry);
+    p2 = bf16_pack(rx - bf16_lo(p1), ry - bf16_hi(p1));
+}
+struct Split8 { bf16x8 pl[3]; };
+__device__ __forceinline__ Split8 split8(float4 u, float4 v) {
+    uint4 w0, w1, w2;
+    split3(u.x, u.y, w0.x, w1.x, w2.x); split3(u.z, u.w, w0.y, w1.y, w2.y);
+    split3(v.x, v.y, w0.z, w1.z, w2.z); split3(v.z, v.w, w0.w, w1.w, w2.w);
+    Split8 s;
+    s.pl[0] = __builtin_bit_cast(bf16x8, w0); s.pl[1] = __builtin_bit_cast(bf16x8, w1); s.pl[2] = __builtin_bit_cast(bf16x8, w2);
+    return s;
+}
+// acc += A . B over 16 k, A and B as three planes each: the nine partial products, smallest first
+__device__ __forceinline__ f32x16 mfma_split9(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    return acc;
+}
+
+constexpr int PLD = BK * 2 + 16;           // bytes per row of a staged bf16 plane (32 k + 16 bytes: conflict-free 16-byte fragment reads)
 
 // per-thread offsets (bytes) of the vector path, computed once per kernel: A rows (tid>>3)+32i at k quad tid&7;
 // B forward: rows n = (tid>>3)+32i of W[N][K]; B backward (BT): row k = tid&31, four n at (tid>>5)*4+32i of W[K][ldb]
@@ -279,7 +324,7 @@ __device__ __forceinline__ void vload_b(const LinArgs& p, const VecRsrc& r, cons
 }
 
 // fused transform + LDS store, vector path: no masks (see the section header).  lrelu(t) = max(t, slope*t), 0 <= slope <= 1.
-template <int AM, int ROWS>
+template <int AM, int ROWS, bool SP = false>
 __device__ __forceinline__ void vstore_a(const LinArgs& p, float* sX, int tid, const Stage<true, ROWS>& st, const RowInfo<true, ROWS>& ri) {
     const float4 sc = st.c_sc, sh = st.c_sh, k2 = st.c_k2, mu = st.c_mu;
 #pragma unroll
@@ -306,15 +351,45 @@ __device__ __forceinline__ void vstore_a(const LinArgs& p, float* sX, int tid, c
             a.x = fmaf(sc.x, du.x, -w * fmaf(k2.x, y.x - mu.x, sh.x)); a.y = fmaf(sc.y, du.y, -w * fmaf(k2.y, y.y - mu.y, sh.y));
             a.z = fmaf(sc.z, du.z, -w * fmaf(k2.z, y.z - mu.z, sh.z)); a.w = fmaf(sc.w, du.w, -w * fmaf(k2.w, y.w - mu.w, sh.w));
         }
-        *reinterpret_cast<float4*>(&sX[((tid >> 3) + 32 * i) * LDS_LD + (tid & 7) * 4]) = a;
+        if constexpr (SP) {                    // three bf16 planes [plane][row][32 k]
+            uint2 w0, w1, w2;
+            split3(a.x, a.y, w0.x, w1.x, w2.x); split3(a.z, a.w, w0.y, w1.y, w2.y);
+            unsigned char* q = reinterpret_cast<unsigned char*>(sX) + ((tid >> 3) + 32 * i) * PLD + (tid & 7) * 8;
+            *reinterpret_cast<uint2*>(q) = w0; *reinterpret_cast<uint2*>(q + ROWS * PLD) = w1; *reinterpret_cast<uint2*>(q + 2 * ROWS * PLD) = w2;
+        } else {
+            *reinterpret_cast<float4*>(&sX[((tid >> 3) + 32 * i) * LDS_LD + (tid & 7) * 4]) = a;
+        }
     }
 }
 
-template <int ROWS, bool BT>
+template <int ROWS, bool BT, bool SP = false>
 __device__ __forceinline__ void vstore_b(float* sX, int tid, const Stage<true, ROWS>& st) {
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
         const float4 v = st.v[i];
+        if constexpr (SP) {
+            unsigned char* base = reinterpret_cast<unsigned char*>(sX);
+            if constexpr (BT) {          // W[k][4 n] -> planes [n][k]: 2-byte writes, lanes run over k
+                uint2 w0, w1, w2;
+                split3(v.x, v.y, w0.x, w1.x, w2.x); split3(v.z, v.w, w0.y, w1.y, w2.y);
+                unsigned char* q = base + ((tid >> 5) * 4 + 32 * i) * PLD + (tid & 31) * 2;
+                const uint2 ww[3] = {w0, w1, w2};
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    unsigned char* r = q + pl * ROWS * PLD;
+                    *reinterpret_cast<unsigned short*>(r) = (unsigned short)(ww[pl].x & 0xffffu);
+                    *reinterpret_cast<unsigned short*>(r + PLD) = (unsigned short)(ww[pl].x >> 16);
+                    *reinterpret_cast<unsigned short*>(r + 2 * PLD) = (unsigned short)(ww[pl].y & 0xffffu);
+                    *reinterpret_cast<unsigned short*>(r + 3 * PLD) = (unsigned short)(ww[pl].y >> 16);
+                }
+            } else {
+                uint2 w0, w1, w2;
+                split3(v.x, v.y, w0.x, w1.x, w2.x); split3(v.z, v.w, w0.y, w1.y, w2.y);
+                unsigned char* q = base + ((tid >> 3) + 32 * i) * PLD + (tid & 7) * 8;
+                *reinterpret_cast<uint2*>(q) = w0; *reinterpret_cast<uint2*>(q + ROWS * PLD) = w1; *reinterpret_cast<uint2*>(q + 2 * ROWS * PLD) = w2;
+            }
+            continue;
+        }
         if constexpr (BT) {              // W[k][4 n] -> [n][k]: lanes run over k, the four dword writes are conflict-free
             const int rl = (tid >> 5) * 4 + 32 * i;
             sX[(rl + 0) * LDS_LD + (tid & 31)] = v.x; sX[(rl + 1) * LDS_LD + (tid & 31)] = v.y;
@@ -529,15 +604,16 @@ __device__ __forceinline__ void quad_transpose4(float& v0, float& v1, float& v2,
     y = quad_xchg2(b1 ? v1 : v3); v1 = b1 ? y : v1; v3 = b1 ? v3 : y;
 }
 
-template <int AM, int EM, bool VEC, int TN, int GM, bool RAG, int TM = 2>
+template <int AM, int EM, bool VEC, int TN, int GM, bool RAG, int TM = 2, bool SP = false>
 __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in) {
     static_assert(GM == 0 || TM == 2, "the fused group max works on 64-row wave slabs");
+    static_assert(!SP || (VEC && GM == 0), "bf16-plane operands: vector path only");
     LinArgs p = p_in;
     if (p.m_dev) p.M = *p.m_dev;                       // compacted rows: the row count lives on the device
     constexpr int TBM = 64 * TM, TBN = 64 * TN;        // TM = 1: 64-row tiles for small M (twice the workgroups)
     constexpr bool BT = AM >= A_DY;              // backward: B is the weight matrix as stored, [K][N]
-    __shared__ __attribute__((aligned(16))) float sA[TBM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float sB[TBN * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float sA[SP ? 3 * TBM * PLD / 4 : TBM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float sB[SP ? 3 * TBN * PLD / 4 : TBN * LDS_LD];
     // multiplicities of the tile's rows for the BatchNorm sums of compacted rows: prefetched with the operands and kept
     // in LDS (a global load in the epilogue would sit behind the tile's own stores in the in-order vmcnt queue)
     constexpr bool NEEDW = RAG && EM == E_STORE_STATS;
@@ -622,8 +698,8 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
         for (int k0 = 0; k0 < p.K; k0 += BK) {
             __syncthreads();                       // previous step's fragment reads are done
             if constexpr (VEC) {
-                vstore_a<AM, TBM>(p, sA, tid, ra, ri);
-                vstore_b<TBN, BT>(sB, tid, rb);
+                vstore_a<AM, TBM, SP>(p, sA, tid, ra, ri);
+                vstore_b<TBN, BT, SP>(sB, tid, rb);
             } else {
                 store_a<AM, VEC, TBM>(p, sA, staged_k0, tid, ra, ri);
                 store_b<VEC, TBN, BT>(p, sB, n0, staged_k0, tid, rb);
@@ -638,6 +714,26 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                 if (nmt < m_tiles) request(nmt, nk, nk == 0, false);     // a new tile adopts its prefetched row records
             }
             const int kc = min(BK, p.K - k0);
+            if constexpr (SP) {                // nine bf16 MFMAs per 16 k and 32x32 tile (k past K was staged as zeros)
+                const unsigned char* pa = reinterpret_cast<const unsigned char*>(sA) + (wr * (32 * TM) + lr) * PLD + lh * 16;
+                const unsigned char* pb = reinterpret_cast<const unsigned char*>(sB) + (wc * 32 * TN + lr) * PLD + lh * 16;
+                const int nks = (kc + 15) >> 4;
+                for (int ks = 0; ks < nks; ++ks) {
+                    bf16x8 af[TM][3], bq[TN][3];
+#pragma unroll
+                    for (int t = 0; t < TM; ++t)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) af[t][pl] = *reinterpret_cast<const bf16x8*>(pa + pl * TBM * PLD + t * 32 * PLD + ks * 32);
+#pragma unroll
+                    for (int t = 0; t < TN; ++t)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) bq[t][pl] = *reinterpret_cast<const bf16x8*>(pb + pl * TBN * PLD + t * 32 * PLD + ks * 32);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_split9(af[tm], bq[tn], acc[tm][tn]);
+                }
+            } else {
             const int nkk = (kc + 7) >> 3;
             for (int kk = 0; kk < nkk; ++kk) {
                 float4 a4[TM], b4[TN];
@@ -659,6 +755,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
                         }
                     }
                 }
+            }
             }
         }
 
@@ -1356,6 +1453,255 @@ __global__ __launch_bounds__(FR_T) void linear_fwd_res_kernel(const FrArgs p_in)
     }
 }
 
+// ---- the same forward on the bf16 matrix pipe, fp32 operands split three ways (round 4; OPT-IN: pcl_set_matrix_form) -------------------
+// gfx950 runs v_mfma_f32_32x32x2_f32 at 157 TF/s -- the packed-FMA rate of the vector ALU, whose issue port it shares -- and
+// v_mfma_f32_32x32x16_bf16 at 2.5 PF/s.  An fp32 value is EXACTLY the sum of three bf16 values (8 + 8 + 8 significant bits:
+// h0 = bf16(v), h1 = bf16(v - h0), h2 = v - h0 - h1; both differences are exact in fp32 and h2 fits 8 bits), so an fp32 product
+// a*b is the sum of the nine products ah_i * bh_j, each of them exact in the fp32 accumulator's format, and
+//      acc += a*b     ==     nine bf16 MFMAs into the same fp32 accumulator (smallest terms first).
+// Nothing is dropped: all 24 bits of both operands enter every product; what differs from the fp32 MFMA is the order in which the
+// partial products are rounded into the accumulator (tests/test_mlp_hip.py::test_split_gemm_error_vs_fp64 measures both against
+// fp64: equally close, mean error 0.7-1.08 x).  Nine 32-cycle MFMAs per 16 k instead of eight 64-cycle ones:
+// 0.56 x the matrix time.  Rows are split ONCE on their way into LDS (three bf16 planes, row-major, 16 bytes of padding per row:
+// conflict-free ds_read_b128 fragments); a wave's weight fragments (32 output columns x all of K) are split once per kernel and
+// stay in registers (48 / 96 VGPRs for K = 64 / 128) -- no LDS copy of the weight, so ONE workgroup covers all Cout <= 256 columns
+// of a row tile and the rows are read, transformed and split once instead of once per 128-column slab.
+// MEASURED: 128 -> 256 runs 122 -> 100 us, 64 -> 128 and 128 -> 128 the same as the fp32 form, 64 -> 64 slower
+// (57 -> 67 us), and the training step 1.91 -> 1.96 ms because a 155-160 KB workgroup per CU leaves no room for the side stream's
+// sampling kernels beside it.  Per tile and SIMD the matrix pipe is busy 8.8 k of 14 k cycles: the epilogue (BatchNorm sums, 4 KB
+// LDS transpose, stores) and the deposit (BatchNorm + activation + the split: ~30 VALU per float4) are ~420 vector instructions per
+// wave and tile beside 144 MFMAs, and vector work beside the partner wave's bf16 MFMAs issues at about a third of its solo rate on
+// this chip (late-wave epilogue 3.7 k cycles beside MFMAs, 1.1 k alone; s_setprio does not change it).  With the MFMAs removed the
+// same kernel streams at 5.4-6.0 TB/s (full-line dwordx4 stores through the LDS transpose; 4.1 TB/s with 16 dword stores per
+// block), with the stores removed it is 15-20 us faster whatever their shape -- the two halves do not overlap inside one
+// workgroup's barrier cadence.  So the fp32 MFMA form stays the default; this kernel is kept selectable, with its tests.
+// Inputs beyond bf16's range behave like fp32 except |v| > 3.39e38 (rounds to inf in h0, then NaN); no such activations exist here.
+template <int CI, int CBK, bool RAG, bool PLAIN>
+__global__ __launch_bounds__(FR_T) void linear_fwd_split_kernel(const FrArgs p_in) {
+    FrArgs p = p_in;
+    if (p.m_dev) p.M = __builtin_amdgcn_readfirstlane(*p.m_dev);
+    constexpr int CIN = 64 * CI, N = 32 * CBK, R = CIN == 64 ? 128 : 64;
+    constexpr int ALDB = CIN * 2 + 16;                                      // bytes per row of a plane
+    constexpr int PSZ = R * ALDB;                                           // one plane of one image
+    constexpr int RB = R / 32, WPC = CBK >= 8 ? 1 : 8 / CBK, TM = RB / WPC; // waves per column block; 32x32 tiles per wave
+    static_assert(RB % WPC == 0 && TM >= 1 && TM <= 2, "wave tiling");
+    constexpr int CPR = CIN / 4, RP = FR_T / CPR, NI = R / RP;               // staging: thread -> 4 k of rows row0 + RP*i
+    constexpr int KS = CIN / 16;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 3 * PSZ + 3 * R * 4 + 2 * FR_T * 16 + 8 * 4096 + 2 * CIN * 4];
+    float* const sFold = reinterpret_cast<float*>(lds + 2 * 3 * PSZ + 3 * R * 4 + 2 * FR_T * 16 + 8 * 4096);        // [2][CIN] scale | shift
+    float* const sMult = reinterpret_cast<float*>(lds + 2 * 3 * PSZ);
+    uint4* const sPiv = reinterpret_cast<uint4*>(lds + 2 * 3 * PSZ + 3 * R * 4);        // [2][FR_T]: this lane's 16 pivots, packed bf16
+    unsigned char* const sOut = lds + 2 * 3 * PSZ + 3 * R * 4 + 2 * FR_T * 16;           // [8 waves][32 rows][32 floats]: store staging
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int bx = blockIdx.x;
+    const int tiles = (p.M + R - 1) / R;
+    const unsigned irow = CIN * 4u, orow = (unsigned)N * 4u;
+    const int k4 = (tid % CPR) * 4, row0 = tid / CPR;
+    if constexpr (!PLAIN) {                                                  // the folded BatchNorm of the layer below, read per deposit
+        if (tid < CIN) { sFold[tid] = p.sc[tid]; sFold[CIN + tid] = p.sh[tid]; }
+    }
+    const int cb = wave % CBK, rb0 = wave / CBK;                             // tiles (rb0 + WPC * t, cb), t < TM
+    const int col = cb * 32 + lr;                                            // the weight row this lane's fragments hold
+
+    float4 rX[NI];
+    float rMu = 0.f;
+    auto request = [&](int tile) {
+        const bool live = tile < tiles;
+        const int m0 = tile * R;
+        const rsrc_t rA = buf_rsrc(p.X, (size_t)m0 * irow, live ? (size_t)p.M * irow : 0);
+        const unsigned vo = (unsigned)row0 * irow + (unsigned)k4 * 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) rX[i] = buf_ld4(rA, vo, (unsigned)(RP * i) * irow);
+        const int row = m0 + tid;
+        if constexpr (RAG) {
+            const rsrc_t rR = buf_rsrc(p.rmeta, 0, live ? (size_t)p.M * 8 : 0);
+            const int2 rec = buf_ld2i(rR, (tid < R && row < p.M) ? (unsigned)row * 8u : BUF_OOB);
+            rMu = (float)(rec.y >> 16);
+        } else {
+            rMu = (live && tid < R && row < p.M) ? 1.f : 0.f;
+        }
+    };
+    auto deposit = [&](int buf, int mb) {
+        unsigned char* a = lds + buf * 3 * PSZ;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float4 z = rX[i];
+            if constexpr (!PLAIN) {             // the layer below's folded BatchNorm + activation, applied once per element
+                const float4 csc = *reinterpret_cast<const float4*>(sFold + k4), csh = *reinterpret_cast<const float4*>(sFold + CIN + k4);
+                float t;
+                t = fmaf(csc.x, rX[i].x, csh.x); z.x = fmaxf(t, t * p.slope);
+                t = fmaf(csc.y, rX[i].y, csh.y); z.y = fmaxf(t, t * p.slope);
+                t = fmaf(csc.z, rX[i].z, csh.z); z.z = fmaxf(t, t * p.slope);
+                t = fmaf(csc.w, rX[i].w, csh.w); z.w = fmaxf(t, t * p.slope);
+            }
+            uint2 w0, w1, w2;
+            split3(z.x, z.y, w0.x, w1.x, w2.x); split3(z.z, z.w, w0.y, w1.y, w2.y);
+            unsigned char* q = a + (row0 + RP * i) * ALDB + k4 * 2;
+            *reinterpret_cast<uint2*>(q) = w0; *reinterpret_cast<uint2*>(q + PSZ) = w1; *reinterpret_cast<uint2*>(q + 2 * PSZ) = w2;
+        }
+        if (tid < R) sMult[mb * R + tid] = rMu;
+    };
+    int tile = bx;
+    request(tile);
+    // this wave's weight fragments: W[col][16 ks + 8 lh .. + 8), split once
+    bf16x8 bw[KS][3];
+    {
+        const float* wrow = p.W + (size_t)col * CIN + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const Split8 s = split8(*reinterpret_cast<const float4*>(wrow + ks * 16), *reinterpret_cast<const float4*>(wrow + ks * 16 + 4));
+            bw[ks][0] = s.pl[0]; bw[ks][1] = s.pl[1]; bw[ks][2] = s.pl[2];
+        }
+    }
+    if constexpr (!PLAIN) __syncthreads();                                   // sFold
+    deposit(0, 0);
+    request(tile + p.gx);
+    __syncthreads();
+    f32x16 acc;
+    // The MFMAs run TRANSPOSED (A = weight fragment, B = row fragment): acc[r] is Y[row lr of the block][channel 8 (r>>2) + 4 lh + (r&3)
+    // of column block cb], four consecutive channels per register quad.  A block leaves through a wave-private 4 KB LDS stage (four
+    // ds_write_b128, four ds_read_b128, 16-byte chunks XOR-swizzled by the row) as four dwordx4 stores of 8 rows x 128 bytes: full
+    // lines, 1 KB per instruction.  (The store path is what bounds this kernel: as 16 dword stores per block -- two 128-byte lines
+    // per instruction -- the epilogue took 4-6 k cycles per tile against 4.4 k of MFMAs; as dwordx4 from the accumulator layout -- 32
+    // rows x 32 bytes per instruction -- no less.)
+    // BatchNorm sums: a lane keeps (sum, sum of squares) of ITS rows for its 16 channels in fp32 about its own pivots (its first
+    // value per channel rounded to bf16, parked in LDS) and converts to fp64 once, after the last tile.
+    float ss[16], qq[16], tw = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ss[r] = 0.f; qq[r] = 0.f; }
+    bool have_piv = false;
+    unsigned char* const stage = sOut + wave * 4096;
+    auto epilogue = [&](int m0, int mb, int t) {    // block t of the tile at row m0
+        const rsrc_t rY = buf_rsrc(p.Y, (size_t)m0 * orow, (size_t)p.M * orow);
+        auto bias4 = [&](int g) { return p.bias ? *reinterpret_cast<const float4*>(p.bias + cb * 32 + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f); };
+        uint4 pk[2];
+        if (have_piv) { pk[0] = sPiv[tid]; pk[1] = sPiv[FR_T + tid]; }
+        else {                                  // (pivots: the bias is left out -- any value near the channel's mean serves)
+            pk[0] = make_uint4(bf16_pack(acc[0], acc[1]), bf16_pack(acc[2], acc[3]), bf16_pack(acc[4], acc[5]), bf16_pack(acc[6], acc[7]));
+            pk[1] = make_uint4(bf16_pack(acc[8], acc[9]), bf16_pack(acc[10], acc[11]), bf16_pack(acc[12], acc[13]), bf16_pack(acc[14], acc[15]));
+            sPiv[tid] = pk[0]; sPiv[FR_T + tid] = pk[1];
+            have_piv = true;
+        }
+        const uint32_t pw[8] = {pk[0].x, pk[0].y, pk[0].z, pk[0].w, pk[1].x, pk[1].y, pk[1].z, pk[1].w};
+        const int rbase = (rb0 + t * WPC) * 32;
+        const float w = sMult[mb * R + rbase + lr];
+        tw += w;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bz = bias4(g);
+            const float4 c = make_float4(acc[4 * g] + bz.x, acc[4 * g + 1] + bz.y, acc[4 * g + 2] + bz.z, acc[4 * g + 3] + bz.w);
+            *reinterpret_cast<float4*>(stage + (lr * 8 + ((2 * g + lh) ^ (lr & 7))) * 16) = c;
+            float d, e;
+            d = c.x - bf16_lo(pw[2 * g]); e = w * d; ss[4 * g] += e; qq[4 * g] = fmaf(e, d, qq[4 * g]);
+            d = c.y - bf16_hi(pw[2 * g]); e = w * d; ss[4 * g + 1] += e; qq[4 * g + 1] = fmaf(e, d, qq[4 * g + 1]);
+            d = c.z - bf16_lo(pw[2 * g + 1]); e = w * d; ss[4 * g + 2] += e; qq[4 * g + 2] = fmaf(e, d, qq[4 * g + 2]);
+            d = c.w - bf16_hi(pw[2 * g + 1]); e = w * d; ss[4 * g + 3] += e; qq[4 * g + 3] = fmaf(e, d, qq[4 * g + 3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 8 + (lane >> 3);
+            const float4 v = *reinterpret_cast<const float4*>(stage + (row * 8 + ((lane & 7) ^ (row & 7))) * 16);
+            buf_st4(rY, (unsigned)(rbase + row) * orow + (unsigned)(cb * 32 + 4 * (lane & 7)) * 4, 0, v);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // The two waves of a SIMD run out of phase: waves 0-3 store a tile right after its MFMAs, waves 4-7 keep the accumulators over
+    // the barrier and store under the other wave's MFMAs of the NEXT tile (bf16 MFMAs leave the vector ALU and the store path free;
+    // in phase, both waves' epilogues would run with the matrix pipe idle).  The multiplicities have three buffers for that.
+    const bool late = wave >= 4;
+    int it = 0, mb = 0;
+#if PCL_EXP == 8                                     // lab build: cycles per phase of the tile loop
+    long long tph[5] = {0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define FS_MARK(i) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tlast; tlast = t_; }
+#else
+#define FS_MARK(i)
+#endif
+    auto mma = [&](int buf, int t) {            // acc = block t of the tile in image buf
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const unsigned char* pa = lds + buf * 3 * PSZ + ((rb0 + t * WPC) * 32 + lr) * ALDB + lh * 16;
+        struct Op { bf16x8 a[3]; };
+        auto ld = [&](int ks) -> Op {
+            Op o;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) o.a[pl] = *reinterpret_cast<const bf16x8*>(pa + pl * PSZ + ks * 32);
+            return o;
+        };
+        {
+            Op cur = ld(0);                     // operands of step k+1 are read before the MFMAs of step k are issued (pinned: hipcc sinks loads)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Op nxt = cur;
+                if (ks + 1 < KS) nxt = ld(ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = mfma_split9(bw[ks], cur.a, acc);
+                cur = nxt;
+            }
+        }
+    };
+    auto refill = [&](int buf) {                // the next tile (requested a tile ago) into the other image, the one after it requested
+        const int mn = mb == 2 ? 0 : mb + 1;
+        deposit(buf ^ 1, mn);
+        request(tile + 2 * p.gx);
+        mb = mn;
+    };
+    for (; tile < tiles; tile += p.gx, ++it) {
+        FS_MARK(0)
+        const int mbt = mb;
+        if (late) refill(it & 1);
+        FS_MARK(1)
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {          // a block's stores drain under the next block's MFMAs
+            __builtin_amdgcn_s_setprio(0);
+            mma(it & 1, t);
+            __builtin_amdgcn_s_setprio(2);      // the vector / memory phases go first: the partner's MFMAs are paced by the pipe anyway
+            if (t + 1 < TM || !late) epilogue(tile * R, mbt, t);
+        }
+        FS_MARK(2)
+        if (!late) refill(it & 1);
+        FS_MARK(3)
+        __syncthreads();
+        FS_MARK(4)
+        if (late) epilogue(tile * R, mbt, TM - 1);
+    }
+#if PCL_EXP == 8
+    if (bx == 37 && (tid == 0 || tid == 448))
+        printf("fs<%d,%d> wave %d tiles %d: late-epi %lld | late-refill %lld | mma+epi %lld | refill %lld | barrier %lld  (cycles/tile)\n", CIN, N, wave, it,
+               tph[0] / it, tph[1] / it, tph[2] / it, tph[3] / it, tph[4] / it);
+#endif
+    {
+        double* red = reinterpret_cast<double*>(lds);             // [8 waves][32 channels][2]
+        __syncthreads();
+        const double n = (double)tw;
+        uint4 pk[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        if (have_piv) { pk[0] = sPiv[tid]; pk[1] = sPiv[FR_T + tid]; }
+        const uint32_t pw[8] = {pk[0].x, pk[0].y, pk[0].z, pk[0].w, pk[1].x, pk[1].y, pk[1].z, pk[1].w};
+#pragma unroll
+        for (int c16 = 0; c16 < 16; ++c16) {
+            const double pvd = (double)((c16 & 1) ? bf16_hi(pw[c16 >> 1]) : bf16_lo(pw[c16 >> 1])), sd = (double)ss[c16];
+            double s = sd + n * pvd, q = (double)qq[c16] + 2.0 * pvd * sd + n * pvd * pvd;
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
+            if (lr == 0) { const int ch = 8 * (c16 >> 2) + 4 * lh + (c16 & 3); red[(wave * 32 + ch) * 2] = s; red[(wave * 32 + ch) * 2 + 1] = q; }
+        }
+        __syncthreads();
+        if (tid < N) {
+            const int cb_ = tid / 32, l = tid & 31;
+            double ss = 0.0, qq = 0.0;
+#pragma unroll
+            for (int w = 0; w < WPC; ++w) { ss += red[((w * CBK + cb_) * 32 + l) * 2]; qq += red[((w * CBK + cb_) * 32 + l) * 2 + 1]; }
+            double* dst = p.stats + (size_t)bx * 2 * N;
+            dst[tid] = ss; dst[N + tid] = qq;
+            for (int r = bx + p.gx; r < p.stat_rows; r += p.gx) {
+                double* z = p.stats + (size_t)r * 2 * N;
+                z[tid] = 0.0; z[N + tid] = 0.0;
+            }
+        }
+    }
+}
+
 // which forward launches take the resident-weight kernel: a hidden layer (folded BatchNorm + activation on the input) of a
 // set-abstraction shape with enough rows to keep one workgroup per CU busy for several tiles
 static bool fwd_res_eligible(const LinArgs& a) {
@@ -1364,6 +1710,7 @@ static bool fwd_res_eligible(const LinArgs& a) {
     if (!((a.K == 64 && (a.N == 64 || a.N == 128)) || (a.K == 128 && (a.N == 128 || a.N == 256)))) return false;
     if (a.M < 32768 || (size_t)a.M * (size_t)(a.N > a.K ? a.N : a.K) * 4 >= 0xffffffffull) return false;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al16(a.bias)) return false;
     if (a.a_mode == A_PLAIN) return al16(a.A) && al16(a.B);
     return al16(a.A) && al16(a.B) && al16(a.sc) && al16(a.sh) && a.slope >= 0.f && a.slope <= 1.f;
 }
@@ -1377,13 +1724,28 @@ static int launch_fwd_res_t(const FrArgs& f, bool rag, hipStream_t st) {
     else PCL_LAUNCH_TIMED((linear_fwd_res_kernel<CI, NS, false, false>), grid, blk, st, f);
     return check_launch("pcl_linear_fwd(resident weight)");
 }
+template <int CI, int CBK>
+static int launch_fwd_split_t(const FrArgs& f, bool rag, hipStream_t st) {
+    const dim3 grid(f.gx), blk(FR_T);
+    const bool plain = f.sc == nullptr;
+    if (rag && plain) PCL_LAUNCH_TIMED((linear_fwd_split_kernel<CI, CBK, true, true>), grid, blk, st, f);
+    else if (rag) PCL_LAUNCH_TIMED((linear_fwd_split_kernel<CI, CBK, true, false>), grid, blk, st, f);
+    else if (plain) PCL_LAUNCH_TIMED((linear_fwd_split_kernel<CI, CBK, false, true>), grid, blk, st, f);
+    else PCL_LAUNCH_TIMED((linear_fwd_split_kernel<CI, CBK, false, false>), grid, blk, st, f);
+    return check_launch("pcl_linear_fwd(split bf16 planes)");
+}
+// the matrix-pipe form of the GEMM family: 1 = fp32 operands as three bf16 planes on the bf16 MFMA (default), 0 = fp32 MFMA
+static int g_split_mfma = 0;               // bit 0: the resident-operand forward, bit 1: the staged GEMMs with K >= g_split_min_k
+static int g_split_min_k = 128;
+static bool fwd_split_on() { return (g_split_mfma & 1) != 0; }
 static int fr_cu_count();
 static int launch_fwd_res(const LinArgs& a, int stat_rows, hipStream_t st) {
     FrArgs f = {};
     f.X = a.A; f.W = a.B; f.bias = a.bias; f.sc = a.a_mode == A_PLAIN ? nullptr : a.sc; f.sh = a.a_mode == A_PLAIN ? nullptr : a.sh; f.slope = a.slope; f.Y = a.C; f.stats = a.stats;
     f.rmeta = a.rmeta; f.m_dev = a.m_dev; f.M = a.M; f.N = a.N; f.stat_rows = stat_rows;
     const int NS = a.N == 64 ? 64 : 128, R = a.K == 64 ? 128 : 64;
-    f.nt = a.N / NS;
+    const bool split = fwd_split_on();
+    f.nt = split ? 1 : a.N / NS;
     const int tiles = (a.M + R - 1) / R;
     int gx = fr_cu_count() / f.nt;                       // one workgroup per CU in all
     if (gx > tiles) gx = tiles;
@@ -1391,6 +1753,12 @@ static int launch_fwd_res(const LinArgs& a, int stat_rows, hipStream_t st) {
     if (gx < 1) gx = 1;
     f.gx = gx;
     const bool rag = a.rmeta != nullptr;
+    if (split) {
+        if (a.K == 64 && a.N == 64) return launch_fwd_split_t<1, 2>(f, rag, st);
+        if (a.K == 64) return launch_fwd_split_t<1, 4>(f, rag, st);
+        if (a.N == 128) return launch_fwd_split_t<2, 4>(f, rag, st);
+        return launch_fwd_split_t<2, 8>(f, rag, st);
+    }
     if (a.K == 64 && NS == 64) return launch_fwd_res_t<1, 64>(f, rag, st);
     if (a.K == 64) return launch_fwd_res_t<1, 128>(f, rag, st);
     return launch_fwd_res_t<2, 128>(f, rag, st);
@@ -2262,6 +2630,14 @@ static int launch_linear_t(const LinArgs& a_in, hipStream_t st) {
     linear_grid(a.M, a.N - a.n_begin, AM >= A_DY, RAG, gx, n_tiles, narrow, low);
     a.gx = gx; a.nt = n_tiles;
     dim3 grid(gx * n_tiles);
+    if constexpr (GM == 0) {                   // matrix-bound shapes: fp32 operands as three bf16 planes on the bf16 matrix pipe
+        if (vec && (g_split_mfma & 2) && a.K >= g_split_min_k) {
+            if (!RAG && low) PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 1, 0, false, 1, true>), grid, dim3(MLP_T), st, a);
+            else if (narrow) PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 1, 0, RAG, 2, true>), grid, dim3(MLP_T), st, a);
+            else PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 2, 0, RAG, 2, true>), grid, dim3(MLP_T), st, a);
+            return check_launch("pcl_linear(split)");
+        }
+    }
     if constexpr (!RAG && GM == 0) {
         if (low) {
             if (vec) PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 1, 0, false, 1>), grid, dim3(MLP_T), st, a);
@@ -2466,6 +2842,10 @@ extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const
 }
 
 extern "C" void pcl_set_fb_max_blocks(int n) { g_fb_cap = n; }
+// 1 (default): the resident-operand GEMMs take fp32 operands as three bf16 planes on the bf16 matrix pipe (nine exact partial
+// products per fp32 product); 0: the fp32 MFMA form of rounds 2-3 (kept for A/B measurements and the error comparison test)
+extern "C" void pcl_set_matrix_form(int split) { g_split_mfma = split & 3; g_split_min_k = (split >> 8) > 0 ? (split >> 8) : 128; }
+extern "C" int pcl_get_matrix_form(void) { return g_split_mfma; }
 
 extern "C" int pcl_linear_bwd_fused_supported(int Cout, int Cin) {
     return ((Cout == 64 || Cout == 128) && (Cin == 64 || Cin == 128)) || (Cout == 256 && Cin == 128);

@@ -4,6 +4,8 @@
 worse than 4x the error of PyTorch's own fp32 GPU path against the same fp64 truth."""
 import copy
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -561,10 +563,18 @@ def test_bn_rows_matches_fp64(dev, P, C, offset):
     assert torch.allclose(rv.cpu().double(), 1.0 + 0.9 * (var - 1.0), rtol=1e-5, atol=1e-6)
 
 
+@pytest.fixture(params=[0, 1], ids=["fp32-mfma", "bf16-planes"])
+def matrix_form(request):
+    from pointcloudlib_amd import _lib
+    _lib.lib().pcl_set_matrix_form(request.param)
+    yield request.param
+    _lib.lib().pcl_set_matrix_form(0)
+
+
 @pytest.mark.parametrize("spec,rows,bias,slope", [([8, 64, 64], 40001, False, 0.0), ([8, 64, 128], 33000, True, 0.2), ([12, 128, 128], 70007, False, 0.0),
                                                   ([12, 128, 256], 36864, False, 0.0), ([8, 64, 64, 128], 50000, False, 0.0),
                                                   ([64, 128], 33333, False, 0.2), ([128, 256, 64], 40000, True, 0.0)])      # first layer = plain input
-def test_resident_weight_forward_kernel_against_fp64(dev, spec, rows, bias, slope):
+def test_resident_weight_forward_kernel_against_fp64(dev, matrix_form, spec, rows, bias, slope):
     """linear_fwd_res_kernel (hidden layers of the set-abstraction shapes at >= 32768 rows: weight slab resident in LDS, 8 waves,
     double-buffered row image): module output and running statistics against fp64 PyTorch, ragged last tile, bias, LeakyReLU,
     Cout = 256 as two slabs."""
@@ -677,3 +687,76 @@ def test_narrow_stack_equals_the_gemm_path_at_size(dev, spec, rows):
         assert d <= 3e-3 * gs + 1e-7, (n, d, gs)
     for n in b[2]:
         assert torch.allclose(a[2][n], b[2][n], rtol=1e-5, atol=1e-6), n
+
+
+# ---- fp32 operands as three bf16 planes on the bf16 matrix pipe (round 4) ----
+def _raw_forward(dev, x, w, sc, sh, slope, split):
+    from pointcloudlib_amd import _lib
+    from pointcloudlib_amd.misc.mlp_hip import _P, _stream
+    P, cin = x.shape
+    cout = w.shape[0]
+    rows = _lib.size_query("pcl_mlp_stat_rows", P, cout, 0)
+    y = torch.empty(P, cout, device=dev)
+    stats = torch.empty(rows, 2, cout, device=dev, dtype=torch.float64)
+    _lib.lib().pcl_set_matrix_form(int(split))
+    try:
+        _lib.call("pcl_linear_fwd_rows_f32", _P(x), _P(w), None, _P(sc), _P(sh), slope, P, cin, cout, _P(y), _P(stats), None, None, _stream())
+    finally:
+        _lib.lib().pcl_set_matrix_form(0)
+    torch.cuda.synchronize()
+    return y, stats.sum(0)
+
+
+@pytest.mark.parametrize("cin,cout,rows,act", [(64, 64, 40001, True), (64, 128, 65536, True), (128, 128, 33333, False), (128, 256, 50000, True)])
+@pytest.mark.parametrize("spread", [1.0, 1e4])
+def test_split_gemm_error_vs_fp64(dev, cin, cout, rows, act, spread):
+    """The nine-product bf16 form of an fp32 GEMM against the fp32 MFMA form, both against fp64: every partial product of the
+    split form is exact, so its error is the accumulator's rounding alone -- the same size as the fp32 MFMA form's (measured: 0.7-1.08 x
+    of its mean error), on operands spanning eight orders of magnitude as well (`spread`: per-row scales 1 .. 1e4 and
+    per-column weights 1 .. 1e-4, where a dropped low-order plane would show)."""
+    torch.manual_seed(cin * 7 + cout)
+    x = torch.randn(rows, cin, device=dev) * torch.logspace(0, float(np.log10(spread)), rows, device=dev)[torch.randperm(rows, device=dev)].unsqueeze(1)
+    w = torch.randn(cout, cin, device=dev) / cin ** 0.5 * torch.logspace(0, -float(np.log10(spread)), cin, device=dev).unsqueeze(0)
+    sc = (torch.rand(cin, device=dev) + 0.5) if act else None
+    sh = (torch.randn(cin, device=dev) * 0.1) if act else None
+    z = x.double()
+    if act:
+        z = torch.relu(torch.addcmul(sh, sc, x)).double()      # the kernel's own fp32 fma + max: the operand both forms multiply
+    want = z @ w.double().t()
+    mag = z.abs() @ w.double().abs().t()                          # sum_k |a_k b_k|: what rounding errors scale with
+    errs = {}
+    for split in (1, 0):
+        y, st = _raw_forward(dev, x, w, sc, sh, 0.0, split)
+        e = ((y.double() - want).abs() / mag.clamp_min(1e-300))
+        errs[split] = (e.max().item(), e.mean().item())
+        assert torch.allclose(st[0], y.double().sum(0), rtol=1e-6, atol=1e-4 * spread)
+    assert errs[1][0] <= 1.5e-6, errs                             # a few fp32 ulps of the magnitude sum, K <= 128 (measured 7-8e-7)
+    assert errs[1][1] <= 1.25 * errs[0][1], errs                  # mean error: that of the fp32 MFMA form (measured 0.7-1.08 x)
+
+
+@pytest.fixture
+def split_gemms():
+    """Every staged GEMM with K >= 16 on the bf16-plane form (pcl_set_matrix_form bit 1), the fused backward off so that dX / dW
+    go through the staged kernels too."""
+    from pointcloudlib_amd import _lib
+    from pointcloudlib_amd.misc import mlp_hip
+    old = mlp_hip._FUSED_BWD
+    _lib.lib().pcl_set_matrix_form(2 | (16 << 8))
+    mlp_hip._FUSED_BWD = False
+    yield
+    mlp_hip._FUSED_BWD = old
+    _lib.lib().pcl_set_matrix_form(0)
+
+
+SPLIT_CASES = [c for c in CASES if max(c[0][:-1]) >= 16] + FB_CASES + [
+    ([512, 1024], (2, 2048), None, False, 0.0),             # DGCNN's conv5 shape at 4096 rows (128x128 tiles, 16 k steps)
+    ([64, 128, 1024], (4, 512), None, False, 0.0),          # PointNet's trunk
+    ([256, 512, 1024], (3, 1, 128), 128, False, 0.0),       # the GroupAll level without the xyz columns (vector path, 64-row tiles)
+]
+
+
+@pytest.mark.parametrize("spec,lead,ns,bias,slope", SPLIT_CASES)
+def test_split_staged_gemms_match_reference(dev, split_gemms, spec, lead, ns, bias, slope):
+    """linear_nt_kernel with bf16-plane operands (forward, dX with the dy transform and the masked epilogue, ragged / max-pooled /
+    sparse modes): the same fp64 checks as the fp32 MFMA form."""
+    _check_against_fp64(dev, spec, lead, ns, bias, slope)
