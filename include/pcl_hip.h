@@ -404,7 +404,8 @@ void pcl_set_fb_max_blocks(int n);
  * nn.Linear, misc/layers.py:60-75).  Default 0: the fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere.  Opt-in, measured and not faster
  * as a whole: every fp32 operand split EXACTLY into three bf16 values, an fp32 product = nine exact bf16 products
  * accumulated in fp32 on v_mfma_f32_32x32x16_bf16.  form bit 0: the resident-operand forward (set-abstraction shapes); bit 1: the
- * staged GEMMs (forward and dX through linear_nt_kernel) with K >= (form >> 8), 128 if that field is 0.  Process-wide; takes effect
+ * staged GEMMs (forward and dX through linear_nt_kernel) with K >= (form >> 8), 128 if that field is 0; bit 2: the resident forward
+ * for 128 -> 256 only.  Process-wide; takes effect
  * for launches enqueued after the call. */
 void pcl_set_matrix_form(int form);
 int pcl_get_matrix_form(void);

@@ -1650,7 +1650,6 @@ __global__ __launch_bounds__(FR_T) void linear_fwd_split_kernel(const FrArgs p_i
     for (; tile < tiles; tile += p.gx, ++it) {
         FS_MARK(0)
         const int mbt = mb;
-        if (late) refill(it & 1);
         FS_MARK(1)
 #pragma unroll
         for (int t = 0; t < TM; ++t) {          // a block's stores drain under the next block's MFMAs
@@ -1660,7 +1659,7 @@ __global__ __launch_bounds__(FR_T) void linear_fwd_split_kernel(const FrArgs p_i
             if (t + 1 < TM || !late) epilogue(tile * R, mbt, t);
         }
         FS_MARK(2)
-        if (!late) refill(it & 1);
+        refill(it & 1);                         // (late waves refilling FIRST, under the early waves' MFMAs, measured 10 % slower)
         FS_MARK(3)
         __syncthreads();
         FS_MARK(4)
@@ -1668,7 +1667,7 @@ __global__ __launch_bounds__(FR_T) void linear_fwd_split_kernel(const FrArgs p_i
     }
 #if PCL_EXP == 8
     if (bx == 37 && (tid == 0 || tid == 448))
-        printf("fs<%d,%d> wave %d tiles %d: late-epi %lld | late-refill %lld | mma+epi %lld | refill %lld | barrier %lld  (cycles/tile)\n", CIN, N, wave, it,
+        printf("fs<%d,%d> wave %d tiles %d: late-epi %lld | - %lld | mma+epi %lld | refill %lld | barrier %lld  (cycles/tile)\n", CIN, N, wave, it,
                tph[0] / it, tph[1] / it, tph[2] / it, tph[3] / it, tph[4] / it);
 #endif
     {
@@ -1744,7 +1743,7 @@ static int launch_fwd_res(const LinArgs& a, int stat_rows, hipStream_t st) {
     f.X = a.A; f.W = a.B; f.bias = a.bias; f.sc = a.a_mode == A_PLAIN ? nullptr : a.sc; f.sh = a.a_mode == A_PLAIN ? nullptr : a.sh; f.slope = a.slope; f.Y = a.C; f.stats = a.stats;
     f.rmeta = a.rmeta; f.m_dev = a.m_dev; f.M = a.M; f.N = a.N; f.stat_rows = stat_rows;
     const int NS = a.N == 64 ? 64 : 128, R = a.K == 64 ? 128 : 64;
-    const bool split = fwd_split_on();
+    const bool split = fwd_split_on() || ((g_split_mfma & 4) && a.K == 128 && a.N == 256);
     f.nt = split ? 1 : a.N / NS;
     const int tiles = (a.M + R - 1) / R;
     int gx = fr_cu_count() / f.nt;                       // one workgroup per CU in all
@@ -2844,7 +2843,7 @@ extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const
 extern "C" void pcl_set_fb_max_blocks(int n) { g_fb_cap = n; }
 // 1 (default): the resident-operand GEMMs take fp32 operands as three bf16 planes on the bf16 matrix pipe (nine exact partial
 // products per fp32 product); 0: the fp32 MFMA form of rounds 2-3 (kept for A/B measurements and the error comparison test)
-extern "C" void pcl_set_matrix_form(int split) { g_split_mfma = split & 3; g_split_min_k = (split >> 8) > 0 ? (split >> 8) : 128; }
+extern "C" void pcl_set_matrix_form(int split) { g_split_mfma = split & 7; g_split_min_k = (split >> 8) > 0 ? (split >> 8) : 128; }
 extern "C" int pcl_get_matrix_form(void) { return g_split_mfma; }
 
 extern "C" int pcl_linear_bwd_fused_supported(int Cout, int Cin) {
