@@ -400,6 +400,10 @@ int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a, const
 /* reference: the autograd backward of nn.Conv 1x1 + nn.BatchNorm + nn.ReLU, networks/cls/pointnet2.py:25-29 */
 /* test / tuning hook: cap the persistent grid of the fused backward at n workgroups (0 = one per CU); process-wide, set between calls */
 void pcl_set_fb_max_blocks(int n);
+/* Lab switches of the kernel selection (no reference counterpart), 1 = on (default), 0 = off, negative = leave as is: the resident-weight
+ * forward (off: linear_nt_kernel), the recompute-per-pass narrow stacks of PointConv's WeightNet / DensityNet (off: the GEMM kernels), the
+ * fused dX + dW backward inside pcl_mlp_stack_bwd_f32 (off: separate kernels).  A C call: the library reads no environment variables. */
+void pcl_set_kernel_paths(int fwd_resident, int narrow_stacks, int fused_backward);
 /* Matrix-pipe form of the GEMM family (no reference counterpart: the reference calls cuDNN / cuBLAS fp32 through jittor's nn.Conv /
  * nn.Linear, misc/layers.py:60-75).  Default 0: the fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere.  Opt-in, measured and not faster
  * as a whole: every fp32 operand split EXACTLY into three bf16 values, an fp32 product = nine exact bf16 products

@@ -121,6 +121,7 @@ _SIGS = {
     "pcl_scatter_rows_add_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_linear_bwd_dw_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "pcl_set_fb_max_blocks": (None, [c_int]),
+    "pcl_set_kernel_paths": (None, [c_int, c_int, c_int]),
     "pcl_set_matrix_form": (None, [c_int]),
     "pcl_get_matrix_form": (c_int, []),
     "pcl_set_fps_tuning": (None, [c_int, c_int]),
@@ -152,6 +153,10 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        # lab switches of the kernel selection: read HERE (host side) and handed over as a C call -- the library itself reads no environment
+        sw = [-1 if os.environ.get(k) is None else int(os.environ[k] != "0") for k in ("PCL_FWD_RES", "PCL_NARROW", "PCL_FUSED_BWD")]
+        if any(v >= 0 for v in sw):
+            L.pcl_set_kernel_paths(*sw)
         _lib = L
     return _lib
 

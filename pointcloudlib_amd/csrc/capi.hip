@@ -21,6 +21,10 @@ void set_launch_tag(const char* tag) {
     h.cur[sizeof h.cur - 1] = 0;
 }
 bool time_hook_matches(const TimeHook& h) { return h.want[0] == 0 || strcmp(h.want, h.cur) == 0; }
+PathSwitches& path_switches() {
+    static PathSwitches s = {1, 1, 1};
+    return s;
+}
 
 }  // namespace pcl
 
@@ -39,6 +43,12 @@ extern "C" void pcl_time_tagged_launch(void* start_event, void* stop_event, cons
     h.want[sizeof h.want - 1] = 0;
 }
 
+extern "C" void pcl_set_kernel_paths(int fwd_resident, int narrow_stacks, int fused_backward) {
+    pcl::PathSwitches& s = pcl::path_switches();
+    if (fwd_resident >= 0) s.fwd_resident = fwd_resident != 0;
+    if (narrow_stacks >= 0) s.narrow_stacks = narrow_stacks != 0;
+    if (fused_backward >= 0) s.fused_backward = fused_backward != 0;
+}
 extern "C" const char* pcl_last_launch_kernel(void) {
     const char* k = pcl::time_hook().last_kernel;
     return k ? k : "";

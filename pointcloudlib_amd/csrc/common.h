@@ -47,6 +47,10 @@ static inline hipStream_t as_stream(void* s) {
 // matches (an empty wanted tag matches anything).
 struct TimeHook { hipEvent_t start, stop; char want[32]; char cur[32]; const char* last_kernel; };
 TimeHook& time_hook();
+// Lab switches of the kernel selection (pcl_set_kernel_paths: a C call -- the library reads no environment variables):
+// resident-weight forward, recompute-per-pass narrow stacks, fused dX + dW backward.  All on by default.
+struct PathSwitches { int fwd_resident, narrow_stacks, fused_backward; };
+PathSwitches& path_switches();
 void set_launch_tag(const char* tag);
 bool time_hook_matches(const TimeHook& h);
 #define PCL_LAUNCH_TIMED(kernel, grid, blk, st, ...)                                                                   \

@@ -1704,8 +1704,7 @@ __global__ __launch_bounds__(FR_T) void linear_fwd_split_kernel(const FrArgs p_i
 // which forward launches take the resident-weight kernel: a hidden layer (folded BatchNorm + activation on the input) of a
 // set-abstraction shape with enough rows to keep one workgroup per CU busy for several tiles
 static bool fwd_res_eligible(const LinArgs& a) {
-    static const int on = [] { const char* e = getenv("PCL_FWD_RES"); return (e && e[0] == '0') ? 0 : 1; }();
-    if (!on || (a.a_mode != A_BNACT && a.a_mode != A_PLAIN) || a.e_mode != E_STORE_STATS || a.gmax || a.n_begin != 0 || a.ldc != a.N) return false;
+    if (!path_switches().fwd_resident || (a.a_mode != A_BNACT && a.a_mode != A_PLAIN) || a.e_mode != E_STORE_STATS || a.gmax || a.n_begin != 0 || a.ldc != a.N) return false;
     if (!((a.K == 64 && (a.N == 64 || a.N == 128)) || (a.K == 128 && (a.N == 128 || a.N == 256)))) return false;
     if (a.M < 32768 || (size_t)a.M * (size_t)(a.N > a.K ? a.N : a.K) * 4 >= 0xffffffffull) return false;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };

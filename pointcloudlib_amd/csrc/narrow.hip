@@ -450,8 +450,7 @@ static inline int nw_shape(const pcl_mlp_stack_t& d) {
     return 0;
 }
 bool narrow_supported(const pcl_mlp_stack_t& d) {
-    static const int on = [] { const char* e = getenv("PCL_NARROW"); return (e && e[0] == '0') ? 0 : 1; }();
-    return on && nw_shape(d) && !d.grouped && d.pool == 0 && !d.need_dx && !d.defer_act && d.P >= 1;
+    return path_switches().narrow_stacks && nw_shape(d) && !d.grouped && d.pool == 0 && !d.need_dx && !d.defer_act && d.P >= 1;
 }
 size_t narrow_save_bytes() { return (size_t)3 * 4 * NW_C * sizeof(float); }
 size_t narrow_fwd_tmp_bytes() { return (size_t)2 * NW_MAXB * NW_SQ * sizeof(double); }

@@ -62,8 +62,7 @@ static SaveLayout save_layout(const pcl_mlp_stack_t& d, void* base) {
 
 static inline bool use_gmax(const pcl_mlp_stack_t& d) { return !d.grouped && (d.pool == 32 || d.pool == 64); }
 static inline bool fused_bwd_enabled() {
-    static const int on = [] { const char* e = getenv("PCL_FUSED_BWD"); return (e && e[0] == '0') ? 0 : 1; }();
-    return on != 0;
+    return path_switches().fused_backward != 0;
 }
 
 // ---- transient buffer of the forward -------------------------------------------------------------------------------
