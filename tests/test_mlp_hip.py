@@ -760,3 +760,34 @@ def test_split_staged_gemms_match_reference(dev, split_gemms, spec, lead, ns, bi
     """linear_nt_kernel with bf16-plane operands (forward, dX with the dy transform and the masked epilogue, ragged / max-pooled /
     sparse modes): the same fp64 checks as the fp32 MFMA form."""
     _check_against_fp64(dev, spec, lead, ns, bias, slope)
+
+
+# ---- kernel-selection lab switches (pcl_set_kernel_paths): every alternative path computes the same layer ----
+@pytest.mark.parametrize("off", ["fwd_resident", "fused_backward", "narrow_stacks"])
+def test_kernel_path_switches_select_equivalent_kernels(dev, off):
+    """Each switch routes a stack to the other kernel family (staged forward instead of the resident-weight one, separate dX / dW
+    instead of the fused backward, GEMM kernels instead of the recompute-per-pass narrow stack): same outputs and gradients up to
+    fp32 summation order.  The switches are C calls -- the library itself reads no environment variable."""
+    from pointcloudlib_amd import _lib
+    torch.manual_seed(11)
+    if off == "narrow_stacks":
+        spec, rows = [3, 8, 8, 16], 40000
+    else:
+        spec, rows = [16, 64, 128, 256], 36000
+    m = PointwiseMLP(spec, bias=(off == "narrow_stacks")).to(dev).train()
+    x = torch.randn(rows, spec[0], device=dev) * 0.5
+    g = torch.randn(rows, spec[-1], device=dev)
+    a = _run_nograd(copy.deepcopy(m), x, g, "hip")
+    args = {"fwd_resident": (0, -1, -1), "narrow_stacks": (-1, 0, -1), "fused_backward": (-1, -1, 0)}[off]
+    _lib.lib().pcl_set_kernel_paths(*args)
+    try:
+        b = _run_nograd(copy.deepcopy(m), x, g, "hip")
+    finally:
+        _lib.lib().pcl_set_kernel_paths(1, 1, 1)
+    scale = max(1.0, a[0].abs().max().item())
+    assert (a[0] - b[0]).abs().max().item() <= 1e-5 * scale
+    for n in a[1]:
+        gs = max(1e-6, a[1][n].abs().max().item())
+        assert (a[1][n] - b[1][n]).abs().max().item() <= 3e-3 * gs + 1e-7, n       # a handful of ReLU masks may differ (see the narrow-stack test)
+    for n in a[2]:
+        assert torch.allclose(a[2][n], b[2][n], rtol=1e-5, atol=1e-6), n
