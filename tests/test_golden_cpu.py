@@ -156,3 +156,22 @@ def test_sa_level_fixture_is_reproduced_by_the_restatement():
         assert np.abs(y.double().numpy() - g[key]).max() <= tol
     # the fp32 evaluation is within 1e-5 of the fp64 one (the tolerance the HIP path is held to)
     assert np.abs(g["pooled_f32"].astype(np.float64) - g["pooled_f64"]).max() <= 1e-5 * max(1.0, np.abs(g["pooled_f64"]).max())
+
+
+def test_host_only_switches_roundtrip():
+    """pcl_set_matrix_form / pcl_set_kernel_paths / pcl_set_fps_tuning are host-side state (no GPU needed): set, read back, restore."""
+    import ctypes
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pointcloudlib_amd", "libpcl_hip.so")
+    if not os.path.exists(so):
+        pytest.skip("libpcl_hip.so not built")
+    L = ctypes.CDLL(so)
+    L.pcl_get_matrix_form.restype = ctypes.c_int
+    assert L.pcl_get_matrix_form() == 0                       # the fp32 MFMA form is the default
+    for form in (1, 2, 3, 2 | (64 << 8), 0):
+        L.pcl_set_matrix_form(form)
+        assert L.pcl_get_matrix_form() == (form & 7)
+    L.pcl_set_kernel_paths(0, 0, 0)
+    L.pcl_set_kernel_paths(-1, -1, -1)                        # negative: leave as is
+    L.pcl_set_kernel_paths(1, 1, 1)
+    L.pcl_set_fps_tuning(256, 0)
+    L.pcl_set_fps_tuning(0, 0)
