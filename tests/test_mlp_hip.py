@@ -788,6 +788,9 @@ def test_kernel_path_switches_select_equivalent_kernels(dev, off):
     assert (a[0] - b[0]).abs().max().item() <= 1e-5 * scale
     for n in a[1]:
         gs = max(1e-6, a[1][n].abs().max().item())
-        assert (a[1][n] - b[1][n]).abs().max().item() <= 3e-3 * gs + 1e-7, n       # a handful of ReLU masks may differ (see the narrow-stack test)
+        # a handful of ReLU masks differ between two fp32 paths (see test_narrow_stack_equals_the_gemm_path_at_size); at 40 000 rows of
+        # 8-wide layers one flipped row weighs 7e-3 of a weight gradient's max-norm
+        tol = 2e-2 if off == "narrow_stacks" else 3e-3
+        assert (a[1][n] - b[1][n]).abs().max().item() <= tol * gs + 1e-7, n
     for n in a[2]:
         assert torch.allclose(a[2][n], b[2][n], rtol=1e-5, atol=1e-6), n
