@@ -113,7 +113,8 @@ __global__ __launch_bounds__(XC_T) void xconv_core_fwd_kernel(const XcArgs p) {
 template <int K, int DM>
 __global__ __launch_bounds__(XC_T) void xconv_core_bwd_kernel(const XcArgs p, int cb, int cw, int accum) {
     constexpr int CS = 256;                                    // channel slots of a pass in LDS (slot * cw + c)
-    __shared__ float sX[32 * K * K];
+    static_assert(K % 4 == 0, "16-byte rows of X");
+    __shared__ __attribute__((aligned(16))) float sX[32 * K * K];
     __shared__ __attribute__((aligned(16))) float sA[K][CS + 4];      // dFX[k][slot*cw + c]
     __shared__ __attribute__((aligned(16))) float sB[K][CS + 4];      // F[k][slot*cw + c]
     const int C = p.C1 + p.C2, tid = threadIdx.x;
@@ -163,12 +164,25 @@ __global__ __launch_bounds__(XC_T) void xconv_core_bwd_kernel(const XcArgs p, in
 #pragma unroll
             for (int j = 0; j < DM; ++j) g[j] = 0.f;
         }
-        const float* x = sX + (active ? slot : 0) * K * K;
+        // ONE pass over the rows of X (16-byte LDS broadcasts): row k gives FX[k] = X[k,:] . F (a dot product) and adds X[k,:] dFX[k] to
+        // dF[:] = sum_k X[k, :] dFX[k] -- the same sums in the same order as two passes (rows for FX, columns for dF), a quarter of the
+        // LDS instructions, and nothing for hipcc to hoist: the column pass used to pull all K*K values of X into registers (424 VGPRs at
+        // K = 16: one wave per SIMD).
+        const float4* x4 = reinterpret_cast<const float4*>(sX + (active ? slot : 0) * K * K);
+        float dF[K];
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) dF[kk] = 0.f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
+            float row[K];
+#pragma unroll
+            for (int q = 0; q < K / 4; ++q) {
+                const float4 t = x4[k * (K / 4) + q];
+                row[4 * q] = t.x; row[4 * q + 1] = t.y; row[4 * q + 2] = t.z; row[4 * q + 3] = t.w;
+            }
             float s = 0.f, d = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < K; ++kk) s = fmaf(x[k * K + kk], f[kk], s);
+            for (int kk = 0; kk < K; ++kk) s = fmaf(row[kk], f[kk], s);
             fx[k] = s;
 #pragma unroll
             for (int j = 0; j < DM; ++j) {
@@ -176,20 +190,23 @@ __global__ __launch_bounds__(XC_T) void xconv_core_bwd_kernel(const XcArgs p, in
                 gw[j][k] = fmaf(g[j], fx[k], gw[j][k]);
             }
             dfx[k] = d;
-            __builtin_amdgcn_sched_barrier(0);                 // (else all K*K LDS values of X are hoisted into registers)
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) dF[kk] = fmaf(row[kk], d, dF[kk]);
+            // one row of X in registers at a time: the row's results are pinned (empty asm with the accumulators as in/out operands)
+            // before the next row's LDS reads may issue -- a scheduling barrier or a memory clobber alone lets hipcc read all K*K
+            // values first and do the arithmetic afterwards (256 registers at K = 16, one wave per SIMD)
+#pragma unroll
+            for (int q = 0; q < K / 4; ++q)
+                asm volatile("" : "+v"(dF[4 * q]), "+v"(dF[4 * q + 1]), "+v"(dF[4 * q + 2]), "+v"(dF[4 * q + 3]) :: "memory");
+            asm volatile("" : "+v"(fx[k]), "+v"(dfx[k]) :: "memory");
         }
 #pragma unroll
         for (int j = 0; j < DM; ++j) gb[j] += g[j];
         if (on) {
-            // dF[k'] = sum_k X[k, k'] dFX[k]
 #pragma unroll
             for (int kk = 0; kk < K; ++kk) {
-                float s = 0.f;
-#pragma unroll
-                for (int k = 0; k < K; ++k) s = fmaf(x[k * K + kk], dfx[k], s);
-                __builtin_amdgcn_sched_barrier(0);
-                if (c < p.C1) p.dF1[((size_t)r * K + kk) * p.C1 + c] = s;
-                else p.dF2[((size_t)r * K + kk) * p.C2 + (c - p.C1)] = s;
+                if (c < p.C1) p.dF1[((size_t)r * K + kk) * p.C1 + c] = dF[kk];
+                else p.dF2[((size_t)r * K + kk) * p.C2 + (c - p.C1)] = dF[kk];
             }
         }
         // (column tid = slot*cw + channel; threads past the last slot write zeros nobody reads)
@@ -230,6 +247,7 @@ __global__ __launch_bounds__(XC_T) void xconv_core_bwd_kernel(const XcArgs p, in
             __syncthreads();
             if (tid < cw) {
                 float s = 0.f;
+#pragma unroll 1                                               // (unrolled, the reads of all DM*(K+1) rounds were hoisted: 424 VGPRs for the whole kernel)
                 for (int sl = 0; sl < slots; ++sl) s += red[sl * cw + tid];
                 const int cc = cb + tid;
                 if (k < K) p.dwd_part[((size_t)blockIdx.x * C + cc) * DM * K + j * K + k] = s;
