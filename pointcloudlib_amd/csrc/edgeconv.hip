@@ -51,12 +51,13 @@ __global__ __launch_bounds__(256) void edgeconv_gather_kernel(const float* __res
         double s = 0.0, q = 0.0;
         float su = 0.f;
         int j = 0;
-        for (; j + 4 <= k; j += 4) {                 // four gathers in flight
-            float u[4];
+        constexpr int GF = 10;                       // gathers in flight per lane (k = 20 / 40: whole rounds): 4 -> 10 took the C = 256 stage
+        for (; j + GF <= k; j += GF) {               // from 167 to 137 us -- the kernel waits on L2 round trips, not on bandwidth
+            float u[GF];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) u[t] = UV[(base + I[j + t]) * 2 * C + c];
+            for (int t = 0; t < GF; ++t) u[t] = UV[(base + I[j + t]) * 2 * C + c];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < GF; ++t) {
                 su += u[t];
                 const float y = u[t] + v;
                 s += (double)y; q += (double)y * (double)y;
@@ -268,13 +269,14 @@ __global__ __launch_bounds__(1024) void edgeconv_hits_lds_kernel(const float* __
     const int n_el = N * CH;
     for (int e = tid; e < n_el; e += 1024) hits[e] = 0.f;
     __syncthreads();
-    for (int e0 = tid; e0 < n_el; e0 += 4096) {       // four independent (point, channel) pairs in flight per lane
-        float g[4], v[4], su[4];
-        int n[4], cc[4];
-        size_t o2[4];
-        bool ok[4];
+    constexpr int HU = 4;                             // (eight: 98 -> 103 us per stage)
+    for (int e0 = tid; e0 < n_el; e0 += HU * 1024) {   // HU independent (point, channel) pairs in flight per lane
+        float g[HU], v[HU], su[HU];
+        int n[HU], cc[HU];
+        size_t o2[HU];
+        bool ok[HU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < HU; ++u) {
             const int e = e0 + u * 1024;
             const int i = min(e, n_el - 1) / CH;
             cc[u] = min(e, n_el - 1) - i * CH;
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(1024) void edgeconv_hits_lds_kernel(const float* __
             su[u] = sumU[o];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < HU; ++u) {
             if (!ok[u]) continue;
             const int c = c0 + cc[u];
             if (g[u] != 0.f) atomicAdd(&hits[n[u] * CH + cc[u]], g[u]);
@@ -317,6 +319,13 @@ __global__ __launch_bounds__(256) void edgeconv_insum_kernel(const float* __rest
     for (int c = lane; c < C; c += 64) {
         float sv = 0.f;
         int e = beg;
+        for (; e + 8 <= end; e += 8) {               // eight gathers in flight, summed as the two groups of four below would be
+            float v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = UV[(base + in_src[e + t]) * 2 * C + C + c];
+            sv += (v[0] + v[1]) + (v[2] + v[3]);
+            sv += (v[4] + v[5]) + (v[6] + v[7]);
+        }
         for (; e + 4 <= end; e += 4) {
             float v[4];
 #pragma unroll
