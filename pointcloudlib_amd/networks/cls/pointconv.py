@@ -33,6 +33,7 @@ class PointConvDensityClsSsg(nn.Module):
         stream = cur if stream is None else stream
         if stream != cur:
             stream.wait_stream(cur)
+            xyz.record_stream(stream)                          # a caller's temporary must outlive the producer stream's reads (pointnet2.py)
         out = []
         with torch.cuda.stream(stream), torch.no_grad():
             pts = xyz.permute(0, 2, 1).contiguous()

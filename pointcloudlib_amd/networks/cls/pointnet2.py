@@ -137,6 +137,9 @@ class SamplingPrefetch:
             stream = cur
         if stream != cur:
             stream.wait_stream(cur)                       # xyz may have just been produced on the current stream
+            # ... and may be a temporary of the caller (x.transpose(1, 2).contiguous()): it dies when this call returns, and the
+            # consumer stream's allocator pool would hand its memory out again while the producer stream still reads it
+            xyz.record_stream(stream)
         out = []
         with torch.cuda.stream(stream), torch.no_grad():
             for module in self.pointnet_modules:
