@@ -137,67 +137,6 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     head_epilogue(y, lane, n, bias, gamma, beta, rmean, rvar, R, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out, drop);
 }
 
-// Wide layers (K >= 4096: PointConv's per-point Linear on the GroupAll level is 32 x 16384 -> 1024): with one column per
-// workgroup every column re-reads all of X from L2 (2 MB x 1024 columns).  Here a workgroup takes 8 columns (two per
-// wave) and stages X 256 k at a time through LDS, so X crosses L2 once per 8 columns and W streams once.  R <= 32.
-constexpr int HW_CB = 8, HW_KC = 256;
-__global__ __launch_bounds__(256) void head_fwd_wide_kernel(const float* __restrict__ X, const float* __restrict__ W,
-                                                            const float* __restrict__ bias, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* __restrict__ rmean,
-                                                            float* __restrict__ rvar, int R, int K, int N, int bn_mode, float eps,
-                                                            float momentum, float slope, float* __restrict__ Ypre,
-                                                            float* __restrict__ OUT, float* __restrict__ mean_out,
-                                                            float* __restrict__ invstd_out, const Drop drop) {
-    constexpr int RMAX = 32;
-    __shared__ __attribute__((aligned(16))) float sX[RMAX][HW_KC + 4];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int n0 = blockIdx.x * HW_CB + wave * 2;
-    const int na = min(n0, N - 1), nb = min(n0 + 1, N - 1);
-    float acc0[RMAX], acc1[RMAX];
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const int xr = tid >> 6, xk = (tid & 63) * 4;             // staging: 4 rows per pass, 64 lanes x 16 B per row
-    float4 px[RMAX / 4];
-    auto load_x = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < RMAX / 4; ++i) {
-            const int r = i * 4 + xr;
-            const float4 v = *reinterpret_cast<const float4*>(X + (size_t)min(r, R - 1) * K + min(k0 + xk, K - 4));
-            px[i] = (r < R && k0 + xk < K) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    load_x(0);
-    for (int k0 = 0; k0 < K; k0 += HW_KC) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < RMAX / 4; ++i) *reinterpret_cast<float4*>(&sX[i * 4 + xr][xk]) = px[i];
-        const int k = k0 + 4 * lane;
-        const bool kin = k < K;                                // K % 4 == 0 (checked by the caller)
-        const float4 wa = *reinterpret_cast<const float4*>(W + (size_t)na * K + min(k, K - 4));
-        const float4 wb = *reinterpret_cast<const float4*>(W + (size_t)nb * K + min(k, K - 4));
-        if (k0 + HW_KC < K) load_x(k0 + HW_KC);
-        __syncthreads();
-        if (kin) {
-#pragma unroll
-            for (int r = 0; r < RMAX; ++r) {
-                const float4 x = *reinterpret_cast<const float4*>(&sX[r][4 * lane]);
-                acc0[r] = fmaf(wa.w, x.w, fmaf(wa.z, x.z, fmaf(wa.y, x.y, fmaf(wa.x, x.x, acc0[r]))));
-                acc1[r] = fmaf(wb.w, x.w, fmaf(wb.z, x.z, fmaf(wb.y, x.y, fmaf(wb.x, x.x, acc1[r]))));
-            }
-        }
-    }
-    float ya = 0.f, yb = 0.f;
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-        float u = acc0[r], v = acc1[r];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { u += __shfl_xor(u, off); v += __shfl_xor(v, off); }
-        if (lane == r) { ya = u; yb = v; }
-    }
-    if (n0 < N) head_epilogue(ya, lane, n0, bias, gamma, beta, rmean, rvar, R, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out, drop);
-    if (n0 + 1 < N) head_epilogue(yb, lane, n0 + 1, bias, gamma, beta, rmean, rvar, R, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out, drop);
-}
-
 // backward, column part: dy[:,n], dW[n,:], dbias[n], dgamma[n], dbeta[n].  One workgroup per column; every wave forms
 // the column's dy (R values, lane r) itself and writes its quarter of dW[n,:].
 template <int RMAX>
@@ -260,9 +199,8 @@ __global__ __launch_bounds__(256) void head_bwd_col_kernel(const float* __restri
     }
 }
 
-// Wide layers, backward column part (see head_fwd_wide_kernel): 8 columns per workgroup, two per wave; every wave forms
-// the dy of its two columns (lane r), the eight dy columns meet in LDS, then X is staged 256 k at a time and
-// dW[n, k..k+3] = sum_r dy[r,n] X[r, k..k+3] for the wave's two columns is written as 16-byte pieces.  R <= 32.
+// Column part of a layer's backward, one full wave per column (lane r = batch row r): du = dout * act', BatchNorm backward over the
+// column, dy stored; dbias / dgamma / dbeta.  Returns this lane's dy.
 __device__ __forceinline__ float head_col_dy(int lane, int n, const float* __restrict__ dOUT, const float* __restrict__ OUT,
                                              const float* __restrict__ Ypre, const float* __restrict__ gamma,
                                              const float* __restrict__ mean, const float* __restrict__ invstd, int R, int N,
@@ -291,62 +229,6 @@ __device__ __forceinline__ float head_col_dy(int lane, int n, const float* __res
         if (lane == 0) dbias[n] = sb;
     }
     return dy;
-}
-
-__global__ __launch_bounds__(256) void head_bwd_col_wide_kernel(const float* __restrict__ X, const float* __restrict__ dOUT,
-                                                                const float* __restrict__ OUT, const float* __restrict__ Ypre,
-                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                                const float* __restrict__ invstd, int R, int K, int N, int bn_mode,
-                                                                float slope, float* __restrict__ dY, float* __restrict__ dW,
-                                                                float* __restrict__ dbias, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta, float* __restrict__ dX_zero, const Drop drop) {
-    constexpr int RMAX = 32;
-    __shared__ __attribute__((aligned(16))) float sX[RMAX][HW_KC + 4];
-    __shared__ float sdy[HW_CB][RMAX];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int nblk = (int)gridDim.x;
-    if (dX_zero) {
-        const int total = R * K, chunk = (total + nblk - 1) / nblk;
-        for (int e = blockIdx.x * chunk + tid; e < min(((int)blockIdx.x + 1) * chunk, total); e += 256) dX_zero[e] = 0.f;
-    }
-    const int n0 = blockIdx.x * HW_CB + wave * 2;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        float dy = 0.f;
-        if (n0 + c < N) dy = head_col_dy(lane, n0 + c, dOUT, OUT, Ypre, gamma, mean, invstd, R, N, bn_mode & 3, slope, dY, dbias, dgamma, dbeta, drop);
-        if (lane < RMAX) sdy[wave * 2 + c][lane] = dy;
-    }
-    const int xr = tid >> 6, xk = (tid & 63) * 4;
-    float4 px[RMAX / 4];
-    auto load_x = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < RMAX / 4; ++i) {
-            const int r = i * 4 + xr;
-            const float4 v = *reinterpret_cast<const float4*>(X + (size_t)min(r, R - 1) * K + min(k0 + xk, K - 4));
-            px[i] = (r < R && k0 + xk < K) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    load_x(0);
-    for (int k0 = 0; k0 < K; k0 += HW_KC) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < RMAX / 4; ++i) *reinterpret_cast<float4*>(&sX[i * 4 + xr][xk]) = px[i];
-        if (k0 + HW_KC < K) load_x(k0 + HW_KC);
-        __syncthreads();
-        const int k = k0 + 4 * lane;
-        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            const float4 x = *reinterpret_cast<const float4*>(&sX[r][4 * lane]);
-            const float d0 = sdy[wave * 2][r], d1 = sdy[wave * 2 + 1][r];
-            a0.x = fmaf(d0, x.x, a0.x); a0.y = fmaf(d0, x.y, a0.y); a0.z = fmaf(d0, x.z, a0.z); a0.w = fmaf(d0, x.w, a0.w);
-            a1.x = fmaf(d1, x.x, a1.x); a1.y = fmaf(d1, x.y, a1.y); a1.z = fmaf(d1, x.z, a1.z); a1.w = fmaf(d1, x.w, a1.w);
-        }
-        if (k < K) {
-            if (n0 < N) *reinterpret_cast<float4*>(dW + (size_t)n0 * K + k) = a0;
-            if (n0 + 1 < N) *reinterpret_cast<float4*>(dW + (size_t)(n0 + 1) * K + k) = a1;
-        }
-    }
 }
 
 // dX[r,k] += sum_{n in this wave's range} dy[r,n] * W[n,k]; grid (ceil(K/64), N splits of HD_NS)
@@ -380,41 +262,167 @@ __global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restric
     }
 }
 
-// Wide layers, dX: workgroup = 64 consecutive k, its four waves split the N columns in quarters (no further split, so
-// 4 atomics per output instead of N/8); a wave stages 64 columns of dy at a time in its own LDS slab ([n][r], rows
-// contiguous: eight broadcast 16-byte reads give the 32 row gradients of a column) and streams W[n, k] coalesced.  R <= 32.
-__global__ __launch_bounds__(256) void head_bwd_dx_wide_kernel(const float* __restrict__ dY, const float* __restrict__ W, int R, int K,
-                                                               int N, float* __restrict__ dX) {
-    constexpr int RMAX = 32, LD = 36;
-    __shared__ __attribute__((aligned(16))) float sD[4][64][LD];
+typedef float hd_f32x16 __attribute__((ext_vector_type(16)));
+// ---- wide layers, forward on the matrix pipe with split K (round 4) ------------------------------------------------------------------
+// part[ks][32][N] = X[32, k range ks] . W[N, k range ks]^T: grid (N / 32, KS) workgroups, X and W chunks of 128 k staged through LDS
+// (coalesced 512-byte row pieces), the four waves split every chunk's k, their tiles meet in LDS in a fixed order.  A second kernel (one
+// wave per column) adds the KS partial sums in order and runs the layer's epilogue: deterministic, 61 + 6 us at 16384 x 1024 where the
+// 8-columns-per-workgroup VALU kernel took 111.  The partial sums live in a stream-ordered allocation (hipMallocAsync) of the call.
+constexpr int HM_KC = 128;
+__global__ __launch_bounds__(256) void head_fwd_part_kernel(const float* __restrict__ X, const float* __restrict__ W, int R, int K, int N, int kper,
+                                                            float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float sX[32][HM_KC + 4];
+    __shared__ __attribute__((aligned(16))) float sW[32][HM_KC + 4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.x * 32, kbeg = blockIdx.y * kper, kend = min(K, kbeg + kper);
+    const int row = tid >> 3, kq = (tid & 7) * 4;
+    hd_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float4 px[4], pw[4];
+    auto load = [&](int k0) {                                  // (K % 4 == 0 and 16-byte rows: checked by the caller)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + kq + 32 * i;
+            const bool kin = k < kend;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            px[i] = (kin && row < R) ? *reinterpret_cast<const float4*>(X + (size_t)row * K + k) : z;
+            pw[i] = (kin && n0 + row < N) ? *reinterpret_cast<const float4*>(W + (size_t)(n0 + row) * K + k) : z;
+        }
+    };
+    load(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += HM_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&sX[row][kq + 32 * i]) = px[i];
+            *reinterpret_cast<float4*>(&sW[row][kq + 32 * i]) = pw[i];
+        }
+        __syncthreads();
+        if (k0 + HM_KC < kend) load(k0 + HM_KC);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {                        // this wave's 32 k of the chunk: lanes lh = 0 / 1 take k 0-3 / 4-7 of every 8
+            const float4 a = *reinterpret_cast<const float4*>(&sX[lr][wave * 32 + kk * 8 + lh * 4]);
+            const float4 b = *reinterpret_cast<const float4*>(&sW[lr][wave * 32 + kk * 8 + lh * 4]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    // the four waves' tiles meet in LDS: waves 0, 1 park theirs in sX, waves 2, 3 in sW (each array holds two [32][33] tiles)
+    float* red = &sX[0][0];
+    float* red2 = &sW[0][0];
+    float* mine = (wave < 2 ? red : red2) + (wave & 1) * 32 * 33;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mine[((i & 3) + 8 * (i >> 2) + 4 * lh) * 33 + lr] = acc[i];
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+        const int r = e >> 5, c = e & 31, o = r * 33 + c;
+        const float s = (red[o] + red[32 * 33 + o]) + (red2[o] + red2[32 * 33 + o]);
+        if (n0 + c < N) part[((size_t)blockIdx.y * 32 + r) * N + n0 + c] = s;
+    }
+}
+__global__ __launch_bounds__(256) void head_fwd_finish_kernel(const float* __restrict__ part, int KS, const float* __restrict__ bias,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ rmean, float* __restrict__ rvar, int R, int N, int bn_mode,
+                                                              float eps, float momentum, float slope, float* __restrict__ Ypre,
+                                                              float* __restrict__ OUT, float* __restrict__ mean_out,
+                                                              float* __restrict__ invstd_out, const Drop drop) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 64 + lane, kc = min(k, K - 1);
-    const int per = (N + 3) / 4, nlo = wave * per, nhi = min(N, nlo + per);
-    float acc[RMAX];
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    float y = 0.f;
+    if (lane < R) for (int ks = 0; ks < KS; ++ks) y += part[((size_t)ks * 32 + lane) * N + n];
+    head_epilogue(y, lane, n, bias, gamma, beta, rmean, rvar, R, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out, drop);
+}
+
+// ---- wide layers, backward on the matrix pipe (round 4) -----------------------------------------------------------------------------
+// The VALU forms above give every workgroup 8 columns and all of K: 128 workgroups of one wave per SIMD, 98 / 79 us for the 67 MB of
+// dW / W that a 16384 -> 1024 layer moves.  With R <= 32 a layer's backward is two GEMMs with a 32-wide dimension, which is one MFMA tile:
+//   dW[n, k] = sum_r dy[r, n] X[r, k]   -- a 32 x 32 tile of dW is 16 v_mfma_f32_32x32x2_f32 (K = the 32 rows); A = dy (LDS, once per
+//                                          workgroup), B = X rows read coalesced (L2-resident), the tile stored as full 128-byte lines;
+//   dX[r, k] = sum_n dy[r, n] W[n, k]   -- a wave owns a 32-wide k block and streams W[n, k block] once (128-byte lines), dy from LDS.
+// 30 / 37 us at 16384 x 1024 (tools/ubench/head_wide_mfma.hip, checked there against fp64).  The column part (du, BatchNorm backward,
+// dbias / dgamma / dbeta, clearing dX) is its own small kernel, one wave per column.
+__global__ __launch_bounds__(256) void head_dy_kernel(const float* __restrict__ dOUT, const float* __restrict__ OUT, const float* __restrict__ Ypre,
+                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, int R, int K, int N, int bn_mode, float slope,
+                                                      float* __restrict__ dY, float* __restrict__ dbias, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta, float* __restrict__ dX_zero, const Drop drop) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (dX_zero) {
+        const int total = R * K, nblk = (int)gridDim.x, chunk = (total + nblk - 1) / nblk;
+        for (int e = blockIdx.x * chunk + tid; e < min(((int)blockIdx.x + 1) * chunk, total); e += 256) dX_zero[e] = 0.f;
+    }
+    const int n = blockIdx.x * 4 + wave;
+    if (n < N) (void)head_col_dy(lane, n, dOUT, OUT, Ypre, gamma, mean, invstd, R, N, bn_mode & 3, slope, dY, dbias, dgamma, dbeta, drop);
+}
+__global__ __launch_bounds__(256) void head_dw_mfma_kernel(const float* __restrict__ dY, const float* __restrict__ X, int R, int K, int N,
+                                                           int kb_per_wg, float* __restrict__ dW) {
+    __shared__ float sD[32][33];                             // dy[r][n0 + n]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    for (int e = tid; e < 1024; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        sD[r][c] = (r < R && n0 + c < N) ? dY[(size_t)r * N + n0 + c] : 0.f;
+    }
+    __syncthreads();
+    float a[16];
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) acc[r] = 0.f;
-    for (int n0 = nlo; n0 < nhi; n0 += 64) {
-        const int cn = min(64, nhi - n0);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < 16; ++j) a[j] = sD[2 * j + lh][lr];   // A operand: row = column n of the layer, k index = batch row r
+    const int kblocks = (K + 31) / 32;
+    for (int kb = blockIdx.y * kb_per_wg + wave; kb < min(kblocks, ((int)blockIdx.y + 1) * kb_per_wg); kb += 4) {
+        const int k = kb * 32 + lr, kc = min(k, K - 1);
+        float b[16];
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) sD[wave][lane][r] = (r < R && lane < cn) ? dY[(size_t)r * N + n0 + lane] : 0.f;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-        for (int j = 0; j < cn; ++j) {
-            const float w = W[(size_t)(n0 + j) * K + kc];
-            const float4* q = reinterpret_cast<const float4*>(&sD[wave][j][0]);
+        for (int j = 0; j < 16; ++j) b[j] = X[(size_t)min(2 * j + lh, R - 1) * K + kc];   // (rows past R: dy is 0 there)
+        hd_f32x16 acc;
 #pragma unroll
-            for (int i = 0; i < RMAX / 4; ++i) {
-                const float4 d = q[i];
-                acc[4 * i] = fmaf(d.x, w, acc[4 * i]); acc[4 * i + 1] = fmaf(d.y, w, acc[4 * i + 1]);
-                acc[4 * i + 2] = fmaf(d.z, w, acc[4 * i + 2]); acc[4 * i + 3] = fmaf(d.w, w, acc[4 * i + 3]);
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+        if (k < K) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = n0 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                if (n < N) dW[(size_t)n * K + k] = acc[i];
             }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void head_dx_mfma_kernel(const float* __restrict__ dY, const float* __restrict__ W, int R, int K, int N,
+                                                           int nper, float* __restrict__ dX) {
+    __shared__ float sD[32][128 + 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int k = (blockIdx.x * 4 + wave) * 32 + lr, kc = min(k, K - 1);
+    const int nbeg = blockIdx.y * nper, nend = min(N, nbeg + nper);
+    hd_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int nb = nbeg; nb < nend; nb += 128) {
+        __syncthreads();
+        for (int e = tid; e < 32 * 128; e += 256) {
+            const int r = e >> 7, c = e & 127;
+            sD[r][c] = (r < R && nb + c < nend) ? dY[(size_t)r * N + nb + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int j0 = 0; j0 < 64; j0 += 16) {
+            float b[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) b[j] = W[(size_t)min(nb + 2 * (j0 + j) + lh, N - 1) * K + kc];   // (past nend: dy is 0)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sD[lr][2 * (j0 + j) + lh], b[j], acc, 0, 0, 0);
         }
     }
     if (k < K) {
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r)
-            if (r < R) unsafeAtomicAdd(&dX[(size_t)r * K + k], acc[r]);
+        for (int i = 0; i < 16; ++i) {
+            const int r = (i & 3) + 8 * (i >> 2) + 4 * lh;
+            if (r < R) unsafeAtomicAdd(&dX[(size_t)r * K + k], acc[i]);
+        }
     }
 }
 
@@ -436,10 +444,18 @@ static int head_layer_fwd_impl(const float* X, const float* W, const float* bias
                 ((bn_mode & 3) != 2 || (running_mean && running_var)), "pcl_head_layer_fwd_f32: bn_mode=%d", bn_mode);
     hipStream_t st = as_stream(stream);
     const dim3 grid(N), block(256);
-    if (head_wide(R, K, X, W))
-        hipLaunchKernelGGL(head_fwd_wide_kernel, dim3((N + HW_CB - 1) / HW_CB), block, 0, st, X, W, bias, gamma, beta, running_mean, running_var,
-                           R, K, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out, drop);
-    else if (R <= 32)
+    if (head_wide(R, K, X, W)) {
+        const int KS = K >= 8192 ? 16 : 8, kper = ((K + KS - 1) / KS + HM_KC - 1) / HM_KC * HM_KC;
+        float* part = nullptr;
+        if (hipMallocAsync(reinterpret_cast<void**>(&part), (size_t)KS * 32 * N * sizeof(float), st) != hipSuccess || !part) {
+            (void)hipGetLastError();
+            return fail(PCL_EHIP, "pcl_head_layer_fwd_f32: hipMallocAsync of the %zu-byte partial sums failed", (size_t)KS * 32 * N * sizeof(float));
+        }
+        hipLaunchKernelGGL(head_fwd_part_kernel, dim3((N + 31) / 32, KS), block, 0, st, X, W, R, K, N, kper, part);
+        hipLaunchKernelGGL(head_fwd_finish_kernel, dim3((N + 3) / 4), block, 0, st, part, KS, bias, gamma, beta, running_mean, running_var, R, N,
+                           bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out, drop);
+        (void)hipFreeAsync(part, st);
+    } else if (R <= 32)
         hipLaunchKernelGGL(head_fwd_kernel<32>, grid, block, 0, st, X, W, bias, gamma, beta, running_mean, running_var, R, K, N, bn_mode, eps,
                            momentum, slope, Ypre, OUT, mean_out, invstd_out, drop);
     else
@@ -465,10 +481,13 @@ static int head_layer_bwd_impl(const float* X, const float* W, const float* dOUT
     PCL_REQUIRE((bn_mode & 3) == 0 || (mean && invstd), "pcl_head_layer_bwd_f32: BatchNorm needs mean / invstd");
     hipStream_t st = as_stream(stream);
     const dim3 grid(N), block(256);
-    if (head_wide(R, K, X, W) && (reinterpret_cast<uintptr_t>(dW) & 15) == 0)
-        hipLaunchKernelGGL(head_bwd_col_wide_kernel, dim3((N + HW_CB - 1) / HW_CB), block, 0, st, X, dOUT, OUT, Ypre, gamma, mean, invstd, R, K,
-                           N, bn_mode, slope, dY_ws, dW, dbias, dgamma, dbeta, dX, drop);
-    else if (R <= 32)
+    const bool wide = head_wide(R, K, X, W);
+    if (wide) {                                   // column part, then dW as 32 x 32 MFMA tiles
+        hipLaunchKernelGGL(head_dy_kernel, dim3((N + 3) / 4), block, 0, st, dOUT, OUT, Ypre, gamma, mean, invstd, R, K, N, bn_mode, slope, dY_ws,
+                           dbias, dgamma, dbeta, dX, drop);
+        const int kblocks = (K + 31) / 32, gy = kblocks >= 128 ? 32 : 8, kb_per_wg = (kblocks + gy - 1) / gy;
+        hipLaunchKernelGGL(head_dw_mfma_kernel, dim3((N + 31) / 32, gy), block, 0, st, dY_ws, X, R, K, N, kb_per_wg, dW);
+    } else if (R <= 32)
         hipLaunchKernelGGL(head_bwd_col_kernel<32>, grid, block, 0, st, X, dOUT, OUT, Ypre, gamma, mean, invstd, R, K, N, bn_mode & 3, slope, dY_ws,
                            dW, dbias, dgamma, dbeta, dX, drop);
     else
@@ -477,7 +496,10 @@ static int head_layer_bwd_impl(const float* X, const float* W, const float* dOUT
     int rc = check_launch("pcl_head_layer_bwd_f32(col)");
     if (rc || !dX) return rc;
     const dim3 g2((K + 63) / 64, (N + 4 * HD_NS - 1) / (4 * HD_NS));
-    if (R <= 32 && K >= 2048 && N >= 256) hipLaunchKernelGGL(head_bwd_dx_wide_kernel, dim3((K + 63) / 64), block, 0, st, dY_ws, W, R, K, N, dX);
+    if (R <= 32 && K >= 2048) {
+        const int NS = N >= 512 ? 2 : 1, nper = ((N + NS - 1) / NS + 127) / 128 * 128;
+        hipLaunchKernelGGL(head_dx_mfma_kernel, dim3((K + 127) / 128, NS), block, 0, st, dY_ws, W, R, K, N, nper, dX);
+    }
     else if (R <= 32) hipLaunchKernelGGL(head_bwd_dx_kernel<32>, g2, block, 0, st, dY_ws, W, R, K, N, dX);
     else hipLaunchKernelGGL(head_bwd_dx_kernel<64>, g2, block, 0, st, dY_ws, W, R, K, N, dX);
     return check_launch("pcl_head_layer_bwd_f32(dx)");
