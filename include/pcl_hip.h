@@ -189,8 +189,9 @@ int pcl_group_linear_bwd_f32(const float* row_loc, const float* row_feat, int CF
  * bn_mode: 0 none, 1 training (batch statistics over the R rows; running_mean/var updated in place torch-style, unbiased
  * running variance), 2 evaluation (running statistics); +4: running_var receives the BIASED batch variance, as
  * pcl_bn_finalize_f32 does for the set-abstraction stacks (PointConv's per-point Linear + BatchNorm1d on the GroupAll level,
- * misc/pointconv_utils.py:395-397, is such a layer: 32 rows x 16384 -> 1024; layers with K >= 2048 and R <= 32 take kernels
- * that share every staged piece of X between 8 output columns).  slope: 1 = no activation, 0 = ReLU, 0.2 = LeakyReLU.
+ * misc/pointconv_utils.py:395-397, is such a layer: 32 rows x 16384 -> 1024; layers with K >= 2048 and R <= 32 run as fp32 MFMA
+ * tiles: the forward as split-K partial tiles summed in a fixed order -- its partial sums live in a stream-ordered allocation,
+ * hipMallocAsync / hipFreeAsync on `stream` -- dW and dX as 32 x 32 tiles).  slope: 1 = no activation, 0 = ReLU, 0.2 = LeakyReLU.
  * Forward keeps Ypre (pre-BatchNorm) and mean/invstd for backward; backward returns dW, dbias/dgamma/dbeta (nullable) and,
  * when dX != NULL, the input gradient (dY_ws: [R,N] scratch). */
 int pcl_head_layer_fwd_f32(const float* X, const float* W, const float* bias, const float* gamma, const float* beta,
