@@ -434,6 +434,22 @@ static bool head_wide(int R, int K, const float* X, const float* W) {
 }  // namespace pcl
 using namespace pcl;
 
+// The split-K forward's partial sums come from the device's default stream-ordered pool: keep what it has allocated across
+// synchronisation points (the default release threshold of 0 hands the memory back at every stream sync -- a training loop that reads
+// its loss each step would pay a fresh allocation per step).  Once per device.
+static void head_pool_keep() {
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || done[dev]) { (void)hipGetLastError(); return; }
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+        uint64_t keep = ~0ull;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    (void)hipGetLastError();
+    done[dev] = true;
+}
+
 static int head_layer_fwd_impl(const float* X, const float* W, const float* bias, const float* gamma, const float* beta,
                                       float* running_mean, float* running_var, int R, int K, int N, int bn_mode, float eps,
                                       float momentum, float slope, float* Ypre, float* OUT, float* mean_out, float* invstd_out,
@@ -446,6 +462,7 @@ static int head_layer_fwd_impl(const float* X, const float* W, const float* bias
     const dim3 grid(N), block(256);
     if (head_wide(R, K, X, W)) {
         const int KS = K >= 8192 ? 16 : 8, kper = ((K + KS - 1) / KS + HM_KC - 1) / HM_KC * HM_KC;
+        head_pool_keep();
         float* part = nullptr;
         if (hipMallocAsync(reinterpret_cast<void**>(&part), (size_t)KS * 32 * N * sizeof(float), st) != hipSuccess || !part) {
             (void)hipGetLastError();
