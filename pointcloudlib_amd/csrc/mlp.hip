@@ -1805,11 +1805,27 @@ struct FbArgs {
     float* part;                                                // [gx * ksplit][Cout][Cin] partial dW tiles
     const int* p_dev; const int2* rmeta;                        // compacted rows
     int P, gx;
+#if PCL_EXP == 7
+    int lab_slot;                                               // lab build: launch number of this shape (ring slot of the time stamps)
+#endif
 };
 
+#if PCL_EXP == 7
+// lab build only: per-workgroup time stamps of the last 8 launches of the four headline shapes, read back by pcl_lab_fbk_read
+// (tools/fb_budget.py).  A device-global buffer instead of printf: 512 hostcall printfs per launch stretched the launch tenfold.
+constexpr int FBK_SHAPES = 4, FBK_RING = 8, FBK_WORDS = 16;
+__device__ long long g_fbk[FBK_SHAPES][FBK_RING][256][2][FBK_WORDS];
+__host__ __device__ constexpr int fbk_shape(bool sparse, int co, int ci) {
+    return sparse && co == 4 && ci == 2 ? 0 : sparse && co == 2 && ci == 1 ? 1 : !sparse && co == 2 && ci == 2 ? 2 : !sparse && co == 1 && ci == 1 ? 3 : -1;
+}
+#endif
 template <bool SPARSE, bool RAG, int CO, int CI>
 __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_in) {
     FbArgs p = p_in;
+#if PCL_EXP == 7
+    const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
+    const long long cy_entry = __builtin_readcyclecounter();
+#endif
     if (p.p_dev) p.P = __builtin_amdgcn_readfirstlane(*p.p_dev);
     constexpr int COUT = 64 * CO, CIN = 64 * CI, R = fb_rows(CIN);
     constexpr bool WRES = fb_resident(COUT, CIN);
@@ -1991,6 +2007,9 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
 #if PCL_EXP == 7                                     // lab build: cycles per phase of the tile loop, printed by two waves of one workgroup
     long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #define FB_MARK(i) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tlast; tlast = t_; }
+    // whole-kernel budget (round 5): shader-clock cycles (s_memtime) beside the constant 100 MHz counter (s_memrealtime) at the
+    // kernel's entry, after the prologue, after the tile loop, after the partial-tile write-out has DRAINED and at the exit
+    long long tk[5] = {cy_entry, 0, 0, 0, 0};
 #else
 #define FB_MARK(i)
 #endif
@@ -2003,6 +2022,9 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
         const ReqCtx c0 = req_open(tile, 0, true);
         req_slice(c0, 0, 1);
     }
+#if PCL_EXP == 7
+    tk[1] = tlast = __builtin_readcyclecounter();
+#endif
     for (; tile < tiles; tile += p.gx, ++it) {
         const int m0 = tile * R, mb = it & 1;
         const bool more = tile + p.gx < tiles;
@@ -2173,9 +2195,7 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
         FB_MARK(5)
     }
 #if PCL_EXP == 7
-    if (bx == 37 && (tid == 0 || tid == 448))
-        printf("fb<%d,%d,%d> wave %d tiles %d: deposit %lld | barA %lld | dX %lld | epi %lld | dW %lld | barB %lld | top %lld  (cycles/tile)\n", (int)SPARSE, CO, CI, wave, it,
-               tph[0] / it, tph[1] / it, tph[2] / it, tph[3] / it, tph[4] / it, tph[5] / it, tph[6] / it);
+    tk[2] = __builtin_readcyclecounter();
 #endif
     // ---- this workgroup's partial dW tile(s) and its row of the BatchNorm sums
     float* out = p.part + ((size_t)bx * KW + kq) * COUT * CIN;
@@ -2203,6 +2223,22 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
             dst[tid] = ss; dst[CIN + tid] = qq;
         }
     }
+#if PCL_EXP == 7
+    tk[3] = __builtin_readcyclecounter();                     // (stores issued, not drained)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tk[4] = __builtin_readcyclecounter();
+    const unsigned long long rt_exit = __builtin_amdgcn_s_memrealtime();
+    constexpr int SH = fbk_shape(SPARSE, CO, CI);
+    if (SH >= 0 && bx < 256 && (tid == 0 || tid == 448)) {
+        long long* q = g_fbk[SH < 0 ? 0 : SH][p.lab_slot & (FBK_RING - 1)][bx][tid == 0 ? 0 : 1];
+        q[0] = (long long)rt_entry; q[1] = (long long)rt_exit;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) q[2 + i] = tk[i];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) q[7 + i] = tph[i];
+        q[14] = it; q[15] = ((long long)p.lab_slot << 8) | wave;
+    }
+#endif
 }
 
 // one persistent workgroup per CU (the device's CU count, asked once); pcl_set_fb_max_blocks caps it (tests: several row tiles
@@ -2855,7 +2891,16 @@ extern "C" size_t pcl_linear_bwd_fused_workspace_bytes(int P, int Cout, int Cin)
 }
 
 template <bool SPARSE, bool RAG>
-static int launch_fb(const FbArgs& a, int Cout, int Cin, hipStream_t st) {
+static int launch_fb(const FbArgs& a_in, int Cout, int Cin, hipStream_t st) {
+#if PCL_EXP == 7
+    FbArgs a = a_in;
+    {
+        static int n_launch[2][8][8];
+        a.lab_slot = n_launch[SPARSE][Cout / 64][Cin / 64]++;
+    }
+#else
+    const FbArgs& a = a_in;
+#endif
     const dim3 grid(a.gx), blk(FB_T);
 #define PCL_FB(CO, CI) PCL_LAUNCH_TIMED((linear_bwd_fused_kernel<SPARSE, RAG, CO, CI>), grid, blk, st, a)
     if (Cout == 64 && Cin == 64) PCL_FB(1, 1);
@@ -2895,6 +2940,15 @@ extern "C" int pcl_linear_bwd_fused_rows_f32(const float* dU, const float* Y, co
     else rc = row_meta ? launch_fb<true, true>(f, Cout, Cin, st) : launch_fb<true, false>(f, Cout, Cin, st);
     return rc;
 }
+
+#if PCL_EXP == 7
+// lab build only (not declared in include/pcl_hip.h): the time stamps of the last launches, after a device synchronisation
+extern "C" int pcl_lab_fbk_read(void* dst, size_t bytes) {
+    if (bytes < sizeof(g_fbk)) return (int)sizeof(g_fbk);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fbk), sizeof(g_fbk), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int pcl_linear_bwd_fused_finish_f32(const void* workspace, size_t workspace_bytes, int P, int Cout, int Cin, float* dW,
                                                const double* stats_ws, const float* gamma_prev, const float* mean_prev,
