@@ -502,6 +502,11 @@ typedef struct pcl_mlp_stack_t {
                                               * rows in ext_stats [ext_stat_rows][2][c[L]] (pcl_pointconv_contract_bn_bwd_f32 leaves both) */
     int32_t ext_stat_rows;
     const double* ext_stats;
+    int32_t flush_k;                         /* 0: the default GEMM kernels.  8 | 32: every forward GEMM of the stack that runs on plain rows (all layers
+                                              * of a plain stack, the per-point product of a grouped one) goes through pcl_frag_linear_fwd_f32 with that
+                                              * flush interval: fp32 fma chains of at most flush_k terms summed in fp64 (the part-seg decoder, where the
+                                              * distance from the fp64 evaluation is accumulation error: DESIGN.md section 10).  Backward unchanged. */
+    int32_t reserved_;
 } pcl_mlp_stack_t;
 /* where, inside `save`, the last layer's pre-BatchNorm output [P, c[L]] and its folded BatchNorm (scale [c[L]], shift [c[L]]) live (byte
  * offsets): what a deferring consumer reads (defer_act) */
@@ -512,6 +517,43 @@ int pcl_mlp_stack_sizes(const pcl_mlp_stack_t* desc, size_t* save_bytes, size_t*
 int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* desc);
 /* reference: the autograd backward of the same module (Jittor derives it; networks/cls/pointnet2.py:33-62) */
 int pcl_mlp_stack_bwd_f32(const pcl_mlp_stack_t* desc);
+
+/* ---- layers with FEW ROWS: fragment-direct GEMMs (csrc/frag.hip, round 5) -----------------------------------------
+ * The GroupAll level (networks/cls/pointnet2.py:131-136: [259, 256, 512, 1024] on B*128 rows), the part-seg decoder's feature
+ * propagation stacks (networks/seg/pointnet2_partseg.py:146-148, misc/ops.py:54-64,:103-106) and DGCNN's per-point product
+ * (networks/cls/dgcnn.py:72-83) have 2 048 .. 32 768 rows: fewer output tiles than the chip has SIMDs.  These entry points run the
+ * same arithmetic as pcl_linear_fwd_f32 / _bwd_dx_f32 / _bwd_dw_f32 (reference: nn.Conv(k=1) + nn.BatchNorm + ReLU and its autograd
+ * backward) with a wave per 32 x 32 output tile reading MFMA fragments straight from L2, K split over the waves of a workgroup and
+ * reduced in LDS in fixed order.  Rows may have any stride and any 4-byte alignment (no padding of K = 259).
+ *   flush_k = 0: fp32 accumulation (one fma chain per output); 8 | 32: the chain is cut every flush_k terms and summed in fp64 --
+ *   the error of a K-term dot product drops by ~sqrt(flush_k / K); Y is the fp32 rounding of that sum.
+ *   stats_ws: [pcl_frag_stat_rows(P)][2][Cout] fp64 (sum y, sum y^2) for pcl_bn_finalize_f32, or NULL (no BatchNorm behind it).
+ *   pcl_frag_dy_f32 forms dy = a*du - (k1 + k2*(y - mu)) of a layer ONCE (du dense, or the sparse max gradient (arg, gz, ns));
+ *   it also clears `n_zero` words at `zero_words` (the dW workspace's counters: pcl_frag_dw_counter_words) when given.
+ *   pcl_frag_linear_bwd_dx_f32: dUprev[:, first_col:] = (dy W)[:, first_col:] * lrelu'(BN_prev(Yprev)) + its BatchNorm-backward sums
+ *   ([pcl_frag_stat_rows(P)][2][Cin]: sum du, sum du*yprev); Yprev = NULL: plain product (the stack's input gradient).
+ *   pcl_frag_linear_bwd_dw_f32: dW[Cout][ldo] = dy^T lrelu(BN_prev(Xprev)) (prev_scale = NULL: plain Xprev); rows split over the waves of
+ *   a workgroup and over several workgroups per 64 x 64 tile, whose partial tiles the LAST workgroup to arrive sums in fixed order:
+ *   deterministic, no second launch.  workspace: pcl_frag_dw_workspace_bytes; its first pcl_frag_dw_counter_words words must be zero
+ *   at launch (counters_cleared = 0: the entry point clears them itself with a memset node).
+ *   pcl_frag_set_tuning: max_rows = largest P for which the per-stack entry points choose these kernels (default 8192; < 0 keeps
+ *   it); the other arguments force launch shapes (0 = automatic) -- tests and timing only. */
+int pcl_frag_stat_rows(int P);
+int pcl_frag_max_rows(void);
+void pcl_frag_set_tuning(int max_rows, int force_tn, int force_ksw, int dw_tm, int dw_tn, int dw_ksw, int dw_ksg);
+int pcl_frag_linear_fwd_f32(const float* X, int ldx, const float* W, int ldw, const float* bias, const float* in_scale,
+                            const float* in_shift, float in_slope, int P, int Cin, int Cout, float* Y, int ldy, double* stats_ws,
+                            int flush_k, void* stream);
+int pcl_frag_dy_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2, const float* mu,
+                    const int32_t* arg, const float* gz, int ns, int P, int C, float* dy, uint32_t* zero_words, int n_zero, void* stream);
+int pcl_frag_linear_bwd_dx_f32(const float* dy, const float* W, int ldw, int P, int Cout, int Cin, const float* Yprev, int ldyp,
+                               const float* prev_scale, const float* prev_shift, float prev_slope, float* dUprev, int ldu,
+                               double* stats_ws, int first_col, void* stream);
+size_t pcl_frag_dw_workspace_bytes(int P, int Cout, int Cin);
+int pcl_frag_dw_counter_words(int P, int Cout, int Cin);
+int pcl_frag_linear_bwd_dw_f32(const float* dy, const float* X, int ldx, const float* prev_scale, const float* prev_shift, float prev_slope,
+                               int P, int Cout, int Cin, float* dW, int ldo, void* workspace, size_t workspace_bytes, int counters_cleared,
+                               void* stream);
 
 /* ---- duplicate-compacted ("ragged") groups --------------------------------------------------------------
  * query_ball_point pads each group with copies of its first hit (misc/ops.py:321-324).  Identical rows stay

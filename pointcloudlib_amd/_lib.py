@@ -120,6 +120,15 @@ _SIGS = {
                                            _P, c_size_t, _P, _P, c_int, _P]),
     "pcl_scatter_rows_add_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_linear_bwd_dw_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "pcl_frag_stat_rows": (c_int, [c_int]),
+    "pcl_frag_max_rows": (c_int, []),
+    "pcl_frag_set_tuning": (None, [c_int] * 7),
+    "pcl_frag_linear_fwd_f32": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_float, c_int, c_int, c_int, _P, c_int, _P, c_int, _P]),
+    "pcl_frag_dy_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, _P]),
+    "pcl_frag_linear_bwd_dx_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_float, _P, c_int, _P, c_int, _P]),
+    "pcl_frag_dw_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "pcl_frag_dw_counter_words": (c_int, [c_int, c_int, c_int]),
+    "pcl_frag_linear_bwd_dw_f32": (c_int, [_P, _P, c_int, _P, _P, c_float, c_int, c_int, c_int, _P, c_int, _P, c_size_t, c_int, _P]),
     "pcl_set_fb_max_blocks": (None, [c_int]),
     "pcl_set_kernel_paths": (None, [c_int, c_int, c_int]),
     "pcl_set_matrix_form": (None, [c_int]),

@@ -60,7 +60,9 @@ static SaveLayout save_layout(const pcl_mlp_stack_t& d, void* base) {
     return s;
 }
 
-static inline bool use_gmax(const pcl_mlp_stack_t& d) { return !d.grouped && (d.pool == 32 || d.pool == 64); }
+// forward GEMMs of a PLAIN stack through the fragment kernels with fp64-flushed accumulation (descriptor field flush_k)
+static inline bool frag_fwd(const pcl_mlp_stack_t& d) { return !d.grouped && d.flush_k != 0; }
+static inline bool use_gmax(const pcl_mlp_stack_t& d) { return !d.grouped && !d.flush_k && (d.pool == 32 || d.pool == 64); }
 static inline bool fused_bwd_enabled() {
     return path_switches().fused_backward != 0;
 }
@@ -80,13 +82,14 @@ static FwdTmp fwd_tmp(const pcl_mlp_stack_t& d, void* base) {
     for (int l = 0; l < L; ++l) {
         size_t r;
         if (l == 0 && d.grouped) r = (size_t)pcl_group_linear_stat_rows(d.B, d.m) * 2 * d.c[1];
+        else if (frag_fwd(d)) r = (size_t)pcl_frag_stat_rows(d.P) * 2 * d.c[l + 1];
         else r = (size_t)pcl_mlp_stat_rows(d.P, d.c[l + 1], d.grouped ? 2 : 0) * 2 * d.c[l + 1];
         if (r > rows_max) rows_max = r;
     }
     t.stats = c.take<double>(rows_max);
     if (grouped_wide(d)) {
         t.Uf = c.take<float>((size_t)d.B * d.N * d.c[1]);
-        t.pt_stats = c.take<double>((size_t)pcl_mlp_stat_rows(d.B * d.N, d.c[1], 0) * 2 * d.c[1]);
+        if (!d.flush_k) t.pt_stats = c.take<double>((size_t)pcl_mlp_stat_rows(d.B * d.N, d.c[1], 0) * 2 * d.c[1]);     // (the flushed product writes no sums)
     }
     if (use_gmax(d)) {
         const size_t n = (size_t)(d.P / d.pool) * d.c[L];
@@ -199,6 +202,7 @@ static int validate(const pcl_mlp_stack_t* dp, const char* who) {
     }
     for (int l = 0; l < d.n_layers; ++l)
         PCL_REQUIRE(d.layer[l].W && d.layer[l].gamma && d.layer[l].beta, "%s: layer %d: W / gamma / beta must be given (training-mode BatchNorm on every layer)", who, l);
+    PCL_REQUIRE(d.flush_k == 0 || d.flush_k == 8 || d.flush_k == 32, "%s: flush_k = %d (0, 8 or 32)", who, d.flush_k);
     return PCL_OK;
 }
 
@@ -274,8 +278,10 @@ extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
                                               st, 1, ly.W + off, d.Wf_dense, d.Cf));
                 tagf("pt%dx%d", d.Cf, cout);
                 // (a conv bias of the folded layer is added here, once per point: every row gathers exactly one Uf row)
-                PCL_TRY(pcl_linear_fwd_rows_f32(d.feature, d.Wf_dense, ly.bias, nullptr, nullptr, 0.f, d.B * d.N, d.Cf, cout, t.Uf,
-                                                t.pt_stats, nullptr, nullptr, st));
+                if (d.flush_k) PCL_TRY(pcl_frag_linear_fwd_f32(d.feature, d.Cf, d.Wf_dense, d.Cf, ly.bias, nullptr, nullptr, 0.f, d.B * d.N, d.Cf, cout, t.Uf, cout,
+                                                               nullptr, d.flush_k, st));
+                else PCL_TRY(pcl_linear_fwd_rows_f32(d.feature, d.Wf_dense, ly.bias, nullptr, nullptr, 0.f, d.B * d.N, d.Cf, cout, t.Uf,
+                                                     t.pt_stats, nullptr, nullptr, st));
             }
             tagf("glin%d", cout, 0);
             PCL_TRY(group_linear_fwd_impl(d.xyz, d.new_xyz, wide ? t.Uf : nullptr, d.use_xyz ? ly.W : nullptr, inl ? d.feature : nullptr,
@@ -288,6 +294,10 @@ extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
             PCL_TRY(pcl_linear_fwd_gmax_f32(cur, ly.W, ly.bias, in_scale, in_shift, d.slope, P, cin, cout, d.pool, Y, t.stats, t.gmax,
                                             t.gmin, t.gamax, t.gamin, st));
             rows = pcl_mlp_stat_rows(P, cout, 0);
+        } else if (frag_fwd(d)) {
+            tagf("fwd%dx%d", cin, cout);
+            PCL_TRY(pcl_frag_linear_fwd_f32(cur, cin, ly.W, cin, ly.bias, in_scale, in_shift, d.slope, P, cin, cout, Y, cout, t.stats, d.flush_k, st));
+            rows = pcl_frag_stat_rows(P);
         } else {
             tagf("fwd%dx%d", cin, cout);
             PCL_TRY(pcl_linear_fwd_rows_f32(cur, ly.W, ly.bias, in_scale, in_shift, d.slope, P, cin, cout, Y, t.stats, rmeta, nrows, st));

@@ -102,7 +102,7 @@ class _PointLinear(torch.autograd.Function):
     (forward, dX and dW); returns the gradient of W itself."""
 
     @staticmethod
-    def forward(ctx, x, W):
+    def forward(ctx, x, W, flush_k=0):
         x = _dev(x, "x")
         B, N, C = x.shape
         Co = W.shape[0]
@@ -111,9 +111,16 @@ class _PointLinear(torch.autograd.Function):
         _lib.call("pcl_edgeconv_wcat_f32", _p(W.contiguous()), Co, C, 0, _p(Wcat), _stream())
         P = B * N
         UV = torch.empty((B, N, 2 * Co), device=dev)
-        rows = _lib.size_query("pcl_mlp_stat_rows", P, 2 * Co, 0)
-        _lib.call("pcl_linear_fwd_rows_f32", _p(x), _p(Wcat), None, None, None, 0.0, P, C, 2 * Co, _p(UV),
-                  _p(torch.empty((rows, 2, 2 * Co), dtype=torch.float64, device=dev)), None, None, _stream(), tag=f"uv{C}x{2 * Co}")
+        if flush_k:
+            # y = U[nbr] + V decides the max-pool winners of the stage: with U | V from one fp32 fma chain per element the winners an
+            # fp32 evaluation picks differ from the fp64 ones more often than PyTorch-CPU's blocked sgemm does (stage 4, K = 128:
+            # DESIGN.md section 9.5c).  Chains of flush_k terms summed in fp64 bring U | V to the fp32 rounding of the exact product.
+            _lib.call("pcl_frag_linear_fwd_f32", _p(x), C, _p(Wcat), C, None, None, None, 0.0, P, C, 2 * Co, _p(UV), 2 * Co, None, int(flush_k), _stream(),
+                      tag=f"uv{C}x{2 * Co}")
+        else:
+            rows = _lib.size_query("pcl_mlp_stat_rows", P, 2 * Co, 0)
+            _lib.call("pcl_linear_fwd_rows_f32", _p(x), _p(Wcat), None, None, None, 0.0, P, C, 2 * Co, _p(UV),
+                      _p(torch.empty((rows, 2, 2 * Co), dtype=torch.float64, device=dev)), None, None, _stream(), tag=f"uv{C}x{2 * Co}")
         ctx.save_for_backward(x, Wcat)
         return UV
 
@@ -143,7 +150,7 @@ class _PointLinear(torch.autograd.Function):
             dx = torch.empty((B, N, C), device=dev)
             _lib.call("pcl_linear_bwd_dx_rows_f32", _p(dUV), _p(dUV), _p(one), _p(zero), _p(zero), _p(zero), None, None, 1, _p(Wcat),
                       P, C2, C, None, None, None, 0.0, _p(dx), None, None, None, 0, 0, st, tag=f"uvdx{C2}x{C}")
-        return dx, dW
+        return dx, dW, None
 
 
 def edge_conv(mlp, x, idx):
@@ -152,7 +159,7 @@ def edge_conv(mlp, x, idx):
     the plain-PyTorch backend (tests) and anything that is not a single bias-free conv+BN layer build the edge tensor."""
     k = idx.shape[2]
     if mlp.resolved_backend(x) == "hip" and mlp.n_layers == 1 and mlp.bn and mlp.biases is None and mlp.last_act:
-        UV = _PointLinear.apply(x, mlp.weights[0])                            # one GEMM over the points
+        UV = _PointLinear.apply(x, mlp.weights[0], int(getattr(mlp, "flush_k", 0)))     # one GEMM over the points
         cfg = (mlp.slope, mlp.eps, mlp.momentum, mlp.training)
         return _EdgeConvPool.apply(UV, idx, mlp.gammas[0], mlp.betas[0], mlp.running_mean_0, mlp.running_var_0, cfg)
     return mlp(edge_features(x, idx), group_max=k)

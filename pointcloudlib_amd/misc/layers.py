@@ -111,6 +111,16 @@ def max_over_group(x, dim):
     return x.max(dim=dim)[0]
 
 
+def set_accumulation(root, flush_k):
+    """Select the accumulation of every ``PointwiseMLP`` under ``root`` (see ``PointwiseMLP.flush_k``): 0, 8 or 32."""
+    if flush_k not in (0, 8, 32):
+        raise ValueError(f"flush_k = {flush_k}: 0 (fp32 chains), 8 or 32 (fp64 sum of fp32 chains of that length)")
+    for m in root.modules():
+        if isinstance(m, PointwiseMLP):
+            m.flush_k = int(flush_k)
+    return root
+
+
 class PointwiseMLP(nn.Module):
     """Stack of [Linear(Cin->Cout, bias) -> BatchNorm(train) -> (Leaky)ReLU] on channel-last rows.
 
@@ -127,6 +137,10 @@ class PointwiseMLP(nn.Module):
         self.eps = eps
         self.backend = backend
         self.last_act = last_act
+        # accumulation of the forward GEMMs that run on plain rows: 0 = one fp32 fma chain per output (the staged MFMA kernels);
+        # 8 | 32 = chains of at most that many terms summed in fp64 (csrc/frag.hip) -- set with ``set_accumulation`` by the networks
+        # whose distance from the fp64 evaluation is accumulation error (part-seg decoders, DGCNN's stage products)
+        self.flush_k = 0
         self.weights = nn.ParameterList()
         self.biases = nn.ParameterList() if bias else None
         self.gammas = nn.ParameterList()

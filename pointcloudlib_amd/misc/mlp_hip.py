@@ -81,7 +81,8 @@ class _FusedMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cfg, *params):
-        ns, slope, eps, momentum, training, bn, last_act, rowset, x_grad_from, link = cfg
+        ns, slope, eps, momentum, training, bn, last_act, rowset, x_grad_from, link = cfg[:10]
+        flush_k = cfg[10] if len(cfg) > 10 else 0          # forward GEMMs on plain rows: fp64-flushed accumulation (csrc/frag.hip)
         L = len(params) // 6
         dev = x.device
         x = x.contiguous()
@@ -104,18 +105,22 @@ class _FusedMLP(torch.autograd.Function):
                 # multiple of 4 floats so that every kernel moves 16-byte pieces): pad W with zero columns to match
                 assert W.shape[1] < cin, f"input has {cin} columns, first layer expects {W.shape[1]}"
                 W = W0p = torch.nn.functional.pad(W.detach(), (0, cin - W.shape[1]))
-            fused_max = (l == L - 1) and ns in (32, 64) and rowset is None
+            fused_max = (l == L - 1) and ns in (32, 64) and rowset is None and not flush_k
             folded = l == 0 and link is not None
+            flushed = bool(flush_k) and rowset is None and not folded
             if folded:
                 # the first layer was folded into the grouping (_GroupLinear): x IS its pre-BatchNorm output
                 assert cout == cin and L >= 2, "folded first layer: x must be the layer's own output"
                 Y, stats, rows = x, link.stats, link.rows
             else:
                 Y = _empty((P, cout), dev)
-                rows = _lib.size_query("pcl_mlp_stat_rows", P, cout, 2 if rowset is not None else 0)
+                rows = _lib.size_query("pcl_frag_stat_rows", P) if flushed else _lib.size_query("pcl_mlp_stat_rows", P, cout, 2 if rowset is not None else 0)
                 stats = _empty((rows, 2, cout), dev, torch.float64)
             if folded:
                 pass                       # nothing to launch: the grouping kernel already produced Y and its sums
+            elif flushed:
+                _lib.call("pcl_frag_linear_fwd_f32", _P(cur), cin, _P(W), cin, _P(bias), _P(in_scale), _P(in_shift), slope, P, cin, cout, _P(Y), cout,
+                          _P(stats), flush_k, st, algo_bytes=4 * P * (cin + cout) + 4 * cin * cout, algo_flops=2 * P * cin * cout, tag=f"fwd{cin}x{cout}")
             elif fused_max:      # last layer of a max-pooled stack: per-group min/max come out of the GEMM epilogue
                 G = P // ns
                 gmax, gmin = _empty((G, cout), dev), _empty((G, cout), dev)
@@ -357,7 +362,7 @@ def pointwise_mlp(module, x, group_max=None, rowset=None, x_grad_from=0):
     # x_grad_from: the first input column whose gradient anybody consumes (3 for a grouped [xyz | features] tensor:
     # xyz never needs a gradient); lower columns of the returned input gradient are left unwritten.
     cfg = (ns, module.slope, module.eps, module.momentum, module.training, module.bn, module.last_act, rowset,
-           int(x_grad_from), None)
+           int(x_grad_from), None, int(getattr(module, "flush_k", 0)) if rowset is None else 0)
     out = _FusedMLP.apply(x2, cfg, *params)
     if rowset is not None:
         return out.reshape(rowset.B, rowset.m, out.shape[-1])
@@ -533,7 +538,7 @@ class _CStack(ctypes.Structure):
                 + [("layer", _CLayer * _MAXL), ("out", ctypes.c_void_p), ("save", ctypes.c_void_p), ("save_bytes", ctypes.c_size_t),
                    ("tmp", ctypes.c_void_p), ("tmp_bytes", ctypes.c_size_t), ("gout", ctypes.c_void_p), ("dx", ctypes.c_void_p),
                    ("stream", ctypes.c_void_p), ("defer_act", ctypes.c_int32), ("ext_stat_rows", ctypes.c_int32),
-                   ("ext_stats", ctypes.c_void_p)])
+                   ("ext_stats", ctypes.c_void_p), ("flush_k", ctypes.c_int32), ("reserved_", ctypes.c_int32)])
 
 
 class _StackPlan:
@@ -547,8 +552,9 @@ _PLANS = {}
 
 
 def _stack_plan(module, P, c0, pool, grouped, geom, need_dx, x_grad_from, defer=False):
+    flush_k = int(getattr(module, "flush_k", 0))
     key = (id(module), P, c0, pool, grouped, geom, need_dx, x_grad_from, module.slope, module.last_act, defer,
-           module.eps, module.momentum, module.biases is not None)      # (everything the filled-in descriptor depends on)
+           module.eps, module.momentum, module.biases is not None, flush_k)      # (everything the filled-in descriptor depends on)
     plan = _PLANS.get(key)
     if plan is not None and plan.spec is module.spec:
         return plan
@@ -562,6 +568,7 @@ def _stack_plan(module, P, c0, pool, grouped, geom, need_dx, x_grad_from, defer=
         d.c[l + 1] = spec[l + 1]
     d.P, d.pool, d.grouped, d.x_grad_from, d.need_dx = P, pool, int(grouped), int(x_grad_from), int(need_dx)
     d.defer_act = int(defer)
+    d.flush_k = flush_k
     if grouped:
         d.B, d.N, d.m, d.Cf, d.use_xyz = geom
     d.slope, d.out_slope, d.eps, d.momentum = module.slope, (module.slope if module.last_act else 1.0), module.eps, module.momentum

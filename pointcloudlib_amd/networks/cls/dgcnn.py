@@ -10,6 +10,8 @@ kNN runs in the HIP KNN kernel (index-exact vs the oracle).  The EdgeConv stages
 misc/edgeconv.py (one GEMM over the points + two streaming kernels, no edge tensor); ``get_graph_feature`` -- the
 reference's edge tensor, via pcl_edge_feature_f32 -- stays available and is what the plain-PyTorch backend uses.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -46,6 +48,9 @@ class DGCNN(nn.Module):
         self.conv3 = PointwiseMLP([64 * 2, 128], slope=0.2)
         self.conv4 = PointwiseMLP([128 * 2, 256], slope=0.2)
         self.conv5 = PointwiseMLP([512, 1024], slope=0.2)
+        # U | V of the EdgeConv stages decide the max-pool winners: chains of 8 terms summed in fp64 (misc/edgeconv.py: _PointLinear)
+        for c in (self.conv1, self.conv2, self.conv3, self.conv4):
+            c.flush_k = int(os.environ.get("PCL_DGCNN_FLUSH", "8"))
         self.linear1 = nn.Linear(1024 * 2, 512, bias=False)
         self.bn6 = nn.BatchNorm1d(512)
         self.dp1 = nn.Dropout(p=0.5)

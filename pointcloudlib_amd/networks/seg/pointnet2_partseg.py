@@ -8,10 +8,12 @@ decoder = three PointNetFeaturePropagation (:146-148, misc/ops.py:54-107); head 
 Deviation from an upstream bug: upstream's PointNetMSG keeps the SSG FP widths 1280/384,
 which cannot match its MSG encoder (640+1024, 320+256); here the MSG variant uses the consistent 1664/576.
 """
+import os
+
 import torch
 from torch import nn
 
-from ...misc.layers import PointwiseMLP
+from ...misc.layers import PointwiseMLP, set_accumulation
 from ...misc.ops import PointNetFeaturePropagation
 from ..cls.pointnet2 import PointnetModule, PointnetModuleMSG, SamplingPrefetch
 
@@ -22,6 +24,11 @@ class PointNet2_partseg(SamplingPrefetch, nn.Module):
         self.part_num = part_num
         self.use_xyz = use_xyz
         self.build_model()
+        # The decoder stacks up to 14 BatchNorms on the encoder's output; with one fp32 fma chain per dot product (K up to 1664) the
+        # logits sit 6-8 x the 1e-5 bound from the fp64 evaluation, 4-5 x of it accumulation error (tools/dbg/partseg_local_err.py).  Every
+        # forward GEMM on plain rows (GroupAll level, feature propagation, head, the per-point products of the grouped levels) therefore
+        # sums chains of 32 terms in fp64 (csrc/frag.hip); PCL_PARTSEG_FLUSH=0 selects the plain kernels (A/B timing).
+        set_accumulation(self, int(os.environ.get("PCL_PARTSEG_FLUSH", "32")))
 
     def build_model(self):
         self.pointnet_modules = nn.ModuleList([
