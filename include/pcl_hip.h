@@ -269,6 +269,11 @@ int pcl_soft_ce_f32(const float* logits, const int64_t* target, float eps, int R
  *   pcl_knn_transpose_i32: idx [B,N,k] -> in_off [B*N+1] (global offsets into in_src), in_src [B*N*k] (for every point the
  *     sources i, index within the cloud, of the edges i->n, ascending).  N <= 8192. */
 int pcl_edgeconv_stat_rows(int B, int N);
+/* reference: the same stage (networks/cls/dgcnn.py:29-50,:100-111); UVlo [B*N, 2C] = the residuals of U | V from pcl_frag_linear_fwd_f32's
+ * Y_lo: y = (U[nbr] + V[i]) + (Ulo[nbr] + Vlo[i]) is the fp32 rounding of the exact edge value -- U[nbr] + V[i] alone is a difference of
+ * two large products once neighbours are close in feature space, and picks other max-pool winners than the fp64 evaluation */
+int pcl_edgeconv_gather_hilo_f32(const float* UV, const float* UVlo, const int32_t* idx, int B, int N, int k, int C, float* ymax, float* ymin,
+                                 int32_t* jmax, int32_t* jmin, double* stats_ws, float* sumU, void* stream);
 /* backward = 0: W = [Wa | Wb] [Co][2C] -> Wcat = [Wa ; Wb - Wa] [2Co][C] (the weight of the per-point GEMM UV = x Wcat^T);
  * backward = 1: dWcat [2Co][C] -> dW [Co][2C] (dWa = top - bottom, dWb = bottom). */
 /* reference: the 1x1 conv over [x_nbr - x_i, x_i] of get_graph_feature + conv, networks/cls/dgcnn.py:29-50,:100-111 */
@@ -542,7 +547,8 @@ int pcl_frag_stat_rows(int P);
 int pcl_frag_max_rows(void);
 void pcl_frag_set_tuning(int max_rows, int force_tn, int force_ksw, int dw_tm, int dw_tn, int dw_ksw, int dw_ksg);
 int pcl_frag_linear_fwd_f32(const float* X, int ldx, const float* W, int ldw, const float* bias, const float* in_scale,
-                            const float* in_shift, float in_slope, int P, int Cin, int Cout, float* Y, int ldy, double* stats_ws,
+                            const float* in_shift, float in_slope, int P, int Cin, int Cout, float* Y, int ldy,
+                            float* Y_lo /* NULL, or (flush_k != 0) [P][ldy]: Y + Y_lo = the fp64 sum to ~2^-48 */, double* stats_ws,
                             int flush_k, void* stream);
 int pcl_frag_dy_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2, const float* mu,
                     const int32_t* arg, const float* gz, int ns, int P, int C, float* dy, uint32_t* zero_words, int n_zero, void* stream);

@@ -47,16 +47,20 @@ ABS_FLOOR = 1e-6
 # Caps (round 4): the measured value of the row + 25 % (profiles/r04_parity_reports.txt), per row -- not one roomy number per network.
 _WF1 = ("feature propagation stacks 2-3 more BatchNorm'd layers on the encoder's output (up to 14 BatchNorms deep); each divides the "
         "accumulated rounding by the batch std.  Even the fp64-accumulating / fp32-storage pipeline is beyond 1e-5 at fp1 and the logits "
-        "(printed as 'fp32-storage floor'); fp32 accumulation -- MFMA chains here, blocked sgemm in PyTorch-CPU, cuBLAS under Jittor -- adds "
-        "the rest in every layer below, and both fp32 pipelines land at 6-9 x the bound")
+        "(printed as 'fp32-storage floor').  Round 5: the decoder's own GEMMs accumulate in fp64 (chains of 32 fp32 terms), which took the rows "
+        "from 6-8 x the bound (PyTorch-CPU fp32: 6-9 x) to 3-6 x; the remainder is the set-abstraction levels' fp32 chains (K = 64 .. 128 on "
+        "10^5 .. 10^6 duplicate-compacted rows, 0.4 x the bound at SA2's output) amplified by the decoder's BatchNorms")
 _WF2 = ("PointConv multiplies the BatchNorm'd features by a learned inverse-density scale and sums 16 x ns products per output before "
         "another BatchNorm: storage rounding of three BatchNorm'd factors, amplified by 1/std of a 16C-wide linear layer; the HIP path sits "
         "ON the fp32-storage floor of these rows, the PyTorch-CPU fp32 restatement 2-3 x above it")
 FEATURE_WAIVERS = [
-    ("PointNet++ part-seg*", "fp3 output", ("W-F1 decoder depth", 4.1, _WF1)),      # measured 3.24 (MSG) / 2.48 (SSG)
-    ("PointNet++ part-seg*", "fp2 output", ("W-F1 decoder depth", 4.6, _WF1)),      # 3.62 / 3.61
-    ("PointNet++ part-seg*", "fp1 output", ("W-F1 decoder depth", 10.1, _WF1)),     # 8.03 / 7.73
-    ("PointNet++ part-seg*", "logits*", ("W-F1 decoder depth", 8.1, "same chain, two layers further")),      # 6.27 / 6.42
+    # round 5: the forward GEMMs of the GroupAll level, the decoder and the head sum fp32 chains of 32 terms in fp64 (csrc/frag.hip) -- every
+    # module's LOCAL error is at 0.06-0.24 x the bound (tools/dbg/partseg_local_err.py, profiles/r05_partseg_local_error_*.txt); what is left
+    # is the encoder's 0.4 x amplified 5 x by fp3 and 2.6 x by fp1.  Caps = the larger of the two variants' measured values + 25 %.
+    ("PointNet++ part-seg*", "fp3 output", ("W-F1 decoder depth", 2.5, _WF1)),      # measured 1.97 (MSG) / 1.96 (SSG); round 4: 3.24 / 2.48
+    ("PointNet++ part-seg*", "fp2 output", ("W-F1 decoder depth", 3.0, _WF1)),      # 1.80 / 2.39; round 4: 3.62 / 3.61
+    ("PointNet++ part-seg*", "fp1 output", ("W-F1 decoder depth", 7.8, _WF1)),      # 5.04 / 6.22 (4.73 - 6.22 over flush lengths); round 4: 8.03 / 7.73
+    ("PointNet++ part-seg*", "logits*", ("W-F1 decoder depth", 5.9, "same chain, two layers further")),      # 3.19 / 4.28 - 4.66; round 4: 6.27 / 6.42
     ("PointConv part-seg*", "logits*",
      ("W-F2 density product", 50.0,           # measured 39.9; fp32-storage floor 42.7; PyTorch-CPU fp32 81.9
       "eight PointConv levels in sequence (four set abstractions, four interpolations), each with the three-factor product of W-F2 and "

@@ -92,6 +92,7 @@ _SIGS = {
     "pcl_edgeconv_stat_rows": (c_int, [c_int, c_int]),
     "pcl_edgeconv_wcat_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "pcl_edgeconv_gather_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "pcl_edgeconv_gather_hilo_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "pcl_edgeconv_scatter_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "pcl_knn_transpose_i32": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "pcl_pointconv_contract_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
@@ -123,7 +124,7 @@ _SIGS = {
     "pcl_frag_stat_rows": (c_int, [c_int]),
     "pcl_frag_max_rows": (c_int, []),
     "pcl_frag_set_tuning": (None, [c_int] * 7),
-    "pcl_frag_linear_fwd_f32": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_float, c_int, c_int, c_int, _P, c_int, _P, c_int, _P]),
+    "pcl_frag_linear_fwd_f32": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_float, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P]),
     "pcl_frag_dy_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "pcl_frag_linear_bwd_dx_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_float, _P, c_int, _P, c_int, _P]),
     "pcl_frag_dw_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

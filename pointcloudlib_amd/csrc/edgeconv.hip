@@ -25,8 +25,14 @@ namespace pcl {
 
 constexpr int EC_PB = 32;        // points per workgroup == BatchNorm partial rows per 32 points
 
-// UV [B*N, 2C] (U | V), idx [B*N, k] (neighbour index within the cloud)
-__global__ __launch_bounds__(256) void edgeconv_gather_kernel(const float* __restrict__ UV, const int32_t* __restrict__ idx,
+// UV [B*N, 2C] (U | V), idx [B*N, k] (neighbour index within the cloud).
+// HILO (round 5): UVlo [B*N, 2C] holds the residuals of U | V (pcl_frag_linear_fwd_f32's Y_lo: U = UV + UVlo to ~2^-48).  y = U[nbr] + V[i]
+// is a DIFFERENCE of two large products when neighbours are close in feature space (y = Wa (x_nbr - x_i) + Wb x_i with |Wa x| >> |Wa (x_nbr
+// - x_i)| in the later stages): the fp32 rounding of U and V, each relative to |U|, is what an fp32 y is then uncertain by -- several times
+// the rounding of a y formed from the edge itself, and enough to pick other max-pool winners than the fp64 evaluation does more often
+// than the edge form does.  With the residuals y = (U + V) + (Ulo + Vlo) is the fp32 rounding of the exact edge value.
+template <bool HILO>
+__global__ __launch_bounds__(256) void edgeconv_gather_kernel(const float* __restrict__ UV, const float* __restrict__ UVlo, const int32_t* __restrict__ idx,
                                                               int N, int k, int C, size_t P /* B*N */, float* __restrict__ ymax,
                                                               float* __restrict__ ymin, int32_t* __restrict__ jmax,
                                                               int32_t* __restrict__ jmin, double* __restrict__ stats,
@@ -45,29 +51,37 @@ __global__ __launch_bounds__(256) void edgeconv_gather_kernel(const float* __res
         if (p >= P) break;
         const size_t base = (p / N) * N;             // first point of this cloud
         const float v = UV[p * 2 * C + C + c];
+        const float vlo = HILO ? UVlo[p * 2 * C + C + c] : 0.f;
         const int32_t* I = idx + p * k;
         float vmax = -INFINITY, vmin = INFINITY;
         int imax = 0, imin = 0;
         double s = 0.0, q = 0.0;
         float su = 0.f;
         int j = 0;
-        constexpr int GF = 10;                       // gathers in flight per lane (k = 20 / 40: whole rounds): 4 -> 10 took the C = 256 stage
+        constexpr int GF = HILO ? 5 : 10;            // gathers in flight per lane (k = 20 / 40: whole rounds): 4 -> 10 took the C = 256 stage
         for (; j + GF <= k; j += GF) {               // from 167 to 137 us -- the kernel waits on L2 round trips, not on bandwidth
-            float u[GF];
+            float u[GF], ul[HILO ? GF : 1];
 #pragma unroll
-            for (int t = 0; t < GF; ++t) u[t] = UV[(base + I[j + t]) * 2 * C + c];
+            for (int t = 0; t < GF; ++t) {
+                const size_t o = (base + I[j + t]) * 2 * C + c;
+                u[t] = UV[o];
+                if constexpr (HILO) ul[t] = UVlo[o];
+            }
 #pragma unroll
             for (int t = 0; t < GF; ++t) {
                 su += u[t];
-                const float y = u[t] + v;
+                float y = u[t] + v;
+                if constexpr (HILO) y += ul[t] + vlo;
                 s += (double)y; q += (double)y * (double)y;
                 if (y > vmax) { vmax = y; imax = j + t; }
                 if (y < vmin) { vmin = y; imin = j + t; }
             }
         }
         for (; j < k; ++j) {
-            const float u = UV[(base + I[j]) * 2 * C + c];
-            const float y = u + v;
+            const size_t o = (base + I[j]) * 2 * C + c;
+            const float u = UV[o];
+            float y = u + v;
+            if constexpr (HILO) y += UVlo[o] + vlo;
             su += u;
             s += (double)y; q += (double)y * (double)y;
             if (y > vmax) { vmax = y; imax = j; }
@@ -377,9 +391,20 @@ extern "C" int pcl_edgeconv_gather_f32(const float* UV, const int32_t* idx, int 
     PCL_REQUIRE(B >= 1 && N >= 1 && k >= 1 && k <= N && C >= 1 && C <= 2048, "pcl_edgeconv_gather_f32: bad sizes B=%d N=%d k=%d C=%d", B, N, k, C);
     const size_t P = (size_t)B * N;
     const int blocks = pcl_edgeconv_stat_rows(B, N);
-    hipLaunchKernelGGL(edgeconv_gather_kernel, dim3(blocks), dim3(256), sizeof(double) * 2 * C, as_stream(stream), UV, idx, N, k, C, P,
+    hipLaunchKernelGGL(edgeconv_gather_kernel<false>, dim3(blocks), dim3(256), sizeof(double) * 2 * C, as_stream(stream), UV, (const float*)nullptr, idx, N, k, C, P,
                        ymax, ymin, jmax, jmin, stats_ws, sumU);
     return check_launch("pcl_edgeconv_gather_f32");
+}
+
+extern "C" int pcl_edgeconv_gather_hilo_f32(const float* UV, const float* UVlo, const int32_t* idx, int B, int N, int k, int C, float* ymax, float* ymin,
+                                            int32_t* jmax, int32_t* jmin, double* stats_ws, float* sumU, void* stream) {
+    PCL_REQUIRE(UV && UVlo && idx && ymax && ymin && jmax && jmin && stats_ws, "pcl_edgeconv_gather_hilo_f32: null pointer");
+    PCL_REQUIRE(B >= 1 && N >= 1 && k >= 1 && k <= N && C >= 1 && C <= 2048, "pcl_edgeconv_gather_hilo_f32: bad sizes B=%d N=%d k=%d C=%d", B, N, k, C);
+    const size_t P = (size_t)B * N;
+    const int blocks = pcl_edgeconv_stat_rows(B, N);
+    hipLaunchKernelGGL(edgeconv_gather_kernel<true>, dim3(blocks), dim3(256), sizeof(double) * 2 * C, as_stream(stream), UV, UVlo, idx, N, k, C, P,
+                       ymax, ymin, jmax, jmin, stats_ws, sumU);
+    return check_launch("pcl_edgeconv_gather_hilo_f32");
 }
 
 extern "C" int pcl_knn_transpose_i32(const int32_t* idx, int B, int N, int k, int32_t* in_off, int32_t* in_src, void* stream) {

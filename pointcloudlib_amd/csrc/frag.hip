@@ -74,6 +74,7 @@ struct GemmArgs {
     const float* bias;                        // [N] or null
     const float* asc; const float* ash; float aslope;      // ACT: A element k becomes lrelu(asc[k] * x + ash[k])
     float* C; int ldc;                        // [M][ldc], columns n_begin .. N written
+    float* Clo;                               // FLUSH only, optional: the fp64 sum's residual, C + Clo = the sum to ~2^-48 (same layout as C)
     double* stats;                            // EP_STATS / EP_MASK_STATS: [nrt][2][N] fp64 (sum c, sum c^2 | sum c * yprev), or null
     const float* Yp; int ldyp;                // EP_MASK_STATS: pre-BatchNorm output of the layer below [M][ldyp]
     const float* esc; const float* esh; float eslope;      //                 and its folded BatchNorm
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(1024) void frag_gemm_kernel(const GemmArgs p) {
     if (ks == 0) {
         const unsigned ldc_b = (unsigned)p.ldc * 4;
         const rsrc_t rC = rsrc(p.C, (size_t)(m0 + wr * 32) * ldc_b, (size_t)p.M * ldc_b);
+        const rsrc_t rLo = rsrc(F64 && p.Clo ? p.Clo : p.C, (size_t)(m0 + wr * 32) * ldc_b, F64 && p.Clo ? (size_t)p.M * ldc_b : 0);
         const bool full_rows = m0 + wr * 32 + 32 <= p.M;
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
@@ -267,8 +269,11 @@ __global__ __launch_bounds__(1024) void frag_gemm_kernel(const GemmArgs p) {
             for (int i = 0; i < 16; ++i) {
                 const int rl = (i & 3) + 8 * (i >> 2);
                 float c;
-                if constexpr (F64) c = (float)(accd[t][i] + (double)bias);
-                else c = acc[t][i] + bias;
+                if constexpr (F64) {
+                    const double cd = accd[t][i] + (double)bias;
+                    c = (float)cd;
+                    if (p.Clo) st1(rLo, vC, (unsigned)rl * ldc_b, (float)(cd - (double)c));
+                } else c = acc[t][i] + bias;
                 if constexpr (EP == EP_MASK_STATS) c = fmaf(esc, yv[i], esh) > 0.f ? c : c * p.eslope;
                 st1(rC, vC, (unsigned)rl * ldc_b, c);
                 if constexpr (EP != EP_STORE) {
@@ -617,7 +622,7 @@ extern "C" int pcl_frag_stat_rows(int P) { return P < 1 ? 1 : frag_stat_rows(P);
 static bool small_enough(const void* base, size_t bytes) { (void)base; return bytes < 0x7fffffffull; }
 
 extern "C" int pcl_frag_linear_fwd_f32(const float* X, int ldx, const float* W, int ldw, const float* bias, const float* in_scale,
-                                       const float* in_shift, float in_slope, int P, int Cin, int Cout, float* Y, int ldy, double* stats_ws,
+                                       const float* in_shift, float in_slope, int P, int Cin, int Cout, float* Y, int ldy, float* Y_lo, double* stats_ws,
                                        int flush_k, void* stream) {
     PCL_REQUIRE(X && W && Y, "pcl_frag_linear_fwd_f32: null pointer");
     PCL_REQUIRE(P >= 1 && Cin >= 1 && Cout >= 1 && ldx >= Cin && ldw >= Cin && ldy >= Cout, "pcl_frag_linear_fwd_f32: bad sizes P=%d Cin=%d Cout=%d ldx=%d ldw=%d ldy=%d", P, Cin,
@@ -628,10 +633,11 @@ extern "C" int pcl_frag_linear_fwd_f32(const float* X, int ldx, const float* W, 
     PCL_REQUIRE(small_enough(X, (size_t)P * ldx * 4) && small_enough(W, (size_t)Cout * ldw * 4) && small_enough(Y, (size_t)P * ldy * 4),
                 "pcl_frag_linear_fwd_f32: operands beyond 2 GiB take the staged kernels");
     PCL_REQUIRE(Cin <= 8192, "pcl_frag_linear_fwd_f32: Cin = %d (the folded BatchNorm of the input lives in LDS: <= 8192)", Cin);
+    PCL_REQUIRE(!Y_lo || flush_k != 0, "pcl_frag_linear_fwd_f32: Y_lo (the residual of the fp64 sum) needs flush_k = 8 or 32");
     hipStream_t st = as_stream(stream);
     GemmArgs g = {};
     g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.bias = bias; g.asc = in_scale; g.ash = in_shift; g.aslope = in_slope;
-    g.C = Y; g.ldc = ldy; g.stats = stats_ws; g.M = P; g.N = Cout; g.K = Cin; g.n_begin = 0;
+    g.C = Y; g.ldc = ldy; g.Clo = Y_lo; g.stats = stats_ws; g.M = P; g.N = Cout; g.K = Cin; g.n_begin = 0;
     const bool act = in_scale != nullptr;
 #define FWD(FL) do { if (stats_ws) { if (act) launch_gemm<FL, true, false, EP_STATS>(g, st, g_force_tn, g_force_ksw); else launch_gemm<FL, false, false, EP_STATS>(g, st, g_force_tn, g_force_ksw); } \
                      else { if (act) launch_gemm<FL, true, false, EP_STORE>(g, st, g_force_tn, g_force_ksw); else launch_gemm<FL, false, false, EP_STORE>(g, st, g_force_tn, g_force_ksw); } } while (0)

@@ -2667,8 +2667,8 @@ static int launch_linear_t(const LinArgs& a_in, hipStream_t st) {
     if constexpr (GM == 0) {                   // matrix-bound shapes: fp32 operands as three bf16 planes on the bf16 matrix pipe
         if (vec && (g_split_mfma & 2) && a.K >= g_split_min_k) {
             if (!RAG && low) PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 1, 0, false, 1, true>), grid, dim3(MLP_T), st, a);
-            else if (narrow) PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 1, 0, RAG, 2, true>), grid, dim3(MLP_T), st, a);
-            else PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 2, 0, RAG, 2, true>), grid, dim3(MLP_T), st, a);
+            else if (narrow || AM >= A_DY) PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 1, 0, RAG, 2, true>), grid, dim3(MLP_T), st, a);
+            else { if constexpr (AM < A_DY) PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 2, 0, RAG, 2, true>), grid, dim3(MLP_T), st, a); }
             return check_launch("pcl_linear(split)");
         }
     }
@@ -2679,12 +2679,16 @@ static int launch_linear_t(const LinArgs& a_in, hipStream_t st) {
             return check_launch("pcl_linear");
         }
     }
-    if (narrow) {
+    // (the backward loaders always take 64-column tiles -- linear_grid: `narrow = ... || bwd` -- so their 128-column instantiations, which
+    //  spilled up to 224 registers, are not compiled at all: round 5)
+    if (narrow || AM >= A_DY) {
         if (vec) PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 1, GM, RAG>), grid, dim3(MLP_T), st, a);
         else PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, false, 1, GM, RAG>), grid, dim3(MLP_T), st, a);
     } else {
-        if (vec) PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 2, GM, RAG>), grid, dim3(MLP_T), st, a);
-        else PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, false, 2, GM, RAG>), grid, dim3(MLP_T), st, a);
+        if constexpr (AM < A_DY) {
+            if (vec) PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 2, GM, RAG>), grid, dim3(MLP_T), st, a);
+            else PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, false, 2, GM, RAG>), grid, dim3(MLP_T), st, a);
+        }
     }
     return check_launch("pcl_linear");
 }

@@ -279,7 +279,7 @@ extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
                 tagf("pt%dx%d", d.Cf, cout);
                 // (a conv bias of the folded layer is added here, once per point: every row gathers exactly one Uf row)
                 if (d.flush_k) PCL_TRY(pcl_frag_linear_fwd_f32(d.feature, d.Cf, d.Wf_dense, d.Cf, ly.bias, nullptr, nullptr, 0.f, d.B * d.N, d.Cf, cout, t.Uf, cout,
-                                                               nullptr, d.flush_k, st));
+                                                               nullptr, nullptr, d.flush_k, st));
                 else PCL_TRY(pcl_linear_fwd_rows_f32(d.feature, d.Wf_dense, ly.bias, nullptr, nullptr, 0.f, d.B * d.N, d.Cf, cout, t.Uf,
                                                      t.pt_stats, nullptr, nullptr, st));
             }
@@ -296,7 +296,7 @@ extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
             rows = pcl_mlp_stat_rows(P, cout, 0);
         } else if (frag_fwd(d)) {
             tagf("fwd%dx%d", cin, cout);
-            PCL_TRY(pcl_frag_linear_fwd_f32(cur, cin, ly.W, cin, ly.bias, in_scale, in_shift, d.slope, P, cin, cout, Y, cout, t.stats, d.flush_k, st));
+            PCL_TRY(pcl_frag_linear_fwd_f32(cur, cin, ly.W, cin, ly.bias, in_scale, in_shift, d.slope, P, cin, cout, Y, cout, nullptr, t.stats, d.flush_k, st));
             rows = pcl_frag_stat_rows(P);
         } else {
             tagf("fwd%dx%d", cin, cout);

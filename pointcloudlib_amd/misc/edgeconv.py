@@ -19,7 +19,7 @@ class _EdgeConvPool(torch.autograd.Function):
     """UV [B,N,2C] (U | V), idx [B,N,k] -> max_j lrelu(BN(U[idx[.,j]] + V)) [B,N,C]."""
 
     @staticmethod
-    def forward(ctx, UV, idx, gamma, beta, rmean, rvar, cfg):
+    def forward(ctx, UV, idx, gamma, beta, rmean, rvar, cfg, UVlo=None):
         slope, eps, momentum, training = cfg
         UV = _dev(UV, "UV")
         idx = _dev(idx, "idx", torch.int32)
@@ -34,8 +34,12 @@ class _EdgeConvPool(torch.autograd.Function):
         jmax, jmin = torch.empty((G, C), dtype=torch.int32, device=dev), torch.empty((G, C), dtype=torch.int32, device=dev)
         need_grad = ctx.needs_input_grad[0]
         sumU = torch.empty((G, C), device=dev) if need_grad else None          # SU[i] = sum_j U[nbr(i,j)] for the backward
-        _lib.call("pcl_edgeconv_gather_f32", _p(UV), _p(idx), B, N, k, C, _p(ymax), _p(ymin), _p(jmax), _p(jmin), _p(stats),
-                  _p(sumU), st, algo_bytes=4 * G * (2 * C + k + 4 * C), tag=f"edge{C}")
+        if UVlo is not None:
+            _lib.call("pcl_edgeconv_gather_hilo_f32", _p(UV), _p(UVlo), _p(idx), B, N, k, C, _p(ymax), _p(ymin), _p(jmax), _p(jmin), _p(stats),
+                      _p(sumU), st, algo_bytes=4 * G * (4 * C + k + 4 * C), tag=f"edge{C}")
+        else:
+            _lib.call("pcl_edgeconv_gather_f32", _p(UV), _p(idx), B, N, k, C, _p(ymax), _p(ymin), _p(jmax), _p(jmin), _p(stats),
+                      _p(sumU), st, algo_bytes=4 * G * (2 * C + k + 4 * C), tag=f"edge{C}")
         in_off = in_src = None
         if need_grad and N <= 8192:
             # the neighbour lists transposed (who points at me), once per graph: the backward sums over them without atomics
@@ -94,7 +98,7 @@ class _EdgeConvPool(torch.autograd.Function):
         lists = in_off is not None
         _lib.call("pcl_edgeconv_scatter_f32", _p(UV), _p(idx), _p(gz), _p(arg), _p(a), _p(k1), _p(k2), _p(mean), B, N, k, C,
                   _p(in_off), _p(in_src), _p(sumU) if lists else None, _p(dUV), st)
-        return dUV, None, dgamma, dbeta, None, None, None
+        return dUV, None, dgamma, dbeta, None, None, None, None
 
 
 class _PointLinear(torch.autograd.Function):
@@ -102,7 +106,7 @@ class _PointLinear(torch.autograd.Function):
     (forward, dX and dW); returns the gradient of W itself."""
 
     @staticmethod
-    def forward(ctx, x, W, flush_k=0):
+    def forward(ctx, x, W, flush_k=0, hilo=False):
         x = _dev(x, "x")
         B, N, C = x.shape
         Co = W.shape[0]
@@ -111,21 +115,28 @@ class _PointLinear(torch.autograd.Function):
         _lib.call("pcl_edgeconv_wcat_f32", _p(W.contiguous()), Co, C, 0, _p(Wcat), _stream())
         P = B * N
         UV = torch.empty((B, N, 2 * Co), device=dev)
+        UVlo = None
         if flush_k:
-            # y = U[nbr] + V decides the max-pool winners of the stage: with U | V from one fp32 fma chain per element the winners an
-            # fp32 evaluation picks differ from the fp64 ones more often than PyTorch-CPU's blocked sgemm does (stage 4, K = 128:
-            # DESIGN.md section 9.5c).  Chains of flush_k terms summed in fp64 bring U | V to the fp32 rounding of the exact product.
-            _lib.call("pcl_frag_linear_fwd_f32", _p(x), C, _p(Wcat), C, None, None, None, 0.0, P, C, 2 * Co, _p(UV), 2 * Co, None, int(flush_k), _stream(),
-                      tag=f"uv{C}x{2 * Co}")
+            # y = U[nbr] + V decides the max-pool winners of the stage.  Chains of flush_k terms summed in fp64 give U | V as the fp32
+            # rounding of the exact product and, with ``hilo``, its residual (UVlo): the gather then forms y from both (csrc/edgeconv.hip:
+            # HILO) -- the fp32 rounding of the exact edge value; against fp64 on EQUAL inputs a stage is then 100 x closer than the edge
+            # form in PyTorch-CPU fp32 (tools/dbg/edgeconv_err.py), for +5 % of the DGCNN step: opt-in
+            if hilo:
+                UVlo = torch.empty((B, N, 2 * Co), device=dev)
+            _lib.call("pcl_frag_linear_fwd_f32", _p(x), C, _p(Wcat), C, None, None, None, 0.0, P, C, 2 * Co, _p(UV), 2 * Co, _p(UVlo), None, int(flush_k),
+                      _stream(), tag=f"uv{C}x{2 * Co}")
         else:
             rows = _lib.size_query("pcl_mlp_stat_rows", P, 2 * Co, 0)
             _lib.call("pcl_linear_fwd_rows_f32", _p(x), _p(Wcat), None, None, None, 0.0, P, C, 2 * Co, _p(UV),
                       _p(torch.empty((rows, 2, 2 * Co), dtype=torch.float64, device=dev)), None, None, _stream(), tag=f"uv{C}x{2 * Co}")
         ctx.save_for_backward(x, Wcat)
+        if UVlo is not None:
+            ctx.mark_non_differentiable(UVlo)
+            return UV, UVlo
         return UV
 
     @staticmethod
-    def backward(ctx, dUV):
+    def backward(ctx, dUV, *unused):
         x, Wcat = ctx.saved_tensors
         B, N, C = x.shape
         C2 = Wcat.shape[0]
@@ -150,7 +161,7 @@ class _PointLinear(torch.autograd.Function):
             dx = torch.empty((B, N, C), device=dev)
             _lib.call("pcl_linear_bwd_dx_rows_f32", _p(dUV), _p(dUV), _p(one), _p(zero), _p(zero), _p(zero), None, None, 1, _p(Wcat),
                       P, C2, C, None, None, None, 0.0, _p(dx), None, None, None, 0, 0, st, tag=f"uvdx{C2}x{C}")
-        return dx, dW, None
+        return dx, dW, None, None
 
 
 def edge_conv(mlp, x, idx):
@@ -159,9 +170,12 @@ def edge_conv(mlp, x, idx):
     the plain-PyTorch backend (tests) and anything that is not a single bias-free conv+BN layer build the edge tensor."""
     k = idx.shape[2]
     if mlp.resolved_backend(x) == "hip" and mlp.n_layers == 1 and mlp.bn and mlp.biases is None and mlp.last_act:
-        UV = _PointLinear.apply(x, mlp.weights[0], int(getattr(mlp, "flush_k", 0)))     # one GEMM over the points
+        flush_k = int(getattr(mlp, "flush_k", 0))
+        hilo = bool(flush_k) and bool(getattr(mlp, "edge_hilo", False))
+        UV = _PointLinear.apply(x, mlp.weights[0], flush_k, hilo)             # one GEMM over the points
+        UV, UVlo = UV if hilo else (UV, None)
         cfg = (mlp.slope, mlp.eps, mlp.momentum, mlp.training)
-        return _EdgeConvPool.apply(UV, idx, mlp.gammas[0], mlp.betas[0], mlp.running_mean_0, mlp.running_var_0, cfg)
+        return _EdgeConvPool.apply(UV, idx, mlp.gammas[0], mlp.betas[0], mlp.running_mean_0, mlp.running_var_0, cfg, UVlo)
     return mlp(edge_features(x, idx), group_max=k)
 
 

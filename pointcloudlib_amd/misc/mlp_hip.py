@@ -120,7 +120,7 @@ class _FusedMLP(torch.autograd.Function):
                 pass                       # nothing to launch: the grouping kernel already produced Y and its sums
             elif flushed:
                 _lib.call("pcl_frag_linear_fwd_f32", _P(cur), cin, _P(W), cin, _P(bias), _P(in_scale), _P(in_shift), slope, P, cin, cout, _P(Y), cout,
-                          _P(stats), flush_k, st, algo_bytes=4 * P * (cin + cout) + 4 * cin * cout, algo_flops=2 * P * cin * cout, tag=f"fwd{cin}x{cout}")
+                          None, _P(stats), flush_k, st, algo_bytes=4 * P * (cin + cout) + 4 * cin * cout, algo_flops=2 * P * cin * cout, tag=f"fwd{cin}x{cout}")
             elif fused_max:      # last layer of a max-pooled stack: per-group min/max come out of the GEMM epilogue
                 G = P // ns
                 gmax, gmin = _empty((G, cout), dev), _empty((G, cout), dev)

@@ -49,8 +49,11 @@ class DGCNN(nn.Module):
         self.conv4 = PointwiseMLP([128 * 2, 256], slope=0.2)
         self.conv5 = PointwiseMLP([512, 1024], slope=0.2)
         # U | V of the EdgeConv stages decide the max-pool winners: chains of 8 terms summed in fp64 (misc/edgeconv.py: _PointLinear)
+        # (PCL_DGCNN_HILO=1 also carries the products' residuals into the gather: exact on equal inputs, +5 % per step -- misc/edgeconv.py)
         for c in (self.conv1, self.conv2, self.conv3, self.conv4):
             c.flush_k = int(os.environ.get("PCL_DGCNN_FLUSH", "8"))
+            c.edge_hilo = os.environ.get("PCL_DGCNN_HILO", "0") != "0"
+
         self.linear1 = nn.Linear(1024 * 2, 512, bias=False)
         self.bn6 = nn.BatchNorm1d(512)
         self.dp1 = nn.Dropout(p=0.5)

@@ -42,7 +42,7 @@ def fwd(dev, X, W, bias, sc, sh, slope, flush=0, stats=True, ldx=None, ldw=None,
     rows = _lib.size_query("pcl_frag_stat_rows", P)
     st = torch.zeros((rows, 2, N), dtype=torch.float64, device=dev) if stats else None
     bd, scd, shd = (None if t is None else t.to(dev) for t in (bias, sc, sh))        # (kept alive across the call)
-    _lib.call("pcl_frag_linear_fwd_f32", _p(Xd), ldx, _p(Wd), ldw, _p(bd), _p(scd), _p(shd), float(slope), P, K, N, _p(Y), ldy, _p(st), flush, _st())
+    _lib.call("pcl_frag_linear_fwd_f32", _p(Xd), ldx, _p(Wd), ldw, _p(bd), _p(scd), _p(shd), float(slope), P, K, N, _p(Y), ldy, None, _p(st), flush, _st())
     torch.cuda.synchronize()
     return Y.cpu(), (None if st is None else st.sum(0).cpu())
 

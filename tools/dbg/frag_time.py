@@ -39,11 +39,11 @@ def main():
             t0 = timeit(lambda: _lib.call("pcl_linear_fwd_rows_f32", _p(X), _p(W), None, _p(sc), _p(sh), 0.0, P, K, N, _p(Y), _p(st_s), None, None, st()))
             res = [f"staged {t0:6.1f} us ({gf / t0:5.1f} TF)"]
             for flush in (0, 32, 8):
-                t1 = timeit(lambda: _lib.call("pcl_frag_linear_fwd_f32", _p(X), K, _p(W), K, None, _p(sc), _p(sh), 0.0, P, K, N, _p(Y), N, _p(st_s), flush, st()))
+                t1 = timeit(lambda: _lib.call("pcl_frag_linear_fwd_f32", _p(X), K, _p(W), K, None, _p(sc), _p(sh), 0.0, P, K, N, _p(Y), N, None, _p(st_s), flush, st()))
                 res.append(f"frag/{flush} {t1:6.1f} us ({gf / t1:5.1f} TF)")
             for tn, ksw in ((1, 1), (1, 2), (1, 4), (2, 1), (2, 2)):
                 L.pcl_frag_set_tuning(-1, tn, ksw, 0, 0, 0, 0)
-                t1 = timeit(lambda: _lib.call("pcl_frag_linear_fwd_f32", _p(X), K, _p(W), K, None, _p(sc), _p(sh), 0.0, P, K, N, _p(Y), N, _p(st_s), 0, st()))
+                t1 = timeit(lambda: _lib.call("pcl_frag_linear_fwd_f32", _p(X), K, _p(W), K, None, _p(sc), _p(sh), 0.0, P, K, N, _p(Y), N, None, _p(st_s), 0, st()))
                 res.append(f"tn{tn}k{ksw} {t1:5.1f}")
             L.pcl_frag_set_tuning(-1, 0, 0, 0, 0, 0, 0)
             print(f"fwd {K:4d} -> {N:4d}: " + " | ".join(res))
