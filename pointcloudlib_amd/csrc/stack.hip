@@ -214,10 +214,186 @@ static void tagf(const char* fmt, int a, int b) {
     set_launch_tag(buf);
 }
 
+// ---- hidden widths the fast kernels do not have: run the stack zero-padded (round 5) ----------------------------------------------------
+// The MSG part-seg encoder has one stack [3, 64, 96, 128] on B*512*128 grouped rows (networks/seg/pointnet2_partseg.py:185-192).  The
+// resident-weight forward and the fused backward exist for widths 64 / 128 / 256; a 96-wide layer took the staged kernels (fwd64x96 +
+// fwd96x128 434 us, dx128x96 464, dw128x96 339, dx96x64 216, dw96x64 209 per step: 1.66 of cfg4's 6.1 ms, profiles/r04_cfg4_kernel_stats.csv).
+// A 96-wide layer IS a 128-wide layer whose last 32 output channels have zero weights, gamma = beta = 0: their pre-BatchNorm output is
+// exactly 0, scale = 0 * invstd = 0 and shift = 0, so the activation is exactly 0, the next layer's extra 32 weight columns multiply zeros,
+// every gradient of the pad is exactly 0, and the 96 real channels see the same fma chains with 32 zero terms appended -- the results
+// are those of the 96-wide stack, bit for bit per kernel.  One tiny launch builds the padded parameters (kept in `save` for the
+// backward), one copies the 96 real entries of the running statistics / the gradients back.  +33 % flops on two layers for kernels that
+// run 2-3 x faster.
+struct PadItem { const float* src; float* dst; int rows, cols, lds, ldd, rows_p, cols_p; };      // dst [rows_p][ldd] <- src [rows][lds], zero elsewhere (pad) or dst [rows][ldd] <- src (unpad: rows_p = cols_p = 0)
+struct PadTable { PadItem it[12]; int n; };
+__global__ __launch_bounds__(256) void pad_copy_kernel(const PadTable t) {
+    const PadItem q = t.it[blockIdx.y];
+    const bool unpad = q.rows_p == 0;
+    const int R = unpad ? q.rows : q.rows_p, C = unpad ? q.cols : q.cols_p;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < R * C; e += gridDim.x * 256) {
+        const int r = e / C, c = e - r * C;
+        q.dst[(size_t)r * q.ldd + c] = (r < q.rows && c < q.cols) ? q.src[(size_t)r * q.lds + c] : 0.f;
+    }
+}
+static int launch_pad(const PadTable& t, void* st) {
+    if (t.n == 0) return PCL_OK;
+    hipLaunchKernelGGL(pad_copy_kernel, dim3(16, t.n), dim3(256), 0, as_stream(st), t);
+    return check_launch("pcl_mlp_stack(pad)");
+}
+static inline int padded_width(const pcl_mlp_stack_t& d, int l) {
+    // hidden widths only (the input is the caller's, the output goes to the caller): 96 -> 128 where the row count makes the fast kernels matter
+    if (l >= 1 && l < d.n_layers && d.c[l] == 96 && d.P >= 32768 && !d.defer_act) return 128;
+    return d.c[l];
+}
+struct PadPlan {
+    bool on;
+    int cp[PCL_STACK_MAX_LAYERS + 1];
+    // scratch (floats), per layer: padded W, gamma, beta, running mean / var (in `save`, behind the padded stack's own layout) and padded
+    // dW, dgamma, dbeta, dbias (in the backward's `tmp`, behind the padded stack's own)
+    size_t w_off[PCL_STACK_MAX_LAYERS], v_off[PCL_STACK_MAX_LAYERS], save_floats;
+    size_t dw_off[PCL_STACK_MAX_LAYERS], dv_off[PCL_STACK_MAX_LAYERS], bwd_floats;
+    bool wpad[PCL_STACK_MAX_LAYERS], opad[PCL_STACK_MAX_LAYERS];      // layer l has a padded weight / padded output channels
+};
+static PadPlan pad_plan(const pcl_mlp_stack_t& d) {
+    PadPlan p = {};
+    const int L = d.n_layers;
+    for (int l = 0; l <= L; ++l) { p.cp[l] = padded_width(d, l); p.on = p.on || p.cp[l] != d.c[l]; }
+    if (!p.on) return p;
+    size_t so = 0, bo = 0;
+    auto take = [](size_t& o, size_t n) { const size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
+    for (int l = 0; l < L; ++l) {
+        p.opad[l] = p.cp[l + 1] != d.c[l + 1];
+        p.wpad[l] = p.opad[l] || p.cp[l] != d.c[l];
+        if (p.wpad[l]) { p.w_off[l] = take(so, (size_t)p.cp[l + 1] * p.cp[l]); p.dw_off[l] = take(bo, (size_t)p.cp[l + 1] * p.cp[l]); }
+        if (p.opad[l]) { p.v_off[l] = take(so, (size_t)5 * p.cp[l + 1]); p.dv_off[l] = take(bo, (size_t)3 * p.cp[l + 1]); }
+    }
+    p.save_floats = so; p.bwd_floats = bo;
+    return p;
+}
+// the padded descriptor: widths, and the padded layers' parameter / gradient pointers into the scratch regions
+static pcl_mlp_stack_t padded_desc(const pcl_mlp_stack_t& d, const PadPlan& p, float* save_x, float* bwd_x) {
+    pcl_mlp_stack_t q = d;
+    const int L = d.n_layers;
+    for (int l = 0; l <= L; ++l) q.c[l] = p.cp[l];
+    for (int l = 0; l < L; ++l) {
+        pcl_stack_layer_t& y = q.layer[l];
+        if (p.wpad[l]) { y.W = save_x + p.w_off[l]; y.dW = bwd_x ? bwd_x + p.dw_off[l] : nullptr; }
+        if (p.opad[l]) {
+            float* v = save_x + p.v_off[l];
+            const int cp = p.cp[l + 1];
+            y.gamma = v; y.beta = v + cp;
+            y.running_mean = d.layer[l].running_mean ? v + 2 * cp : nullptr; y.running_var = d.layer[l].running_var ? v + 3 * cp : nullptr;
+            y.bias = d.layer[l].bias ? v + 4 * cp : nullptr;
+            if (bwd_x) { float* g = bwd_x + p.dv_off[l]; y.dgamma = g; y.dbeta = g + cp; y.dbias = d.layer[l].bias ? g + 2 * cp : nullptr; }
+            else { y.dgamma = y.dbeta = y.dbias = nullptr; }
+        }
+    }
+    return q;
+}
+
 }  // namespace pcl
 using namespace pcl;
 
+static int stack_sizes_impl(const pcl_mlp_stack_t* d, size_t* save_bytes, size_t* fwd_tmp_bytes, size_t* bwd_tmp_bytes);
+static int stack_fwd_impl(const pcl_mlp_stack_t* dp);
+static int stack_bwd_impl(const pcl_mlp_stack_t* dp);
+
 extern "C" int pcl_mlp_stack_sizes(const pcl_mlp_stack_t* d, size_t* save_bytes, size_t* fwd_tmp_bytes, size_t* bwd_tmp_bytes) {
+    PCL_TRY(validate(d, "pcl_mlp_stack_sizes"));
+    const PadPlan p = narrow_supported(*d) ? PadPlan{} : pad_plan(*d);
+    if (!p.on) return stack_sizes_impl(d, save_bytes, fwd_tmp_bytes, bwd_tmp_bytes);
+    const pcl_mlp_stack_t q = padded_desc(*d, p, reinterpret_cast<float*>(uintptr_t(4096)), reinterpret_cast<float*>(uintptr_t(4096)));
+    size_t sv = 0, ft = 0, bt = 0;
+    PCL_TRY(stack_sizes_impl(&q, &sv, &ft, &bt));
+    if (save_bytes) *save_bytes = al256(sv) + p.save_floats * 4;
+    if (fwd_tmp_bytes) *fwd_tmp_bytes = ft;
+    if (bwd_tmp_bytes) *bwd_tmp_bytes = al256(bt) + p.bwd_floats * 4;
+    return PCL_OK;
+}
+
+extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
+    PCL_TRY(validate(dp, "pcl_mlp_stack_fwd_f32"));
+    const pcl_mlp_stack_t& d = *dp;
+    const PadPlan p = narrow_supported(d) ? PadPlan{} : pad_plan(d);
+    if (!p.on) return stack_fwd_impl(dp);
+    PCL_REQUIRE(d.save && d.tmp, "pcl_mlp_stack_fwd_f32: null save / tmp");
+    size_t sv = 0, ft = 0, bt = 0;
+    pcl_mlp_stack_t q = padded_desc(d, p, nullptr, nullptr);
+    {   // (sizes of the padded stack proper; its parameter pointers are patched below)
+        pcl_mlp_stack_t probe = padded_desc(d, p, reinterpret_cast<float*>(uintptr_t(4096)), nullptr);
+        PCL_TRY(stack_sizes_impl(&probe, &sv, &ft, &bt));
+    }
+    if (d.save_bytes < al256(sv) + p.save_floats * 4) return fail(PCL_EWS, "pcl_mlp_stack_fwd_f32: save %zu < %zu", d.save_bytes, al256(sv) + p.save_floats * 4);
+    float* sx = reinterpret_cast<float*>(static_cast<char*>(d.save) + al256(sv));
+    q = padded_desc(d, p, sx, nullptr);
+    q.save_bytes = sv;
+    PadTable t = {};
+    const int L = d.n_layers;
+    for (int l = 0; l < L; ++l) {
+        const pcl_stack_layer_t& y = d.layer[l];
+        if (p.wpad[l]) t.it[t.n++] = PadItem{y.W, sx + p.w_off[l], d.c[l + 1], d.c[l], d.c[l], p.cp[l], p.cp[l + 1], p.cp[l]};
+        if (p.opad[l]) {
+            float* v = sx + p.v_off[l];
+            const int c = d.c[l + 1], cp = p.cp[l + 1];
+            // gamma | beta | running mean | running var | bias: five rows of one [5][cp] block; absent ones are copied from gamma (never read)
+            const float* srcs[5] = {y.gamma, y.beta, y.running_mean, y.running_var, y.bias};
+            for (int k = 0; k < 5; ++k) if (srcs[k]) t.it[t.n++] = PadItem{srcs[k], v + (size_t)k * cp, 1, c, c, cp, 1, cp};
+        }
+        PCL_REQUIRE(t.n <= 12, "pcl_mlp_stack_fwd_f32: more padded layers than the pad table holds");
+    }
+    PCL_TRY(launch_pad(t, d.stream));
+    PCL_TRY(stack_fwd_impl(&q));
+    // the running statistics of the padded layers: their real entries back to the caller's buffers
+    PadTable u = {};
+    for (int l = 0; l < L; ++l) {
+        if (!p.opad[l]) continue;
+        const pcl_stack_layer_t& y = d.layer[l];
+        float* v = sx + p.v_off[l];
+        const int c = d.c[l + 1], cp = p.cp[l + 1];
+        if (y.running_mean) u.it[u.n++] = PadItem{v + 2 * (size_t)cp, y.running_mean, 1, c, cp, c, 0, 0};
+        if (y.running_var) u.it[u.n++] = PadItem{v + 3 * (size_t)cp, y.running_var, 1, c, cp, c, 0, 0};
+    }
+    return launch_pad(u, d.stream);
+}
+
+extern "C" int pcl_mlp_stack_bwd_f32(const pcl_mlp_stack_t* dp) {
+    PCL_TRY(validate(dp, "pcl_mlp_stack_bwd_f32"));
+    const pcl_mlp_stack_t& d = *dp;
+    const PadPlan p = narrow_supported(d) ? PadPlan{} : pad_plan(d);
+    if (!p.on) return stack_bwd_impl(dp);
+    PCL_REQUIRE(d.save && d.tmp, "pcl_mlp_stack_bwd_f32: null save / tmp");
+    const int L = d.n_layers;
+    for (int l = 0; l < L; ++l)
+        PCL_REQUIRE(d.layer[l].dW && d.layer[l].dgamma && d.layer[l].dbeta && (!d.layer[l].bias || d.layer[l].dbias), "pcl_mlp_stack_bwd_f32: layer %d: null gradient output", l);
+    size_t sv = 0, ft = 0, bt = 0;
+    {
+        pcl_mlp_stack_t probe = padded_desc(d, p, reinterpret_cast<float*>(uintptr_t(4096)), reinterpret_cast<float*>(uintptr_t(4096)));
+        PCL_TRY(stack_sizes_impl(&probe, &sv, &ft, &bt));
+    }
+    if (d.save_bytes < al256(sv) + p.save_floats * 4 || d.tmp_bytes < al256(bt) + p.bwd_floats * 4)
+        return fail(PCL_EWS, "pcl_mlp_stack_bwd_f32: save %zu < %zu or tmp %zu < %zu", d.save_bytes, al256(sv) + p.save_floats * 4, d.tmp_bytes, al256(bt) + p.bwd_floats * 4);
+    float* sx = reinterpret_cast<float*>(static_cast<char*>(d.save) + al256(sv));      // padded parameters: written by the forward
+    float* bx = reinterpret_cast<float*>(static_cast<char*>(d.tmp) + al256(bt));
+    pcl_mlp_stack_t q = padded_desc(d, p, sx, bx);
+    q.save_bytes = sv; q.tmp_bytes = bt;
+    PCL_TRY(stack_bwd_impl(&q));
+    PadTable u = {};
+    for (int l = 0; l < L; ++l) {
+        const pcl_stack_layer_t& y = d.layer[l];
+        if (p.wpad[l]) u.it[u.n++] = PadItem{bx + p.dw_off[l], y.dW, d.c[l + 1], d.c[l], p.cp[l], d.c[l], 0, 0};
+        if (p.opad[l]) {
+            float* g = bx + p.dv_off[l];
+            const int c = d.c[l + 1], cp = p.cp[l + 1];
+            u.it[u.n++] = PadItem{g, y.dgamma, 1, c, cp, c, 0, 0};
+            u.it[u.n++] = PadItem{g + cp, y.dbeta, 1, c, cp, c, 0, 0};
+            if (y.bias) u.it[u.n++] = PadItem{g + 2 * (size_t)cp, y.dbias, 1, c, cp, c, 0, 0};
+        }
+        PCL_REQUIRE(u.n <= 12, "pcl_mlp_stack_bwd_f32: more padded layers than the pad table holds");
+    }
+    return launch_pad(u, d.stream);
+}
+
+static int stack_sizes_impl(const pcl_mlp_stack_t* d, size_t* save_bytes, size_t* fwd_tmp_bytes, size_t* bwd_tmp_bytes) {
     PCL_TRY(validate(d, "pcl_mlp_stack_sizes"));
     if (narrow_supported(*d)) {
         if (save_bytes) *save_bytes = narrow_save_bytes();
@@ -242,7 +418,7 @@ extern "C" int pcl_mlp_stack_last(const pcl_mlp_stack_t* d, size_t* y_offset, si
     return PCL_OK;
 }
 
-extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
+static int stack_fwd_impl(const pcl_mlp_stack_t* dp) {
     PCL_TRY(validate(dp, "pcl_mlp_stack_fwd_f32"));
     const pcl_mlp_stack_t& d = *dp;
     PCL_REQUIRE((d.out || d.defer_act) && d.save && d.tmp, "pcl_mlp_stack_fwd_f32: null out / save / tmp");
@@ -320,7 +496,7 @@ extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
     return PCL_OK;
 }
 
-extern "C" int pcl_mlp_stack_bwd_f32(const pcl_mlp_stack_t* dp) {
+static int stack_bwd_impl(const pcl_mlp_stack_t* dp) {
     PCL_TRY(validate(dp, "pcl_mlp_stack_bwd_f32"));
     const pcl_mlp_stack_t& d = *dp;
     PCL_REQUIRE((d.out || d.defer_act) && d.save && d.tmp && d.gout, "pcl_mlp_stack_bwd_f32: null out / save / tmp / gout");

@@ -448,6 +448,57 @@ def test_stack_entry_points_equal_per_kernel_path_grouped(dev, C, feat_grad, use
         assert (a[1] - b[1]).abs().max().item() <= 1e-5 * max(1e-6, a[1].abs().max().item())
 
 
+@pytest.mark.parametrize("grouped", [False, True])
+def test_stack_with_a_96_wide_hidden_layer_runs_zero_padded(dev, grouped):
+    """csrc/stack.hip runs a hidden width of 96 (the MSG part-seg encoder's [3, 64, 96, 128]) as 128 with zero weights / gamma / beta in
+    the pad once the stack has >= 32768 rows: the 96 real channels see the same products, so outputs, input gradient, every parameter
+    gradient (shapes of the 96-wide module) and the running statistics must equal the per-kernel path (which does not pad) to fp32
+    summation order -- the two paths tile the rows differently."""
+    from pointcloudlib_amd import synth
+    from pointcloudlib_amd.misc import ops
+    torch.manual_seed(11)
+    if grouped:
+        B, N, m, ns = 8, 1024, 512, 32                 # 131072 grouped rows
+        x = torch.from_numpy(synth.gauss_ball(B, N, 33)).to(dev)
+        feat0 = torch.randn(B, N, 3, device=dev)
+        _, new_xyz = ops.furthest_point_sample(x, m)
+        idx, cnt = ops.ball_query(new_xyz, x, 0.3, ns, return_cnt=True)
+        goff = ops.group_offsets(cnt)
+        mlp = PointwiseMLP([6, 64, 96, 128]).to(dev).train()
+        gout = torch.randn(B, m, 128, device=dev)
+    else:
+        mlp = PointwiseMLP([32, 64, 96, 128], bias=True).to(dev).train()
+        xin = torch.randn(40000, 32, device=dev)
+        gout = torch.randn(40000, 128, device=dev)
+    with torch.no_grad():
+        for g in mlp.gammas:
+            g.uniform_(0.5, 1.5); g[::4] *= -1.0
+
+    def go():
+        mm = copy.deepcopy(mlp)
+        if grouped:
+            out = mm.forward_grouped(x, new_xyz, feat0, idx, cnt, goff, True)
+            xg = None
+        else:
+            xi = xin.clone().requires_grad_(True)
+            out = mm(xi)
+        out.backward(gout)
+        if not grouped:
+            xg = xi.grad.detach()
+        return out.detach(), xg, {n: p.grad.detach() for n, p in mm.named_parameters()}, {n: b.detach().clone() for n, b in mm.named_buffers()}
+
+    a, b = _with_stack(False, go), _with_stack(True, go)
+    close = lambda u, v, tol: (u - v).abs().max().item() <= tol * max(1e-6, u.abs().max().item())
+    assert close(a[0], b[0], 2e-6), (a[0] - b[0]).abs().max().item()
+    if a[1] is not None:
+        assert close(a[1], b[1], 1e-4)
+    for n in a[2]:
+        assert a[2][n].shape == b[2][n].shape, n
+        assert close(a[2][n], b[2][n], 2e-4), (n, (a[2][n] - b[2][n]).abs().max().item(), a[2][n].abs().max().item())
+    for n in a[3]:
+        assert a[3][n].shape == b[3][n].shape and close(a[3][n].float(), b[3][n].float(), 1e-5), n
+
+
 # ---- the whole FC head as one call per direction (pcl_fc_head_*_f32) ---------------------------------------------------
 def _head_mods(dev, spec, bn, bias, slope, p):
     from torch import nn
