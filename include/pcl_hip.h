@@ -190,13 +190,16 @@ int pcl_group_linear_bwd_f32(const float* row_loc, const float* row_feat, int CF
  * running variance), 2 evaluation (running statistics); +4: running_var receives the BIASED batch variance, as
  * pcl_bn_finalize_f32 does for the set-abstraction stacks (PointConv's per-point Linear + BatchNorm1d on the GroupAll level,
  * misc/pointconv_utils.py:395-397, is such a layer: 32 rows x 16384 -> 1024; layers with K >= 2048 and R <= 32 run as fp32 MFMA
- * tiles: the forward as split-K partial tiles summed in a fixed order -- its partial sums live in a stream-ordered allocation,
- * hipMallocAsync / hipFreeAsync on `stream` -- dW and dX as 32 x 32 tiles).  slope: 1 = no activation, 0 = ReLU, 0.2 = LeakyReLU.
+ * tiles: the forward as split-K partial tiles summed in a fixed order -- its partial sums live in `workspace`
+ * (pcl_head_layer_fwd_workspace_bytes(R, K, N) bytes, 16-byte aligned; 0 bytes / NULL for every other shape) -- dW and dX as
+ * 32 x 32 tiles).  slope: 1 = no activation, 0 = ReLU, 0.2 = LeakyReLU.
  * Forward keeps Ypre (pre-BatchNorm) and mean/invstd for backward; backward returns dW, dbias/dgamma/dbeta (nullable) and,
  * when dX != NULL, the input gradient (dY_ws: [R,N] scratch). */
 int pcl_head_layer_fwd_f32(const float* X, const float* W, const float* bias, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, int R, int K, int N, int bn_mode, float eps, float momentum,
-                           float slope, float* Ypre, float* OUT, float* mean_out, float* invstd_out, void* stream);
+                           float slope, float* Ypre, float* OUT, float* mean_out, float* invstd_out, void* workspace,
+                           size_t workspace_bytes, void* stream);
+size_t pcl_head_layer_fwd_workspace_bytes(int R, int K, int N);
 /* reference: gradient of Linear + BatchNorm1d + ReLU of the heads, networks/cls/pointnet2.py:138-147, :155-158 */
 int pcl_head_layer_bwd_f32(const float* X, const float* W, const float* dOUT, const float* OUT, const float* Ypre,
                            const float* gamma, const float* mean, const float* invstd, int R, int K, int N, int bn_mode,
@@ -402,7 +405,10 @@ int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a, const
  * fp64) and this workgroup's partial of dW = dy^T lrelu(BN_prev(Yprev)) in `workspace`
  * (pcl_linear_bwd_fused_workspace_bytes(P, Cout, Cin)); Yprev is read once.  Arguments as pcl_linear_bwd_dx_rows_f32.
  * pcl_linear_bwd_fused_finish_f32 (second launch) sums the partial tiles into dW[Cout][Cin] and -- when stats_ws is given --
- * computes the BatchNorm-backward constants of the layer below from those sums (what pcl_bn_bwd_consts_f32 does). */
+ * computes the BatchNorm-backward constants of the layer below from those sums (what pcl_bn_bwd_consts_f32 does).
+ * Precondition of the sparse mode (arg, gz) with row_meta: the compacted rows of a group are CONTIGUOUS and their row-in-group
+ * ascends by one from the group's first row (what pcl_group_compact_f32 / pcl_group_linear_f32 produce): the kernel locates a
+ * group's winner as (tile row of the group's first row) + arg - (row-in-group of that first row). */
 /* reference: the autograd backward of nn.Conv 1x1 + nn.BatchNorm + nn.ReLU, networks/cls/pointnet2.py:25-29 */
 /* test / tuning hook: cap the persistent grid of the fused backward at n workgroups (0 = one per CU); process-wide, set between calls */
 void pcl_set_fb_max_blocks(int n);

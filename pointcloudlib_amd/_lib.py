@@ -86,7 +86,8 @@ _SIGS = {
     "pcl_group_linear_stat_rows": (c_int, [c_int, c_int]),
     "pcl_group_linear_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "pcl_group_linear_bwd_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P]),
-    "pcl_head_layer_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P]),
+    "pcl_head_layer_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "pcl_head_layer_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "pcl_head_layer_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "pcl_soft_ce_f32": (c_int, [_P, _P, c_float, c_int, c_int, _P, _P, _P]),
     "pcl_edgeconv_stat_rows": (c_int, [c_int, c_int]),

@@ -267,7 +267,7 @@ typedef float hd_f32x16 __attribute__((ext_vector_type(16)));
 // part[ks][32][N] = X[32, k range ks] . W[N, k range ks]^T: grid (N / 32, KS) workgroups, X and W chunks of 128 k staged through LDS
 // (coalesced 512-byte row pieces), the four waves split every chunk's k, their tiles meet in LDS in a fixed order.  A second kernel (one
 // wave per column) adds the KS partial sums in order and runs the layer's epilogue: deterministic, 61 + 6 us at 16384 x 1024 where the
-// 8-columns-per-workgroup VALU kernel took 111.  The partial sums live in a stream-ordered allocation (hipMallocAsync) of the call.
+// 8-columns-per-workgroup VALU kernel took 111.  The partial sums live in a workspace of the caller (pcl_head_layer_fwd_workspace_bytes).
 constexpr int HM_KC = 128;
 __global__ __launch_bounds__(256) void head_fwd_part_kernel(const float* __restrict__ X, const float* __restrict__ W, int R, int K, int N, int kper,
                                                             float* __restrict__ part) {
@@ -434,26 +434,15 @@ static bool head_wide(int R, int K, const float* X, const float* W) {
 }  // namespace pcl
 using namespace pcl;
 
-// The split-K forward's partial sums come from the device's default stream-ordered pool: keep what it has allocated across
-// synchronisation points (the default release threshold of 0 hands the memory back at every stream sync -- a training loop that reads
-// its loss each step would pay a fresh allocation per step).  Once per device.
-static void head_pool_keep() {
-    static bool done[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || done[dev]) { (void)hipGetLastError(); return; }
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-        uint64_t keep = ~0ull;
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-    }
-    (void)hipGetLastError();
-    done[dev] = true;
-}
+// The split-K forward's partial sums [KS][32][N] live in a workspace of the caller (round 5; before: a stream-ordered allocation of the
+// call, which set a process-wide mempool attribute and could not be captured into a graph)
+static inline int head_wide_ks(int K) { return K >= 8192 ? 16 : 8; }
+static inline size_t head_fwd_ws_bytes(int R, int K, int N) { return (R <= 32 && K >= 2048) ? (size_t)head_wide_ks(K) * 32 * N * sizeof(float) : 0; }
 
 static int head_layer_fwd_impl(const float* X, const float* W, const float* bias, const float* gamma, const float* beta,
                                       float* running_mean, float* running_var, int R, int K, int N, int bn_mode, float eps,
                                       float momentum, float slope, float* Ypre, float* OUT, float* mean_out, float* invstd_out,
-                                      void* stream, const Drop drop) {
+                                      void* workspace, size_t workspace_bytes, void* stream, const Drop drop) {
     PCL_REQUIRE(X && W && Ypre && OUT, "pcl_head_layer_fwd_f32: null pointer");
     PCL_REQUIRE(R >= 1 && R <= 64 && K >= 1 && N >= 1, "pcl_head_layer_fwd_f32: bad sizes R=%d K=%d N=%d (R <= 64)", R, K, N);
     PCL_REQUIRE((bn_mode & ~7) == 0 && (bn_mode & 3) <= 2 && ((bn_mode & 3) == 0 || (mean_out && invstd_out)) &&
@@ -461,17 +450,14 @@ static int head_layer_fwd_impl(const float* X, const float* W, const float* bias
     hipStream_t st = as_stream(stream);
     const dim3 grid(N), block(256);
     if (head_wide(R, K, X, W)) {
-        const int KS = K >= 8192 ? 16 : 8, kper = ((K + KS - 1) / KS + HM_KC - 1) / HM_KC * HM_KC;
-        head_pool_keep();
-        float* part = nullptr;
-        if (hipMallocAsync(reinterpret_cast<void**>(&part), (size_t)KS * 32 * N * sizeof(float), st) != hipSuccess || !part) {
-            (void)hipGetLastError();
-            return fail(PCL_EHIP, "pcl_head_layer_fwd_f32: hipMallocAsync of the %zu-byte partial sums failed", (size_t)KS * 32 * N * sizeof(float));
-        }
+        const int KS = head_wide_ks(K), kper = ((K + KS - 1) / KS + HM_KC - 1) / HM_KC * HM_KC;
+        const size_t need = (size_t)KS * 32 * N * sizeof(float);
+        if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
+            return fail(PCL_EWS, "pcl_head_layer_fwd_f32: workspace %zu < %zu (pcl_head_layer_fwd_workspace_bytes; 16-byte aligned)", workspace ? workspace_bytes : (size_t)0, need);
+        float* part = static_cast<float*>(workspace);
         hipLaunchKernelGGL(head_fwd_part_kernel, dim3((N + 31) / 32, KS), block, 0, st, X, W, R, K, N, kper, part);
         hipLaunchKernelGGL(head_fwd_finish_kernel, dim3((N + 3) / 4), block, 0, st, part, KS, bias, gamma, beta, running_mean, running_var, R, N,
                            bn_mode, eps, momentum, slope, Ypre, OUT, mean_out, invstd_out, drop);
-        (void)hipFreeAsync(part, st);
     } else if (R <= 32)
         hipLaunchKernelGGL(head_fwd_kernel<32>, grid, block, 0, st, X, W, bias, gamma, beta, running_mean, running_var, R, K, N, bn_mode, eps,
                            momentum, slope, Ypre, OUT, mean_out, invstd_out, drop);
@@ -484,10 +470,11 @@ static int head_layer_fwd_impl(const float* X, const float* W, const float* bias
 extern "C" int pcl_head_layer_fwd_f32(const float* X, const float* W, const float* bias, const float* gamma, const float* beta,
                                       float* running_mean, float* running_var, int R, int K, int N, int bn_mode, float eps,
                                       float momentum, float slope, float* Ypre, float* OUT, float* mean_out, float* invstd_out,
-                                      void* stream) {
+                                      void* workspace, size_t workspace_bytes, void* stream) {
     return head_layer_fwd_impl(X, W, bias, gamma, beta, running_mean, running_var, R, K, N, bn_mode, eps, momentum, slope, Ypre, OUT, mean_out,
-                               invstd_out, stream, Drop{0.f, 0u, 0u});
+                               invstd_out, workspace, workspace_bytes, stream, Drop{0.f, 0u, 0u});
 }
+extern "C" size_t pcl_head_layer_fwd_workspace_bytes(int R, int K, int N) { return (R < 1 || K < 1 || N < 1) ? 0 : head_fwd_ws_bytes(R, K, N); }
 
 static int head_layer_bwd_impl(const float* X, const float* W, const float* dOUT, const float* OUT, const float* Ypre,
                                       const float* gamma, const float* mean, const float* invstd, int R, int K, int N, int bn_mode,
@@ -535,7 +522,7 @@ extern "C" int pcl_head_layer_bwd_f32(const float* X, const float* W, const floa
 // above, launched from ONE call per direction with the buffers carved here.  Backward start is where a training step is
 // host-bound (a dozen 5-10 us kernels, each behind its own autograd node): one node + one call instead.
 namespace pcl {
-struct HeadSave { float* Ypre[PCL_HEAD_MAX_LAYERS]; float* OUT[PCL_HEAD_MAX_LAYERS]; float* mean[PCL_HEAD_MAX_LAYERS]; float* invstd[PCL_HEAD_MAX_LAYERS]; size_t bytes; };
+struct HeadSave { float* Ypre[PCL_HEAD_MAX_LAYERS]; float* OUT[PCL_HEAD_MAX_LAYERS]; float* mean[PCL_HEAD_MAX_LAYERS]; float* invstd[PCL_HEAD_MAX_LAYERS]; float* fws; size_t fws_bytes; size_t bytes; };
 static inline size_t hal(size_t n) { return (n + 255) & ~(size_t)255; }
 static HeadSave head_save(const pcl_fc_head_t& d, void* base) {
     HeadSave h = {};
@@ -548,6 +535,11 @@ static HeadSave head_save(const pcl_fc_head_t& d, void* base) {
         h.OUT[l] = l == d.n_layers - 1 ? nullptr : take(rn);        // the last layer's output is the caller's `out`
         h.mean[l] = take(d.layer[l].N); h.invstd[l] = take(d.layer[l].N);
     }
+    // the wide layers' split-K partial sums (forward only; one region, reused layer after layer in stream order)
+    size_t wmax = 0;
+    for (int l = 0; l < d.n_layers; ++l) { const size_t w = head_fwd_ws_bytes(d.R, d.layer[l].K, d.layer[l].N); wmax = w > wmax ? w : wmax; }
+    h.fws_bytes = wmax;
+    h.fws = wmax ? take(wmax / sizeof(float)) : nullptr;
     h.bytes = off;
     return h;
 }
@@ -599,7 +591,7 @@ extern "C" int pcl_fc_head_fwd_f32(const pcl_fc_head_t* dp) {
         const pcl_head_layer_t& y = d.layer[l];
         float* out = l == d.n_layers - 1 ? d.out : h.OUT[l];
         rc = head_layer_fwd_impl(cur, y.W, y.bias, y.gamma, y.beta, y.running_mean, y.running_var, d.R, y.K, y.N, y.bn_mode, y.eps, y.momentum,
-                                 y.slope, h.Ypre[l], out, h.mean[l], h.invstd[l], d.stream, head_drop(d, l));
+                                 y.slope, h.Ypre[l], out, h.mean[l], h.invstd[l], h.fws, h.fws_bytes, d.stream, head_drop(d, l));
         if (rc) return rc;
         cur = out;
     }

@@ -1732,7 +1732,7 @@ static int launch_fwd_split_t(const FrArgs& f, bool rag, hipStream_t st) {
     else PCL_LAUNCH_TIMED((linear_fwd_split_kernel<CI, CBK, false, false>), grid, blk, st, f);
     return check_launch("pcl_linear_fwd(split bf16 planes)");
 }
-// the matrix-pipe form of the GEMM family: 1 = fp32 operands as three bf16 planes on the bf16 MFMA (default), 0 = fp32 MFMA
+// the matrix-pipe form of the GEMM family: 0 (DEFAULT) = fp32 MFMA, bit 0 / 1 = fp32 operands as three bf16 planes on the bf16 MFMA (opt-in)
 static int g_split_mfma = 0;               // bit 0: the resident-operand forward, bit 1: the staged GEMMs with K >= g_split_min_k
 static int g_split_min_k = 128;
 static bool fwd_split_on() { return (g_split_mfma & 1) != 0; }
@@ -2880,7 +2880,7 @@ extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const
 }
 
 extern "C" void pcl_set_fb_max_blocks(int n) { g_fb_cap = n; }
-// 1 (default): the resident-operand GEMMs take fp32 operands as three bf16 planes on the bf16 matrix pipe (nine exact partial
+// 1 (opt-in; the default is 0, the fp32 MFMA): the resident-operand GEMMs take fp32 operands as three bf16 planes on the bf16 matrix pipe (nine exact partial
 // products per fp32 product); 0: the fp32 MFMA form of rounds 2-3 (kept for A/B measurements and the error comparison test)
 extern "C" void pcl_set_matrix_form(int split) { g_split_mfma = split & 7; g_split_min_k = (split >> 8) > 0 ? (split >> 8) : 128; }
 extern "C" int pcl_get_matrix_form(void) { return g_split_mfma; }

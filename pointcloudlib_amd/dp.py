@@ -136,8 +136,6 @@ class FlatBucketDP:
         """Average the gradients over ranks: finish the bucketed all-reduces (sum), then scale by 1/world."""
         if not self.active:
             return
-        if not self._bn_checked:
-            self._check_batchnorms()
         self._armed = False
         for b in self.buckets:
             if b.work is None:
@@ -149,6 +147,9 @@ class FlatBucketDP:
             self.flat.mul_(1.0 / self.world)
         for p, v in zip(self.params, self.views):
             p.grad = v
+        # (after the exchange: a failed check must not leave collectives issued and un-waited on this rank only -- ADVICE r4)
+        if not self._bn_checked:
+            self._check_batchnorms()
 
     def _check_batchnorms(self):
         """After the first forward + backward of a ``sync_bn=True`` wrapper: every training-mode BatchNorm module of the model must
@@ -166,8 +167,6 @@ class FlatBucketDP:
         (hooks must not issue collectives inside a capture)."""
         if not self.active:
             return
-        if not self._bn_checked:
-            self._check_batchnorms()
         self._armed = False
         grads = [p.grad for p in self.params if p.grad is not None]
         views = [v for p, v in zip(self.params, self.views) if p.grad is not None]
@@ -176,6 +175,8 @@ class FlatBucketDP:
         if self.world > 1:
             self.flat.mul_(1.0 / self.world)
         torch._foreach_copy_(grads, views)
+        if not self._bn_checked:
+            self._check_batchnorms()
 
 
 def _unsynced_batchnorms(module):

@@ -33,8 +33,10 @@ class _HeadLayer(torch.autograd.Function):
         mean = invstd = None
         if bn_mode:
             mean, invstd = torch.empty((N,), device=dev), torch.empty((N,), device=dev)
+        nws = _lib.size_query("pcl_head_layer_fwd_workspace_bytes", R, K, N)      # split-K partial sums of a wide layer (else 0)
+        ws = torch.empty((nws // 4,), device=dev) if nws else None
         _lib.call("pcl_head_layer_fwd_f32", _p(x), _p(W), _p(b), _p(gamma), _p(beta), _p(rmean), _p(rvar), R, K, N, bn_mode, eps,
-                  momentum, slope, _p(ypre), _p(out), _p(mean), _p(invstd), _stream())
+                  momentum, slope, _p(ypre), _p(out), _p(mean), _p(invstd), _p(ws), nws, _stream())
         ctx.cfg = (bn_mode, slope, b is not None, gamma is not None)
         ctx.save_for_backward(x, W, out, ypre, gamma, mean, invstd)
         return out
@@ -73,17 +75,20 @@ def head_layer(x, linear, bn=None, act=None):
     slope = float(act) if isinstance(act, (int, float)) else _slope_of(act)
     if not x.is_cuda:
         raise RuntimeError("head_layer: expected a tensor on the GPU (libpcl_hip has no CPU path)")
-    if bn is not None and bn.training and syncbn.active():
-        bn._pcl_sync_routed = True               # dp.FlatBucketDP(sync_bn=True) checks that every BatchNorm module came through here
+    def synced(y):
+        # dp.FlatBucketDP(sync_bn=True) checks that every training-mode BatchNorm module came through HERE: the mark is set only where
+        # the synchronised statistics are actually used (it used to be set before the per-rank ``bn(y)`` branch below)
+        bn._pcl_sync_routed = True
+        return syncbn.batch_norm_1d(y, bn)
     if x.shape[0] > MAX_ROWS or x.dim() != 2 or x.dtype != torch.float32:     # large batches: plain library GEMMs
         y = linear(x)
         if bn is not None:
-            y = syncbn.batch_norm_1d(y, bn) if (bn.training and syncbn.active() and y.dim() == 2) else bn(y)
+            y = synced(y) if (bn.training and syncbn.active() and y.dim() == 2) else bn(y)
         return y if slope == 1.0 else F.leaky_relu(y, slope)
     if bn is not None and bn.training and syncbn.active():
         # synchronised statistics over all ranks' rows: the one-kernel layer computes its batch statistics inside the kernel,
         # so this case (R <= 64 rows per rank) runs the library GEMM + syncbn.batch_norm_1d (fp64 sums, biased running variance)
-        y = syncbn.batch_norm_1d(linear(x), bn)
+        y = synced(linear(x))
         return y if slope == 1.0 else F.leaky_relu(y, slope)
     if bn is None:
         cfg = (0, 0.0, 0.0, slope)

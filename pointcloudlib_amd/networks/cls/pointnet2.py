@@ -100,9 +100,10 @@ _AB_RECORD_STREAM = bool(os.environ.get("PCL_AB_RECORD_STREAM"))        # lab sw
 
 
 _OWN_SAMPLING_STREAM = {}          # device index -> the library's private producer stream
+_OWN_LAST_CONSUMER = {}            # device index -> the consumer stream the private stream was last fed from
 
 
-def sampling_stream(owner, stream):
+def sampling_stream(owner, stream, device=None):
     """-> (stream, owned).  ``stream="own"`` selects the library's PRIVATE producer stream of the current device: created here on
     first use (high priority: the work is a short latency-bound chain), never handed to anybody else, so the only allocations and
     kernels it ever sees are those of ``precompute_sampling`` calls -- each of which starts by waiting for its consumer stream.  That
@@ -113,10 +114,10 @@ def sampling_stream(owner, stream):
     if isinstance(stream, str):
         if stream != "own":
             raise ValueError(f"stream={stream!r}: pass a torch.cuda.Stream, None or 'own'")
-        dev = torch.cuda.current_device()
+        dev = torch.cuda.current_device() if device is None or device.index is None else device.index      # (the tensor's device)
         s = _OWN_SAMPLING_STREAM.get(dev)
         if s is None:
-            s = _OWN_SAMPLING_STREAM[dev] = torch.cuda.Stream(priority=-1)
+            s = _OWN_SAMPLING_STREAM[dev] = torch.cuda.Stream(device=dev, priority=-1)
         return s, True
     return stream, False
 
@@ -132,11 +133,20 @@ class SamplingPrefetch:
         ``forward(xyz, feature, sampling=handle)``.  The chain of m-1 dependent FPS steps occupies only B
         workgroups, so it costs nothing to run it beside the MFMA kernels."""
         cur = torch.cuda.current_stream()
-        stream, owned = sampling_stream(self, stream)
+        stream, owned = sampling_stream(self, stream, xyz.device)
         if stream is None:
             stream = cur
         if stream != cur:
             stream.wait_stream(cur)                       # xyz may have just been produced on the current stream
+            if owned:
+                # the private stream is shared by every network of the process: a handle produced for ANOTHER consumer stream may still be
+                # read there, and this call is about to recycle its freed memory from the side pool -- wait for that consumer too
+                # (ADVICE r4: the ordering argument of adopt_sampling needs every consumer the stream was fed from)
+                dev = xyz.device.index if xyz.device.index is not None else torch.cuda.current_device()
+                last = _OWN_LAST_CONSUMER.get(dev)
+                if last is not None and last != cur:
+                    stream.wait_stream(last)
+                _OWN_LAST_CONSUMER[dev] = cur
             # ... and may be a temporary of the caller (x.transpose(1, 2).contiguous()): it dies when this call returns, and the
             # consumer stream's allocator pool would hand its memory out again while the producer stream still reads it
             xyz.record_stream(stream)
