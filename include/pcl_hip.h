@@ -416,6 +416,37 @@ void pcl_set_fb_max_blocks(int n);
  * forward (off: linear_nt_kernel), the recompute-per-pass narrow stacks of PointConv's WeightNet / DensityNet (off: the GEMM kernels), the
  * fused dX + dW backward inside pcl_mlp_stack_bwd_f32 (off: separate kernels).  A C call: the library reads no environment variables. */
 void pcl_set_kernel_paths(int fwd_resident, int narrow_stacks, int fused_backward);
+/* Weight gradients of few-row plain stacks on a second stream (no reference counterpart; round 5).  In pcl_mlp_stack_bwd_f32 the chain
+ * that later layers wait for is consts(l) -> dX(l) -> consts(l - 1) -> ...; dW(l) (+ its split-K reduce) only has to be done when the call
+ * returns.  For plain stacks of <= max_rows rows (default 8192: the GroupAll level, the part-seg decoder) whose layers have no fused
+ * dX + dW kernel, every dW launch is forked to a stream the library owns (event after consts(l)) and joined into the caller's stream at
+ * the end of the call, so it runs in the holes of the dX chain; same kernels, same grids, per-layer buffers: results are bit-identical
+ * to the serial order.  side_dw: 1 on (default), 0 off, negative = leave as is; max_rows <= 0 = leave as is.  Capturable in a HIP graph
+ * (event fork / join from the capturing stream). */
+void pcl_set_stack_overlap(int side_dw, int max_rows);
+int pcl_get_stack_overlap(void);
+/* Few-row layers (round 5; the reference's autograd of nn.Conv 1x1 + nn.BatchNorm + nn.ReLU on the GroupAll level,
+ * networks/cls/pointnet2.py:131-136: [259, 256, 512, 1024] on B * 128 rows, and the part-seg decoder's FP stacks,
+ * networks/seg/pointnet2_partseg.py:146-156).  On <= pcl_frag_max_rows() rows the staged backward GEMMs re-form
+ * dy = a du - k1 - k2 (y - mean) once per output tile that reads it, and on gfx950 those vector instructions are matrix time.
+ * pcl_bn_bwd_dy_f32 = pcl_bn_bwd_consts_f32 (same arguments, bit-identical constants / dgamma / dbeta) + dy[P][C] formed ONCE from
+ * dU [P][C] or the max pool's (arg, gz) [P / ns][C] and Y [P][C]; C % 32 == 0.  pcl_linear_bwd_dw_plain_f32: dW[Cout][Cin] = dy^T z with
+ * z = lrelu(prev_scale x + prev_shift) (or x when prev_scale is NULL) on the staged dW kernel reading dy as a plain operand (workspace:
+ * pcl_linear_bwd_dw_plain_workspace_bytes); the input gradient of such a layer is pcl_frag_linear_bwd_dx_f32 on the same dy.
+ * pcl_mlp_fewrow_layer: does layer (Cout <- Cin) of a plain stack on P rows take this path inside pcl_mlp_stack_bwd_f32 (the host's
+ * per-kernel path asks the same question).  pcl_set_fewrow_backward: lab switch, 1 on (default) / 0 off / negative leave as is.
+ * pcl_set_dw_tuning: lab knob, row-chunk workgroups per output tile of the plain-dy dW (0 = the library's choice). */
+int pcl_bn_bwd_dy_supported(int P, int C);
+int pcl_bn_bwd_dy_f32(const double* stats_ws, int stat_rows, const float* gamma, const float* mean, const float* invstd, int P_bn, int C,
+                      float* dgamma, float* dbeta, float* a_out, float* k1, float* k2, float* dbias_zero, const float* dU, const float* Y,
+                      const int32_t* arg, const float* gz, int ns, int P, float* dy, void* stream);
+size_t pcl_linear_bwd_dw_plain_workspace_bytes(int P, int Cout, int Cin);
+int pcl_linear_bwd_dw_plain_f32(const float* dy, const float* Xprev, const float* prev_scale, const float* prev_shift, float prev_slope, int P,
+                                int Cout, int Cin, float* dW, void* workspace, size_t workspace_bytes, int dw_ld, void* stream);
+int pcl_mlp_fewrow_layer(int P, int Cout, int Cin, int first_layer);
+void pcl_set_fewrow_backward(int on);
+int pcl_get_fewrow_backward(void);
+void pcl_set_dw_tuning(int gx);
 /* Matrix-pipe form of the GEMM family (no reference counterpart: the reference calls cuDNN / cuBLAS fp32 through jittor's nn.Conv /
  * nn.Linear, misc/layers.py:60-75).  Default 0: the fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere.  Opt-in, measured and not faster
  * as a whole: every fp32 operand split EXACTLY into three bf16 values, an fp32 product = nine exact bf16 products

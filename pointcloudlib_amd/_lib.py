@@ -133,6 +133,16 @@ _SIGS = {
     "pcl_frag_linear_bwd_dw_f32": (c_int, [_P, _P, c_int, _P, _P, c_float, c_int, c_int, c_int, _P, c_int, _P, c_size_t, c_int, _P]),
     "pcl_set_fb_max_blocks": (None, [c_int]),
     "pcl_set_kernel_paths": (None, [c_int, c_int, c_int]),
+    "pcl_set_stack_overlap": (None, [c_int, c_int]),
+    "pcl_get_stack_overlap": (c_int, []),
+    "pcl_bn_bwd_dy_supported": (c_int, [c_int, c_int]),
+    "pcl_bn_bwd_dy_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "pcl_linear_bwd_dw_plain_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "pcl_linear_bwd_dw_plain_f32": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, c_size_t, c_int, _P]),
+    "pcl_mlp_fewrow_layer": (c_int, [c_int, c_int, c_int, c_int]),
+    "pcl_set_fewrow_backward": (None, [c_int]),
+    "pcl_get_fewrow_backward": (c_int, []),
+    "pcl_set_dw_tuning": (None, [c_int]),
     "pcl_set_matrix_form": (None, [c_int]),
     "pcl_get_matrix_form": (c_int, []),
     "pcl_set_fps_tuning": (None, [c_int, c_int]),
@@ -168,6 +178,12 @@ def lib():
         sw = [-1 if os.environ.get(k) is None else int(os.environ[k] != "0") for k in ("PCL_FWD_RES", "PCL_NARROW", "PCL_FUSED_BWD")]
         if any(v >= 0 for v in sw):
             L.pcl_set_kernel_paths(*sw)
+        if os.environ.get("PCL_SIDE_DW") is not None:
+            L.pcl_set_stack_overlap(int(os.environ["PCL_SIDE_DW"] != "0"), -1)
+        if os.environ.get("PCL_FEWROW") is not None:
+            L.pcl_set_fewrow_backward(int(os.environ["PCL_FEWROW"] != "0"))
+        if os.environ.get("PCL_DW_GX") is not None:
+            L.pcl_set_dw_tuning(int(os.environ["PCL_DW_GX"]))
         _lib = L
     return _lib
 
@@ -187,6 +203,7 @@ PROFILER = None   # set to a KernelTimer by bench.py; None in normal operation (
 # entry points that launch exactly one GEMM-family kernel (plus, for dW, small reductions that are not the kernel of interest)
 KERNEL_TIMED = {"pcl_linear_fwd_rows_f32", "pcl_linear_fwd_f32", "pcl_linear_bwd_dx_rows_f32", "pcl_linear_bwd_dx_f32",
                 "pcl_linear_bwd_dw_rows_f32", "pcl_linear_bwd_dw_f32", "pcl_linear_bwd_fused_rows_f32",
+                "pcl_linear_bwd_dw_plain_f32", "pcl_frag_linear_bwd_dx_f32", "pcl_frag_linear_fwd_f32",
                 "pcl_knn_f32", "pcl_knn_fma_f32"}      # (k-NN: the fused kernel; the two-pass form arms nothing and is not recorded)
 _hip = None
 

@@ -567,6 +567,9 @@ static void launch_gemm(GemmArgs g, hipStream_t st, int force_tn, int force_ksw)
     g.nrt = (g.M + 63) / 64;
     // 128-column wave pairs (two B fragments per A fragment) when the output still fills the chip twice over with them
     int tn = (width >= 128 && g.nrt * ((width + 127) / 128) * 4 >= 8 * cu_count()) ? 2 : 1;
+    // ... or one workgroup per CU with them on a long contraction (4 096 x 1024 -> 512: 48.1 -> 41.2 us with two k groups; 512 -> 1024 forward:
+    // 55.9 -> 51.4; tools/dbg/frag_time.py)
+    if (width >= 256 && g.K >= 512 && g.nrt * ((width + 127) / 128) >= cu_count()) tn = 2;
     if (force_tn) tn = force_tn;
     if (FLUSH > 0) tn = 1;              // (fp64 accumulators: 32 more registers per tile -- two tiles do not fit 128 registers at 4 waves per SIMD)
     g.nct = (width + 64 * tn - 1) / (64 * tn);

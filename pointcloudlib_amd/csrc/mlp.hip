@@ -1034,7 +1034,10 @@ __device__ __forceinline__ void dw_load_a(const DwArgs& p, int p0, int c0, int t
         if constexpr (RAG) row_meta(st.raw[i], g, srow, w);          // records fetched one chunk ahead (dw_fetch_meta)
         else if constexpr (AM == A_DY_SPARSE) { g = r / p.ns; srow = r - g * p.ns; }
         st.rw[i] = w; st.rs[i] = srow;
-        if constexpr (VEC) {
+        if constexpr (AM == A_PLAIN) {                  // dy already formed (few-row layers: bn_bwd_dy_kernel)
+            if constexpr (VEC) st.v[i] = *reinterpret_cast<const float4*>(p.A + off);
+            else st.s[i] = p.A[off];
+        } else if constexpr (VEC) {
             st.v2[i] = *reinterpret_cast<const float4*>(p.A2 + off);
             if constexpr (AM == A_DY) st.v[i] = *reinterpret_cast<const float4*>(p.A + off);
             else {
@@ -1065,7 +1068,10 @@ __device__ __forceinline__ void dw_store_a(const DwArgs& p, float* sX, int c0, i
         const int rl = tid / S::CPR + S::RP * i;
         const int r = st.p0 + rl;
         const bool in = cin && r < p.P;
-        if constexpr (VEC) {
+        if constexpr (AM == A_PLAIN) {
+            if constexpr (VEC) *reinterpret_cast<float4*>(&sX[rl * (W + 4) + cl]) = in ? st.v[i] : make_float4(0, 0, 0, 0);
+            else sX[rl * (W + 4) + cl] = in ? st.s[i] : 0.f;
+        } else if constexpr (VEC) {
             float4 a = make_float4(0, 0, 0, 0);
             if (in) {
                 float4 du;
@@ -1172,11 +1178,13 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p_in) 
         const int ca = i0 + (tid % SA::CPR) * (VEC ? 4 : 1), cb = j0 + (tid % SB::CPR) * (VEC ? 4 : 1);
         const int cac = min(ca, p.I - (VEC ? 4 : 1)), cbc = min(cb, p.J - (VEC ? 4 : 1));
         if constexpr (VEC) {
-            asc = *reinterpret_cast<const float4*>(p.sc + cac); ash = *reinterpret_cast<const float4*>(p.sh + cac);
-            ak2 = *reinterpret_cast<const float4*>(p.k2 + cac); amu = *reinterpret_cast<const float4*>(p.mu + cac);
+            if constexpr (AM != A_PLAIN) {
+                asc = *reinterpret_cast<const float4*>(p.sc + cac); ash = *reinterpret_cast<const float4*>(p.sh + cac);
+                ak2 = *reinterpret_cast<const float4*>(p.k2 + cac); amu = *reinterpret_cast<const float4*>(p.mu + cac);
+            }
             if (p.b_mode == A_BNACT) { bsc = *reinterpret_cast<const float4*>(p.bsc + cbc); bsh = *reinterpret_cast<const float4*>(p.bsh + cbc); }
         } else {
-            asc.x = p.sc[cac]; ash.x = p.sh[cac]; ak2.x = p.k2[cac]; amu.x = p.mu[cac];
+            if constexpr (AM != A_PLAIN) { asc.x = p.sc[cac]; ash.x = p.sh[cac]; ak2.x = p.k2[cac]; amu.x = p.mu[cac]; }
             if (p.b_mode == A_BNACT) { bsc.x = p.bsc[cbc]; bsh.x = p.bsh[cbc]; }
         }
     }
@@ -2349,6 +2357,104 @@ __global__ __launch_bounds__(256) void bn_bwd_consts_kernel(const BnConstsArgs q
     __shared__ double red[2 * 64 * 4];
     bn_bwd_consts_block(q, blockIdx.x, red);
 }
+// ---- few-row layers (round 5): BatchNorm-backward constants AND dy of a layer in one launch ---------------------------------------------
+// On a few thousand rows (the GroupAll level: 4 096; the part-seg decoder: 2 048 .. 8 192) the two GEMMs of a layer's backward re-form
+// dy = a du - k1 - k2 (y - mean) in their loaders once per output tile that reads it: 8 times for a 512-wide dX, again per 128-column
+// slab of dW, and every one of those vector instructions is matrix time on gfx950 (fp32 MFMA and VALU share the issue port: co-running
+// dW beside dX on a second stream changed nothing, 104.7 + 63.0 us against 51.8 and 52.3 alone).  Here dy is formed ONCE, by the launch
+// that used to compute only the constants: a block owns 32 channels x a slab of rows, sums the partial rows of its channels
+// (stat_colsum's order, four channels at a time: the constants are bit-identical to pcl_bn_bwd_consts_f32's) and writes dy; the row slab 0
+// blocks also write dgamma / dbeta / the constants.  The GEMMs behind it read plain operands.
+struct BnDyArgs {
+    BnConstsArgs q;
+    const float* dU; const float* Y; const int32_t* arg; const float* gz; int ns;      // dU dense, or (arg, gz) of the max pool
+    float* dy; int M;
+};
+__global__ __launch_bounds__(256) void bn_bwd_dy_kernel(const BnDyArgs p) {
+    __shared__ double red[8][32];
+    __shared__ __attribute__((aligned(16))) float sk[4][32];      // a, k1, k2, mean of this block's 32 channels
+    const BnConstsArgs& q = p.q;
+    const int c0 = blockIdx.x * 32;
+    {
+        // stat_colsum's summation order for each channel (row lane ry sums rows ry, ry + 64, ... in four streams; 16 row lanes of a wave by
+        // xor shuffles; four waves through LDS), with the partial rows of all eight channel quads requested together: one memory round trip
+        // instead of eight
+        const int cl = threadIdx.x & 3, ry = threadIdx.x >> 2, wave = threadIdx.x >> 6;
+        const size_t st = (size_t)2 * q.C;
+        double s[8], t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + 4 * j + cl;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+            if (c < q.C) {
+                const double* b = q.stats + c;
+                int r = ry;
+                for (; r + 192 < q.rows; r += 256) {
+                    s0 += b[(size_t)r * st]; q0 += b[(size_t)r * st + q.C];
+                    s1 += b[(size_t)(r + 64) * st]; q1 += b[(size_t)(r + 64) * st + q.C];
+                    s2 += b[(size_t)(r + 128) * st]; q2 += b[(size_t)(r + 128) * st + q.C];
+                    s3 += b[(size_t)(r + 192) * st]; q3 += b[(size_t)(r + 192) * st + q.C];
+                }
+                for (; r < q.rows; r += 64) { s0 += b[(size_t)r * st]; q0 += b[(size_t)r * st + q.C]; }
+            }
+            s[j] = (s0 + s1) + (s2 + s3); t[j] = (q0 + q1) + (q2 + q3);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int off = 4; off < 64; off <<= 1) { s[j] += __shfl_xor(s[j], off); t[j] += __shfl_xor(t[j], off); }
+            if ((threadIdx.x & 63) < 4) { red[j][wave * 4 + cl] = s[j]; red[j][16 + wave * 4 + cl] = t[j]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const int j = threadIdx.x >> 2, c = c0 + threadIdx.x;              // (threadIdx.x = 4 j + cl)
+            if (c < q.C) {
+                const double* r = red[j];
+                const double s1 = (r[cl] + r[4 + cl]) + (r[8 + cl] + r[12 + cl]);
+                const double s2 = (r[16 + cl] + r[20 + cl]) + (r[24 + cl] + r[28 + cl]);
+                const double mu = q.mean[c], is = q.invstd[c];
+                const double g = q.gamma ? q.gamma[c] : 1.0;
+                const double dg = (s2 - mu * s1) * is;
+                const double a = g * is;
+                const double kk2 = a * dg * is / q.P;
+                const float fa = (float)a, fk2 = (float)kk2, fk1 = (float)(a * s1 / q.P);
+                sk[0][threadIdx.x] = fa; sk[1][threadIdx.x] = fk1; sk[2][threadIdx.x] = fk2; sk[3][threadIdx.x] = q.mean[c];
+                if (blockIdx.y == 0) {
+                    if (q.dgamma) q.dgamma[c] = (float)dg;
+                    if (q.dbeta) q.dbeta[c] = (float)s1;
+                    if (q.dbias_zero) q.dbias_zero[c] = 0.f;
+                    q.a_out[c] = fa; q.k2[c] = fk2; q.k1[c] = fk1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // rows of this block's slab, 32 per pass: thread = (row-in-pass, channel quad)
+    const int cq = (threadIdx.x & 7) * 4, c = c0 + cq;
+    if (c >= q.C) return;                                          // (C % 4 == 0: a quad is inside or outside)
+    const float4 a = *reinterpret_cast<const float4*>(&sk[0][cq]), k1 = *reinterpret_cast<const float4*>(&sk[1][cq]);
+    const float4 k2 = *reinterpret_cast<const float4*>(&sk[2][cq]), mu = *reinterpret_cast<const float4*>(&sk[3][cq]);
+    const int per = (p.M + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * per, r1 = min(p.M, r0 + per);
+#pragma unroll 2
+    for (int m = r0 + (threadIdx.x >> 3); m < r1; m += 32) {
+        const size_t off = (size_t)m * q.C + c;
+        const float4 y = *reinterpret_cast<const float4*>(p.Y + off);
+        float4 du;
+        if (p.dU) du = *reinterpret_cast<const float4*>(p.dU + off);
+        else {
+            const int g = m / p.ns, srow = m - g * p.ns;
+            const int4 ar = *reinterpret_cast<const int4*>(p.arg + (size_t)g * q.C + c);
+            const float4 gz = *reinterpret_cast<const float4*>(p.gz + (size_t)g * q.C + c);
+            du.x = ar.x == srow ? gz.x : 0.f; du.y = ar.y == srow ? gz.y : 0.f; du.z = ar.z == srow ? gz.z : 0.f; du.w = ar.w == srow ? gz.w : 0.f;
+        }
+        float4 d;        // (the arithmetic of the dy-forming loaders: the staged kernels and this path agree bit for bit on dy)
+        d.x = fmaf(a.x, du.x, -fmaf(k2.x, y.x - mu.x, k1.x)); d.y = fmaf(a.y, du.y, -fmaf(k2.y, y.y - mu.y, k1.y));
+        d.z = fmaf(a.z, du.z, -fmaf(k2.z, y.z - mu.z, k1.z)); d.w = fmaf(a.w, du.w, -fmaf(k2.w, y.w - mu.w, k1.w));
+        *reinterpret_cast<float4*>(p.dy + off) = d;
+    }
+}
+
 // second (and last) launch of the fused backward of a layer: blocks [0, nred) sum the workgroups' partial dW tiles (as
 // reduce_rows_kernel), the blocks after them turn the BatchNorm sums the fused kernel left into the constants of the layer below.
 __global__ __launch_bounds__(256) void fused_finish_kernel(const float* __restrict__ part, int rows, size_t n, int ncols, float* __restrict__ out,
@@ -2877,6 +2983,76 @@ extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const
     const int blocks = (int)((n + 31) / 32);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(blocks), dim3(256), 0, st, d.part, gx, n, Cin, dw_ld ? dw_ld : Cin, dW);
     return check_launch("pcl_linear_bwd_dw_f32(reduce)");
+}
+
+// ---- few-row layers: constants + dy in one launch, weight gradient on the formed dy (round 5) ----------------------------------------
+static int g_dw_force_gx = 0;            // lab knob (pcl_set_dw_tuning): row-chunk workgroups per output tile of the plain-dy dW
+extern "C" void pcl_set_dw_tuning(int gx) { g_dw_force_gx = gx > 0 ? gx : 0; }
+
+extern "C" int pcl_bn_bwd_dy_supported(int P, int C) { return P >= 1 && C >= 32 && C % 32 == 0; }
+
+extern "C" int pcl_bn_bwd_dy_f32(const double* stats_ws, int stat_rows, const float* gamma, const float* mean, const float* invstd, int P_bn, int C,
+                                 float* dgamma, float* dbeta, float* a_out, float* k1, float* k2, float* dbias_zero, const float* dU, const float* Y,
+                                 const int32_t* arg, const float* gz, int ns, int P, float* dy, void* stream) {
+    PCL_REQUIRE(stats_ws && mean && invstd && a_out && k1 && k2 && Y && dy, "pcl_bn_bwd_dy_f32: null pointer");
+    PCL_REQUIRE(stat_rows >= 1 && P_bn >= 1 && pcl_bn_bwd_dy_supported(P, C), "pcl_bn_bwd_dy_f32: bad sizes P=%d C=%d (C must be a multiple of 32) stat_rows=%d", P, C, stat_rows);
+    PCL_REQUIRE((dU != nullptr) != (arg != nullptr && gz != nullptr), "pcl_bn_bwd_dy_f32: pass dU or (arg, gz)");
+    PCL_REQUIRE(dU || ns >= 1, "pcl_bn_bwd_dy_f32: ns = %d", ns);
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    PCL_REQUIRE(al16(Y) && al16(dy) && (!dU || al16(dU)) && (!gz || (al16(gz) && al16(arg))), "pcl_bn_bwd_dy_f32: operands must be 16-byte aligned");
+    BnDyArgs a = {};
+    a.q = BnConstsArgs{stats_ws, stat_rows, gamma, mean, invstd, P_bn, C, dgamma, dbeta, a_out, k1, k2, dbias_zero};
+    a.dU = dU; a.Y = Y; a.arg = arg; a.gz = gz; a.ns = ns; a.dy = dy; a.M = P;
+    const int cg = C / 32;
+    int rs = (512 + cg - 1) / cg;                        // ~2 blocks per CU; a block's row slab >= 64 rows
+    if (rs > (P + 63) / 64) rs = (P + 63) / 64;
+    if (rs < 1) rs = 1;
+    hipLaunchKernelGGL(bn_bwd_dy_kernel, dim3(cg, rs), dim3(256), 0, as_stream(stream), a);
+    return check_launch("pcl_bn_bwd_dy_f32");
+}
+
+static void dw_plain_grid(int P, int I, int J, int& gx, int& ti, int& tj, int& tm, int& tn) {
+    dw_grid(P, I, J, gx, ti, tj, tm, tn);
+    if (g_dw_force_gx) {
+        const int chunks = (P + DW_BP - 1) / DW_BP;
+        gx = g_dw_force_gx < chunks ? g_dw_force_gx : chunks;
+    }
+}
+extern "C" size_t pcl_linear_bwd_dw_plain_workspace_bytes(int P, int Cout, int Cin) {
+    if (P < 1 || Cout < 1 || Cin < 1) return 0;
+    int gx, ti, tj, tm, tn;
+    dw_plain_grid(P, Cout, Cin, gx, ti, tj, tm, tn);
+    return sizeof(float) * (size_t)gx * Cout * Cin;
+}
+/* dW[Cout][Cin] = dy^T z, z = lrelu(prev_scale x + prev_shift) or x: the staged dW kernel on an already formed dy */
+extern "C" int pcl_linear_bwd_dw_plain_f32(const float* dy, const float* Xprev, const float* prev_scale, const float* prev_shift, float prev_slope, int P,
+                                           int Cout, int Cin, float* dW, void* workspace, size_t workspace_bytes, int dw_ld, void* stream) {
+    PCL_REQUIRE(dy && Xprev && dW, "pcl_linear_bwd_dw_plain_f32: null pointer");
+    PCL_REQUIRE(dw_ld == 0 || dw_ld >= Cin, "pcl_linear_bwd_dw_plain_f32: dw_ld=%d < Cin=%d", dw_ld, Cin);
+    PCL_REQUIRE((prev_scale == nullptr) == (prev_shift == nullptr), "pcl_linear_bwd_dw_plain_f32: scale/shift together");
+    PCL_REQUIRE(P >= 1 && Cin >= 1 && Cout >= 1, "pcl_linear_bwd_dw_plain_f32: bad sizes");
+    const size_t need = pcl_linear_bwd_dw_plain_workspace_bytes(P, Cout, Cin);
+    if (!workspace || workspace_bytes < need) return fail(PCL_EWS, "pcl_linear_bwd_dw_plain_f32: workspace %zu < %zu", workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    int gx, ti, tj, tm, tn;
+    dw_plain_grid(P, Cout, Cin, gx, ti, tj, tm, tn);
+    DwArgs d = {};
+    d.A = dy; d.Bsrc = Xprev; d.bsc = prev_scale; d.bsh = prev_shift; d.bslope = prev_slope;
+    d.part = static_cast<float*>(workspace); d.P = P; d.I = Cout; d.J = Cin;
+    d.a_mode = A_PLAIN; d.b_mode = prev_scale ? A_BNACT : A_PLAIN;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool vec = (Cout % 4 == 0) && (Cin % 4 == 0) && al16(dy) && al16(Xprev);
+    d.gx = gx; d.ti = ti; d.tj = tj; d.ldo = Cin;
+    const bool direct = gx == 1;
+    if (direct) { d.part = dW; d.ldo = dw_ld ? dw_ld : Cin; }
+    dim3 grid(gx * ti * tj);
+    if (vec) launch_dw_t2<A_PLAIN, true, false>(d, grid, tm, tn, st); else launch_dw_t2<A_PLAIN, false, false>(d, grid, tm, tn, st);
+    int rc = check_launch("pcl_linear_bwd_dw_plain_f32");
+    if (rc || direct) return rc;
+    const size_t n = (size_t)Cout * Cin;
+    const int blocks = (int)((n + 31) / 32);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(blocks), dim3(256), 0, st, d.part, gx, n, Cin, dw_ld ? dw_ld : Cin, dW);
+    return check_launch("pcl_linear_bwd_dw_plain_f32(reduce)");
 }
 
 extern "C" void pcl_set_fb_max_blocks(int n) { g_fb_cap = n; }

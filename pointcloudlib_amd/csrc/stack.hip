@@ -110,8 +110,53 @@ struct BwdTmp {
     float* dUf; float* dWxp; float* dWfp;      // grouped
     float* unit;                               // grouped wide: [C1] ones then [2*C1] zeros: (a, k1, k2, mu) of the plain point GEMMs
     float* ptws; size_t ptws_bytes;            // grouped wide: workspace of the point dW GEMM
+    // weight gradients on the side stream (side_dw): what a dW launch reads must outlive the main chain's next layers, so the
+    // BatchNorm-backward constants and the dU tensors are per layer instead of ping-pong
+    float* consts_l[PCL_STACK_MAX_LAYERS];
+    float* dU_l[PCL_STACK_MAX_LAYERS];         // dU_l[l] = gradient w.r.t. the BatchNorm output of layer l (written by layer l + 1's dX)
+    float* dy_l[PCL_STACK_MAX_LAYERS];         // few-row layers: dy formed once per layer (pcl_bn_bwd_dy_f32), read by its dX and dW
     size_t bytes;
 };
+// Few-row plain stacks (the GroupAll level: 4 096 rows; the part-seg decoder: 2 048 .. 8 192): the weight gradient of a layer is not
+// on the critical path of the backward -- the chain is consts(l) -> dX(l) -> consts(l - 1) -> ... -- and every GEMM of these layers is
+// too short to fill the chip (fill / drain, a split-K tail and a reduce launch around 20-50 us of matrix work).  So the dW launches
+// (+ their reduces) go to a second stream of the library, forked after consts(l) and joined at the end of the call: they run in the
+// holes of the dX chain.  Results do not depend on the interleaving (same kernels, same grids, per-layer buffers).
+static int g_side_dw = 0, g_side_dw_max_rows = 8192;
+// Few-row layers (same stacks): BatchNorm-backward constants + dy in ONE launch, then dX on the fragment-direct kernel and dW on the staged
+// kernel, both reading the formed dy (csrc/mlp.hip: bn_bwd_dy_kernel).  Per layer: no fused dX + dW kernel for the shape, Cout % 32 == 0.
+static int g_fewrow = 0;
+bool frag_rows_eligible(int P);
+int frag_stat_rows(int P);
+static inline bool fewrow_layer(const pcl_mlp_stack_t& d, int l) {
+    if (!g_fewrow || d.grouped || !frag_rows_eligible(d.P)) return false;
+    if (l > 0 && fused_bwd_enabled() && pcl_linear_bwd_fused_supported(d.c[l + 1], d.c[l])) return false;
+    return pcl_bn_bwd_dy_supported(d.P, d.c[l + 1]) != 0;
+}
+static inline bool side_dw(const pcl_mlp_stack_t& d) {
+    if (!g_side_dw || d.grouped || d.P > g_side_dw_max_rows || d.n_layers < 2) return false;
+    for (int l = 1; l < d.n_layers; ++l) if (fused_bwd_enabled() && pcl_linear_bwd_fused_supported(d.c[l + 1], d.c[l])) return false;
+    return true;
+}
+
+// the library's second stream and the two events of a fork / join, per host thread and device (created on first use, never destroyed:
+// process lifetime).  Non-blocking stream: it synchronises with the caller's stream through the events only.
+struct SideCtx { hipStream_t st; hipEvent_t fork, join; int state; };       // state: 0 = not created, 1 = ready, -1 = creation failed
+static SideCtx* side_ctx() {
+    static thread_local SideCtx ctx[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return nullptr; }
+    SideCtx& c = ctx[dev];
+    if (c.state == 0) {
+        const bool ok = hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking) == hipSuccess &&
+                        hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) == hipSuccess &&
+                        hipEventCreateWithFlags(&c.join, hipEventDisableTiming) == hipSuccess;
+        c.state = ok ? 1 : -1;
+        if (!ok) (void)hipGetLastError();
+    }
+    return c.state == 1 ? &c : nullptr;
+}
+
 static BwdTmp bwd_tmp(const pcl_mlp_stack_t& d, void* base) {
     BwdTmp t = {};
     Carver c(base);
@@ -133,6 +178,10 @@ static BwdTmp bwd_tmp(const pcl_mlp_stack_t& d, void* base) {
         if (l == 0 && d.grouped) continue;
         const int cin = d.c[l], cout = d.c[l + 1];
         size_t b = pcl_linear_bwd_dw_workspace_bytes(d.P, cout, cin);
+        if (fewrow_layer(d, l)) {
+            const size_t f = pcl_linear_bwd_dw_plain_workspace_bytes(d.P, cout, cin);
+            if (f > b) b = f;
+        }
         if (l > 0 && pcl_linear_bwd_fused_supported(cout, cin)) {
             const size_t f = pcl_linear_bwd_fused_workspace_bytes(d.P, cout, cin);
             if (f > b) b = f;
@@ -141,6 +190,14 @@ static BwdTmp bwd_tmp(const pcl_mlp_stack_t& d, void* base) {
     }
     t.ws_bytes = wsb;
     t.ws = c.take<float>((wsb + 3) / 4);
+    for (int l = 0; l < L; ++l)
+        if (fewrow_layer(d, l)) t.dy_l[l] = c.take<float>((size_t)d.P * d.c[l + 1]);
+    if (side_dw(d)) {
+        for (int l = 0; l < L; ++l) {
+            t.consts_l[l] = c.take<float>((size_t)3 * d.c[l + 1]);
+            if (l < L - 1 || !G) t.dU_l[l] = c.take<float>((size_t)d.P * d.c[l + 1]);
+        }
+    }
     if (d.grouped) {
         const int rows = pcl_group_linear_stat_rows(d.B, d.m), C1 = d.c[1];
         if (grouped_wide(d)) {
@@ -528,6 +585,22 @@ static int stack_bwd_impl(const pcl_mlp_stack_t* dp) {
     const double* ext_stats = nullptr;  // defer_act: the first layer's sums come from the consumer
     bool sparse;
     const float* vL = s.vec[L - 1];
+    const bool sd = side_dw(d) && !d.defer_act;
+    SideCtx* const sc = sd ? side_ctx() : nullptr;
+    if (sd && !sc) return fail(PCL_EHIP, "pcl_mlp_stack_bwd_f32: could not create the side stream / events");
+    // join on every way out once forked: the caller's stream continues after the last weight gradient (the caller may release tmp /
+    // save right after this call, also when it failed half way)
+    struct Join {
+        SideCtx* sc; hipStream_t main; bool forked;
+        int now() {
+            if (!forked) return PCL_OK;
+            forked = false;
+            if (hipEventRecord(sc->join, sc->st) != hipSuccess || hipStreamWaitEvent(main, sc->join, 0) != hipSuccess)
+                return fail(PCL_EHIP, "pcl_mlp_stack_bwd_f32: join of the side stream failed");
+            return PCL_OK;
+        }
+        ~Join() { (void)now(); }
+    } join = {sc, reinterpret_cast<hipStream_t>(st), false};
     if (d.defer_act) {
         // the consumer already formed du (masked by the activation) and its two channel sums
         dU = d.gout; ext_stats = d.ext_stats; rows = d.ext_stat_rows; cur_du = 0; sparse = false;
@@ -546,8 +619,9 @@ static int stack_bwd_impl(const pcl_mlp_stack_t* dp) {
                                   t.unit ? 2 * d.c[1] : 0));
         sparse = true;
     } else {
-        PCL_TRY(pcl_bn_act_bwd_f32(d.gout, s.Y[L - 1], vL, vL + cl, d.out_slope, P, cl, t.dU[0], t.stats[0], &rows, st));
-        dU = t.dU[0]; cur_du = 1; sparse = false;
+        float* du0 = sd ? t.dU_l[L - 1] : t.dU[0];
+        PCL_TRY(pcl_bn_act_bwd_f32(d.gout, s.Y[L - 1], vL, vL + cl, d.out_slope, P, cl, du0, t.stats[0], &rows, st));
+        dU = du0; cur_du = 1; sparse = false;
     }
     bool have_pre = false;              // constants of layer l already computed by the fused finish of layer l + 1
     for (int l = L - 1; l >= 0; --l) {
@@ -555,9 +629,13 @@ static int stack_bwd_impl(const pcl_mlp_stack_t* dp) {
         const int cin = d.c[l], cout = d.c[l + 1];
         const float* v = s.vec[l];
         const float *mean = v + 2 * cout, *invstd = v + 3 * cout;
-        float* k = t.consts[cur_c];
+        float* k = sd ? t.consts_l[l] : t.consts[cur_c];
         float *a = k, *k1 = k + cout, *k2 = k + 2 * cout;
-        if (!have_pre)
+        const bool fr = fewrow_layer(d, l) && !have_pre;
+        if (fr)             // the constants AND dy = a du - k1 - k2 (y - mean), formed once for both GEMMs of the layer
+            PCL_TRY(pcl_bn_bwd_dy_f32(ext_stats ? ext_stats : t.stats[cur_stats], rows, ly.gamma, mean, invstd, P, cout, ly.dgamma, ly.dbeta, a, k1, k2,
+                                      ly.dbias, sparse ? nullptr : dU, s.Y[l], sparse ? s.arg : nullptr, sparse ? t.gz : nullptr, ns, P, t.dy_l[l], st));
+        else if (!have_pre)
             PCL_TRY(pcl_bn_bwd_consts_f32(ext_stats ? ext_stats : t.stats[cur_stats], rows, ly.gamma, mean, invstd, P, cout, ly.dgamma, ly.dbeta, a, k1,
                                           k2, ly.dbias, st));
         if (ext_stats) { ext_stats = nullptr; cur_stats = 1 - cur_stats; }      // (the layer below writes stats[1 - cur_stats]: keep the ping-pong consistent)
@@ -608,11 +686,34 @@ static int stack_bwd_impl(const pcl_mlp_stack_t* dp) {
             rows = pcl_linear_bwd_fused_stat_rows(P, cin);
             continue;
         }
+        void* dw_st = st;
+        if (sd) {
+            // fork: everything the dW launch reads is complete at this point of the caller's stream (consts(l) was the last to be written)
+            if (hipEventRecord(sc->fork, as_stream(st)) != hipSuccess || hipStreamWaitEvent(sc->st, sc->fork, 0) != hipSuccess)
+                return fail(PCL_EHIP, "pcl_mlp_stack_bwd_f32: fork to the side stream failed");
+            dw_st = sc->st; join.forked = true;
+        }
         tagf("dw%dx%d", cout, cin);
+        if (fr) {
+            PCL_TRY(pcl_linear_bwd_dw_plain_f32(t.dy_l[l], Xprev, psc, psh, d.slope, P, cout, cin, ly.dW, t.ws, t.ws_bytes, 0, dw_st));
+            if (l > 0 || d.need_dx) {
+                float* dUp = l > 0 ? (sd ? t.dU_l[l - 1] : t.dU[cur_du]) : d.dx;
+                PCL_REQUIRE(dUp, "pcl_mlp_stack_bwd_f32: need_dx without dx");
+                double* stn = l > 0 ? t.stats[1 - cur_stats] : nullptr;
+                tagf("dx%dx%d", cout, cin);
+                PCL_TRY(pcl_frag_linear_bwd_dx_f32(t.dy_l[l], ly.W, cin, P, cout, cin, l > 0 ? Xprev : nullptr, cin, l > 0 ? psc : nullptr, l > 0 ? psh : nullptr,
+                                                   d.slope, dUp, cin, stn, l == 0 ? d.x_grad_from : 0, st));
+                if (l > 0) {
+                    rows = frag_stat_rows(P);
+                    dU = dUp; sparse = false; cur_du = 1 - cur_du; cur_stats = 1 - cur_stats; cur_c = 1 - cur_c;
+                }
+            }
+            continue;
+        }
         PCL_TRY(pcl_linear_bwd_dw_rows_f32(dU, Yl, a, k1, k2, mean, sparse ? s.arg : nullptr, sparse ? t.gz : nullptr, ns, Xprev, psc, psh, d.slope,
-                                           P, cout, cin, ly.dW, t.ws, t.ws_bytes, rmeta, nrows, 0, st));
+                                           P, cout, cin, ly.dW, t.ws, t.ws_bytes, rmeta, nrows, 0, dw_st));
         if (l > 0 || d.need_dx) {
-            float* dUp = l > 0 ? t.dU[cur_du] : d.dx;
+            float* dUp = l > 0 ? (sd ? t.dU_l[l - 1] : t.dU[cur_du]) : d.dx;
             PCL_REQUIRE(dUp, "pcl_mlp_stack_bwd_f32: need_dx without dx");
             double* stn = l > 0 ? t.stats[1 - cur_stats] : nullptr;
             tagf("dx%dx%d", cout, cin);
@@ -624,6 +725,22 @@ static int stack_bwd_impl(const pcl_mlp_stack_t* dp) {
             }
         }
     }
+    PCL_TRY(join.now());
     set_launch_tag("");
     return PCL_OK;
+}
+
+extern "C" void pcl_set_stack_overlap(int side_dw_on, int max_rows) {
+    if (side_dw_on >= 0) g_side_dw = side_dw_on != 0;
+    if (max_rows > 0) g_side_dw_max_rows = max_rows;
+}
+extern "C" int pcl_get_stack_overlap(void) { return g_side_dw; }
+extern "C" void pcl_set_fewrow_backward(int on) { if (on >= 0) g_fewrow = on != 0; }
+extern "C" int pcl_get_fewrow_backward(void) { return g_fewrow; }
+/* does layer (Cout <- Cin) of a plain stack on P rows take the few-row backward (constants + dy in one launch, dX and dW on the formed dy)?
+ * The per-kernel host path asks the same question so that both paths launch the same kernels. */
+extern "C" int pcl_mlp_fewrow_layer(int P, int Cout, int Cin, int first_layer) {
+    if (!g_fewrow || !frag_rows_eligible(P)) return 0;
+    if (!first_layer && fused_bwd_enabled() && pcl_linear_bwd_fused_supported(Cout, Cin)) return 0;
+    return pcl_bn_bwd_dy_supported(P, Cout);
 }

@@ -231,6 +231,7 @@ class _FusedMLP(torch.autograd.Function):
             if l == 0 and sv["W0p"] is not None:
                 W = sv["W0p"]
             cout, cin = W.shape
+            fewrow = False
             if pre is not None:
                 # (the layer above ran the fused kernel: its second launch already turned the sums into these constants)
                 a, k1, k2, dgamma, dbeta, dbias = pre
@@ -240,8 +241,17 @@ class _FusedMLP(torch.autograd.Function):
                 a, k1, k2 = _empty((3, cout), dev).unbind(0)
                 dgamma, dbeta = _empty((cout,), dev), _empty((cout,), dev)
                 dbias = _empty((cout,), dev) if bias is not None else None        # exactly zero under BatchNorm: cleared there
-                _lib.call("pcl_bn_bwd_consts_f32", _P(stats), rows, _P(gamma), _P(means[l]), _P(invstds[l]), P, cout,
-                          _P(dgamma), _P(dbeta), _P(a), _P(k1), _P(k2), _P(dbias), st)
+                # few-row layers (csrc/stack.hip: fewrow_layer -- the same question, the same kernels): constants AND dy in one launch
+                fewrow = (rmeta is None and ctx.link is None and cin == fan_in and not syncbn.active()
+                          and bool(_lib.size_query("pcl_mlp_fewrow_layer", P, cout, cin, int(l == 0))))
+                if fewrow:
+                    dy = _empty((P, cout), dev)
+                    _lib.call("pcl_bn_bwd_dy_f32", _P(stats), rows, _P(gamma), _P(means[l]), _P(invstds[l]), P, cout, _P(dgamma), _P(dbeta), _P(a),
+                              _P(k1), _P(k2), _P(dbias), None if sparse else _P(dU), _P(Ys[l]), _P(arg) if sparse else None,
+                              _P(gz) if sparse else None, ns or 1, P, _P(dy), st)
+                else:
+                    _lib.call("pcl_bn_bwd_consts_f32", _P(stats), rows, _P(gamma), _P(means[l]), _P(invstds[l]), P, cout,
+                              _P(dgamma), _P(dbeta), _P(a), _P(k1), _P(k2), _P(dbias), st)
                 if syncbn.active():
                     # dgamma / dbeta above: sums over THIS rank's rows (the gradient all-reduce averages them); the constants
                     # of dy = a*du - k1 - k2*(y - mean) come from the global sums over the global row count (syncbn.py)
@@ -304,6 +314,26 @@ class _FusedMLP(torch.autograd.Function):
                               None, None, None, None, None, None, st)
                 grads[6 * l] = dW
                 dU, sparse, stats, rows = dUp, False, stats_n, rows_n
+                continue
+            if fewrow:
+                nbytes = _lib.size_query("pcl_linear_bwd_dw_plain_workspace_bytes", P, cout, cin)
+                ws = _empty(((nbytes + 3) // 4,), dev)
+                dW = _empty((cout, cin), dev)
+                _lib.call("pcl_linear_bwd_dw_plain_f32", _P(dy), _P(Xprev), _P(psc), _P(psh), slope, P, cout, cin, _P(dW), _P(ws), nbytes, 0, st,
+                          algo_bytes=4 * P * (cin + cout) + 4 * cin * cout, algo_flops=2 * P * cin * cout, tag=f"dw{cout}x{cin}")
+                grads[6 * l] = dW
+                if l > 0 or need_x:
+                    dUp = _empty((P, cin), dev)
+                    rows_n = _lib.size_query("pcl_frag_stat_rows", P)
+                    stats_n = _empty((rows_n, 2, cin), dev, torch.float64) if l > 0 else None
+                    _lib.call("pcl_frag_linear_bwd_dx_f32", _P(dy), _P(W), cin, P, cout, cin, _P(Xprev) if l > 0 else None, cin,
+                              _P(psc) if l > 0 else None, _P(psh) if l > 0 else None, slope, _P(dUp), cin, _P(stats_n),
+                              x_grad_from if l == 0 else 0, st, algo_bytes=4 * P * (cin * (2 if l > 0 else 1) + cout) + 4 * cin * cout,
+                              algo_flops=2 * P * cin * cout, tag=f"dx{cout}x{cin}")
+                    if l > 0:
+                        dU, sparse, stats, rows = dUp, False, stats_n, rows_n
+                    else:
+                        gx = dUp
                 continue
             nbytes = _lib.size_query("pcl_linear_bwd_dw_workspace_bytes", P, cout, cin)
             ws = _empty(((nbytes + 3) // 4,), dev)

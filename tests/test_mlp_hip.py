@@ -845,3 +845,72 @@ def test_kernel_path_switches_select_equivalent_kernels(dev, off):
         assert (a[1][n] - b[1][n]).abs().max().item() <= tol * gs + 1e-7, n
     for n in a[2]:
         assert torch.allclose(a[2][n], b[2][n], rtol=1e-5, atol=1e-6), n
+
+
+# ---- weight gradients on the library's side stream (pcl_set_stack_overlap): same kernels, any interleaving ----
+@pytest.mark.parametrize("spec,lead,ns,bias", [([259, 256, 512, 1024], (32, 1, 128), 128, False),     # the GroupAll level at full size
+                                               ([1664, 256, 256], (16, 128), None, True),               # part-seg decoder fp3 (no max, bias)
+                                               ([20, 96, 32], (2, 300), None, True)])
+def test_side_stream_weight_gradients_equal_the_serial_order(dev, spec, lead, ns, bias):
+    """pcl_mlp_stack_bwd_f32 forks the dW launches of few-row plain stacks to a second stream and joins at the end of the call
+    (csrc/stack.hip: side_dw): outputs and every gradient must be BIT-identical to the serial order, call after call."""
+    from pointcloudlib_amd import _lib
+    from pointcloudlib_amd.misc import mlp_hip
+    L = _lib.lib()
+    torch.manual_seed(11)
+    mlp = PointwiseMLP(spec, bias=bias, slope=0.0).to(dev).train()
+    x = torch.randn(*lead, spec[0], device=dev)
+    gshape = (lead[:-1] if ns else lead) + (spec[-1],)
+    gout = torch.randn(*gshape, device=dev)
+    prev = L.pcl_get_stack_overlap()
+    try:
+        L.pcl_set_stack_overlap(0, -1); mlp_hip._PLANS.clear()          # (buffer sizes depend on the mode)
+        ref = run(copy.deepcopy(mlp), x, ns, gout, "auto")
+        L.pcl_set_stack_overlap(1, -1); mlp_hip._PLANS.clear()
+        for _ in range(4):
+            got = run(copy.deepcopy(mlp), x, ns, gout, "auto")
+            # consume the gradients right away on the caller's stream: the join must order them behind the side stream's writes
+            assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+            for n in ref[2]:
+                assert torch.equal(ref[2][n], got[2][n]), n
+    finally:
+        L.pcl_set_stack_overlap(prev, -1); mlp_hip._PLANS.clear()
+
+
+@pytest.mark.parametrize("spec,lead,ns,bias", [([259, 256, 512, 1024], (32, 1, 128), 128, False),     # the GroupAll level at full size (sparse max gradient)
+                                               ([1664, 256, 256], (16, 128), None, True),               # part-seg decoder fp3 (dense, bias)
+                                               ([131, 128, 96, 64], (3, 50, 8), 8, False)])             # 96 = 3 x 32 channels, ragged row slabs
+def test_few_row_backward_matches_the_staged_kernels(dev, spec, lead, ns, bias):
+    """pcl_set_fewrow_backward(1): BatchNorm-backward constants + dy in one launch (pcl_bn_bwd_dy_f32), dX on the fragment kernel and dW on
+    the staged kernel reading the formed dy.  dgamma / dbeta come from the same sums in the same order (bit-identical); the GEMMs sum in
+    another order: 1e-4 of the gradient's max-norm (this file's gradient tolerance).  The per-stack and the per-kernel host path must launch the same kernels (bit-identical)."""
+    from pointcloudlib_amd import _lib
+    from pointcloudlib_amd.misc import mlp_hip
+    L = _lib.lib()
+    torch.manual_seed(5)
+    mlp = PointwiseMLP(spec, bias=bias, slope=0.0).to(dev).train()
+    x = torch.randn(*lead, spec[0], device=dev)
+    gshape = (lead[:-1] if ns else lead) + (spec[-1],)
+    gout = torch.randn(*gshape, device=dev)
+    prev = L.pcl_get_fewrow_backward()
+    def fresh():
+        _lib.size_query.cache_clear(); mlp_hip._PLANS.clear()
+    try:
+        L.pcl_set_fewrow_backward(0); fresh()
+        ref = run(copy.deepcopy(mlp), x, ns, gout, "auto")
+        L.pcl_set_fewrow_backward(1); fresh()
+        assert L.pcl_mlp_fewrow_layer(x.numel() // spec[0], spec[-1], spec[-2], 0) == 1
+        got = _with_stack(True, lambda: run(copy.deepcopy(mlp), x, ns, gout, "auto"))
+        per = _with_stack(False, lambda: run(copy.deepcopy(mlp), x, ns, gout, "auto"))
+    finally:
+        L.pcl_set_fewrow_backward(prev); fresh()
+    assert torch.equal(ref[0], got[0])
+    L_ = len(spec) - 1
+    for n in ref[2]:
+        assert torch.equal(got[2][n], per[2][n]), n
+        if n.startswith(("gammas", "betas")) and n.endswith(str(L_ - 1)):
+            assert torch.equal(ref[2][n], got[2][n]), n          # the last layer's sums come from the same upstream gradient
+        err = (ref[2][n] - got[2][n]).abs().max().item()
+        assert err <= 1e-4 * max(1e-30, ref[2][n].abs().max().item()) + 1e-7, (n, err)
+    assert torch.equal(got[1], per[1])
+    assert (ref[1] - got[1]).abs().max().item() <= 1e-4 * ref[1].abs().max().item() + 1e-7
