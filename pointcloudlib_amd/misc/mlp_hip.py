@@ -365,6 +365,37 @@ class _FusedMLP(torch.autograd.Function):
         return (gx, None) + tuple(grads)
 
 
+def _profiling_pad(module, P, params, folded_first=False):
+    """The per-stack entry points run a 96-wide hidden layer zero-padded to 128 channels (csrc/stack.hip: padded_width -- the
+    resident-weight forward and the fused backward exist for 64 / 128 / 256).  The per-kernel path is what the profiling passes time
+    (``per_kernel_path``), so it has to launch the same kernels: the same padding, built here with torch ops (pad: zero weights,
+    gamma = beta = 0 -> the extra channels are exactly 0 everywhere; autograd slices the gradients back).  Returns the padded
+    parameter list and a closure that copies the 96 real running statistics back after the forward."""
+    L = module.n_layers
+    spec = module.spec
+    widths = [128 if (1 <= l < L and spec[l] == 96 and P >= 32768) else spec[l] for l in range(L + 1)]
+    if widths == list(spec[:L + 1]) or not (module.bn and module.training) or (folded_first and widths[1] != spec[1]):
+        return params, None
+    F = torch.nn.functional
+    out, fix = list(params), []
+    for l in range(L):
+        W, bias, gamma, beta, rm, rv = params[6 * l:6 * l + 6]
+        co, ci = widths[l + 1] - spec[l + 1], widths[l] - spec[l]
+        if W is not None and (co or ci):
+            out[6 * l] = F.pad(W, (0, ci, 0, co))
+        if co:
+            out[6 * l + 1] = None if bias is None else F.pad(bias, (0, co))
+            out[6 * l + 2], out[6 * l + 3] = F.pad(gamma, (0, co)), F.pad(beta, (0, co))
+            rmp, rvp = F.pad(rm, (0, co)), F.pad(rv, (0, co), value=1.0)
+            out[6 * l + 4], out[6 * l + 5] = rmp, rvp
+            fix.append((rm, rmp, rv, rvp, spec[l + 1]))
+    def finish():
+        with torch.no_grad():
+            for rm, rmp, rv, rvp, c in fix:
+                rm.copy_(rmp[:c]); rv.copy_(rvp[:c])
+    return out, finish
+
+
 def pointwise_mlp(module, x, group_max=None, rowset=None, x_grad_from=0):
     """Run ``PointwiseMLP`` ``module`` on channel-last ``x`` [..., C0] through the fused HIP path.  With a ``RowSet``
     (duplicate-compacted ball-query groups) ``x`` is the [capacity, C0] row table and the result is [B, m, CL]."""
@@ -393,7 +424,10 @@ def pointwise_mlp(module, x, group_max=None, rowset=None, x_grad_from=0):
     # xyz never needs a gradient); lower columns of the returned input gradient are left unwritten.
     cfg = (ns, module.slope, module.eps, module.momentum, module.training, module.bn, module.last_act, rowset,
            int(x_grad_from), None, int(getattr(module, "flush_k", 0)) if rowset is None else 0)
+    params, finish = _profiling_pad(module, x2.shape[0], params) if rowset is None else (params, None)
     out = _FusedMLP.apply(x2, cfg, *params)
+    if finish is not None:
+        finish()
     if rowset is not None:
         return out.reshape(rowset.B, rowset.m, out.shape[-1])
     if ns:
@@ -541,7 +575,10 @@ def grouped_mlp(module, xyz, new_xyz, feature, idx, cnt, group_off, use_xyz):
                    getattr(module, f"running_var_{i}") if module.bn else None]
     params[0] = module.weights[0].detach()          # shape carrier only: the folded layer's weight gets its gradient outside
     cfg = (ns, module.slope, module.eps, module.momentum, module.training, module.bn, module.last_act, rowset, 0, link)
+    params, finish = _profiling_pad(module, B * m * ns, params, folded_first=True)
     out = _FusedMLP.apply(Y0, cfg, *params)
+    if finish is not None:
+        finish()
     return out.reshape(B, m, out.shape[-1])
 
 

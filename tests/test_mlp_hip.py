@@ -497,6 +497,10 @@ def test_stack_with_a_96_wide_hidden_layer_runs_zero_padded(dev, grouped):
         assert close(a[2][n], b[2][n], 2e-4), (n, (a[2][n] - b[2][n]).abs().max().item(), a[2][n].abs().max().item())
     for n in a[3]:
         assert a[3][n].shape == b[3][n].shape and close(a[3][n].float(), b[3][n].float(), 1e-5), n
+    # the per-kernel path pads the same way (mlp_hip._profiling_pad: it is what the profiling passes time): same kernels, same operands
+    assert torch.equal(a[0], b[0])
+    for n in a[2]:
+        assert torch.equal(a[2][n], b[2][n]), n
 
 
 # ---- the whole FC head as one call per direction (pcl_fc_head_*_f32) ---------------------------------------------------
