@@ -61,75 +61,117 @@ __global__ __launch_bounds__(256) void pointconv_contract_bwd_feat_kernel(const 
 
 // The same with the feature MLP's last BatchNorm + activation folded in (see FeatBN): what leaves is du = d_feat * lrelu'(fsc*y+fsh),
 // the gradient w.r.t. that BatchNorm's output, and this workgroup's partial row of (sum du, sum du*y) -- the separate
-// elementwise pass (read d_feat and y, write du: 805 MB at the first two levels) is gone.  Persistent over the groups
-// (workgroup bx takes g = bx, bx + gridDim.x, ...), so that a workgroup owns one partial row: no atomics.
-// Block = CB channel lanes x TG groups in flight (512 threads): a workgroup owns one partial row and enough waves to hide the
-// latency of a streaming kernel (one group per workgroup at a time measured 189 us per 268 MB level; this form: see DESIGN).
-constexpr int PCB_T = 512;
-__global__ __launch_bounds__(PCB_T) void pointconv_contract_bwd_feat_bn_kernel(const float* __restrict__ dout, const float* __restrict__ dens,
-                                                                               const float* __restrict__ w, const float* __restrict__ Y,
-                                                                               const FeatBN bn, int G, int ns, int C, int CB, float* __restrict__ du,
-                                                                               double* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) float dyn[];                 // [TG][PC_SCH*PC_M] staged weights, then [2][TG][CB] doubles
-    const int TG = PCB_T / CB;
-    const int tid = threadIdx.x, cl = tid % CB, tg = tid / CB;
-    float* swd = dyn + tg * PC_SCH * PC_M;
-    const int gstep = gridDim.x * TG;
-    const int iters = (G + gstep - 1) / gstep;                                   // the same for every thread: block barriers inside
-    for (int c0 = blockIdx.y * CB; c0 < C; c0 += gridDim.y * CB) {
-        const int c = c0 + cl;
+// elementwise pass (read d_feat and y, write du: 805 MB at the first two levels) is gone.
+// Round 5: on the matrix pipe.  Per group d_feat [ns x C] = wd [ns x 16] . dout^T [16 x C] with wd[s][m] = dens[s] w[s][m]: a K = 16
+// product, eight v_mfma_f32_32x32x2_f32 per 32 rows x 32 channels.  A wave owns a 32-channel block (a lane one channel: its dout row is the
+// B operand, 8 of the 16 m per half-wave, the contraction index permuted the same way on both operands) and walks the workgroup's groups:
+// the A operand is two 16-byte loads of w per lane, the 32 x 32 results arrive in the C/D layout -- lane = channel, registers = rows --
+// which is exactly the layout y is loaded and du stored in (128-byte row segments per half-wave), and the channel sums stay in the lane.
+// The vector form (a lane per channel, 16 fma + four 16-byte LDS broadcasts per element, the group's wd staged behind two block barriers,
+// 117 registers) ran 156 us per 268 MB level = 3.4 TB/s inside a training step; this form has no LDS, no barrier, and the next unit's y
+// rows in flight behind the current unit's MFMAs.  A workgroup (4 waves = 4 channel blocks at a time) owns one partial row: no atomics.
+typedef float pc_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned pc_u32x4 __attribute__((ext_vector_type(4)));
+using pc_rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr unsigned PC_OOB = 0xfffffff0u;             // a per-lane offset no descriptor here covers: loads return 0, stores are dropped
+// descriptor over [base + first_byte, + bytes): wave-uniform (tensors here are < 4 GiB; the range check does the row / column masking)
+__device__ __forceinline__ pc_rsrc_t pc_rsrc(const void* base, size_t first_byte, unsigned bytes) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(base) + first_byte;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* q = reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ float pc_ld1(pc_rsrc_t r, unsigned voff, unsigned soff) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
+__device__ __forceinline__ float4 pc_ld4(pc_rsrc_t r, unsigned voff, unsigned soff) {
+    const pc_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void pc_st1(pc_rsrc_t r, unsigned voff, unsigned soff, float x) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0); }
+
+// operands of one unit = (group, 32-row block) as a lane holds them: requested a unit ahead, untouched until consumed
+struct PcUnit { float y[16]; float4 a0, a1, b0, b1; float dn; };
+
+__global__ __launch_bounds__(256) void pointconv_contract_bwd_feat_bn_kernel(const float* __restrict__ dout, const float* __restrict__ dens,
+                                                                             const float* __restrict__ w, const float* __restrict__ Y,
+                                                                             const FeatBN bn, int G, int ns, int C, float* __restrict__ du,
+                                                                             double* __restrict__ stats) {
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 31, lh = lane >> 5;
+    const int ncb = (C + 31) >> 5;
+    const int per = (ncb + gridDim.y - 1) / gridDim.y;                        // channel blocks of this grid.y slice
+    const int cb_end = min(ncb, ((int)blockIdx.y + 1) * per);
+    const int nmb = (ns + 31) >> 5;
+    const int ng = (G - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // groups of this workgroup: blockIdx.x, + gridDim.x, ...
+    const int units = ng * nmb;
+    const unsigned Cb = (unsigned)C * 4u;
+    const unsigned grp_bytes = (unsigned)ns * Cb;                             // one group's rows of Y / du
+    for (int cb = blockIdx.y * per + wv; cb < cb_end; cb += 4) {
+        const int c = cb * 32 + lr;
         const bool cok = c < C;
-        const float ba = bn.sc[min(c, C - 1)], bb = bn.sh[min(c, C - 1)];
+        const int cc = cok ? c : C - 1;
+        const float ba = bn.sc[cc], bb = bn.sh[cc];
+        // per-lane offsets: Y / du element (row 4 lh, channel c) of a group; the dout row of channel c, its half of the 16 m; the w row lr
+        const unsigned vy = cok ? (unsigned)(4 * lh) * Cb + (unsigned)c * 4u : PC_OOB;
+        const unsigned vb = cok ? (unsigned)c * (PC_M * 4u) + (unsigned)lh * 32u : PC_OOB;
+        const unsigned va = (unsigned)lr * (PC_M * 4u) + (unsigned)lh * 32u;
         double s1 = 0.0, s2 = 0.0;
-        for (int it = 0; it < iters; ++it) {
-            const int g = blockIdx.x * TG + tg + it * gstep;
-            const bool gok = g < G;
-            const int gg = gok ? g : G - 1;
-            float d[PC_M];
-            {
-                const float4* q = reinterpret_cast<const float4*>(dout + ((size_t)gg * C + min(c, C - 1)) * PC_M);
+        float t1 = 0.f, t2 = 0.f;
+        // unit u -> (group, 32-row block); a unit past the end reads through empty descriptors (zeros) so that the requests need no branch
+        auto request = [&](int u, PcUnit& q) {
+            const bool live = u < units;
+            const int gi = u / nmb, mb = u - gi * nmb;
+            const int g = blockIdx.x + gi * gridDim.x;
+            const pc_rsrc_t rY = pc_rsrc(Y, (size_t)g * grp_bytes, live ? grp_bytes : 0u);
+            const pc_rsrc_t rW = pc_rsrc(w, (size_t)g * ns * (PC_M * 4), live ? (unsigned)ns * (PC_M * 4u) : 0u);
+            const pc_rsrc_t rD = pc_rsrc(dens, (size_t)g * ns * 4, live ? (unsigned)ns * 4u : 0u);
+            const pc_rsrc_t rB = pc_rsrc(dout, (size_t)g * C * (PC_M * 4), live ? (unsigned)C * (PC_M * 4u) : 0u);
+            const unsigned row0 = (unsigned)mb * 32u;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const float4 v = q[j]; d[4 * j] = v.x; d[4 * j + 1] = v.y; d[4 * j + 2] = v.z; d[4 * j + 3] = v.w; }
+            for (int i = 0; i < 16; ++i) q.y[i] = pc_ld1(rY, vy, (row0 + (unsigned)((i & 3) + 8 * (i >> 2))) * Cb);       // rows past ns: 0
+            q.a0 = pc_ld4(rW, va, row0 * (PC_M * 4u)); q.a1 = pc_ld4(rW, va + 16u, row0 * (PC_M * 4u));
+            q.dn = pc_ld1(rD, (unsigned)lr * 4u, row0 * 4u);
+            q.b0 = pc_ld4(rB, vb, 0u); q.b1 = pc_ld4(rB, vb + 16u, 0u);
+        };
+        auto consume = [&](int u, const PcUnit& q) {
+            const int gi = u / nmb, mb = u - gi * nmb;
+            const int g = blockIdx.x + gi * gridDim.x;
+            if (mb == 0) { t1 = 0.f; t2 = 0.f; }
+            const float dn = q.dn;
+            pc_f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.a0.x * dn, q.b0.x, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.a0.y * dn, q.b0.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.a0.z * dn, q.b0.z, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.a0.w * dn, q.b0.w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.a1.x * dn, q.b1.x, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.a1.y * dn, q.b1.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.a1.z * dn, q.b1.z, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.a1.w * dn, q.b1.w, acc, 0, 0, 0);
+            const pc_rsrc_t rU = pc_rsrc(du, (size_t)g * grp_bytes, grp_bytes);
+            const unsigned row0 = (unsigned)mb * 32u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                // rows past ns: the A row read 0 -> acc = 0 -> v = 0, y = 0: nothing stored (range check), nothing summed; channels past C alike
+                const float a = acc[i];
+                const float v = fmaf(ba, q.y[i], bb) > 0.f ? a : a * bn.slope;
+                pc_st1(rU, vy, (row0 + (unsigned)((i & 3) + 8 * (i >> 2))) * Cb, v);
+                t1 += v; t2 = fmaf(v, q.y[i], t2);
             }
-            const size_t base = (size_t)gg * ns * C;
-            float t1 = 0.f, t2 = 0.f;
-            for (int s0 = 0; s0 < ns; s0 += PC_SCH) {
-                const int len = min(PC_SCH, ns - s0);
-                __syncthreads();
-                for (int e = cl; e < len * PC_M; e += CB)
-                    swd[e] = w[((size_t)gg * ns + s0) * PC_M + e] * dens[(size_t)gg * ns + s0 + e / PC_M];
-                __syncthreads();
-                if (cok && gok) {
-                    for (int sb = 0; sb < len; sb += 8) {
-                        float y[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) y[u] = Y[base + (size_t)(s0 + min(sb + u, len - 1)) * C + c];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            if (sb + u >= len) break;
-                            float a = 0.f;
-#pragma unroll
-                            for (int m = 0; m < PC_M; ++m) a = fmaf(d[m], swd[(sb + u) * PC_M + m], a);
-                            const float v = fmaf(ba, y[u], bb) > 0.f ? a : a * bn.slope;
-                            du[base + (size_t)(s0 + sb + u) * C + c] = v;
-                            t1 += v; t2 = fmaf(v, y[u], t2);
-                        }
-                    }
-                }
-            }
-            s1 += (double)t1; s2 += (double)t2;
+            if (mb == nmb - 1) { s1 += (double)t1; s2 += (double)t2; }
+        };
+        PcUnit q0, q1;
+        request(0, q0);
+        for (int u = 0; u < units; u += 2) {
+            // (scheduling fences: the next unit's requests go out BEFORE this unit is consumed -- hipcc otherwise sinks them behind the MFMAs and
+            //  the wait for them then also waits for this unit's 16 stores, which count in the same counter)
+            request(u + 1, q1);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(u, q0);
+            __builtin_amdgcn_sched_barrier(0);
+            request(u + 2, q0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u + 1 < units) consume(u + 1, q1);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // fold the TG group lanes of a channel (fixed order), one row per workgroup
-        __syncthreads();
-        double* red = reinterpret_cast<double*>(dyn);
-        red[tg * CB + cl] = s1; red[(TG + tg) * CB + cl] = s2;
-        __syncthreads();
-        if (tg == 0 && cok) {
-            double a = 0.0, b = 0.0;
-            for (int k = 0; k < TG; ++k) { a += red[k * CB + cl]; b += red[(TG + k) * CB + cl]; }
-            stats[(size_t)blockIdx.x * 2 * C + c] = a; stats[(size_t)blockIdx.x * 2 * C + C + c] = b;
-        }
-        __syncthreads();
+        // the two half-waves hold the same channels (rows 4 lh + ...): fold them, one partial row per workgroup
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (lh == 0 && cok) { stats[(size_t)blockIdx.x * 2 * C + c] = s1; stats[(size_t)blockIdx.x * 2 * C + C + c] = s2; }
     }
 }
 
@@ -519,11 +561,11 @@ extern "C" int pcl_pointconv_contract_bn_bwd_f32(const float* dout, const float*
     hipStream_t st = as_stream(stream);
     const FeatBN bn = {scale, shift, slope};
     const int rows = pcl_pointconv_contract_bn_stat_rows(G);
-    const int CB = pc_block(C) == 192 ? 256 : pc_block(C), TG = PCB_T / CB;          // CB divides 512
-    const size_t lds = (size_t)TG * PC_SCH * PC_M * sizeof(float) > (size_t)2 * TG * CB * sizeof(double) ? (size_t)TG * PC_SCH * PC_M * sizeof(float)
-                                                                                                           : (size_t)2 * TG * CB * sizeof(double);
-    hipLaunchKernelGGL(pointconv_contract_bwd_feat_bn_kernel, dim3(rows, pc_chan_blocks(rows, C)), dim3(PCB_T), lds, st, dout, density, weights, Y, bn,
-                       G, ns, C, CB, du, stats_ws);
+    // few groups (the GroupAll level): channel blocks spread over grid.y, >= 4 per slice (one per wave)
+    const int ncb = (C + 31) / 32;
+    int cslices = rows >= 512 ? 1 : (512 + rows - 1) / rows;
+    if (cslices > (ncb + 3) / 4) cslices = (ncb + 3) / 4;
+    hipLaunchKernelGGL(pointconv_contract_bwd_feat_bn_kernel, dim3(rows, cslices), dim3(256), 0, st, dout, density, weights, Y, bn, G, ns, C, du, stats_ws);
     int rc = check_launch("pcl_pointconv_contract_bn_bwd_f32(feat)");
     if (rc) return rc;
     const int wgs = (G + 4 * bwd_w_gpw(ns) - 1) / (4 * bwd_w_gpw(ns));
