@@ -412,6 +412,13 @@ int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a, const
 /* reference: the autograd backward of nn.Conv 1x1 + nn.BatchNorm + nn.ReLU, networks/cls/pointnet2.py:25-29 */
 /* test / tuning hook: cap the persistent grid of the fused backward at n workgroups (0 = one per CU); process-wide, set between calls */
 void pcl_set_fb_max_blocks(int n);
+/* The optimiser step (reference: nn.SGD(net.parameters(), lr, momentum), train_cls.py:404; train_partseg.py: weight_decay 1e-4):
+ *   g += weight_decay * p;  v = momentum * v + (1 - dampening) * g;  p -= lr * v        (no Nesterov, every tensor has its buffer v)
+ * for n_tensors fp32 tensors in one launch per 96 tensors.  params / grads / bufs / numel are HOST arrays (device pointers, element
+ * counts); pointers need 4-byte alignment only.  The arithmetic is torch.optim.SGD(fused=True)'s: products and sums in fp64 of the fp32
+ * operands, one rounding per statement (tests/test_networks_gpu.py::test_lean_sgd_is_torch_fused_sgd: bit-identical). */
+int pcl_sgd_momentum_f32(const uint64_t* params, const uint64_t* grads, const uint64_t* bufs, const int64_t* numel, int n_tensors, double lr,
+                         double momentum, double weight_decay, double dampening, void* stream);
 /* Lab switches of the kernel selection (no reference counterpart), 1 = on (default), 0 = off, negative = leave as is: the resident-weight
  * forward (off: linear_nt_kernel), the recompute-per-pass narrow stacks of PointConv's WeightNet / DensityNet (off: the GEMM kernels), the
  * fused dX + dW backward inside pcl_mlp_stack_bwd_f32 (off: separate kernels).  A C call: the library reads no environment variables. */

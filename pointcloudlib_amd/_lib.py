@@ -133,6 +133,7 @@ _SIGS = {
     "pcl_frag_linear_bwd_dw_f32": (c_int, [_P, _P, c_int, _P, _P, c_float, c_int, c_int, c_int, _P, c_int, _P, c_size_t, c_int, _P]),
     "pcl_set_fb_max_blocks": (None, [c_int]),
     "pcl_set_kernel_paths": (None, [c_int, c_int, c_int]),
+    "pcl_sgd_momentum_f32": (c_int, [_P, _P, _P, _P, c_int, c_double, c_double, c_double, c_double, _P]),
     "pcl_set_stack_overlap": (None, [c_int, c_int]),
     "pcl_get_stack_overlap": (c_int, []),
     "pcl_bn_bwd_dy_supported": (c_int, [c_int, c_int]),

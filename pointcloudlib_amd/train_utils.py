@@ -64,15 +64,16 @@ class _LeanFusedSGD(torch.optim.SGD):
     def __init__(self, params, **kw):
         super().__init__(params, fused=True, **kw)
         self._lean = None
+        self._own = None          # pointer tables of the library's own kernel (csrc/sgd.hip), built with the cached lists
 
     def load_state_dict(self, state_dict):
         # the parent replaces every momentum buffer with a new tensor: drop the cached lists, the next step() rebuilds them
-        self._lean = None
+        self._lean = self._own = None
         return super().load_state_dict(state_dict)
 
     def __setstate__(self, state):
         super().__setstate__(state)
-        self._lean = None
+        self._lean = self._own = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -83,17 +84,44 @@ class _LeanFusedSGD(torch.optim.SGD):
             out = super().step()                                       # creates the momentum buffers
             ps = [p for p in g["params"] if p.grad is not None]
             if g["momentum"] != 0 and len(ps) == len(g["params"]) and len({(p.device, p.dtype) for p in ps}) == 1:
-                self._lean = (ps, [self.state[p]["momentum_buffer"] for p in ps])
+                bufs = [self.state[p]["momentum_buffer"] for p in ps]
+                self._lean = (ps, bufs)
+                self._own = None
+                if ps and ps[0].dtype == torch.float32 and all(p.is_contiguous() for p in ps) and all(b.is_contiguous() for b in bufs):
+                    import ctypes
+                    n = len(ps)
+                    U64, I64 = ctypes.c_uint64 * n, ctypes.c_int64 * n
+                    self._own = (U64(*[p.data_ptr() for p in ps]), U64(*[b.data_ptr() for b in bufs]), I64(*[p.numel() for p in ps]), U64(), n)
             return out
         ps, bufs = self._lean
         # optimizer.state cleared or re-created behind our back: the cached buffers would be stale (first + last identity check)
         st0, st1 = self.state.get(ps[0]), self.state.get(ps[-1])
         if st0 is None or st1 is None or st0.get("momentum_buffer") is not bufs[0] or st1.get("momentum_buffer") is not bufs[-1]:
-            self._lean = None
+            self._lean = self._own = None
             return self.step()
         grads = [p.grad for p in ps]
         if any(x is None for x in grads):
             return super().step()
+        if self._own is not None and not g["nesterov"] and not g["maximize"]:
+            # one launch of the library's own kernel per 96 tensors (csrc/sgd.hip: torch's arithmetic, bit-identical): the pointer tables of
+            # the parameters and the momentum buffers are built once, the gradients' every step (they are new slices of the stacks' flat
+            # gradient buffers each backward)
+            from . import _lib
+            pa, ba, na, ga, n = self._own
+            try:
+                for i, x in enumerate(grads):
+                    if x.dtype != torch.float32 or not x.is_contiguous():
+                        raise TypeError
+                    ga[i] = x.data_ptr()
+            except TypeError:
+                grads = [x.contiguous() for x in grads]
+                for p, x in zip(ps, grads):
+                    p.grad = x
+                for i, x in enumerate(grads):
+                    ga[i] = x.data_ptr()
+            _lib.call("pcl_sgd_momentum_f32", pa, ga, ba, na, n, float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), float(g["dampening"]),
+                      torch._C._cuda_getCurrentRawStream(ps[0].device.index))
+            return None
         torch._fused_sgd_(ps, grads, bufs, weight_decay=g["weight_decay"], momentum=g["momentum"], lr=g["lr"],
                           dampening=g["dampening"], nesterov=g["nesterov"], maximize=g["maximize"], is_first_step=False,
                           grad_scale=None, found_inf=None)
