@@ -341,143 +341,88 @@ __global__ __launch_bounds__(256, 2) void pointconv_contract_bwd_w_kernel(const 
     }
 }
 
-// ---- forward on the matrix pipe -----------------------------------------------------------------------------------------
-// out[g, c, m] = sum_s z[g,s,c] * (dens[g,s] * w[g,s,m]): per group a (C x ns)(ns x 16) product -- M = channels, N = 16 = the
-// MFMA's N, K = the group's rows.  Same skeleton as the weight-gradient kernel above: persistent waves, a unit = GPW groups x one
-// pass of 64 / GPW rows, 32-channel chunks of the feature rows staged ROW-major through the wave's LDS slab (A operand
-// z[4kk + q][16mb + j], row stride 48 dwords: 2-way), the density-scaled weights of the unit's rows beside it (B operand: 64
-// consecutive dwords per k step), the next (unit, chunk, pass) in flight while this one is consumed, loaded values untouched
-// until they are stored to LDS.  A chunk's 32 x 16 outputs per group are complete after the group's last pass and leave in the
-// C/D layout as 64-byte rows.  PointConv cls, first two levels (435 / 352 MB of features, weights and outputs): 114 / 97 us =
-// 3.8 / 3.6 TB/s inside a training step (the vector version -- one workgroup per group, a lane per channel, 16 accumulators, one
-// short-lived wave per group paying the memory latency -- 150 / 140 us); streaming reads of this pattern reach 5.8 TB/s from cold
-// HBM (tools/ubench/rowpattern.hip).
-constexpr int PC_RLD = 48;
-template <int GPW>
-__global__ __launch_bounds__(256) void pointconv_contract_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ dens,
-                                                                     const float* __restrict__ w, int G, int ns, int C,
-                                                                     float* __restrict__ out, const FeatBN bn) {
-    constexpr int RG = 64 / GPW;
-    __shared__ __attribute__((aligned(16))) float sfr[4][64][PC_RLD];
-    __shared__ __attribute__((aligned(16))) float swd[4][64 * PC_M];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool vec = (C & 3) == 0;
-    const int q = lane >> 4, j = lane & 15;
-    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-    const int npass = (ns + RG - 1) / RG;
-    const int units = (G + GPW - 1) / GPW;
+// ---- forward, fragment-direct (round 5) ---------------------------------------------------------------------------------------------
+// out[g][c][m] = sum_s wd[s][m] z[s][c] as D = A B with A = wd^T (M = the 16 m, rows 16..31 of the 32 x 32 tile idle), B = z (N = 32
+// channels), K = the group's rows: v_mfma_f32_32x32x2_f32, lane (c = lane & 31, h = lane >> 5) supplies z[row][c] -- 128-byte row
+// segments per half-wave straight from memory, no LDS -- and holds the results for ITS channel: out[g][c][4h .. 4h+3] and [8+4h .. 8+4h+3],
+// two 16-byte stores.  The contraction index of step kk is row 32 mb + 16 h + kk on both operands, so that a lane's 16 densities are four
+// 16-byte loads.  A wave owns (group, 32-channel block) units, consecutive waves consecutive blocks of a group (a workgroup covers whole
+// rows); the next unit's z rows are requested before the current unit's MFMAs (scheduling fences, as in the kernel above).  The LDS-staged
+// 16x16x4 form above it: 116 / 99 us per level (3.8 / 3.6 TB/s).
+__global__ __launch_bounds__(256) void pointconv_contract_fwd_frag_kernel(const float* __restrict__ feat, const float* __restrict__ dens,
+                                                                          const float* __restrict__ w, int G, int ns, int C,
+                                                                          float* __restrict__ out, const FeatBN bn) {
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 31, lh = lane >> 5;
+    const int ncb = (C + 31) >> 5, nmb = (ns + 31) >> 5;
+    const int units = G * ncb;                                                // (group, channel block); a wave walks a unit's 32-row blocks itself
     const int W = gridDim.x * 4;
-    const int cfirst = blockIdx.y * PC_CCH, cstep = gridDim.y * PC_CCH;
-    float4 pv[8], pw[4];
-    float pdn[4];
-    // position = (unit u, chunk c0, pass ps); order: passes innermost (a chunk's outputs accumulate over the passes of its groups)
-    auto load_pos = [&](int u, int c0, int ps) {
-        const int g0 = u * GPW, s0 = ps * RG;
-        const int len = min(RG, ns - s0);
-        const int cl = min(PC_CCH, C - c0);
-        const int cq = (lane & 7) * 4;
+    const unsigned Cb = (unsigned)C * 4u, grp_bytes = (unsigned)ns * Cb;
+    const bool act = bn.sc != nullptr;
+    // this lane's A rows: m = lr (lanes 16..31 of each half idle: their offset is out of range -> 0)
+    const unsigned va = lr < PC_M ? (unsigned)(16 * lh) * (PC_M * 4u) + (unsigned)lr * 4u : PC_OOB;
+    const int u0 = blockIdx.x * 4 + wv;
+    const int steps = u0 < units ? ((units - u0 + W - 1) / W) * nmb : 0;     // step t -> unit u0 + (t / nmb) W, row block t % nmb
+    float zq[2][16];
+    auto request = [&](int t, float (&z)[16]) {
+        const bool live = t < steps;
+        const int mb = t % nmb, u = u0 + (t / nmb) * W;
+        const int cb = u % ncb, g = u / ncb;
+        const int c = cb * 32 + lr;
+        const pc_rsrc_t rF = pc_rsrc(feat, (size_t)g * grp_bytes, live ? grp_bytes : 0u);
+        const unsigned vz = c < C ? (unsigned)(16 * lh) * Cb + (unsigned)c * 4u : PC_OOB;
+        const unsigned row0 = (unsigned)mb * 32u;
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int r = pass * 8 + (lane >> 3);
-            const int grp = r / RG, rr = r % RG;
-            const int gg = min(g0 + grp, G - 1);
-            const float* src = feat + ((size_t)gg * ns + s0 + min(rr, len - 1)) * C + c0;
-            if (vec) pv[pass] = *reinterpret_cast<const float4*>(src + min(cq, cl - 4));
-            else { pv[pass].x = src[min(cq, cl - 1)]; pv[pass].y = src[min(cq + 1, cl - 1)]; pv[pass].z = src[min(cq + 2, cl - 1)]; pv[pass].w = src[min(cq + 3, cl - 1)]; }
+        for (int kk = 0; kk < 16; ++kk) z[kk] = pc_ld1(rF, vz, (row0 + (unsigned)kk) * Cb);              // rows past ns: 0
+    };
+    request(0, zq[0]);
+    pc_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    auto consume = [&](int t, const float (&z)[16]) {
+        const int mb = t % nmb, u = u0 + (t / nmb) * W;
+        const int cb = u % ncb, g = u / ncb;
+        const int c = cb * 32 + lr;
+        const int cc = min(c, C - 1);
+        // A operand of this (group, row block): wd[row][m] = w[row][m] dens[row], rows 32 mb + 16 h + kk (L1 / L2 hits after the group's first unit)
+        const pc_rsrc_t rW = pc_rsrc(w, (size_t)g * ns * (PC_M * 4), (unsigned)ns * (PC_M * 4u));
+        const pc_rsrc_t rD = pc_rsrc(dens, (size_t)g * ns * 4, (unsigned)ns * 4u);
+        const unsigned row0 = (unsigned)mb * 32u;
+        float a[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) a[kk] = pc_ld1(rW, va, (row0 + (unsigned)kk) * (PC_M * 4u));
+        float dn[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            // (16-byte loads of 4-byte-aligned rows: ns is any number; the range check is per dword on gfx950)
+            dn[4 * q4] = pc_ld1(rD, (unsigned)(16 * lh + 4 * q4) * 4u, row0 * 4u); dn[4 * q4 + 1] = pc_ld1(rD, (unsigned)(16 * lh + 4 * q4 + 1) * 4u, row0 * 4u);
+            dn[4 * q4 + 2] = pc_ld1(rD, (unsigned)(16 * lh + 4 * q4 + 2) * 4u, row0 * 4u); dn[4 * q4 + 3] = pc_ld1(rD, (unsigned)(16 * lh + 4 * q4 + 3) * 4u, row0 * 4u);
         }
-        if (npass > 1 || c0 == cfirst) {                  // the rows' weights and densities (once per unit when there is one pass)
+        float ba = 1.f, bb = 0.f;
+        if (act) { ba = bn.sc[cc]; bb = bn.sh[cc]; }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = i * 16 + (lane >> 2);       // row of the pass, 4 lanes x 16 B per row
-                const int grp = r / RG, rr = r % RG;
-                const size_t row = (size_t)min(g0 + grp, G - 1) * ns + s0 + min(rr, len - 1);
-                pw[i] = *reinterpret_cast<const float4*>(w + row * PC_M + (lane & 3) * 4);
-                pdn[i] = dens[row];
+        for (int kk = 0; kk < 16; ++kk) {
+            const float zz = act ? feat_act(z[kk], ba, bb, bn.slope) : z[kk];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk] * dn[kk], zz, acc, 0, 0, 0);
+        }
+        if (mb == nmb - 1) {
+            if (c < C) {
+                float* o = out + ((size_t)g * C + c) * PC_M + 4 * lh;
+                *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                *reinterpret_cast<float4*>(o + 8) = make_float4(acc[4], acc[5], acc[6], acc[7]);
             }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         }
     };
-    auto stash_pos = [&](int u, int c0, int ps) {
-        const int g0 = u * GPW, s0 = ps * RG;
-        const int len = min(RG, ns - s0);
-        const int cl = min(PC_CCH, C - c0);
-        const int cq = (lane & 7) * 4;
-        float4 ba4 = make_float4(1.f, 1.f, 1.f, 1.f), bb4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bn.sc) {
-            if (vec) {
-                const int cb0 = c0 + min(cq, cl - 4);
-                ba4 = *reinterpret_cast<const float4*>(bn.sc + cb0); bb4 = *reinterpret_cast<const float4*>(bn.sh + cb0);
-            } else {
-                ba4 = make_float4(bn.sc[c0 + min(cq, cl - 1)], bn.sc[c0 + min(cq + 1, cl - 1)], bn.sc[c0 + min(cq + 2, cl - 1)], bn.sc[c0 + min(cq + 3, cl - 1)]);
-                bb4 = make_float4(bn.sh[c0 + min(cq, cl - 1)], bn.sh[c0 + min(cq + 1, cl - 1)], bn.sh[c0 + min(cq + 2, cl - 1)], bn.sh[c0 + min(cq + 3, cl - 1)]);
-            }
-        }
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int r = pass * 8 + (lane >> 3);
-            float4 v = pv[pass];
-            if (bn.sc) {
-                v.x = feat_act(v.x, ba4.x, bb4.x, bn.slope); v.y = feat_act(v.y, ba4.y, bb4.y, bn.slope);
-                v.z = feat_act(v.z, ba4.z, bb4.z, bn.slope); v.w = feat_act(v.w, ba4.w, bb4.w, bn.slope);
-            }
-            const bool okr = r % RG < len && g0 + r / RG < G;
-            v.x = okr && cq < cl ? v.x : 0.f; v.y = okr && cq + 1 < cl ? v.y : 0.f;
-            v.z = okr && cq + 2 < cl ? v.z : 0.f; v.w = okr && cq + 3 < cl ? v.w : 0.f;
-            *reinterpret_cast<float4*>(&sfr[wave][r][cq]) = v;
-        }
-        if (npass > 1 || c0 == cfirst) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = i * 16 + (lane >> 2);
-                const bool okr = r % RG < len && g0 + r / RG < G;
-                const float d = okr ? pdn[i] : 0.f;
-                *reinterpret_cast<float4*>(&swd[wave][r * PC_M + (lane & 3) * 4]) = make_float4(pw[i].x * d, pw[i].y * d, pw[i].z * d, pw[i].w * d);
-            }
-        }
-    };
-    int u = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave), c0 = cfirst, ps = 0;
-    if (u >= units || cfirst >= C) return;
-    load_pos(u, c0, ps);
-    pc_f32x4 acc[GPW][2];
-#pragma unroll
-    for (int gi = 0; gi < GPW; ++gi) { acc[gi][0] = pc_f32x4{0.f, 0.f, 0.f, 0.f}; acc[gi][1] = pc_f32x4{0.f, 0.f, 0.f, 0.f}; }
-    while (u < units) {
-        wave_sync();
-        stash_pos(u, c0, ps);
-        const bool lastp = ps + 1 >= npass, lastc = c0 + cstep >= C;
-        const int nps = lastp ? 0 : ps + 1, nc = !lastp ? c0 : (lastc ? cfirst : c0 + cstep), nu = (lastp && lastc) ? u + W : u;
-        if (nu < units) load_pos(nu, nc, nps);
-        wave_sync();
-        // sixteen k steps of four rows: A = z[4kk + q][16mb + j], B = wd[4kk + q][j]; the rows of group gi are k steps gi*RG/4 ..
-        struct FOps { float a0, a1, b; };
-        auto f_ld = [&](int kk) -> FOps {
-            const float* arow = &sfr[wave][4 * kk + q][j];
-            return FOps{arow[0], arow[16], swd[wave][(4 * kk + q) * PC_M + j]};
-        };
-        FOps cur = f_ld(0);
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {                 // (operands of step k+1 read before the MFMAs of step k)
-            FOps nxt = cur;
-            if (kk + 1 < 16) nxt = f_ld(kk + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[(4 * kk) / RG][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a0, cur.b, acc[(4 * kk) / RG][0], 0, 0, 0);
-            acc[(4 * kk) / RG][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a1, cur.b, acc[(4 * kk) / RG][1], 0, 0, 0);
-            cur = nxt;
-        }
-        if (lastp) {                                      // C/D layout: acc[gi][mb][r] = out[g0 + gi][c0 + 16mb + 4q + r][j]
-#pragma unroll
-            for (int gi = 0; gi < GPW; ++gi) {
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = c0 + 16 * mb + 4 * q + r;
-                        if (c < C && u * GPW + gi < G) out[((size_t)(u * GPW + gi) * C + c) * PC_M + j] = acc[gi][mb][r];
-                    }
-                    acc[gi][mb] = pc_f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-        }
-        u = nu; c0 = nc; ps = nps;
+    for (int t = 0; t < steps; t += 2) {
+        request(t + 1, zq[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(t, zq[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        request(t + 2, zq[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < steps) consume(t + 1, zq[1]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -521,23 +466,19 @@ static int pc_chan_blocks(int G, int C) {
 
 static void launch_contract_fwd(hipStream_t st, const float* feat, const float* dens, const float* w, int G, int ns, int C, float* out,
                                 const FeatBN bn) {
-    const int gpw = bwd_w_gpw(ns);
-    const int units = (G + gpw - 1) / gpw;
-    int wgs = (units + 3) / 4;
-    // few groups (the GroupAll level): the channel chunks spread over grid.y (a chunk's outputs belong to one workgroup: no atomics)
-    int slices = wgs >= 512 ? 1 : (512 + wgs - 1) / wgs;
-    if (slices > (C + PC_CCH - 1) / PC_CCH) slices = (C + PC_CCH - 1) / PC_CCH;
-    const int cap = bwd_w_max_wgs(slices);                // persistent: two workgroups per CU (64 KB of LDS each)
+    // fragment-direct kernel: a wave per (group, 32-channel block) unit, persistent over the units
+    const long long units = (long long)G * ((C + 31) / 32);
+    long long wgs = (units + 3) / 4;
+    const long long cap = 2ll * bwd_w_max_wgs(1);                     // 4 workgroups per CU (128 registers: 4 waves per SIMD), all resident
     if (wgs > cap) wgs = cap;
-    const dim3 grid(wgs, slices), blk(256);
-    if (gpw == 2) hipLaunchKernelGGL(pointconv_contract_fwd_kernel<2>, grid, blk, 0, st, feat, dens, w, G, ns, C, out, bn);
-    else hipLaunchKernelGGL(pointconv_contract_fwd_kernel<1>, grid, blk, 0, st, feat, dens, w, G, ns, C, out, bn);
+    hipLaunchKernelGGL(pointconv_contract_fwd_frag_kernel, dim3((unsigned)wgs), dim3(256), 0, st, feat, dens, w, G, ns, C, out, bn);
 }
 
 extern "C" int pcl_pointconv_contract_f32(const float* feat, const float* density, const float* weights, int G, int ns, int C,
                                           int M, float* out, void* stream) {
     PCL_REQUIRE(feat && density && weights && out, "pcl_pointconv_contract_f32: null pointer");
     PCL_REQUIRE(G >= 1 && ns >= 1 && C >= 1 && M == PC_M, "pcl_pointconv_contract_f32: bad sizes G=%d ns=%d C=%d M=%d (M must be 16)", G, ns, C, M);
+    PCL_REQUIRE((long long)G * ((C + 31) / 32) < (1ll << 30) && (size_t)ns * C * 4 < 0xffffffffull, "pcl_pointconv_contract_f32: G=%d ns=%d C=%d beyond the kernel's 32-bit unit / group offsets", G, ns, C);
     launch_contract_fwd(as_stream(stream), feat, density, weights, G, ns, C, out, FeatBN{nullptr, nullptr, 1.f});
     return check_launch("pcl_pointconv_contract_f32");
 }
@@ -546,6 +487,7 @@ extern "C" int pcl_pointconv_contract_bn_f32(const float* Y, const float* scale,
                                              const float* weights, int G, int ns, int C, int M, float* out, void* stream) {
     PCL_REQUIRE(Y && scale && shift && density && weights && out, "pcl_pointconv_contract_bn_f32: null pointer");
     PCL_REQUIRE(G >= 1 && ns >= 1 && C >= 1 && M == PC_M && slope >= 0.f && slope <= 1.f, "pcl_pointconv_contract_bn_f32: bad sizes G=%d ns=%d C=%d M=%d slope=%g", G, ns, C, M, (double)slope);
+    PCL_REQUIRE((long long)G * ((C + 31) / 32) < (1ll << 30) && (size_t)ns * C * 4 < 0xffffffffull, "pcl_pointconv_contract_bn_f32: G=%d ns=%d C=%d beyond the kernel's 32-bit unit / group offsets", G, ns, C);
     launch_contract_fwd(as_stream(stream), Y, density, weights, G, ns, C, out, FeatBN{scale, shift, slope});
     return check_launch("pcl_pointconv_contract_bn_f32");
 }
