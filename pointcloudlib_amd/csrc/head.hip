@@ -269,6 +269,18 @@ typedef float hd_f32x16 __attribute__((ext_vector_type(16)));
 // wave per column) adds the KS partial sums in order and runs the layer's epilogue: deterministic, 61 + 6 us at 16384 x 1024 where the
 // 8-columns-per-workgroup VALU kernel took 111.  The partial sums live in a workspace of the caller (pcl_head_layer_fwd_workspace_bytes).
 constexpr int HM_KC = 128;
+typedef unsigned hd_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t hd_rsrc(const void* base, size_t first_byte, size_t bytes) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(base) + first_byte;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* q = reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo);
+    const unsigned n = bytes > 0x7fffffffull ? 0x7fffffffu : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
+}
+__device__ __forceinline__ float4 hd_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const hd_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 __global__ __launch_bounds__(256) void head_fwd_part_kernel(const float* __restrict__ X, const float* __restrict__ W, int R, int K, int N, int kper,
                                                             float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) float sX[32][HM_KC + 4];
@@ -279,15 +291,20 @@ __global__ __launch_bounds__(256) void head_fwd_part_kernel(const float* __restr
     hd_f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // operands through buffer descriptors over this workgroup's k range of the 32 rows / columns: rows past R, columns past N and k past
+    // kend read 0 by the range check -- no branch around a load (the branchy form kept px / pw in 160 B of scratch and waited for every
+    // load right after issuing it: 85 us inside a training step for a kernel that moves 67 MB)
     float4 px[4], pw[4];
+    const unsigned rowb = (unsigned)K * 4u;
+    const __amdgpu_buffer_rsrc_t rX = hd_rsrc(X, 0, (size_t)R * rowb), rW = hd_rsrc(W, (size_t)n0 * rowb, (size_t)min(32, N - n0) * rowb);
+    const unsigned vo = (unsigned)row * rowb + (unsigned)kq * 4u;
     auto load = [&](int k0) {                                  // (K % 4 == 0 and 16-byte rows: checked by the caller)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int k = k0 + kq + 32 * i;
-            const bool kin = k < kend;
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            px[i] = (kin && row < R) ? *reinterpret_cast<const float4*>(X + (size_t)row * K + k) : z;
-            pw[i] = (kin && n0 + row < N) ? *reinterpret_cast<const float4*>(W + (size_t)(n0 + row) * K + k) : z;
+            const int k = k0 + 32 * i;                         // wave-uniform part of the k index; k + kq < kend <=> k < kend (kend % 4 == 0 ... HM_KC)
+            const unsigned dead = (k + kq < kend) ? 0u : 0x80000000u;
+            px[i] = hd_ld4(rX, vo | dead, (unsigned)k * 4u);
+            pw[i] = hd_ld4(rW, vo | dead, (unsigned)k * 4u);
         }
     };
     load(kbeg);
