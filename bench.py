@@ -335,12 +335,13 @@ def main():
                 ach = r["algo_flops"] / (r["avg_ms"] * 1e-3) / 1e12
                 peak, unit = FP32_PEAK_TFLOPS, "TFLOP/s"
             # PMC HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py ->
-            # profiles/r04_traffic.json).  They are only valid for the kernel sources they were measured on: the file records
+            # profiles/rNN_traffic.json, the newest one).  They are only valid for the kernel sources they were measured on: the file records
             # the git blob hashes of csrc/*.hip + common.h, and a mismatch (or another workload) prints null.
             traffic, traffic_src = None, None
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
-                if (B, N, args.dist) == (32, 1024, "gauss_ball") and tj.get("csrc_sha") == csrc_sha():
+                from pointcloudlib_amd.buildinfo import traffic_profile
+                tj = traffic_profile()
+                if tj is not None and (B, N, args.dist) == (32, 1024, "gauss_ball"):
                     traffic = tj["per_launch_hbm_bytes"].get(f"{key[0]}:{key[1]}")
                 traffic_src = tj["source"] if traffic is not None else None
             except Exception:

@@ -204,12 +204,12 @@ def _run_prefetch(name, make, inputs, loss_fn, steps, warmup=120, windows=1):   
 
 
 def traffic_of(key, roofline):
-    """PMC HBM bytes per launch of the row's dominant kernel from profiles/r04_traffic_<key>.json (two separate rocprofv3 --pmc
+    """PMC HBM bytes per launch of the row's dominant kernel from the newest profiles/rNN_traffic_<key>.json (two separate rocprofv3 --pmc
     passes of `tools/bench_models.py --only ...`, tools/prof_cfg.sh) -- only while the kernel sources still hash to what was measured."""
-    from pointcloudlib_amd.buildinfo import csrc_sha
+    from pointcloudlib_amd.buildinfo import traffic_profile
     try:
-        tj = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"r04_traffic_{key}.json")))
-        if tj.get("csrc_sha") == csrc_sha():
+        tj = traffic_profile("_" + key)
+        if tj is not None:
             return tj["per_launch_hbm_bytes"].get(f"{roofline['kernel']}:{roofline['shape']}"), tj["source"]
     except Exception:
         pass
