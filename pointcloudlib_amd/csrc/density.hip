@@ -2,10 +2,10 @@
 //
 // Semantics: compute_density, /root/reference/misc/pointconv_utils.py:174-184:
 //   density[b,i] = mean_j exp(-d2(i,j) / (2 bw^2)) / (2.5 bw)
-// The reference materialises the dense [B,N,N] matrix (134 MB at N=1024) in matmul form; here one lane per
-// point i streams the cloud from LDS (SoA, broadcast reads) and keeps a running sum -- nothing N^2 touches HBM.
+// The reference materialises the dense [B,N,N] matrix (134 MB at N=1024) in matmul form; here eight lanes per
+// point i stream the cloud from LDS (SoA, broadcast reads) and keep running sums -- nothing N^2 touches HBM.
 // d2 is evaluated in direct form (x_i-x_j)^2+... (the matmul form -2ab+a^2+b^2 differs in the last ulps); the sum
-// runs over j ascending and is kept in fp64: a running fp32 sum of N terms is ~1e-5 relative off, and DensityNet's
+// is kept in fp64 (eight interleaved partial sums over j ascending, folded in a fixed tree): a running fp32 sum of N terms is ~1e-5 relative off, and DensityNet's
 // BatchNorm over this ONE channel divides by its spread (mean/std amplification) -- measured at B=32, N=1024 as a 7x
 // larger DensityNet weight-gradient error than the fp32 CPU restatement's.  Float parity with the oracle is to tolerance
 // (expf), not bits.
@@ -14,11 +14,14 @@
 namespace pcl {
 
 constexpr int DEN_T = 256, DEN_CHUNK = 2048;
-
+constexpr int DEN_S = 8;                       // lanes per point: point i's sum over j runs as DEN_S interleaved partial sums
+// One lane per point put 4 x B workgroups on the chip for N = 1024 (128 of 1 024 wave slots, 1 024 dependent exp + fp64 add per lane:
+// 60 us inline in PointConv's step); eight lanes per point give 8 x the workgroups and an eighth of the chain.  The eight fp64 partial
+// sums are folded in a fixed tree, so the result is run-to-run identical (against the single ascending fp64 sum: ~1e-16 relative).
 __global__ __launch_bounds__(DEN_T) void density_kernel(const float* __restrict__ xyz, int N, float inv_2bw2, double norm,
                                                         float* __restrict__ out) {
     __shared__ float sx[DEN_CHUNK], sy[DEN_CHUNK], sz[DEN_CHUNK];
-    const int b = blockIdx.y, i = blockIdx.x * DEN_T + threadIdx.x;
+    const int b = blockIdx.y, sub = threadIdx.x % DEN_S, i = blockIdx.x * (DEN_T / DEN_S) + threadIdx.x / DEN_S;
     const float* P = xyz + (size_t)b * N * 3;
     float px = 0.f, py = 0.f, pz = 0.f;
     if (i < N) { px = P[3 * i]; py = P[3 * i + 1]; pz = P[3 * i + 2]; }
@@ -32,12 +35,13 @@ __global__ __launch_bounds__(DEN_T) void density_kernel(const float* __restrict_
             if (c == 0) sx[k] = v; else if (c == 1) sy[k] = v; else sz[k] = v;
         }
         __syncthreads();
-        for (int k = 0; k < len; ++k) {
+        for (int k = sub; k < len; k += DEN_S) {
             const float d = sq_dist3(px, py, pz, sx[k], sy[k], sz[k]);
             acc += (double)expf(-d * inv_2bw2);
         }
     }
-    if (i < N) out[(size_t)b * N + i] = (float)(acc * norm);
+    acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+    if (i < N && sub == 0) out[(size_t)b * N + i] = (float)(acc * norm);
 }
 
 }  // namespace pcl
@@ -49,7 +53,7 @@ extern "C" int pcl_density_f32(const float* xyz, int B, int N, float bandwidth, 
     if (B == 0) return PCL_OK;
     const float inv_2bw2 = 1.0f / (2.0f * bandwidth * bandwidth);
     const double norm = 1.0 / (2.5 * (double)bandwidth) / (double)N;
-    hipLaunchKernelGGL(density_kernel, dim3((N + DEN_T - 1) / DEN_T, B), dim3(DEN_T), 0, as_stream(stream), xyz, N, inv_2bw2, norm,
+    hipLaunchKernelGGL(density_kernel, dim3((N * DEN_S + DEN_T - 1) / DEN_T, B), dim3(DEN_T), 0, as_stream(stream), xyz, N, inv_2bw2, norm,
                        density_out);
     return check_launch("pcl_density_f32");
 }
