@@ -271,7 +271,9 @@ extern "C" int pcl_fps_f32(const float* xyz, int B, int N, int m, int tie_stride
         PCL_FPS_CASE(128, 1) PCL_FPS_CASE(128, 2) PCL_FPS_CASE(128, 4) PCL_FPS_CASE(128, 8) PCL_FPS_CASE(128, 16)
         PCL_FPS_CASE(256, 1) PCL_FPS_CASE(256, 2) PCL_FPS_CASE(256, 4) PCL_FPS_CASE(256, 8) PCL_FPS_CASE(256, 16)
         PCL_FPS_CASE(512, 1) PCL_FPS_CASE(512, 2) PCL_FPS_CASE(512, 4) PCL_FPS_CASE(512, 8) PCL_FPS_CASE(512, 16)
-        PCL_FPS_CASE(1024, 1) PCL_FPS_CASE(1024, 2) PCL_FPS_CASE(1024, 4) PCL_FPS_CASE(1024, 8) PCL_FPS_CASE(1024, 16)
+        PCL_FPS_CASE(1024, 1) PCL_FPS_CASE(1024, 2) PCL_FPS_CASE(1024, 4) PCL_FPS_CASE(1024, 8)
+        // (1024 threads x 16 points per lane does not fit the 128 registers of a 1024-thread workgroup -- it spilled 16 of them into the step
+        //  loop; clouds of 8 193 .. 10 100 points take the LDS-resident kernel below like the larger ones)
     }
 #undef PCL_FPS_CASE
     // large clouds: min-distance array in LDS (4 B/point), coordinates re-read from L2 each step

@@ -2789,7 +2789,11 @@ static int launch_linear_t(const LinArgs& a_in, hipStream_t st) {
     //  spilled up to 224 registers, are not compiled at all: round 5)
     if (narrow || AM >= A_DY) {
         if (vec) PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 1, GM, RAG>), grid, dim3(MLP_T), st, a);
-        else PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, false, 1, GM, RAG>), grid, dim3(MLP_T), st, a);
+        else if constexpr (AM == A_DY_SPARSE && RAG && GM == 0) {
+            // scalar staging of the sparse max gradient on compacted rows (Cout % 4 != 0): three operand streams per row for 128-row tiles
+            // spilled 23 registers; 64-row tiles fit (the persistent loop and the statistics rows do not depend on the tile height)
+            PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, false, 1, GM, RAG, 1>), grid, dim3(MLP_T), st, a);
+        } else PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, false, 1, GM, RAG>), grid, dim3(MLP_T), st, a);
     } else {
         if constexpr (AM < A_DY) {
             if (vec) PCL_LAUNCH_TIMED((linear_nt_kernel<AM, EM, true, 2, GM, RAG>), grid, dim3(MLP_T), st, a);

@@ -179,7 +179,8 @@ def test_full_size_sa1_statistics_property(dev):
     assert (rv - (0.9 + 0.1 * var)).abs().max().item() < 1e-5
 
 
-def test_duplicate_compacted_rows_match_padded_groups(oracle, dev):
+@pytest.mark.parametrize("last", [64, 30])      # 30: Cout % 4 != 0 -> the scalar staging of the sparse max gradient on compacted rows (64-row tiles)
+def test_duplicate_compacted_rows_match_padded_groups(oracle, dev, last):
     """The ragged path (MLP on the DISTINCT rows of ball-query groups + multiplicities) must reproduce the padded
     computation: pooled features, every parameter gradient, the feature gradient and the running statistics."""
     from pointcloudlib_amd import synth
@@ -192,11 +193,11 @@ def test_duplicate_compacted_rows_match_padded_groups(oracle, dev):
     idx_f, new_xyz = ops.furthest_point_sample(x, m)
     idx, cnt = ops.ball_query(new_xyz, x, 0.25, ns, return_cnt=True)
     assert 0.2 < (cnt.float().mean().item() / ns) < 0.95          # a real mix of padded and saturated groups
-    mlp = PointwiseMLP([3 + C, 32, 32, 64]).to(dev).train()
+    mlp = PointwiseMLP([3 + C, 32, 32, last]).to(dev).train()
     with torch.no_grad():
         for g in mlp.gammas:
             g.uniform_(0.5, 1.5); g[::4] *= -1.0
-    gout = torch.randn(B, m, 64, device=dev)
+    gout = torch.randn(B, m, last, device=dev)
     res = []
     for compact in (False, True):
         mm = copy.deepcopy(mlp)
