@@ -183,6 +183,19 @@ int pcl_group_linear_bwd_f32(const float* row_loc, const float* row_feat, int CF
                              const float* a, const float* k1, const float* k2, const float* mu, const int32_t* row_src,
                              const int32_t* n_rows_dev /* &group_off[B*m] */, int B, int N, int C1, float* dUf,
                              float* dWx_part, float* dWf_part, float* dW0, int ldw, int off, void* stream);
+/* The same scatter as a GATHER over the points' row lists (round 5): pcl_group_rows_transpose_i32 turns row_src into
+ * in_off [B*N + 1] / in_rows [group_off[B*m]] -- every source point's rows, ascending (one workgroup per cloud; 17 N + 1 + m ns ints in
+ * LDS: pcl_group_rows_transpose_supported; a group names a point at most once, as ball query / k-NN groups do) -- and pcl_group_linear_bwd_gather_f32 walks the rows by source point: dUf [B*N][C1]
+ * is WRITTEN (no zero-fill, no atomics; sums in list order: run-to-run identical), dWx_part [pcl_group_linear_stat_rows][C1][3] as in
+ * pcl_group_linear_bwd_f32, dW0[c][0..2] (leading dimension ldw) optionally reduced in the same call.  C1 in {64, 128, 256}. */
+int pcl_group_rows_transpose_supported(int N, int m, int ns);
+int pcl_group_rows_transpose_i32(const int32_t* row_src, const int32_t* group_off, int B, int N, int m, int ns, int32_t* in_off,
+                                 int32_t* in_rows, void* stream);
+int pcl_group_linear_bwd_gather_supported(int C1);
+void pcl_set_scatter_form(int gather);        /* lab switch: 1 (default) the gather where supported, 0 the fp32-atomic scatter everywhere, < 0 leave as is */
+int pcl_group_linear_bwd_gather_f32(const float* row_loc, const float* dU, const float* Y, const float* a, const float* k1,
+                                    const float* k2, const float* mu, const int32_t* in_off, const int32_t* in_rows, int B, int N,
+                                    int C1, float* dUf, float* dWx_part, float* dW0, int ldw, void* stream);
 
 /* The classification head on R <= 64 rows (one row per cloud): Linear (+bias) -> BatchNorm1d -> (Leaky)ReLU as ONE kernel
  * per layer (networks/cls/pointnet2.py:138-147, dgcnn.py:87-93, pointnet.py:22-38).  X [R,K], W [N,K] (nn.Linear layout).

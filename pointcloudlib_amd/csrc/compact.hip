@@ -518,6 +518,149 @@ __global__ __launch_bounds__(256) void group_linear_bwd_v4_kernel(const float4* 
     }
 }
 
+// ---- the scatter to the points as a gather over the points' row lists (round 5) ---------------------------------------------------------
+// With wide point features every row's dy [C1] went to dUf[source point] by one fp32 atomic per element: 22.5 M of them at the second
+// level of PointNet++, 52 of the kernel's 82 us (tools/dbg/glinbwd_atomics.py; the reads alone run at 6 TB/s), in an order the hardware
+// picks.  Here the rows are walked BY SOURCE POINT: in_off [B*N + 1] / in_rows [rows] list each point's rows in ascending order
+// (rows_transpose_kernel, built once per forward from row_src), a wave per point, a lane owns four channels: every row is still read
+// exactly once (512-byte rows), the sums run in a fixed order -- run-to-run identical -- and dUf is written once, not zero-filled and
+// atomically updated.  dWx partial sums as before (per workgroup, fixed order).
+template <int LPR>
+__global__ __launch_bounds__(256) void group_linear_bwd_gather_kernel(const float4* __restrict__ rloc, const float* __restrict__ dU,
+                                                                      const float* __restrict__ Y, const float* __restrict__ a_,
+                                                                      const float* __restrict__ k1_, const float* __restrict__ k2_,
+                                                                      const float* __restrict__ mu_, const int32_t* __restrict__ in_off,
+                                                                      const int32_t* __restrict__ in_rows, int P, float* __restrict__ dUf,
+                                                                      float* __restrict__ dWx_part) {
+    constexpr int C1 = 4 * LPR, PPW = 64 / LPR, U = 4;
+    __shared__ float red[3][4][C1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cl = lane % LPR, psub = lane / LPR, c4 = 4 * cl;
+    const float4 a = *reinterpret_cast<const float4*>(a_ + c4), k1 = *reinterpret_cast<const float4*>(k1_ + c4);
+    const float4 k2 = *reinterpret_cast<const float4*>(k2_ + c4), mu = *reinterpret_cast<const float4*>(mu_ + c4);
+    float gw[3][4];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) gw[d][v] = 0.f;
+    // a wave takes ONE point at a time and its 64 / LPR row-lanes alternate over the point's list in chunks of U rows: the lists of popular
+    // points (the centre of a cloud is in every group: 100+ rows) are the kernel's tail, and this halves / quarters their dependent chain;
+    // the row-lanes' sums meet by shuffles in a fixed order.  The next chunk's row indices are requested before this chunk's rows are used.
+    const int stride = gridDim.x * 4;
+    for (int p = blockIdx.x * 4 + wave; p < P; p += stride) {
+        const int o0 = in_off[p], o1 = in_off[p + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int o = o0 + psub * U;
+        int r[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) r[j] = in_rows[max(o0, min(o + j, o1 - 1))];
+        for (; o < o1; o += PPW * U) {
+            float4 L[U], du[U], yv[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                L[j] = rloc[r[j]];
+                du[j] = *reinterpret_cast<const float4*>(dU + (size_t)r[j] * C1 + c4);
+                yv[j] = *reinterpret_cast<const float4*>(Y + (size_t)r[j] * C1 + c4);
+            }
+            int rn[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) rn[j] = in_rows[max(o0, min(o + PPW * U + j, o1 - 1))];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                if (o + j < o1) {
+                    const float w = L[j].w;
+                    const float d0 = fmaf(a.x, du[j].x, -w * fmaf(k2.x, yv[j].x - mu.x, k1.x)), d1 = fmaf(a.y, du[j].y, -w * fmaf(k2.y, yv[j].y - mu.y, k1.y));
+                    const float d2 = fmaf(a.z, du[j].z, -w * fmaf(k2.z, yv[j].z - mu.z, k1.z)), d3 = fmaf(a.w, du[j].w, -w * fmaf(k2.w, yv[j].w - mu.w, k1.w));
+                    acc.x += d0; acc.y += d1; acc.z += d2; acc.w += d3;
+                    gw[0][0] = fmaf(d0, L[j].x, gw[0][0]); gw[0][1] = fmaf(d1, L[j].x, gw[0][1]); gw[0][2] = fmaf(d2, L[j].x, gw[0][2]); gw[0][3] = fmaf(d3, L[j].x, gw[0][3]);
+                    gw[1][0] = fmaf(d0, L[j].y, gw[1][0]); gw[1][1] = fmaf(d1, L[j].y, gw[1][1]); gw[1][2] = fmaf(d2, L[j].y, gw[1][2]); gw[1][3] = fmaf(d3, L[j].y, gw[1][3]);
+                    gw[2][0] = fmaf(d0, L[j].z, gw[2][0]); gw[2][1] = fmaf(d1, L[j].z, gw[2][1]); gw[2][2] = fmaf(d2, L[j].z, gw[2][2]); gw[2][3] = fmaf(d3, L[j].z, gw[2][3]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) r[j] = rn[j];
+        }
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off); acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+        }
+        if (psub == 0) *reinterpret_cast<float4*>(dUf + (size_t)p * C1 + c4) = acc;
+    }
+    if (dWx_part) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float t = gw[d][v];
+#pragma unroll
+                for (int off = LPR; off < 64; off <<= 1) t += __shfl_xor(t, off);
+                if (psub == 0) red[d][wave][c4 + v] = t;
+            }
+        __syncthreads();
+        for (int e = threadIdx.x; e < C1 * 3; e += 256) {
+            const int ch = e / 3, d = e - ch * 3;
+            dWx_part[(size_t)blockIdx.x * C1 * 3 + e] = (red[d][0][ch] + red[d][1][ch]) + (red[d][2][ch] + red[d][3][ch]);
+        }
+    }
+}
+
+// in_off / in_rows from row_src: one workgroup per cloud (a cloud's rows are contiguous: groups are ordered by cloud).  A point's rows
+// ascend with the group index -- a group holds a point at most once (ball query / k-NN return distinct indices) -- so the lists come out
+// sorted if the groups are filled in order: each of the 16 waves owns a contiguous range of the cloud's groups, counts its rows per point
+// (cnt[w][p]), the counts become start positions (a scan over the points, then over the waves), and every wave files its groups ONE AFTER
+// THE OTHER (a wave's LDS operations execute in order; no sort: popular points have lists of 100+ rows and a per-point insertion sort took
+// 53 us inside a training step).  Should a group name a point twice, both rows are filed (LDS atomics) in an unspecified mutual order.
+constexpr int RT_T = 1024, RT_W = RT_T / 64;
+__global__ __launch_bounds__(RT_T) void rows_transpose_kernel(const int32_t* __restrict__ rsrc, const int32_t* __restrict__ group_off, int m, int N,
+                                                              int B, int32_t* __restrict__ in_off, int32_t* __restrict__ in_rows) {
+    extern __shared__ int rt_lds[];                        // cnt [RT_W][N] | off [N + 1] | lst [rows of the cloud]
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int* cnt = rt_lds; int* off = rt_lds + RT_W * N; int* lst = off + N + 1;
+    const int g_first = b * m, pbase = b * N;
+    const int rb = group_off[g_first], re = group_off[g_first + m];
+    const int gpw = (m + RT_W - 1) / RT_W;
+    const int g0 = min(m, wave * gpw), g1 = min(m, g0 + gpw);       // this wave's groups (relative to the cloud)
+    for (int i = tid; i < RT_W * N; i += RT_T) cnt[i] = 0;
+    __syncthreads();
+    int* mycnt = cnt + wave * N;
+    {
+        const int w0 = group_off[g_first + g0], w1 = group_off[g_first + g1];
+        for (int r = w0 + lane; r < w1; r += 64) atomicAdd(&mycnt[rsrc[r] - pbase], 1);
+    }
+    __syncthreads();
+    // totals per point, exclusive scan over the points (thread t owns a contiguous piece), then the waves' start positions
+    __shared__ int wtot[RT_W];
+    const int per = (N + RT_T - 1) / RT_T, i0 = tid * per, i1 = min(N, i0 + per);
+    int s = 0;
+    for (int i = i0; i < i1; ++i) { int t = 0; for (int w = 0; w < RT_W; ++w) t += cnt[w * N + i]; off[i] = t; s += t; }
+    int inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d); if (lane >= d) inc += v; }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    int run = inc - s;
+    for (int w = 0; w < wave; ++w) run += wtot[w];
+    for (int i = i0; i < i1; ++i) {
+        const int t = off[i];
+        off[i] = run;
+        int pos = run;
+        for (int w = 0; w < RT_W; ++w) { const int c = cnt[w * N + i]; cnt[w * N + i] = pos; pos += c; }
+        run += t;
+    }
+    if (tid == 0) off[N] = re - rb;
+    __syncthreads();
+    for (int g = g0; g < g1; ++g) {                        // one group after the other: ascending rows per point
+        const int q0 = group_off[g_first + g], q1 = group_off[g_first + g + 1];
+        for (int r = q0 + lane; r < q1; r += 64) lst[atomicAdd(&mycnt[rsrc[r] - pbase], 1)] = r;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (int pl = tid; pl < N; pl += RT_T) in_off[pbase + pl] = rb + off[pl];
+    if (b == B - 1 && tid == 0) in_off[pbase + N] = re;
+    for (int i = tid; i < re - rb; i += RT_T) in_rows[rb + i] = lst[i];
+}
+
 // dW0[c, 0..2] = sum_r dWx_part[r][c][0..2];  dW0[c, off + f] = sum_r dWf_part[r][c][f]  (dW0 has leading dimension ld):
 // one wave per output element group -- 64 row-lanes per element, partials are L2-resident.
 __global__ __launch_bounds__(256) void group_linear_dw_kernel(const float* __restrict__ px, const float* __restrict__ pf, int rows,
@@ -699,4 +842,46 @@ int pcl::group_linear_bwd_impl(const float* row_loc, const float* row_feat, int 
     const int n = (dWx_part ? C1 * 3 : 0) + (dWf_part ? C1 * CF : 0);
     hipLaunchKernelGGL(group_linear_dw_kernel, dim3((n + 3) / 4), block, 0, st, dWx_part, dWf_part, GL_BLOCKS, C1, CF, off, ldw, dW0);
     return check_launch("pcl_group_linear_bwd_f32(dW)");
+}
+
+/* in_off [B*N + 1], in_rows [group_off[B*m]]: every source point's rows (indices into the compacted row table), ascending */
+extern "C" int pcl_group_rows_transpose_supported(int N, int m, int ns) {
+    return N >= 1 && m >= 1 && ns >= 1 && ((size_t)(RT_W + 1) * N + 1 + (size_t)m * ns) * 4 <= 150 * 1024;
+}
+extern "C" int pcl_group_rows_transpose_i32(const int32_t* row_src, const int32_t* group_off, int B, int N, int m, int ns, int32_t* in_off,
+                                            int32_t* in_rows, void* stream) {
+    PCL_REQUIRE(row_src && group_off && in_off && in_rows && B >= 1 && m >= 1 && ns >= 1, "pcl_group_rows_transpose_i32: bad arguments");
+    PCL_REQUIRE(pcl_group_rows_transpose_supported(N, m, ns), "pcl_group_rows_transpose_i32: N=%d m=%d ns=%d beyond the LDS-resident form", N, m, ns);
+    const size_t lds = ((size_t)(RT_W + 1) * N + 1 + (size_t)m * ns) * 4;
+    auto kern = rows_transpose_kernel;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(PCL_EHIP, "pcl_group_rows_transpose_i32: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(RT_T), lds, as_stream(stream), row_src, group_off, m, N, B, in_off, in_rows);
+    return check_launch("pcl_group_rows_transpose_i32");
+}
+/* pcl_group_linear_bwd_f32 with the scatter as a gather over the points' row lists: dUf [B*N][C1] is WRITTEN (no zero-fill, no atomics),
+ * dWx_part as there; C1 in {64, 128, 256}, 16-byte aligned rows */
+static int g_scatter_gather = 1;        // lab switch (pcl_set_scatter_form): 0 = the fp32-atomic scatter everywhere
+extern "C" void pcl_set_scatter_form(int gather) { if (gather >= 0) g_scatter_gather = gather != 0; }
+extern "C" int pcl_group_linear_bwd_gather_supported(int C1) { return g_scatter_gather && (C1 == 64 || C1 == 128 || C1 == 256); }
+extern "C" int pcl_group_linear_bwd_gather_f32(const float* row_loc, const float* dU, const float* Y, const float* a, const float* k1,
+                                               const float* k2, const float* mu, const int32_t* in_off, const int32_t* in_rows, int B, int N,
+                                               int C1, float* dUf, float* dWx_part, float* dW0, int ldw, void* stream) {
+    PCL_REQUIRE(row_loc && dU && Y && a && k1 && k2 && mu && in_off && in_rows && dUf, "pcl_group_linear_bwd_gather_f32: null pointer");
+    PCL_REQUIRE(B >= 1 && N >= 1 && pcl_group_linear_bwd_gather_supported(C1), "pcl_group_linear_bwd_gather_f32: bad sizes (C1 = %d: 64, 128 or 256)", C1);
+    PCL_REQUIRE(((reinterpret_cast<uintptr_t>(dU) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(dUf)) & 15) == 0, "pcl_group_linear_bwd_gather_f32: 16-byte aligned rows");
+    PCL_REQUIRE(!dW0 || (dWx_part && ldw >= 3), "pcl_group_linear_bwd_gather_f32: dW0 needs dWx_part and ldw >= 3");
+    hipStream_t st = as_stream(stream);
+    const float4* rl = reinterpret_cast<const float4*>(row_loc);
+    const dim3 grid(GL_BLOCKS), block(256);
+    const int P = B * N;
+    if (C1 == 64) hipLaunchKernelGGL(group_linear_bwd_gather_kernel<16>, grid, block, 0, st, rl, dU, Y, a, k1, k2, mu, in_off, in_rows, P, dUf, dWx_part);
+    else if (C1 == 128) hipLaunchKernelGGL(group_linear_bwd_gather_kernel<32>, grid, block, 0, st, rl, dU, Y, a, k1, k2, mu, in_off, in_rows, P, dUf, dWx_part);
+    else hipLaunchKernelGGL(group_linear_bwd_gather_kernel<64>, grid, block, 0, st, rl, dU, Y, a, k1, k2, mu, in_off, in_rows, P, dUf, dWx_part);
+    int rc = check_launch("pcl_group_linear_bwd_gather_f32");
+    if (rc || !dW0) return rc;
+    hipLaunchKernelGGL(group_linear_dw_kernel, dim3((C1 * 3 + 3) / 4), block, 0, st, dWx_part, (const float*)nullptr, GL_BLOCKS, C1, 0, 0, ldw, dW0);
+    return check_launch("pcl_group_linear_bwd_gather_f32(dW)");
 }

@@ -33,12 +33,17 @@ struct SaveLayout {
     float* vec[PCL_STACK_MAX_LAYERS];      // [4][cout]: scale, shift, mean, invstd
     int32_t* arg; float* ymax;             // pooled stacks: [G, cL]
     int32_t* row_meta; int32_t* row_src; float* row_loc; float* row_feat;     // grouped stacks
+    int32_t* in_off; int32_t* in_rows;     // grouped, wide features: every source point's rows (the backward's scatter as a gather)
     size_t bytes;
 };
 
 static inline bool grouped_inline(const pcl_mlp_stack_t& d) { return d.grouped && d.Cf > 0 && d.Cf <= 4 && !d.need_dx; }
 static inline bool grouped_wide(const pcl_mlp_stack_t& d) { return d.grouped && d.Cf > 0 && !grouped_inline(d); }
 static inline int pooled_groups(const pcl_mlp_stack_t& d) { return d.grouped ? d.B * d.m : (d.pool ? d.P / d.pool : 0); }
+// the folded first layer's backward walks the rows by source point (compact.hip: group_linear_bwd_gather_kernel) where the lists can be built
+static inline bool gather_scatter(const pcl_mlp_stack_t& d) {
+    return grouped_wide(d) && pcl_group_linear_bwd_gather_supported(d.c[1]) && pcl_group_rows_transpose_supported(d.N, d.m, d.pool);
+}
 
 static SaveLayout save_layout(const pcl_mlp_stack_t& d, void* base) {
     SaveLayout s = {};
@@ -55,6 +60,7 @@ static SaveLayout save_layout(const pcl_mlp_stack_t& d, void* base) {
         s.row_src = c.take<int32_t>((size_t)d.P);
         s.row_loc = c.take<float>((size_t)d.P * 4);
         if (grouped_inline(d)) s.row_feat = c.take<float>((size_t)d.P * 4);
+        if (gather_scatter(d)) { s.in_off = c.take<int32_t>((size_t)d.B * d.N + 1); s.in_rows = c.take<int32_t>((size_t)d.P); }
     }
     s.bytes = c.off;
     return s;
@@ -516,6 +522,8 @@ static int stack_fwd_impl(const pcl_mlp_stack_t* dp) {
                 else PCL_TRY(pcl_linear_fwd_rows_f32(d.feature, d.Wf_dense, ly.bias, nullptr, nullptr, 0.f, d.B * d.N, d.Cf, cout, t.Uf,
                                                      t.pt_stats, nullptr, nullptr, st));
             }
+            if (gather_scatter(d))         // the rows by source point, for the backward (row_src is complete after the metadata launch)
+                PCL_TRY(pcl_group_rows_transpose_i32(s.row_src, d.group_off, d.B, d.N, d.m, d.pool, s.in_off, s.in_rows, st));
             tagf("glin%d", cout, 0);
             PCL_TRY(group_linear_fwd_impl(d.xyz, d.new_xyz, wide ? t.Uf : nullptr, d.use_xyz ? ly.W : nullptr, inl ? d.feature : nullptr,
                                           inl ? ly.W + off : nullptr, inl ? d.Cf : 0, ldw, d.idx, d.cnt, d.group_off, d.B, d.N, d.m,
@@ -605,16 +613,17 @@ static int stack_bwd_impl(const pcl_mlp_stack_t* dp) {
         // the consumer already formed du (masked by the activation) and its two channel sums
         dU = d.gout; ext_stats = d.ext_stats; rows = d.ext_stat_rows; cur_du = 0; sparse = false;
         if (t.dUf) {                    // (grouped, wide features: what the max-gradient launch does on the side in the pooled case)
-            const size_t nz4 = ((size_t)d.B * d.N * d.c[1] + 3) / 4;
+            const size_t nz4 = gather_scatter(d) ? 0 : ((size_t)d.B * d.N * d.c[1] + 3) / 4;      // (the gather WRITES dUf: only the unit constants then)
             int blocks = (int)((nz4 + 255) / 256);
             if (blocks > 2048) blocks = 2048;
+            if (blocks < 1) blocks = 1;
             hipLaunchKernelGGL(aux_fill_kernel, dim3(blocks), dim3(256), 0, as_stream(st), reinterpret_cast<float4*>(t.dUf), nz4, t.unit, d.c[1], 2 * d.c[1]);
             PCL_TRY(check_launch("pcl_mlp_stack_bwd_f32(aux)"));
         }
     } else if (G) {
         // side jobs of this first launch (grouped stacks with wide features): clear the target of the folded layer's atomics and
         // write the unit constants of its point GEMMs -- a memset and a fill launch less
-        const size_t nz = t.dUf ? ((size_t)d.B * d.N * d.c[1] + 3) / 4 * 4 : 0;
+        const size_t nz = (t.dUf && !gather_scatter(d)) ? ((size_t)d.B * d.N * d.c[1] + 3) / 4 * 4 : 0;      // (the gather WRITES dUf)
         PCL_TRY(maxgrad_prep_impl(d.gout, d.out, s.ymax, d.out_slope, G, cl, t.gz, t.stats[0], &rows, st, t.dUf, nz, t.unit, t.unit ? d.c[1] : 0,
                                   t.unit ? 2 * d.c[1] : 0));
         sparse = true;
@@ -645,6 +654,10 @@ static int stack_bwd_impl(const pcl_mlp_stack_t* dp) {
             const int off = d.use_xyz ? 3 : 0, fan_in = d.c[0], C1 = cout;
             const bool inl = grouped_inline(d), wide = grouped_wide(d);
             tagf("glinbwd%d", C1, 0);
+            if (gather_scatter(d))
+                PCL_TRY(pcl_group_linear_bwd_gather_f32(s.row_loc, dU, s.Y[0], a, k1, k2, mean, s.in_off, s.in_rows, d.B, d.N, C1, t.dUf, t.dWxp,
+                                                        t.dWxp ? ly.dW : nullptr, fan_in, st));
+            else
             PCL_TRY(group_linear_bwd_impl(s.row_loc, s.row_feat, inl ? d.Cf : 0, dU, s.Y[0], a, k1, k2, mean, s.row_src, nrows, d.B, d.N, C1,
                                           t.dUf, t.dWxp, t.dWfp, (t.dWxp || t.dWfp) ? ly.dW : nullptr, fan_in, off, st, /*duf_is_zero=*/true));
             if (wide) {

@@ -496,17 +496,23 @@ class _GroupLinear(torch.autograd.Function):
                   # per distinct row: Y written, Uf row gathered (L2), 16-byte records; idx read once
                   algo_bytes=_rows_cost(group_off[B * m:], cap, 4 * C1 * (2 if Uf is not None else 1) + 36, 4 * cap), tag=f"glin{C1}")
         link.stats, link.rows = stats, rows
+        # wide features: the backward's scatter runs as a gather over every source point's rows (what the per-stack entry point does)
+        in_off = in_rows = None
+        if (Uf is not None and _lib.size_query("pcl_group_linear_bwd_gather_supported", C1)
+                and _lib.size_query("pcl_group_rows_transpose_supported", N, m, ns)):
+            in_off, in_rows = _empty((B * N + 1,), dev, torch.int32), _empty((cap,), dev, torch.int32)
+            _lib.call("pcl_group_rows_transpose_i32", _P(row_src), _P(group_off), B, N, m, ns, _P(in_off), _P(in_rows), st)
         ctx.link = link
         ctx.dims = (B, N, m, ns, C1, C, off, inline, rows)
         ctx.mark_non_differentiable(row_meta, row_src)
         ctx.set_materialize_grads(False)          # no zero tensors for the (integer) metadata outputs
-        ctx.save_for_backward(group_off, Y, row_src, row_loc, row_feat, feat2, None if inline else Wf)
+        ctx.save_for_backward(group_off, Y, row_src, row_loc, row_feat, feat2, None if inline else Wf, in_off, in_rows)
         return Y, row_meta, row_src
 
     @staticmethod
     def backward(ctx, du, *_):
         B, N, m, ns, C1, C, off, inline, rows = ctx.dims
-        group_off, Y, row_src, row_loc, row_feat, feat2, Wf = ctx.saved_tensors
+        group_off, Y, row_src, row_loc, row_feat, feat2, Wf, in_off, in_rows = ctx.saved_tensors
         a, k1, k2, mu = ctx.link.consts
         ctx.link.consts = None
         dev = Y.device
@@ -521,7 +527,11 @@ class _GroupLinear(torch.autograd.Function):
         dWxp = _empty((rows, C1, 3), dev) if (off and need_w) else None
         dWfp = _empty((rows, C1, C), dev) if (inline and need_w) else None
         dW0 = _empty((C1, fan_in), dev) if need_w else None
-        if dUf is not None or dWxp is not None or dWfp is not None:
+        if dUf is not None and in_off is not None:
+            _lib.call("pcl_group_linear_bwd_gather_f32", _P(row_loc), _P(du.contiguous()), _P(Y), _P(a), _P(k1), _P(k2), _P(mu), _P(in_off), _P(in_rows),
+                      B, N, C1, _P(dUf), _P(dWxp), _P(dW0) if (dW0 is not None and dWxp is not None) else None, fan_in, st,
+                      algo_bytes=_rows_cost(group_off[B * m:], B * m * ns, 4 * C1 * 2 + 36, 4 * B * N * C1), tag=f"glinbwd{C1}")
+        elif dUf is not None or dWxp is not None or dWfp is not None:
             fin = dW0 is not None and (dWxp is not None or dWfp is not None)       # partial sums -> dW0 columns, in the same call
             _lib.call("pcl_group_linear_bwd_f32", _P(row_loc), _P(row_feat), C if inline else 0, _P(du.contiguous()), _P(Y),
                       _P(a), _P(k1), _P(k2), _P(mu), _P(row_src), _P(group_off[B * m:]), B, N, C1, _P(dUf), _P(dWxp), _P(dWfp),

@@ -919,3 +919,57 @@ def test_few_row_backward_matches_the_staged_kernels(dev, spec, lead, ns, bias):
         assert err <= 1e-4 * max(1e-30, ref[2][n].abs().max().item()) + 1e-7, (n, err)
     assert torch.equal(got[1], per[1])
     assert (ref[1] - got[1]).abs().max().item() <= 1e-4 * ref[1].abs().max().item() + 1e-7
+
+
+@pytest.mark.parametrize("B,N,m,ns,C1", [(4, 512, 96, 32, 128), (3, 200, 40, 16, 64), (2, 1024, 128, 24, 256)])
+def test_scatter_as_a_gather_over_the_points_row_lists(dev, B, N, m, ns, C1):
+    """pcl_group_rows_transpose_i32 (every source point's rows, ascending) against a torch sort, and pcl_group_linear_bwd_gather_f32 (the
+    folded first layer's backward walking the rows by source point: dUf written once, no atomics) against an fp64 index_add and against
+    pcl_group_linear_bwd_f32 (fp32 atomics): same sums to fp32 rounding, run-to-run identical, unreferenced points exactly zero."""
+    import ctypes
+    from pointcloudlib_amd import _lib
+    L = _lib.lib()
+    _p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(B * N + C1)
+    assert L.pcl_group_rows_transpose_supported(N, m, ns) and L.pcl_group_linear_bwd_gather_supported(C1)
+    cnt = torch.randint(1, ns + 1, (B * m,), device=dev)
+    goff = torch.zeros(B * m + 1, dtype=torch.int32, device=dev); goff[1:] = torch.cumsum(cnt, 0).int()
+    R = int(goff[-1].item())
+    grp = torch.repeat_interleave(torch.arange(B * m, device=dev), cnt)
+    # distinct sources within a group (what ball query / k-NN produce), from the first half of the cloud: the other half is never referenced
+    pick = torch.rand(B * m, max(1, N // 2), device=dev).argsort(1)[:, :ns]                    # a random subset per group
+    slot = torch.arange(R, device=dev) - goff[:-1].long()[grp]
+    src = ((grp // m) * N + pick[grp, slot]).int()
+    loc = torch.randn(R, 4, device=dev); loc[:, 3] = torch.randint(1, 4, (R,), device=dev).float()
+    dU, Y = torch.randn(R, C1, device=dev), torch.randn(R, C1, device=dev)
+    a, k1, k2, mu = (torch.randn(C1, device=dev) for _ in range(4))
+    rows_blk = L.pcl_group_linear_stat_rows(B, m)
+    in_off = torch.empty(B * N + 1, dtype=torch.int32, device=dev)
+    in_rows = torch.empty(R, dtype=torch.int32, device=dev)
+    _lib.call("pcl_group_rows_transpose_i32", _p(src), _p(goff), B, N, m, ns, _p(in_off), _p(in_rows), st)
+    order = torch.sort(src.long() * (R + 1) + torch.arange(R, device=dev)).indices.int()
+    ref_off = torch.zeros(B * N + 1, dtype=torch.int64, device=dev)
+    ref_off[1:] = torch.cumsum(torch.bincount(src.long(), minlength=B * N), 0)
+    assert torch.equal(in_off.long(), ref_off) and torch.equal(in_rows, order)
+    dy = a * dU - loc[:, 3:4] * (k1 + k2 * (Y - mu))
+    ref = torch.zeros(B * N, C1, device=dev, dtype=torch.float64).index_add_(0, src.long(), dy.double())
+    refw = torch.einsum("rc,rd->cd", dy.double(), loc[:, :3].double())
+    outs = []
+    for which in ("atomics", "gather", "gather"):
+        dUf = torch.full((B * N, C1), float("nan"), device=dev)
+        dWx = torch.empty(rows_blk, C1, 3, device=dev)
+        dW0 = torch.empty(C1, 3, device=dev)
+        if which == "atomics":
+            _lib.call("pcl_group_linear_bwd_f32", _p(loc), None, 0, _p(dU), _p(Y), _p(a), _p(k1), _p(k2), _p(mu), _p(src), _p(goff[B * m:]), B, N, C1,
+                      _p(dUf), _p(dWx), None, _p(dW0), 3, 0, st)
+        else:
+            _lib.call("pcl_group_linear_bwd_gather_f32", _p(loc), _p(dU), _p(Y), _p(a), _p(k1), _p(k2), _p(mu), _p(in_off), _p(in_rows), B, N, C1,
+                      _p(dUf), _p(dWx), _p(dW0), 3, st)
+        outs.append((dUf, dW0))
+    sc, scw = ref.abs().max().item(), refw.abs().max().item()
+    for dUf, dW0 in outs:
+        assert (dUf.double() - ref).abs().max().item() <= 1e-5 * sc
+        assert (dW0.double() - refw).abs().max().item() <= 1e-4 * scw
+    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
+    assert (outs[1][0][ref == 0] == 0).all()
