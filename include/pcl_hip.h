@@ -192,6 +192,7 @@ int pcl_group_rows_transpose_supported(int N, int m, int ns);
 int pcl_group_rows_transpose_i32(const int32_t* row_src, const int32_t* group_off, int B, int N, int m, int ns, int32_t* in_off,
                                  int32_t* in_rows, void* stream);
 int pcl_group_linear_bwd_gather_supported(int C1);
+void pcl_set_pointconv_paths(int bwd_w_rows);  /* lab switch: the weight-gradient contraction with the row-major LDS image (1, default) or the transposed one (0) */
 void pcl_set_scatter_form(int gather);        /* lab switch: 1 (default) the gather where supported, 0 the fp32-atomic scatter everywhere, < 0 leave as is */
 int pcl_group_linear_bwd_gather_f32(const float* row_loc, const float* dU, const float* Y, const float* a, const float* k1,
                                     const float* k2, const float* mu, const int32_t* in_off, const int32_t* in_rows, int B, int N,

@@ -90,6 +90,7 @@ _SIGS = {
     "pcl_group_rows_transpose_i32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "pcl_group_linear_bwd_gather_supported": (c_int, [c_int]),
     "pcl_set_scatter_form": (None, [c_int]),
+    "pcl_set_pointconv_paths": (None, [c_int]),
     "pcl_group_linear_bwd_gather_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, c_int, _P]),
     "pcl_head_layer_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "pcl_head_layer_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -186,6 +187,8 @@ def lib():
             L.pcl_set_kernel_paths(*sw)
         if os.environ.get("PCL_SIDE_DW") is not None:
             L.pcl_set_stack_overlap(int(os.environ["PCL_SIDE_DW"] != "0"), -1)
+        if os.environ.get("PCL_BWD_W_ROWS") is not None:
+            L.pcl_set_pointconv_paths(int(os.environ["PCL_BWD_W_ROWS"] != "0"))
         if os.environ.get("PCL_SCATTER") is not None:
             L.pcl_set_scatter_form(int(os.environ["PCL_SCATTER"] != "0"))
         if os.environ.get("PCL_FEWROW") is not None:

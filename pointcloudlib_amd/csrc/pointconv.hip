@@ -341,6 +341,124 @@ __global__ __launch_bounds__(256, 2) void pointconv_contract_bwd_w_kernel(const 
     }
 }
 
+// ---- weight gradient with a ROW-major LDS image (round 5) ----------------------------------------------------------------------------
+// t[s][m] = sum_c z[s][c] dout[c][m] as D = A B on v_mfma_f32_32x32x2_f32 with A = z (M = 32 rows of the group), B = dout (N = the 16 m, half
+// of the tile idle), K = the channels.  The kernel above transposes every feature chunk on its way into LDS (32 ds_write_b32 per lane and
+// chunk) because the 16x16x4 A operand wants lane = (row, channel); with the contraction index permuted -- lane (row s, h) supplies channels
+// 8 kk + 4 h .. + 3 as the k slots of four consecutive MFMAs, the same permutation on the dout side -- the A operand is a 16-byte read of
+// the row AS STORED: the rows go into LDS with 16-byte writes (row stride 36 dwords: conflict-free) and come back with 16-byte reads, a
+// quarter of the LDS instructions, and the loads are the rows' own 128-byte segments.  A wave owns its slab (no block barrier), a unit =
+// one group with its NSB blocks of 32 rows sharing the dout fragments (staged beside the rows, 2 KB per chunk), the next chunk's rows in
+// registers while this one is consumed.  Results arrive as lane = row: d_w[s][4h ..] and [8 + 4h ..] are two 16-byte stores, d_dens one
+// shuffle away.  C % 4 == 0; few groups (the GroupAll level) split the channel chunks over grid.y with atomics as above.
+constexpr int PW_LD = 36;
+template <int NSB>
+__global__ __launch_bounds__(256) void pointconv_contract_bwd_w_rows_kernel(const float* __restrict__ feat, const float* __restrict__ dout,
+                                                                            const float* __restrict__ dens, const float* __restrict__ w,
+                                                                            int G, int ns, int C, float* __restrict__ dw,
+                                                                            float* __restrict__ ddens, const FeatBN bn) {
+    __shared__ __attribute__((aligned(16))) float sz[4][NSB * 32][PW_LD];     // the chunk's rows, row-major
+    __shared__ __attribute__((aligned(16))) float sdo[4][PC_CCH * PC_M];      // dout[g][c0 .. c0 + 32][16]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
+    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    const int W = gridDim.x * 4;
+    const int cfirst = blockIdx.y * PC_CCH, cstep = gridDim.y * PC_CCH;
+    const unsigned Cb = (unsigned)C * 4u;
+    const bool act = bn.sc != nullptr;
+    // staging: lane = (row r8 of a pass of 8 rows, channel quad q4): 8 lanes x 16 B per row
+    const int r8 = lane >> 3, q4 = (lane & 7) * 4;
+    float4 pz[NSB * 4], pd[2];
+    auto request = [&](int g, int c0) {                                       // raw loads; masks / BatchNorm when they are stored to LDS
+        const bool live = g < G;
+        const pc_rsrc_t rF = pc_rsrc(feat, (size_t)(live ? g : 0) * ns * Cb, live ? (unsigned)ns * Cb : 0u);
+        const pc_rsrc_t rD = pc_rsrc(dout, (size_t)(live ? g : 0) * C * (PC_M * 4), live ? (unsigned)C * (PC_M * 4u) : 0u);
+        const unsigned vz = (unsigned)r8 * Cb + (unsigned)(c0 + q4) * 4u;      // (channels past C: c0 + q4 >= C only in the last chunk -> masked below)
+        const bool cok = c0 + q4 < C;
+#pragma unroll
+        for (int i = 0; i < NSB * 4; ++i) pz[i] = pc_ld4(rF, cok ? vz : PC_OOB, (unsigned)(8 * i) * Cb);        // rows past ns: 0
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned e = (unsigned)(i * 64 + lane) * 16u;                 // 512 floats of dout rows c0 .. c0 + 31
+            pd[i] = pc_ld4(rD, e, (unsigned)c0 * (PC_M * 4u));                  // (rows past C: beyond the descriptor -> 0)
+        }
+    };
+    auto stash = [&](int c0) {
+        float4 ba = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool cok = c0 + q4 < C;
+        if (act && cok) { ba = *reinterpret_cast<const float4*>(bn.sc + c0 + q4); bb = *reinterpret_cast<const float4*>(bn.sh + c0 + q4); }
+#pragma unroll
+        for (int i = 0; i < NSB * 4; ++i) {
+            float4 v = pz[i];
+            if (act) {
+                v.x = feat_act(v.x, ba.x, bb.x, bn.slope); v.y = feat_act(v.y, ba.y, bb.y, bn.slope);
+                v.z = feat_act(v.z, ba.z, bb.z, bn.slope); v.w = feat_act(v.w, ba.w, bb.w, bn.slope);
+            }
+            const bool ok = cok && (8 * i + r8) < ns;                            // (act(0) != 0: rows past the group and channels past C are zeros)
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&sz[wave][8 * i + r8][q4]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&sdo[wave][(i * 64 + lane) * 4]) = pd[i];
+    };
+    int g = blockIdx.x * 4 + wave, c0 = cfirst;
+    if (cfirst >= C) return;
+    request(g, c0);
+    pc_f32x16 acc[NSB];
+#pragma unroll
+    for (int b = 0; b < NSB; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+    while (g < G) {
+        wave_sync();
+        stash(c0);
+        const bool last = c0 + cstep >= C;
+        const int ng = last ? g + W : g, nc = last ? cfirst : c0 + cstep;
+        request(ng, nc);
+        wave_sync();
+#pragma unroll
+        for (int kk = 0; kk < PC_CCH / 8; ++kk) {
+            float bq[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bq[j] = lr < PC_M ? sdo[wave][(8 * kk + 4 * lh + j) * PC_M + lr] : 0.f;
+#pragma unroll
+            for (int b = 0; b < NSB; ++b) {
+                const float4 a = *reinterpret_cast<const float4*>(&sz[wave][32 * b + lr][8 * kk + 4 * lh]);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[0], a.x, acc[b], 0, 0, 0); acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[1], a.y, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[2], a.z, acc[b], 0, 0, 0); acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[3], a.w, acc[b], 0, 0, 0);
+            }
+        }
+        if (last) {
+            // D = dout^T z^T: lane = row s of block b (column of D), registers = m: t[s][4h + i] = acc[b][i], t[s][8 + 4h + i] = acc[b][4 + i]
+#pragma unroll
+            for (int b = 0; b < NSB; ++b) {
+                const int srow = 32 * b + lr;
+                const bool ok = srow < ns;
+                const size_t row = (size_t)g * ns + (ok ? srow : 0);
+                const float4 w0 = *reinterpret_cast<const float4*>(w + row * PC_M + 4 * lh), w1 = *reinterpret_cast<const float4*>(w + row * PC_M + 8 + 4 * lh);
+                const float de = dens[row];
+                float dd = ((w0.x * acc[b][0] + w0.y * acc[b][1]) + (w0.z * acc[b][2] + w0.w * acc[b][3])) +
+                           ((w1.x * acc[b][4] + w1.y * acc[b][5]) + (w1.z * acc[b][6] + w1.w * acc[b][7]));
+                dd += __shfl_xor(dd, 32);
+                if (ok) {
+                    float* o = dw + row * PC_M + 4 * lh;
+                    if (gridDim.y == 1) {
+                        *reinterpret_cast<float4*>(o) = make_float4(de * acc[b][0], de * acc[b][1], de * acc[b][2], de * acc[b][3]);
+                        *reinterpret_cast<float4*>(o + 8) = make_float4(de * acc[b][4], de * acc[b][5], de * acc[b][6], de * acc[b][7]);
+                        if (lh == 0) ddens[row] = dd;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { unsafeAtomicAdd(o + i, de * acc[b][i]); unsafeAtomicAdd(o + 8 + i, de * acc[b][4 + i]); }
+                        if (lh == 0) unsafeAtomicAdd(ddens + row, dd);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+            }
+        }
+        g = ng; c0 = nc;
+    }
+}
+
 // ---- forward, fragment-direct (round 5) ---------------------------------------------------------------------------------------------
 // out[g][c][m] = sum_s wd[s][m] z[s][c] as D = A B with A = wd^T (M = the 16 m, rows 16..31 of the 32 x 32 tile idle), B = z (N = 32
 // channels), K = the group's rows: v_mfma_f32_32x32x2_f32, lane (c = lane & 31, h = lane >> 5) supplies z[row][c] -- 128-byte row
@@ -441,8 +559,20 @@ static int bwd_w_max_wgs(int slices) {
     const int n = 2 * cus / (slices < 1 ? 1 : slices);
     return n < 1 ? 1 : n;
 }
+static int g_bwd_w_rows = 1;             // lab switch (pcl_set_pointconv_paths)
+extern "C" void pcl_set_pointconv_paths(int bwd_w_rows) { if (bwd_w_rows >= 0) g_bwd_w_rows = bwd_w_rows != 0; }
 static void launch_bwd_w(int slices, hipStream_t st, const float* feat, const float* dout, const float* dens, const float* w, int G, int ns, int C,
                          float* dw, float* ddens, const FeatBN bn) {
+    if (g_bwd_w_rows && C % 4 == 0 && ns <= 64 && (size_t)ns * C * 4 < 0x7fffffffull && ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(dout)) & 15) == 0) {
+        // row-major LDS image, a wave per group (ns <= 64: the GroupAll level's 128-row groups keep the kernel above)
+        int wgs = (G + 3) / 4;
+        const int cap = 3 * bwd_w_max_wgs(slices) / 2;                   // persistent: three workgroups per CU (LDS: 26 / 45 KB each)
+        if (wgs > cap) wgs = cap;
+        const dim3 grid(wgs, slices), blk(256);
+        if (ns <= 32) hipLaunchKernelGGL(pointconv_contract_bwd_w_rows_kernel<1>, grid, blk, 0, st, feat, dout, dens, w, G, ns, C, dw, ddens, bn);
+        else hipLaunchKernelGGL(pointconv_contract_bwd_w_rows_kernel<2>, grid, blk, 0, st, feat, dout, dens, w, G, ns, C, dw, ddens, bn);
+        return;
+    }
     const int gpw = bwd_w_gpw(ns);
     const int RG = 64 / gpw, units = ((G + gpw - 1) / gpw) * ((ns + RG - 1) / RG);
     int wgs = (units + 3) / 4;
