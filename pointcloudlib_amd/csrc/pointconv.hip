@@ -629,6 +629,7 @@ extern "C" int pcl_pointconv_contract_bn_bwd_f32(const float* dout, const float*
                                                  float* dweights, float* ddensity, double* stats_ws, void* stream) {
     PCL_REQUIRE(dout && Y && scale && shift && density && weights && du && dweights && ddensity && stats_ws, "pcl_pointconv_contract_bn_bwd_f32: null pointer");
     PCL_REQUIRE(G >= 1 && ns >= 1 && C >= 1 && M == PC_M && slope >= 0.f && slope <= 1.f, "pcl_pointconv_contract_bn_bwd_f32: bad sizes G=%d ns=%d C=%d M=%d", G, ns, C, M);
+    PCL_REQUIRE((size_t)ns * C * 4 < 0x7fffffffull && (size_t)C * PC_M * 4 < 0x7fffffffull, "pcl_pointconv_contract_bn_bwd_f32: a group of ns=%d x C=%d floats is beyond the kernels' 32-bit group offsets", ns, C);
     PCL_REQUIRE(C % 4 != 0 || ((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0, "pcl_pointconv_contract_bn_bwd_f32: scale / shift must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
     const FeatBN bn = {scale, shift, slope};

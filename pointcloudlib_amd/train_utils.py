@@ -108,20 +108,16 @@ class _LeanFusedSGD(torch.optim.SGD):
             # gradient buffers each backward)
             from . import _lib
             pa, ba, na, ga, n = self._own
-            try:
-                for i, x in enumerate(grads):
-                    if x.dtype != torch.float32 or not x.is_contiguous():
-                        raise TypeError
-                    ga[i] = x.data_ptr()
-            except TypeError:
-                grads = [x.contiguous() for x in grads]
-                for p, x in zip(ps, grads):
-                    p.grad = x
-                for i, x in enumerate(grads):
-                    ga[i] = x.data_ptr()
-            _lib.call("pcl_sgd_momentum_f32", pa, ga, ba, na, n, float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), float(g["dampening"]),
-                      torch._C._cuda_getCurrentRawStream(ps[0].device.index))
-            return None
+            ok = True
+            for i, x in enumerate(grads):
+                if x.dtype != torch.float32 or not x.is_contiguous() or x.device != ps[i].device:
+                    ok = False              # (an fp64 / strided / foreign-device gradient: torch's kernel below handles it)
+                    break
+                ga[i] = x.data_ptr()
+            if ok:
+                _lib.call("pcl_sgd_momentum_f32", pa, ga, ba, na, n, float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]),
+                          float(g["dampening"]), torch._C._cuda_getCurrentRawStream(ps[0].device.index))
+                return None
         torch._fused_sgd_(ps, grads, bufs, weight_decay=g["weight_decay"], momentum=g["momentum"], lr=g["lr"],
                           dampening=g["dampening"], nesterov=g["nesterov"], maximize=g["maximize"], is_first_step=False,
                           grad_scale=None, found_inf=None)

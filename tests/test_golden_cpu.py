@@ -175,3 +175,32 @@ def test_host_only_switches_roundtrip():
     L.pcl_set_kernel_paths(1, 1, 1)
     L.pcl_set_fps_tuning(256, 0)
     L.pcl_set_fps_tuning(0, 0)
+
+
+def test_round5_entry_points_validate_on_the_host():
+    """The round-5 entry points (optimiser step, few-row backward, the scatter as a gather, lab switches): argument errors and size
+    queries need no GPU; the switches read back and default to what DESIGN section 10 says."""
+    import ctypes
+    from pointcloudlib_amd import _lib
+    lib = _lib.lib()
+    buf = ctypes.create_string_buffer(256)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.pcl_sgd_momentum_f32(None, None, None, None, 3, 0.1, 0.9, 0.0, 0.0, None) == -1
+    assert lib.pcl_sgd_momentum_f32(p, p, p, p, 0, 0.1, 0.9, 0.0, 0.0, None) == 0            # no tensors: nothing launched
+    assert lib.pcl_bn_bwd_dy_supported(4096, 1024) == 1 and lib.pcl_bn_bwd_dy_supported(4096, 259) == 0
+    assert lib.pcl_get_fewrow_backward() == 0 and lib.pcl_get_stack_overlap() == 0            # measured, not faster: off by default
+    lib.pcl_set_fewrow_backward(1)
+    assert lib.pcl_mlp_fewrow_layer(4096, 1024, 512, 0) == 1 and lib.pcl_mlp_fewrow_layer(100000, 1024, 512, 0) == 0
+    assert lib.pcl_mlp_fewrow_layer(4096, 128, 64, 0) == 0                                    # a shape the fused dX + dW kernel has
+    lib.pcl_set_fewrow_backward(0)
+    assert lib.pcl_mlp_fewrow_layer(4096, 1024, 512, 0) == 0
+    assert lib.pcl_linear_bwd_dw_plain_workspace_bytes(4096, 1024, 512) % (1024 * 512 * 4) == 0
+    assert lib.pcl_group_rows_transpose_supported(512, 128, 64) == 1 and lib.pcl_group_rows_transpose_supported(16384, 128, 64) == 0
+    assert lib.pcl_group_linear_bwd_gather_supported(128) == 1 and lib.pcl_group_linear_bwd_gather_supported(96) == 0
+    lib.pcl_set_scatter_form(0)
+    assert lib.pcl_group_linear_bwd_gather_supported(128) == 0
+    lib.pcl_set_scatter_form(1)
+    assert lib.pcl_group_rows_transpose_i32(None, None, 1, 8, 2, 2, None, None, None) == -1
+    assert lib.pcl_group_linear_bwd_gather_f32(p, p, p, p, p, p, p, p, p, 1, 8, 96, p, None, None, 0, None) == -1      # C1 = 96
+    assert b"C1" in lib.pcl_last_error()
+    assert lib.pcl_frag_linear_fwd_f32(p, 8, p, 8, None, None, None, 0.0, 4, 8, 8, p, 8, None, None, 16, None) == -1  # flush_k not 0 / 8 / 32
