@@ -21,7 +21,7 @@ python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<true, true, 2, 1>' 1
 python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 2, 2>' 1 0=fb128x128 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
 python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 1, 1>' 1 0=fb64x64 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
 rm -rf $O/kt/*/*.db $O/fetch $O/write $O/sq/*/*.db 2>/dev/null
-python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
+# (the bench line is taken at the END of this script, after every traffic profile of THESE sources has been copied to profiles/ on this box)
 # every C-ABI entry point event-timed (GEMM kernels: their own begin/end timestamps), algorithmic GB/s and TF per launch shape
 python bench.py --steps 20 --warmup 3 --profile-all --no-cpu-baseline --no-other-configs --roofline-kernel none 2>&1 >/dev/null | grep -E "n/step|entry" > $O/${R}_entry_point_roofline.txt
 python -m pytest tests/test_parity_pointnet_gpu.py tests/test_parity_pointnet2_gpu.py tests/test_parity_dgcnn_gpu.py tests/test_parity_partseg_gpu.py tests/test_parity_pointconv_gpu.py tests/test_pointcnn_gpu.py tests/test_parity_partseg_zoo_gpu.py -k "not xconv and not stage and not partseg_network and not cls_network" -m gpu -s -q 2>&1 | grep -v Warning > $O/${R}_parity_reports.txt
@@ -35,4 +35,6 @@ bash tools/traffic_cfg.sh $R cfg2_n4096 "cfg2'" > $O/tc_cfg2.log 2>&1
 bash tools/traffic_cfg.sh $R cfg3 "cfg3" > $O/tc_cfg3.log 2>&1
 bash tools/traffic_cfg.sh $R cfg4 "cfg4 PointNet++ MSG part-seg B=16 N=2048 (BASELINE" > $O/tc_cfg4.log 2>&1
 bash tools/traffic_cfg.sh $R cfg5 "cfg5 PointConv cls B=32 N=1024$" > $O/tc_cfg5.log 2>&1
+cp $O/${R}_traffic.json $O/${R}_traffic_cfg*.json profiles/ 2>/dev/null
+python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
 tail -3 $O/kt.log; cat $O/traffic.txt | head -40; cat $O/${R}_dominant_kernel_by_shape.csv; tail -1 $O/${R}_bench_line.json
