@@ -110,10 +110,13 @@ class _LeanFusedSGD(torch.optim.SGD):
             pa, ba, na, ga, n = self._own
             ok = True
             for i, x in enumerate(grads):
-                if x.dtype != torch.float32 or not x.is_contiguous() or x.device != ps[i].device:
-                    ok = False              # (an fp64 / strided / foreign-device gradient: torch's kernel below handles it)
+                if x.dtype != torch.float32 or x.device != ps[i].device:
+                    ok = False              # (an fp64 / foreign-device gradient: torch's kernel below takes or refuses it)
                     break
+                if not x.is_contiguous():   # (same values, dense: torch's multi-tensor kernel refuses strided gradients altogether)
+                    x = ps[i].grad = grads[i] = x.contiguous()
                 ga[i] = x.data_ptr()
+                pa[i] = ps[i].data_ptr()    # (re-read every step: `p.data = ...` / `.to()` re-seat a parameter's storage without telling anybody)
             if ok:
                 _lib.call("pcl_sgd_momentum_f32", pa, ga, ba, na, n, float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]),
                           float(g["dampening"]), torch._C._cuda_getCurrentRawStream(ps[0].device.index))

@@ -337,6 +337,16 @@ def test_lean_sgd_is_torch_fused_sgd(dev):
             assert torch.equal(p.data, q.data), step
     for p, q in zip(pa, pb):
         assert torch.equal(oa.state[p]["momentum_buffer"], ob.state[q]["momentum_buffer"])
+    # a parameter whose storage is re-seated (`p.data = ...`, what `.to()` does) and a gradient the own kernel cannot take (fp64 view cast
+    # back, non-contiguous): the cached pointer tables must follow / step aside
+    pa[0].data = pa[0].data.clone(); pb[0].data = pb[0].data.clone()
+    gs = [torch.randn_like(w) for w in ws]
+    for p, q, g in zip(pa, pb, gs):
+        p.grad, q.grad = g.clone(), g.clone()
+    pa[2].grad = pa[2].grad.transpose(0, 1).contiguous().transpose(0, 1)          # same values, non-contiguous
+    oa.step(); ob.step()
+    for p, q in zip(pa, pb):
+        assert torch.equal(p.data, q.data)
 
 
 @pytest.mark.parametrize("B,S,ns,Cin,spec,slope", [(4, 96, 32, 19, [64, 64, 128], 0.0), (2, 1, 128, 35, [32, 96], 0.0), (3, 40, 24, 7, [16, 8], 0.2)])
