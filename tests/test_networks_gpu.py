@@ -206,7 +206,10 @@ def test_stn_identity_at_zero_weights(dev):
 
 
 @pytest.mark.parametrize("B,S,ns,C", [(2, 5, 32, 128), (1, 3, 7, 20), (2, 1, 200, 64), (1, 4, 64, 300), (3, 7, 48, 33), (1, 5, 16, 64),
-                                      (2, 3, 24, 36), (1, 9, 33, 8)])
+                                      (2, 3, 24, 36), (1, 9, 33, 8),
+                                      # round 5 kernels: fragment-direct forward (any C, row blocks of 32), row-major weight gradient (C % 4 == 0, ns <= 64:
+                                      # either side of both limits), one row block exactly, C < 32, the GroupAll shape
+                                      (1, 2, 65, 36), (2, 2, 63, 128), (1, 9, 32, 33), (2, 3, 31, 4), (1, 1, 128, 1024), (2, 7, 5, 3)])
 def test_pointconv_contraction_kernel(dev, B, S, ns, C):
     """pcl_pointconv_contract_f32 (+bwd) against the reference formula (misc/pointconv_utils.py:393-394) in PyTorch."""
     from pointcloudlib_amd.misc.pointconv_utils import pointconv_contract
