@@ -141,6 +141,11 @@ def test_pointconv_pieces_and_network(oracle, dev):
     for bw in (0.1, 0.4):
         d = pu.compute_density(x, bw).cpu().numpy()
         np.testing.assert_allclose(d, oracle.density(pts, bw), rtol=2e-5, atol=1e-7)
+    # (eight lanes per point since round 5: sizes that are no multiple of 8 / 32, more points than one LDS chunk, a single point)
+    for n in (1, 7, 100, 2500):
+        q = synth.gauss_ball(2, n, 3 + n)
+        dq = pu.compute_density(torch.from_numpy(q).to(dev), 0.2).cpu().numpy()
+        np.testing.assert_allclose(dq, oracle.density(q, 0.2), rtol=2e-5, atol=1e-7)
     # FPS variant: random start, no origin skip -> the oracle with skip disabled
     start = np.array([5, 0, 511, 77], np.int32)
     fidx = pu.farthest_point_sample(x, 64, torch.from_numpy(start).to(dev)).cpu().numpy()
