@@ -921,7 +921,7 @@ def test_few_row_backward_matches_the_staged_kernels(dev, spec, lead, ns, bias):
     assert (ref[1] - got[1]).abs().max().item() <= 1e-4 * ref[1].abs().max().item() + 1e-7
 
 
-@pytest.mark.parametrize("B,N,m,ns,C1", [(4, 512, 96, 32, 128), (3, 200, 40, 16, 64), (2, 1024, 128, 24, 256)])
+@pytest.mark.parametrize("B,N,m,ns,C1", [(4, 512, 96, 32, 128), (3, 200, 40, 16, 64), (2, 1024, 128, 24, 256), (2, 2048, 64, 32, 128)])
 def test_scatter_as_a_gather_over_the_points_row_lists(dev, B, N, m, ns, C1):
     """pcl_group_rows_transpose_i32 (every source point's rows, ascending) against a torch sort, and pcl_group_linear_bwd_gather_f32 (the
     folded first layer's backward walking the rows by source point: dUf written once, no atomics) against an fp64 index_add and against

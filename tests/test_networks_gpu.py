@@ -269,7 +269,7 @@ def test_edgeconv_factorised_matches_edge_tensor(oracle, dev, B, N, C, Cout, k):
         assert torch.allclose(getattr(mlp, b).double(), getattr(ref, b), rtol=1e-5, atol=1e-6), b
 
 
-@pytest.mark.parametrize("B,N,k", [(3, 64, 5), (2, 1024, 20), (1, 300, 40), (2, 17, 17)])
+@pytest.mark.parametrize("B,N,k", [(3, 64, 5), (2, 1024, 20), (1, 300, 40), (2, 17, 17), (1, 4096, 6), (1, 130, 70)])     # (4096: fewer waves share the LDS counters; k = 70 > 64: the sorted form)
 def test_knn_transpose_lists(dev, B, N, k):
     """pcl_knn_transpose_i32: for every point the ascending list of the points that name it as a neighbour."""
     from pointcloudlib_amd import _lib
