@@ -569,7 +569,8 @@ typedef struct pcl_mlp_stack_t {
                                               * of a plain stack, the per-point product of a grouped one) goes through pcl_frag_linear_fwd_f32 with that
                                               * flush interval: fp32 fma chains of at most flush_k terms summed in fp64 (the part-seg decoder, where the
                                               * distance from the fp64 evaluation is accumulation error: DESIGN.md section 10).  Backward unchanged. */
-    int32_t reserved_;
+    int32_t gout_ld;                         /* backward of a pooled stack: gout rows are gout_ld floats apart (0: dense, c[L]) -- the consumer concatenated
+                                              * several stacks' outputs (multi-scale grouping) and hands each its column slice of the wide gradient */
 } pcl_mlp_stack_t;
 /* where, inside `save`, the last layer's pre-BatchNorm output [P, c[L]] and its folded BatchNorm (scale [c[L]], shift [c[L]]) live (byte
  * offsets): what a deferring consumer reads (defer_act) */

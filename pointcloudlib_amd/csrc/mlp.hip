@@ -2622,9 +2622,10 @@ __device__ __forceinline__ void fold_row_lanes(double s1, double s2, int c, int 
 // (a, k1, k2, mu) = (1, 0, 0, 0) constants of its plain point GEMMs to [ones, ones + n_one) / [ones + n_one, .. + n_one0).
 struct PrepAux { float4* zero; size_t n_zero4; float* ones; int n_one, n_one0; };
 __global__ __launch_bounds__(256) void maxgrad_prep_kernel(const float* __restrict__ gout, const float* __restrict__ out,
-                                                           const float* __restrict__ ymax, float slope, int G, int C, int CW,
+                                                           const float* __restrict__ ymax, float slope, int G, int C, int CW, int ldg,
                                                            float* __restrict__ gz, double* __restrict__ stats, const PrepAux aux) {
-    // grid.x = channel blocks of CW, grid.y = row slices (<= STAT_ROWS)
+    // grid.x = channel blocks of CW, grid.y = row slices (<= STAT_ROWS); gout rows are ldg floats apart (a slice of a wider
+    // gradient: the consumer concatenated several stacks' outputs), everything else is dense [G, C]
     __shared__ double red[2 * 256];
     if (aux.zero || aux.ones) {
         const size_t nb = (size_t)gridDim.x * gridDim.y, b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
@@ -2638,7 +2639,7 @@ __global__ __launch_bounds__(256) void maxgrad_prep_kernel(const float* __restri
     if (c < C)
         for (int g = blockIdx.y * RS + rsub; g < G; g += gridDim.y * RS) {
             const size_t e = (size_t)g * C + c;
-            const float v = gout[e] * (out[e] > 0.f ? 1.f : slope);
+            const float v = gout[(size_t)g * ldg + c] * (out[e] > 0.f ? 1.f : slope);
             gz[e] = v;
             s1 += v; s2 += (double)v * ymax[e];
         }
@@ -3221,15 +3222,16 @@ extern "C" int pcl_bn_act_max_mean_bwd_f32(const float* gmax, const float* gmean
 
 namespace pcl {
 int maxgrad_prep_impl(const float* gout, const float* out, const float* ymax, float slope, int G, int C, float* gz, double* stats_ws,
-                      int* stat_rows_out, void* stream, float* zero, size_t n_zero, float* ones, int n_one, int n_one0);
+                      int* stat_rows_out, void* stream, float* zero, size_t n_zero, float* ones, int n_one, int n_one0, int ldg);
 }
 extern "C" int pcl_maxgrad_prep_f32(const float* gout, const float* out, const float* ymax, float slope, int G, int C,
                                     float* gz, double* stats_ws, int* stat_rows_out, void* stream) {
-    return maxgrad_prep_impl(gout, out, ymax, slope, G, C, gz, stats_ws, stat_rows_out, stream, nullptr, 0, nullptr, 0, 0);
+    return maxgrad_prep_impl(gout, out, ymax, slope, G, C, gz, stats_ws, stat_rows_out, stream, nullptr, 0, nullptr, 0, 0, C);
 }
 int pcl::maxgrad_prep_impl(const float* gout, const float* out, const float* ymax, float slope, int G, int C, float* gz, double* stats_ws,
-                           int* stat_rows_out, void* stream, float* zero, size_t n_zero, float* ones, int n_one, int n_one0) {
+                           int* stat_rows_out, void* stream, float* zero, size_t n_zero, float* ones, int n_one, int n_one0, int ldg) {
     PCL_REQUIRE(gout && out && ymax && gz && stats_ws && stat_rows_out, "pcl_maxgrad_prep_f32: null pointer");
+    PCL_REQUIRE(ldg >= C, "pcl_maxgrad_prep_f32: gout row stride %d below the width %d", ldg, C);
     PCL_REQUIRE(!zero || ((reinterpret_cast<uintptr_t>(zero) & 15) == 0 && n_zero % 4 == 0), "pcl_maxgrad_prep_f32: the zero-fill region must be 16-byte aligned and a multiple of 4 floats");
     const PrepAux aux = {reinterpret_cast<float4*>(zero), n_zero / 4, ones, n_one, n_one0};
     PCL_REQUIRE(G >= 1 && C >= 1, "pcl_maxgrad_prep_f32: bad sizes");
@@ -3239,7 +3241,7 @@ int pcl::maxgrad_prep_impl(const float* gout, const float* out, const float* yma
     int rows = (G + RS - 1) / RS < 512 ? (G + RS - 1) / RS : 512;
     *stat_rows_out = rows;
     hipLaunchKernelGGL(maxgrad_prep_kernel, dim3((C + CW - 1) / CW, rows), dim3(256), 0, as_stream(stream), gout, out, ymax,
-                       slope, G, C, CW, gz, stats_ws, aux);
+                       slope, G, C, CW, ldg, gz, stats_ws, aux);
     return check_launch("pcl_maxgrad_prep_f32");
 }
 

@@ -226,7 +226,7 @@ size_t narrow_bwd_tmp_bytes();
 int narrow_fwd(const pcl_mlp_stack_t& d);
 int narrow_bwd(const pcl_mlp_stack_t& d);
 int maxgrad_prep_impl(const float* gout, const float* out, const float* ymax, float slope, int G, int C, float* gz, double* stats_ws,
-                      int* stat_rows_out, void* stream, float* zero, size_t n_zero, float* ones, int n_one, int n_one0);
+                      int* stat_rows_out, void* stream, float* zero, size_t n_zero, float* ones, int n_one, int n_one0, int ldg);
 int group_linear_fwd_impl(const float* xyz, const float* new_xyz, const float* Uf, const float* Wx, const float* feat_small,
                           const float* Wf_small, int CF, int ldw, const int32_t* idx, const int32_t* cnt, const int32_t* group_off, int B,
                           int N, int m, int ns, int C1, float* Y, int32_t* row_meta, int32_t* row_src, float* row_loc, float* row_feat,
@@ -565,6 +565,8 @@ static int stack_bwd_impl(const pcl_mlp_stack_t* dp) {
     PCL_TRY(validate(dp, "pcl_mlp_stack_bwd_f32"));
     const pcl_mlp_stack_t& d = *dp;
     PCL_REQUIRE((d.out || d.defer_act) && d.save && d.tmp && d.gout, "pcl_mlp_stack_bwd_f32: null out / save / tmp / gout");
+    PCL_REQUIRE(d.gout_ld == 0 || d.gout_ld == d.c[d.n_layers] || (d.gout_ld > d.c[d.n_layers] && !d.defer_act && pooled_groups(d) > 0),
+                "pcl_mlp_stack_bwd_f32: gout_ld %d (a row stride for gout is taken by pooled stacks only, and is at least the width %d)", d.gout_ld, d.c[d.n_layers]);
     PCL_REQUIRE(!d.defer_act || (d.ext_stats && d.ext_stat_rows >= 1), "pcl_mlp_stack_bwd_f32: defer_act needs ext_stats / ext_stat_rows");
     if (narrow_supported(d)) {
         if (d.save_bytes < narrow_save_bytes() || d.tmp_bytes < narrow_bwd_tmp_bytes())
@@ -625,7 +627,7 @@ static int stack_bwd_impl(const pcl_mlp_stack_t* dp) {
         // write the unit constants of its point GEMMs -- a memset and a fill launch less
         const size_t nz = (t.dUf && !gather_scatter(d)) ? ((size_t)d.B * d.N * d.c[1] + 3) / 4 * 4 : 0;      // (the gather WRITES dUf)
         PCL_TRY(maxgrad_prep_impl(d.gout, d.out, s.ymax, d.out_slope, G, cl, t.gz, t.stats[0], &rows, st, t.dUf, nz, t.unit, t.unit ? d.c[1] : 0,
-                                  t.unit ? 2 * d.c[1] : 0));
+                                  t.unit ? 2 * d.c[1] : 0, d.gout_ld ? d.gout_ld : cl));
         sparse = true;
     } else {
         float* du0 = sd ? t.dU_l[L - 1] : t.dU[0];

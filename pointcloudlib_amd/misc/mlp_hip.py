@@ -607,6 +607,10 @@ class _CLayer(ctypes.Structure):
                                                "dgamma", "dbeta")]
 
 
+_GOUT_IN_PLACE = __import__("os").environ.get("PCL_GOUT_IN_PLACE", "1") != "0"      # lab switch (A/B on one box)
+COUNTERS = {"strided_gout": 0}        # calls of the stack backward that read their gout in place from a wider gradient
+
+
 class _CStack(ctypes.Structure):
     _fields_ = ([("struct_bytes", ctypes.c_int32), ("n_layers", ctypes.c_int32), ("c", ctypes.c_int32 * (_MAXL + 1))]
                 + [(n, ctypes.c_int32) for n in ("P", "pool", "grouped", "x_grad_from", "need_dx", "B", "N", "m", "Cf", "use_xyz")]
@@ -615,7 +619,7 @@ class _CStack(ctypes.Structure):
                 + [("layer", _CLayer * _MAXL), ("out", ctypes.c_void_p), ("save", ctypes.c_void_p), ("save_bytes", ctypes.c_size_t),
                    ("tmp", ctypes.c_void_p), ("tmp_bytes", ctypes.c_size_t), ("gout", ctypes.c_void_p), ("dx", ctypes.c_void_p),
                    ("stream", ctypes.c_void_p), ("defer_act", ctypes.c_int32), ("ext_stat_rows", ctypes.c_int32),
-                   ("ext_stats", ctypes.c_void_p), ("flush_k", ctypes.c_int32), ("reserved_", ctypes.c_int32)])
+                   ("ext_stats", ctypes.c_void_p), ("flush_k", ctypes.c_int32), ("gout_ld", ctypes.c_int32)])
 
 
 class _StackPlan:
@@ -772,7 +776,15 @@ class _StackFn(torch.autograd.Function):
         params = sv[n0:]
         dev = out.device
         npl = 4 if plan.has_bias else 3
-        gout = gout.contiguous()
+        # a pooled stack whose output went into a concatenation (multi-scale grouping) gets a column slice of the wide gradient:
+        # the max-gradient kernel reads it in place (row stride gout_ld), no copy per scale
+        d.gout_ld = 0
+        if (_GOUT_IN_PLACE and plan.G and not plan.defer and gout.dim() == 2 and gout.stride(1) == 1 and gout.stride(0) > gout.shape[1]
+                and gout.stride(0) < 2 ** 31 and gout.dtype == torch.float32):
+            d.gout_ld = gout.stride(0)
+            COUNTERS["strided_gout"] += 1
+        else:
+            gout = gout.contiguous()
         tmp = torch.empty((plan.bwd_tmp,), dtype=torch.uint8, device=dev)
         flat = torch.empty((plan.gtotal,), dtype=torch.float32, device=dev)
         pieces = flat.split_with_sizes(plan.gsizes)

@@ -449,6 +449,49 @@ def test_stack_entry_points_equal_per_kernel_path_grouped(dev, C, feat_grad, use
         assert (a[1] - b[1]).abs().max().item() <= 1e-5 * max(1e-6, a[1].abs().max().item())
 
 
+@pytest.mark.parametrize("grouped", [True, False])
+def test_stack_backward_reads_a_column_slice_of_a_wider_gradient_in_place(dev, grouped):
+    """Multi-scale grouping concatenates the pooled outputs of several stacks: each stack's backward gets a column slice of the
+    wide gradient (row stride = the concatenated width).  The max-gradient kernel reads it in place (pcl_mlp_stack_t.gout_ld):
+    same bits as from a dense copy, and no copy made."""
+    from pointcloudlib_amd import synth
+    from pointcloudlib_amd.misc import ops, mlp_hip
+    torch.manual_seed(11)
+    B, N, m, ns, cl = 3, 512, 64, 32, 128
+    x = torch.from_numpy(synth.gauss_ball(B, N, 5)).to(dev)
+    feat0 = torch.randn(B, N, 16, device=dev)
+    _, new_xyz = ops.furthest_point_sample(x, m)
+    idx, cnt = ops.ball_query(new_xyz, x, 0.3, ns, return_cnt=True)
+    goff = ops.group_offsets(cnt)
+    mlp = PointwiseMLP([19, 64, 96, cl]).to(dev).train()
+    rows = torch.randn(B, m, ns, 19, device=dev)
+    wide = torch.randn(B, m, cl + 64 + 320, device=dev)
+
+    def go(strided):
+        mm = copy.deepcopy(mlp)
+        f = feat0.clone().requires_grad_(True)
+        r = rows.clone().requires_grad_(True)
+        out = mm.forward_grouped(x, new_xyz, f, idx, cnt, goff, True) if grouped else mm(r, group_max=ns)
+        assert out.shape == (B, m, cl)
+        g = wide[..., 64:64 + cl]
+        out.backward(g if strided else g.contiguous())
+        return ((f if grouped else r).grad.detach(), {n: p.grad.detach() for n, p in mm.named_parameters()})
+
+    def both():
+        n0 = mlp_hip.COUNTERS["strided_gout"]
+        a = go(True)
+        assert mlp_hip.COUNTERS["strided_gout"] == n0 + 1
+        b = go(False)
+        assert mlp_hip.COUNTERS["strided_gout"] == n0 + 1
+        return a, b
+
+    a, b = _with_stack(True, both)
+    # (the scatter to the points is a gather over row lists: deterministic, so everything is bit-identical)
+    assert torch.equal(a[0], b[0])
+    for n in a[1]:
+        assert torch.equal(a[1][n], b[1][n]), n
+
+
 @pytest.mark.parametrize("grouped", [False, True])
 def test_stack_with_a_96_wide_hidden_layer_runs_zero_padded(dev, grouped):
     """csrc/stack.hip runs a hidden width of 96 (the MSG part-seg encoder's [3, 64, 96, 128]) as 128 with zero weights / gamma / beta in
