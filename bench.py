@@ -27,6 +27,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HOST_DELAY_US = float(os.environ.get("PCL_HOST_DELAY_US", "0"))
+HOST_DELAY_AT = os.environ.get("PCL_HOST_DELAY_AT", "step")          # "step": at the head of the step; "bwd": between the loss and loss.backward()
 PREFETCH_AT = os.environ.get("PCL_PREFETCH_AT", "fwd")     # where batch t+1's sampling is enqueued: beside step t's forward (default) or backward
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_PEAK_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
@@ -163,10 +164,12 @@ def main():
         i+1 are produced on a side stream while step i runs (input-pipeline style; enqueued ahead of its forward); every step still
         executes exactly one full set of index ops, and batch i's own set was produced during step i-1."""
         x, f, y = batches[i % len(batches)]
-        if HOST_DELAY_US:                      # lab switch: is the host on the critical path?  (busy-wait, no GPU interaction)
+        def spin():                            # lab switch: is the host on the critical path?  (busy-wait, no GPU interaction)
             t_end = time.perf_counter() + HOST_DELAY_US * 1e-6
             while time.perf_counter() < t_end:
                 pass
+        if HOST_DELAY_US and HOST_DELAY_AT == "step":
+            spin()
         dp.zero_grad()
         samp = pending.pop(i, None)
         if side is not None and PREFETCH_AT == "fwd":          # the next batch's sampling beside THIS step's forward (A/B: 1.900 vs 1.914 ms beside the backward)
@@ -175,6 +178,8 @@ def main():
         if side is not None and PREFETCH_AT != "fwd":
             pending[i + 1] = net.precompute_sampling(batches[(i + 1) % len(batches)][0], stream=side)
         loss = soft_cross_entropy_loss(out, y)
+        if HOST_DELAY_US and HOST_DELAY_AT == "bwd":
+            spin()
         loss.backward()
         dp.all_reduce()
         opt.step()
