@@ -204,3 +204,31 @@ def test_round5_entry_points_validate_on_the_host():
     assert lib.pcl_group_linear_bwd_gather_f32(p, p, p, p, p, p, p, p, p, 1, 8, 96, p, None, None, 0, None) == -1      # C1 = 96
     assert b"C1" in lib.pcl_last_error()
     assert lib.pcl_frag_linear_fwd_f32(p, 8, p, 8, None, None, None, 0.0, 4, 8, 8, p, 8, None, None, 16, None) == -1  # flush_k not 0 / 8 / 32
+
+
+def test_stack_backward_refuses_a_gout_stride_it_cannot_honour():
+    """pcl_mlp_stack_t.gout_ld (a pooled stack reads its slice of a concatenated gradient in place): a stride below the width, or any
+    stride but the width on a stack without pooling, is an argument error raised on the host before anything is launched."""
+    import ctypes
+    from pointcloudlib_amd import _lib
+    from pointcloudlib_amd.misc.mlp_hip import _CStack
+    lib = _lib.lib()
+    buf = ctypes.create_string_buffer(4096)
+    p = ctypes.cast(buf, ctypes.c_void_p).value
+
+    def desc(pool, gout_ld):
+        d = _CStack()
+        d.struct_bytes, d.n_layers, d.P, d.pool = ctypes.sizeof(_CStack), 2, 64, pool
+        d.c[0], d.c[1], d.c[2] = 16, 64, 128
+        d.slope, d.out_slope, d.eps, d.momentum = 0.0, 0.0, 1e-5, 0.1
+        d.x = p
+        for l in range(2):
+            d.layer[l].W = d.layer[l].gamma = d.layer[l].beta = p
+        d.out = d.save = d.tmp = d.gout = p
+        d.gout_ld = gout_ld
+        return d
+
+    for pool, ld, word in ((32, 100, b"gout_ld"), (0, 320, b"gout_ld"), (32, -4, b"gout_ld")):
+        d = desc(pool, ld)
+        assert lib.pcl_mlp_stack_bwd_f32(ctypes.byref(d)) == -1, (pool, ld)
+        assert word in lib.pcl_last_error(), lib.pcl_last_error()
