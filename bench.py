@@ -348,7 +348,8 @@ def main():
                 tj = traffic_profile()
                 if tj is not None and (B, N, args.dist) == (32, 1024, "gauss_ball"):
                     traffic = tj["per_launch_hbm_bytes"].get(f"{key[0]}:{key[1]}")
-                traffic_src = tj["source"] if traffic is not None else None
+                # (the pass writes under gpurun_out/ on the GPU box; the committed copy of the same file is under profiles/)
+                traffic_src = ("profiles/" + os.path.basename(tj["source"])) if traffic is not None else None
             except Exception:
                 pass
             roofline = {"kernel": key[0], "shape": key[1], "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
