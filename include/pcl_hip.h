@@ -82,6 +82,12 @@ int pcl_fps_f32(const float* xyz, int B, int N, int m, int tie_stride, double sk
  * rows without any hit are zero-filled with cnt 0 (undefined in the reference). */
 int pcl_ball_query_f32(const float* new_xyz, const float* xyz, int B, int m, int N, float radius,
                        int nsample, int32_t* idx_out, int32_t* cnt_out, void* stream);
+/* n_radii (1..4) ball queries around the SAME centres in one scan of the cloud (round 5): replaces the per-scale BallQueryGrouper calls of
+ * PointnetModuleMSG (networks/seg/pointnet2_partseg.py:93-103, :39-41 of the base class' loop over groupers; networks/cls/pointnet2.py:83-93).
+ * radii / nsamples / idx_out / cnt_out are HOST arrays of n_radii entries (cnt_out or any of its entries may be NULL); idx_out[r] is
+ * [B,m,nsamples[r]], cnt_out[r] [B,m] on the device.  Every list is identical to pcl_ball_query_f32's for that radius. */
+int pcl_ball_query_multi_f32(const float* new_xyz, const float* xyz, int B, int m, int N, int n_radii, const float* radii,
+                             const int32_t* nsamples, int32_t* const* idx_out, int32_t* const* cnt_out, void* stream);
 
 /* ---- grouping ---------------------------------------------------------------------------------
  * Replaces the three Var.reindex gathers + subtract + concat of BallQueryGrouper.execute,
@@ -634,6 +640,9 @@ int pcl_frag_linear_bwd_dw_f32(const float* dy, const float* X, int ldx, const f
  *   pcl_bn_act_max_rows_f32: max over each group's valid rows (arg = slot in the compacted group).
  *   pcl_scatter_rows_add_f32: gfeat[row_src[r], c] += grows[r, off+c]  (zero-fills gfeat [n_dst_rows, C]). */
 int pcl_group_offsets_i32(const int32_t* cnt, int G, int32_t* group_off, void* stream);   /* exclusive scan of max(cnt,1) */
+/* the same scan for n (1..4) count arrays of G entries in one launch (the scales of a PointnetModuleMSG level, round 5); cnt / group_off are
+ * HOST arrays of n device pointers */
+int pcl_group_offsets_multi_i32(int n, const int32_t* const* cnt, int G, int32_t* const* group_off, void* stream);
 /* reference: replaces BallQueryGrouper.execute's gathers + concat, misc/ops.py:383-407, on rows without the padding duplicates of misc/ops.py:321-324 */
 int pcl_group_compact_f32(const float* xyz, const float* new_xyz, const float* feat, const int32_t* idx,
                           const int32_t* cnt, const int32_t* group_off, int B, int N, int m, int ns, int C, int use_xyz,

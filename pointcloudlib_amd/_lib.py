@@ -67,6 +67,7 @@ _SIGS = {
     "pcl_optimal_block": (c_int, [c_int]),
     "pcl_fps_f32": (c_int, [_P, c_int, c_int, c_int, c_int, c_double, _P, _P, _P, _P]),
     "pcl_ball_query_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),
+    "pcl_ball_query_multi_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "pcl_group_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_group_bwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_group_all_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
@@ -119,6 +120,7 @@ _SIGS = {
     "pcl_linear_bwd_dx_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_float,
                                       _P, _P, _P]),
     "pcl_group_offsets_i32": (c_int, [_P, c_int, _P, _P]),
+    "pcl_group_offsets_multi_i32": (c_int, [c_int, _P, c_int, _P, _P]),
     "pcl_group_compact_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "pcl_linear_fwd_rows_f32": (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "pcl_bn_act_max_rows_f32": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P, _P]),

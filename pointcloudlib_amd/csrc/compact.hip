@@ -13,7 +13,16 @@
 namespace pcl {
 
 // goff[g] = sum_{h<g} max(cnt[h],1); goff[G] = P_eff.  One workgroup, 1024 lanes, sequential chunks + LDS scan.
+struct GoffMulti { const int32_t* cnt[4]; int32_t* goff[4]; };
+__device__ __forceinline__ void group_offsets_body(const int32_t* __restrict__ cnt, int G, int32_t* __restrict__ goff);
 __global__ __launch_bounds__(1024) void group_offsets_kernel(const int32_t* __restrict__ cnt, int G, int32_t* __restrict__ goff) {
+    group_offsets_body(cnt, G, goff);
+}
+// the same scan for up to four count arrays of one size (the scales of a multi-scale level): workgroup i takes array i
+__global__ __launch_bounds__(1024) void group_offsets_multi_kernel(const GoffMulti a, int G) {
+    group_offsets_body(a.cnt[blockIdx.x], G, a.goff[blockIdx.x]);
+}
+__device__ __forceinline__ void group_offsets_body(const int32_t* __restrict__ cnt, int G, int32_t* __restrict__ goff) {
     __shared__ int part[1024];
     const int t = threadIdx.x;
     const int per = (G + 1023) / 1024;
@@ -688,6 +697,17 @@ extern "C" int pcl_group_offsets_i32(const int32_t* cnt, int G, int32_t* group_o
     PCL_REQUIRE(cnt && group_off && G >= 1, "pcl_group_offsets_i32: bad arguments");
     hipLaunchKernelGGL(group_offsets_kernel, dim3(1), dim3(1024), 0, as_stream(stream), cnt, G, group_off);
     return check_launch("pcl_group_offsets_i32");
+}
+
+extern "C" int pcl_group_offsets_multi_i32(int n, const int32_t* const* cnt, int G, int32_t* const* group_off, void* stream) {
+    PCL_REQUIRE(cnt && group_off && G >= 1 && n >= 1 && n <= 4, "pcl_group_offsets_multi_i32: bad arguments (n = %d: 1..4)", n);
+    GoffMulti a = {};
+    for (int i = 0; i < n; ++i) {
+        PCL_REQUIRE(cnt[i] && group_off[i], "pcl_group_offsets_multi_i32: null array %d", i);
+        a.cnt[i] = cnt[i]; a.goff[i] = group_off[i];
+    }
+    hipLaunchKernelGGL(group_offsets_multi_kernel, dim3(n), dim3(1024), 0, as_stream(stream), a, G);
+    return check_launch("pcl_group_offsets_multi_i32");
 }
 
 extern "C" int pcl_group_compact_f32(const float* xyz, const float* new_xyz, const float* feat, const int32_t* idx,

@@ -17,7 +17,7 @@ from torch import nn
 from .. import _lib
 
 __all__ = [
-    "optimal_block", "furthest_point_sample", "ball_query", "group_points", "group_points_compact", "RowSet", "group_all",
+    "optimal_block", "furthest_point_sample", "ball_query", "ball_query_multi", "group_offsets_multi", "group_points", "group_points_compact", "RowSet", "group_all",
     "index_points",
     "knn_indices", "edge_features", "three_nn", "three_interpolate", "FurthestPointSampler", "BallQueryGrouper", "GroupAll",
     "KNN", "PointNetFeaturePropagation",
@@ -88,6 +88,36 @@ def ball_query(new_xyz, xyz, radius, n_samples, return_cnt=False):
     _lib.call("pcl_ball_query_f32", _p(new_xyz), _p(xyz), B, m, N, float(radius), int(n_samples), _p(idx),
                                              _p(cnt), _stream(), algo_bytes=B * (12 * (N + m) + 4 * m * n_samples))
     return (idx, cnt) if return_cnt else idx
+
+
+BALL_QUERY_MULTI_MAX = 4          # radii per pcl_ball_query_multi_f32 call
+
+
+def ball_query_multi(new_xyz, xyz, radii, n_samples, return_cnt=False):
+    """Ball queries of several radii around the same centres in ONE scan of the cloud (multi-scale grouping: one BallQueryGrouper per
+    scale on the same new_xyz, reference networks/seg/pointnet2_partseg.py:93-103).  -> [idx [B,m,ns_r]] or [(idx, cnt)] per radius,
+    each identical to ``ball_query(new_xyz, xyz, radii[r], n_samples[r])``."""
+    import ctypes
+    new_xyz = _dev(new_xyz, "new_xyz")
+    xyz = _dev(xyz, "xyz")
+    if new_xyz.dim() != 3 or new_xyz.shape[2] != 3 or xyz.dim() != 3 or xyz.shape[2] != 3:
+        raise ValueError("new_xyz / xyz must be [B,*,3]")
+    if new_xyz.shape[0] != xyz.shape[0]:
+        raise ValueError("batch size mismatch")
+    n = len(radii)
+    if n != len(n_samples) or not 1 <= n <= BALL_QUERY_MULTI_MAX:
+        raise ValueError(f"{n} radii / {len(n_samples)} sample counts: 1..{BALL_QUERY_MULTI_MAX} of each")
+    B, m, _ = new_xyz.shape
+    N = xyz.shape[1]
+    idx = [torch.empty((B, m, int(s)), dtype=torch.int32, device=xyz.device) for s in n_samples]
+    cnt = [torch.empty((B, m), dtype=torch.int32, device=xyz.device) for _ in range(n)] if return_cnt else None
+    c_r = (ctypes.c_float * n)(*[float(r) for r in radii])
+    c_s = (ctypes.c_int32 * n)(*[int(s) for s in n_samples])
+    c_i = (ctypes.c_void_p * n)(*[t.data_ptr() for t in idx])
+    c_c = (ctypes.c_void_p * n)(*[t.data_ptr() for t in cnt]) if return_cnt else None
+    _lib.call("pcl_ball_query_multi_f32", _p(new_xyz), _p(xyz), B, m, N, n, c_r, c_s, c_i, c_c, _stream(),
+              algo_bytes=B * (12 * (N + m) + 4 * m * sum(int(s) for s in n_samples)))
+    return list(zip(idx, cnt)) if return_cnt else idx
 
 
 # The k-NN distance has two definitions in this library (DESIGN.md section 3.4): the default rounds `tmp*tmp` and the sum
@@ -214,6 +244,20 @@ def group_offsets(cnt):
     group_off = torch.empty((G + 1,), dtype=torch.int32, device=cnt.device)
     _lib.call("pcl_group_offsets_i32", _p(cnt), G, _p(group_off), _stream())
     return group_off
+
+
+def group_offsets_multi(cnts):
+    """``group_offsets`` of up to four count arrays of one size in one launch (the scales of a multi-scale level)."""
+    import ctypes
+    cnts = [_dev(c, "cnt", torch.int32) for c in cnts]
+    n, G = len(cnts), cnts[0].numel()
+    if not 1 <= n <= BALL_QUERY_MULTI_MAX or any(c.numel() != G for c in cnts):
+        raise ValueError("group_offsets_multi: 1..4 count arrays of equal size")
+    offs = [torch.empty((G + 1,), dtype=torch.int32, device=cnts[0].device) for _ in range(n)]
+    c_c = (ctypes.c_void_p * n)(*[t.data_ptr() for t in cnts])
+    c_o = (ctypes.c_void_p * n)(*[t.data_ptr() for t in offs])
+    _lib.call("pcl_group_offsets_multi_i32", n, c_c, G, c_o, _stream())
+    return offs
 
 
 class _GroupCompact(torch.autograd.Function):

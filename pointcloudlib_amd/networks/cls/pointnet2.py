@@ -16,7 +16,11 @@ from torch import nn
 
 from ...misc.head import fc_head
 from ...misc.layers import PointwiseMLP
-from ...misc.ops import BallQueryGrouper, FurthestPointSampler, GroupAll, ball_query, group_offsets, group_points
+from ...misc.ops import (BALL_QUERY_MULTI_MAX, BallQueryGrouper, FurthestPointSampler, GroupAll, ball_query, ball_query_multi, group_offsets,
+                         group_offsets_multi, group_points)
+
+
+_MULTI_BALL_QUERY = os.environ.get("PCL_MULTI_BALL_QUERY", "1") != "0"        # lab switch for A/B timing on one box
 
 
 class PointNetModuleBase(nn.Module):
@@ -41,9 +45,18 @@ class PointNetModuleBase(nn.Module):
             return None, [None] * len(self.groupers)
         new_xyz = self.sampler(xyz)                                             # :45
         out = []
-        for g in self.groupers:
-            idx, cnt = ball_query(new_xyz, xyz, g.radius, g.n_samples, return_cnt=True)
-            out.append((idx, cnt, group_offsets(cnt) if self.compact_duplicates else None))
+        gs = list(self.groupers)
+        if 1 < len(gs) <= BALL_QUERY_MULTI_MAX and _MULTI_BALL_QUERY:
+            # multi-scale grouping: every scale's list from one scan of the cloud (same lists as one ball_query per scale)
+            lists = ball_query_multi(new_xyz, xyz, [g.radius for g in gs], [g.n_samples for g in gs], return_cnt=True)
+        else:
+            lists = [ball_query(new_xyz, xyz, g.radius, g.n_samples, return_cnt=True) for g in gs]
+        if self.compact_duplicates and 1 < len(gs) <= BALL_QUERY_MULTI_MAX and _MULTI_BALL_QUERY:
+            offs = group_offsets_multi([cnt for _, cnt in lists])
+        else:
+            offs = [group_offsets(cnt) if self.compact_duplicates else None for _, cnt in lists]
+        for (idx, cnt), off in zip(lists, offs):
+            out.append((idx, cnt, off))
         return new_xyz, out
 
     def forward(self, xyz: torch.Tensor, feature: Optional[torch.Tensor], sampling=None):

@@ -232,3 +232,22 @@ def test_stack_backward_refuses_a_gout_stride_it_cannot_honour():
         d = desc(pool, ld)
         assert lib.pcl_mlp_stack_bwd_f32(ctypes.byref(d)) == -1, (pool, ld)
         assert word in lib.pcl_last_error(), lib.pcl_last_error()
+
+
+def test_ball_query_multi_validates_on_the_host():
+    """pcl_ball_query_multi_f32: the radius count, the per-radius sample counts and output pointers are checked before any launch."""
+    import ctypes
+    from pointcloudlib_amd import _lib
+    lib = _lib.lib()
+    buf = ctypes.create_string_buffer(256)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    r = (ctypes.c_float * 5)(0.1, 0.2, 0.3, 0.4, 0.5)
+    s = (ctypes.c_int32 * 5)(4, 4, 0, 4, 4)
+    out = (ctypes.c_void_p * 5)(*[p.value] * 5)
+    assert lib.pcl_ball_query_multi_f32(p, p, 1, 1, 8, 5, r, s, out, None, None) == -1 and b"n_radii" in lib.pcl_last_error()
+    assert lib.pcl_ball_query_multi_f32(p, p, 1, 1, 8, 3, r, s, out, None, None) == -1 and b"radius 2" in lib.pcl_last_error()
+    assert lib.pcl_ball_query_multi_f32(p, p, 1, 1, 8, 2, r, s, None, None, None) == -1
+    assert lib.pcl_ball_query_multi_f32(p, p, 0, 1, 8, 2, r, s, out, None, None) == 0            # empty batch: nothing launched
+    assert lib.pcl_group_offsets_multi_i32(5, out, 8, out, None) == -1 and lib.pcl_group_offsets_multi_i32(2, None, 8, out, None) == -1
+    bad = (ctypes.c_void_p * 2)(p.value, None)
+    assert lib.pcl_group_offsets_multi_i32(2, bad, 8, out, None) == -1 and b"array 1" in lib.pcl_last_error()

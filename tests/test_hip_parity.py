@@ -344,3 +344,33 @@ def test_knn_point_matmul_form_matches_oracle(oracle, dev, B, N, S, k):
         out = torch.empty((B, S, k), dtype=torch.int32, device=dev)
         _lib.call("pcl_knn_point_matmul_f32", _p(x), _p(qd), B, N, S, k, fma_dot, _p(out), _stream())
         assert np.array_equal(out.cpu().numpy(), want), (B, N, S, k, fma_dot)
+
+
+@pytest.mark.parametrize("B,N,m,radii,ns", [(4, 2048, 512, [0.1, 0.2, 0.4], [16, 32, 128]), (3, 512, 128, [0.2, 0.4, 0.8], [32, 64, 128]),
+                                            (2, 1000, 77, [0.05, 10.0], [8, 4]), (2, 300, 300, [0.3], [16]),
+                                            (1, 64, 5, [1e-6, 0.2, 0.25, 0.3], [4, 1, 70, 64])])
+def test_ball_query_multi_equals_one_query_per_radius(oracle, dev, B, N, m, radii, ns):
+    """pcl_ball_query_multi_f32 (multi-scale grouping: every scale's list out of one scan of the cloud) against pcl_ball_query_f32 per
+    radius and against the oracle: lists and counts identical, including radii with no hit at all, radii that fill their list in the
+    first 64 points (early exit per radius) and sample counts above / below the wave width."""
+    xyz = synth.gauss_ball(B, N, 11 + N + m)
+    cent = synth.gauss_ball(B, m, 5 + m)
+    h = min(m // 2, N)
+    cent[:, :h] = xyz[:, :h]                                   # half of the centres are cloud points (as after FPS), half are not
+    X, Q = T(xyz, dev), T(cent, dev)
+    got = ops.ball_query_multi(Q, X, radii, ns, return_cnt=True)
+    assert len(got) == len(radii)
+    for (idx, cnt), r, s in zip(got, radii, ns):
+        one_idx, one_cnt = ops.ball_query(Q, X, r, s, return_cnt=True)
+        assert torch.equal(idx, one_idx) and torch.equal(cnt, one_cnt), r
+        np.testing.assert_array_equal(idx.cpu().numpy(), oracle.ball_query(cent, xyz, r, s))
+    offs = ops.group_offsets_multi([c for _, c in got])                       # the scales' row offsets in one launch
+    for off, (_, c) in zip(offs, got):
+        assert torch.equal(off, ops.group_offsets(c))
+        want = np.concatenate([[0], np.cumsum(np.maximum(c.cpu().numpy().reshape(-1), 1))]).astype(np.int32)
+        np.testing.assert_array_equal(off.cpu().numpy(), want)
+    only = ops.ball_query_multi(Q, X, radii, ns)
+    for a, (b, _) in zip(only, got):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        ops.ball_query_multi(Q, X, [0.1] * 5, [4] * 5)
