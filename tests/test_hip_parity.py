@@ -257,6 +257,23 @@ def test_three_nn_interp(oracle, dev, N, S):
     np.testing.assert_allclose(p.grad.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("N,S", [(100, 27), (33, 3), (257, 64), (40, 9000)])
+def test_three_nn_ties_across_the_lane_split(oracle, dev, N, S):
+    """Eight lanes per target each scan every eighth source and the eight top-3 lists are merged by (distance, index): on clouds made of
+    repeated points and lattice points -- equal distances at indices that fall to different lanes -- the lists still equal the oracle's
+    sequential scan (the lower index first), bit for bit, weights included."""
+    B = 2
+    rng = np.random.default_rng(N * S)
+    lattice = rng.integers(-2, 3, size=(B, S, 3)).astype(np.float32) * 0.25          # 125 distinct sites: many exact ties, many repeats
+    lattice[:, S // 2:] = lattice[:, : S - S // 2]                                    # ... and every site at least twice
+    tgt = rng.integers(-2, 3, size=(B, N, 3)).astype(np.float32) * 0.25
+    tgt[:, ::3] += 0.125                                                              # targets between sites: four / eight equidistant sites
+    wi, ww = oracle.three_nn(tgt, lattice)
+    idx, w = ops.three_nn(T(tgt, dev), T(lattice, dev))
+    assert np.array_equal(idx.cpu().numpy(), wi)
+    assert np.array_equal(w.cpu().numpy(), ww)
+
+
 # ------------------------------------------------------------------------------------ fixtures at full size
 def test_full_size_digests(dev):
     big = json.load(open(os.path.join(GOLD, "full_size_digests.json")))
