@@ -107,11 +107,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=5,
+                    help="consecutive timed windows of --steps steps each (every one bracketed by barrier + synchronize, MAX over ranks); "
+                         "the line reports the MEDIAN window and lists all of them")
+    ap.add_argument("--rewarm", type=int, default=10, help="untimed product-path steps between the per-kernel profiling pre-pass and the timed region")
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU (BASELINE config 2: 32)")
     ap.add_argument("--npoints", type=int, default=1024, help="points per cloud (1024; 4096 is the north-star extra)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
-                    help="skip the short legs for N=4096 and BASELINE configs 3, 4, 5 that follow the timed region (N=1 only; ~20 s)")
+                    help="skip the short legs for BASELINE configs 1, 3, 4, 5 and config 2 on sphere_shell clouds / at N=4096 that follow the timed region (N=1 only; ~25 s)")
+    ap.add_argument("--cpu-baselines", action="store_true",
+                    help="every other_configs row also carries the CPU restatement of its own workload (tools/bench_models.py's leg: minutes; off by default so "
+                         "that the default run stays inside a few minutes)")
     ap.add_argument("--roofline-kernel", default="auto")
     ap.add_argument("--no-prefetch-sampling", dest="prefetch_sampling", action="store_false",
                     help="run FPS/ball query inline at the head of each forward instead of one step ahead on a side stream")
@@ -255,8 +262,8 @@ def main():
         summ = _lib.PROFILER.summary()
         _lib.PROFILER = None
         mlp_hip.USE_STACK = stack_default; _head.USE_STACK = head_default
-        for _ in range(2):                        # back on the product path before anything is timed
-            step(it); it += 1
+        for _ in range(max(2, args.rewarm)):      # back on the product path before anything is timed (the per-kernel pass leaves the
+            step(it); it += 1                     # caching allocator's pools in another shape: the first stack-path steps after it re-grow them)
         torch.cuda.synchronize()
         # dominant = the C-ABI entry point with the largest total time, then its most expensive launch shape
         # (FPS is excluded: it is a latency-bound chain that runs on the side stream beside the GEMMs)
@@ -288,19 +295,33 @@ def main():
     import gc
     gc.collect()
     gc.disable()                 # no collector pauses inside the timed region (a gen-2 pass over the autograd objects is ~ms)
-    fence()
-    t0 = time.perf_counter()
-    _lib.PROFILER = timer
+    # The timed region: `--windows` consecutive windows of EXACTLY `--steps` steps, each bracketed by barrier + synchronize on both
+    # sides.  ms_per_step / value come from the MEDIAN window (MAX over ranks per window); every window is listed in the line.  One
+    # window of 20 steps is 40 ms -- the size of one host hiccup or one clock ramp (round 5's driver line: 2.135 ms from a single window
+    # whose neighbours ran 1.9) -- so a single window is not a measurement of the kernels; the same estimator serves `other_configs`.
+    # The dominant kernel's event pair is armed in every OTHER window (0, 2, 4, ...): `windows_timer_armed` in the line shows whether
+    # the in-stack timer moves a window (it is two events filled from the kernel's own dispatch packet, no marker packets).
     host_trace = [] if os.environ.get("PCL_HOST_TRACE") else None      # lab switch: when does the HOST leave each step?
-    for j in range(args.steps):
-        step(it)
-        it += 1
-        if host_trace is not None:
-            host_trace.append(time.perf_counter() - t0)
-    fence()
-    dt = time.perf_counter() - t0
-    if host_trace is not None and rank == 0:
-        print("host left step j at [ms]: " + " ".join(f"{t * 1e3:.2f}" for t in host_trace) + f" | fence at {dt * 1e3:.2f}", file=sys.stderr)
+    win_dt, win_host, win_armed = [], [], []
+    if timer is not None:
+        timer.max_records = None
+    for w in range(max(1, args.windows)):
+        _lib.PROFILER = timer if w % 2 == 0 else None
+        win_armed.append(timer is not None and w % 2 == 0)
+        fence()
+        t0 = time.perf_counter()
+        for j in range(args.steps):
+            step(it)
+            it += 1
+            if host_trace is not None:
+                host_trace.append(time.perf_counter() - t0)
+        th = time.perf_counter() - t0
+        fence()
+        win_dt.append(time.perf_counter() - t0)
+        win_host.append(th)
+        if host_trace is not None and rank == 0:
+            print(f"window {w}: host left step j at [ms]: " + " ".join(f"{t * 1e3:.2f}" for t in host_trace) + f" | fence at {win_dt[-1] * 1e3:.2f}", file=sys.stderr)
+            host_trace.clear()
     _lib.PROFILER = None
     # host side of a step (untimed extras): the time Python needs to ENQUEUE one step with the stream empty behind it (4
     # steps back to back without a sync; the launch queue is deeper than that), and the number of own C-ABI launches
@@ -320,9 +341,11 @@ def main():
         fence()
     gc.enable()
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor(win_dt, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        win_dt = [float(v) for v in t.tolist()]
+    import statistics
+    dt = statistics.median(win_dt)
 
     if rank == 0:
         roofline = None
@@ -372,7 +395,7 @@ def main():
                 torch.cuda.empty_cache()
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import bench_models
-                others = bench_models.other_configs(steps=20)
+                others = bench_models.other_configs(steps=20, windows=max(1, args.windows), cpu_baselines=args.cpu_baselines)
             except Exception as e:                                  # noqa: BLE001 -- reported in the line
                 others = [{"key": "other_configs", "error": f"{type(e).__name__}: {e}"[:400]}]
         value = world * B * args.steps / dt
@@ -380,6 +403,10 @@ def main():
             "metric": f"point-clouds/sec fwd+bwd, PointNet++ SSG B={B} N={N}", "value": round(value, 2),
             "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "timing": f"median of {len(win_dt)} consecutive windows of {args.steps} steps, each bracketed by barrier + synchronize (MAX over ranks per window)",
+            "windows_ms_per_step": [round(v / args.steps * 1e3, 4) for v in win_dt],
+            "windows_host_enqueue_ms_per_step": [round(v / args.steps * 1e3, 4) for v in win_host],
+            "windows_timer_armed": win_armed,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"PointNet++ SSG cls train step (fwd+bwd+SGD), B={B}/GPU, N={N} xyz+normal, "
                                    f"{args.dist} clouds (BASELINE configs[1])",

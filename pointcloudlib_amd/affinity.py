@@ -59,7 +59,12 @@ def pin_to_gpu_node(local_rank=0):
         allowed = os.sched_getaffinity(0)
         gpus = gpu_numa_nodes()
         node, why = None, ""
-        if local_rank < len(gpus) and gpus[local_rank] >= 0:
+        forced = os.environ.get("PCL_PIN_NODE")              # lab switch (tools/driver_dist.sh): "-1" = do not pin, "n" = pin to node n
+        if forced is not None and forced.lstrip("-").isdigit():
+            if int(forced) < 0:
+                return None
+            node, why = int(forced), "PCL_PIN_NODE"
+        elif local_rank < len(gpus) and gpus[local_rank] >= 0:
             node, why = gpus[local_rank], f"gpu{local_rank}"
         else:
             with open("/proc/self/stat") as f:

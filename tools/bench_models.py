@@ -133,17 +133,20 @@ def _selected(name):
     return name == ONLY[:-1] if ONLY.endswith("$") else ONLY in name
 
 
+WINDOWS = []                                           # the windows of the last _timed() call, seconds per step
+
+
 def _timed(step, steps, windows=1):
-    """seconds per step: the best of `windows` consecutive windows of `steps` steps (one window unless a caller asks for more: an
-    allocator growth or a clock dip inside a 20-step window moved a row by 40 % once in ten runs)"""
-    best = None
+    """seconds per step: the MEDIAN of `windows` consecutive windows of `steps` steps, each bracketed by a synchronize -- bench.py's
+    estimator for the headline (one window unless a caller asks for more; every window is kept in WINDOWS for the row)"""
+    import statistics
+    del WINDOWS[:]
     for _ in range(windows):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(steps):
             step()
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-        best = dt if best is None or dt < best else best
-    return best
+        torch.cuda.synchronize(); WINDOWS.append((time.perf_counter() - t0) / steps)
+    return statistics.median(WINDOWS)
 
 
 def run(name, make, inputs, loss_fn, steps, warmup=3, cpu_kind=None, windows=1):
@@ -161,6 +164,7 @@ def run(name, make, inputs, loss_fn, steps, warmup=3, cpu_kind=None, windows=1):
     dt = _timed(step, steps, windows)
     B = inputs[0].shape[0]
     r = {"config": name, "ms_per_step": round(dt * 1e3, 3), "clouds_per_s": round(B / dt, 1), "batch": B,
+         "windows_ms_per_step": [round(w * 1e3, 3) for w in WINDOWS],
          "params": sum(p.numel() for p in net.parameters()), "roofline": roofline_of(step)}
     if CPU_BASELINE and cpu_kind:
         # (timed after ALL GPU configs: the CPU legs spin up 32 OpenMP / PyTorch threads that would compete with the Python
@@ -197,6 +201,7 @@ def _run_prefetch(name, make, inputs, loss_fn, steps, warmup=120, windows=1):   
     dt = _timed(step, steps, windows)
     B = inputs[0].shape[0]
     r = {"config": name, "ms_per_step": round(dt * 1e3, 3), "clouds_per_s": round(B / dt, 1), "batch": B,
+         "windows_ms_per_step": [round(w * 1e3, 3) for w in WINDOWS],
          "params": sum(p.numel() for p in net.parameters())}
     if not QUIET:
         print(json.dumps(r), flush=True)
@@ -216,11 +221,14 @@ def traffic_of(key, roofline):
     return None, None
 
 
-def other_configs(steps=20, keys=("cfg2_n4096", "cfg3", "cfg4", "cfg5")):
-    """bench.py's `other_configs` leg: the BASELINE workloads besides the headline (N = 4096 row of config 2, configs 3, 4 (MSG), 5), one
-    short train-step timing each on the same GPU with the roofline of its dominant kernel; networks with a sampling front end are timed
-    both inline and with the headline's one-batch-ahead protocol."""
-    global QUIET
+def other_configs(steps=20, keys=("cfg1", "cfg2_sphere_shell", "cfg2_n4096", "cfg3", "cfg4", "cfg5"), windows=5, cpu_baselines=False):
+    """bench.py's `other_configs` leg: the BASELINE workloads besides the headline (config 1; config 2 on the never-saturating
+    sphere_shell clouds of SURVEY 8d and at N = 4096; configs 3, 4 (MSG), 5), timed with the headline's estimator -- the MEDIAN of
+    `windows` consecutive windows of `steps` train steps, every window listed -- each with the roofline of its dominant kernel;
+    networks with a sampling front end are timed both inline and with the headline's one-batch-ahead protocol.  With
+    `cpu_baselines` every row also carries the CPU restatement of its workload (tens of seconds each: off by default)."""
+    global QUIET, CPU_BASELINE
+    from pointcloudlib_amd.networks.cls.pointnet import PointNet
     from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
     from pointcloudlib_amd.networks.cls.dgcnn import DGCNN
     from pointcloudlib_amd.networks.cls.pointconv import PointConvDensityClsSsg
@@ -229,42 +237,55 @@ def other_configs(steps=20, keys=("cfg2_n4096", "cfg3", "cfg4", "cfg5")):
     cloud = lambda B, N, seed: torch.from_numpy(synth.gauss_ball(B, N, seed)).to(dev)
     y32 = torch.from_numpy(synth.labels(32, 40, 1)).to(dev)
     ce = lambda o: soft_cross_entropy_loss(o, y32)
+    timing = f"median of {windows} consecutive windows of `steps` steps after 10+ warm-up steps (bench.py's estimator)"
     def one(key):
         pre = None
-        if key == "cfg2_n4096":
+        if key == "cfg1":
+            y8 = torch.from_numpy(synth.labels(8, 40, 1)).to(dev)
+            r = run("PointNet cls B=8 N=1024 (BASELINE configs[0] on the GPU path)", PointNet, (cloud(8, 1024, 20241).transpose(1, 2).contiguous(),),
+                    lambda o: soft_cross_entropy_loss(o, y8), steps, warmup=10, windows=windows, cpu_kind="cfg1")
+        elif key == "cfg2_sphere_shell":
+            x = torch.from_numpy(synth.sphere_shell(32, 1024, 20242)).to(dev)
+            inp = (x, torch.from_numpy(synth.unit_normals(32, 1024, 7)).to(dev))
+            r = run("PointNet++ SSG cls B=32 N=1024, sphere_shell clouds (SURVEY 8d: ball queries never saturate)", PointNet2_cls, inp, ce, steps, warmup=10, windows=windows)
+            pre = (PointNet2_cls, inp, ce)
+        elif key == "cfg2_n4096":
             x = cloud(32, 4096, 20242)
             inp = (x, torch.from_numpy(synth.unit_normals(32, 4096, 7)).to(dev))
-            r = run("PointNet++ SSG cls B=32 N=4096 (north_star's second cloud size)", PointNet2_cls, inp, ce, steps, warmup=10, windows=2)
+            r = run("PointNet++ SSG cls B=32 N=4096 (north_star's second cloud size)", PointNet2_cls, inp, ce, steps, warmup=10, windows=windows, cpu_kind="cfg2_n4096")
             pre = (PointNet2_cls, inp, ce)
         elif key == "cfg3":
-            r = run("DGCNN cls B=32 N=1024 k=20 (BASELINE configs[2])", DGCNN, (cloud(32, 1024, 20242).transpose(1, 2).contiguous(),), ce, steps, warmup=10, windows=2)
+            r = run("DGCNN cls B=32 N=1024 k=20 (BASELINE configs[2])", DGCNN, (cloud(32, 1024, 20242).transpose(1, 2).contiguous(),), ce, steps, warmup=10, windows=windows, cpu_kind="cfg3")
         elif key == "cfg4":
             xs = cloud(16, 2048, 20244)
             oh = torch.zeros(16, 16, device=dev); oh[torch.arange(16), torch.arange(16) % 16] = 1
             seg = torch.randint(0, 50, (16, 2048), device=dev)
             lossf = lambda o: torch.nn.functional.cross_entropy(o, seg)
-            r = run("PointNet++ MSG part-seg B=16 N=2048 (BASELINE configs[3])", PointNetMSG, (xs, xs, oh), lossf, steps, warmup=10, windows=2)
+            r = run("PointNet++ MSG part-seg B=16 N=2048 (BASELINE configs[3])", PointNetMSG, (xs, xs, oh), lossf, steps, warmup=10, windows=windows, cpu_kind="cfg4_msg")
             pre = (PointNetMSG, (xs, xs, oh), lossf)
         elif key == "cfg5":
             inp = (cloud(32, 1024, 20242).transpose(1, 2).contiguous(),)
-            r = run("PointConv cls B=32 N=1024 (BASELINE configs[4])", PointConvDensityClsSsg, inp, ce, steps, warmup=10, windows=2)
+            r = run("PointConv cls B=32 N=1024 (BASELINE configs[4])", PointConvDensityClsSsg, inp, ce, steps, warmup=10, windows=windows, cpu_kind="cfg5")
             pre = (PointConvDensityClsSsg, inp, ce)
         else:
             return None
         row = {"key": key, "workload": r["config"] + ", train step fwd+bwd+SGD", "ms_per_step": r["ms_per_step"],
-               "value": r["clouds_per_s"], "unit": "point-clouds/s", "steps": steps, "timing": "best of two consecutive windows of `steps` steps after 10+ warm-up steps",
-               "sampling": "inline", "roofline": r["roofline"]}
+               "value": r["clouds_per_s"], "unit": "point-clouds/s", "steps": steps, "timing": timing,
+               "windows_ms_per_step": r["windows_ms_per_step"], "sampling": "inline", "roofline": r["roofline"], "_r": r}
         if pre is not None:
             # the headline's protocol: the coordinate-only work of batch t+1 (FPS, ball query / k-NN groups, kernel densities) on the
             # network's side stream during step t; the inline figure stays beside it
-            rp = _run_prefetch(r["config"], pre[0], pre[1], pre[2], steps, warmup=40, windows=2)
-            row.update({"ms_per_step_inline": r["ms_per_step"], "ms_per_step": rp["ms_per_step"], "value": rp["clouds_per_s"],
+            rp = _run_prefetch(r["config"], pre[0], pre[1], pre[2], steps, warmup=40, windows=windows)
+            row.update({"ms_per_step_inline": r["ms_per_step"], "windows_ms_per_step_inline": r["windows_ms_per_step"],
+                        "ms_per_step": rp["ms_per_step"], "windows_ms_per_step": rp["windows_ms_per_step"], "value": rp["clouds_per_s"],
                         "sampling": "coordinate-only work of batch t+1 on a side stream during step t (the headline's protocol); "
                                     "ms_per_step_inline = the same step with it inline"})
         if row["roofline"]:
             row["roofline"]["traffic"], row["roofline"]["traffic_source"] = traffic_of(key, row["roofline"])
         return row
     QUIET, out = True, []
+    cpu_before, CPU_BASELINE = CPU_BASELINE, bool(cpu_baselines)
+    del CPU_JOBS[:]
     try:
         for key in keys:
             # one failing auxiliary workload (an allocation failure, a kernel error in a less exercised network) must not take the
@@ -279,8 +300,19 @@ def other_configs(steps=20, keys=("cfg2_n4096", "cfg3", "cfg4", "cfg5")):
                 torch.cuda.empty_cache()
             except Exception:                                       # noqa: BLE001
                 pass
+        # the CPU legs after ALL GPU rows (their 32 threads would compete with the launch thread of the host-sensitive rows)
+        for r, kind, state in CPU_JOBS:
+            try:
+                r["cpu_baseline"] = cpu_baseline_of(kind, state, n_warm=1, n_steps=3)
+            except Exception as e:                                  # noqa: BLE001
+                r["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        for row in out:
+            r = row.pop("_r", None)
+            if r is not None and "cpu_baseline" in r:
+                row["cpu_baseline"] = r["cpu_baseline"]
     finally:
-        QUIET = False
+        QUIET, CPU_BASELINE = False, cpu_before
+        del CPU_JOBS[:]
     return out
 
 

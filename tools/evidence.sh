@@ -3,9 +3,9 @@
 #   bash tools/evidence.sh r04
 # kernel trace + stats, FETCH_SIZE / WRITE_SIZE passes (separate runs, counters only), SQ wave-state pass, the bench line.
 R=${1:-r04}; O=gpurun_out/$R; mkdir -p $O; cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-B="python bench.py --steps 20 --warmup 3 --no-settle --no-cpu-baseline --no-other-configs"
+B="python bench.py --steps 20 --warmup 3 --no-settle --no-cpu-baseline --no-other-configs --windows 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o b -- $B > $O/kt.log 2>&1
-S="python bench.py --steps 3 --warmup 1 --no-settle --no-cpu-baseline --no-other-configs --roofline-kernel none"
+S="python bench.py --steps 3 --warmup 1 --no-settle --no-cpu-baseline --no-other-configs --roofline-kernel none --windows 1"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o b -- $S --dump-launch-order $O/order.json > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o b -- $S > $O/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
