@@ -293,8 +293,11 @@ def main():
             timer = _lib.KernelTimer([target[0]], tags=None if target[1] is None else [target[1]], max_records=64)
 
     import gc
-    gc.collect()
-    gc.disable()                 # no collector pauses inside the timed region (a gen-2 pass over the autograd objects is ~ms)
+    lab_no_gc = bool(os.environ.get("PCL_BENCH_NO_GC"))                   # lab switches (tools/first_window.sh): what makes the FIRST window slow?
+    lab_idle_ms = float(os.environ.get("PCL_BENCH_IDLE_MS", "0"))         # host sleep (GPU idle) in front of window 2
+    if not lab_no_gc:
+        gc.collect()
+        gc.disable()             # no collector pauses inside the timed region (a gen-2 pass over the autograd objects is ~ms)
     # The timed region: `--windows` consecutive windows of EXACTLY `--steps` steps, each bracketed by barrier + synchronize on both
     # sides.  ms_per_step / value come from the MEDIAN window (MAX over ranks per window); every window is listed in the line.  One
     # window of 20 steps is 40 ms -- the size of one host hiccup or one clock ramp (round 5's driver line: 2.135 ms from a single window
@@ -308,6 +311,8 @@ def main():
     for w in range(max(1, args.windows)):
         _lib.PROFILER = timer if w % 2 == 0 else None
         win_armed.append(timer is not None and w % 2 == 0)
+        if lab_idle_ms and w == 2:
+            torch.cuda.synchronize(); time.sleep(lab_idle_ms * 1e-3)
         fence()
         t0 = time.perf_counter()
         for j in range(args.steps):

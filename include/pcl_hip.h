@@ -448,7 +448,7 @@ void pcl_set_kernel_paths(int fwd_resident, int narrow_stacks, int fused_backwar
  * returns.  For plain stacks of <= max_rows rows (default 8192: the GroupAll level, the part-seg decoder) whose layers have no fused
  * dX + dW kernel, every dW launch is forked to a stream the library owns (event after consts(l)) and joined into the caller's stream at
  * the end of the call, so it runs in the holes of the dX chain; same kernels, same grids, per-layer buffers: results are bit-identical
- * to the serial order.  side_dw: 1 on (default), 0 off, negative = leave as is; max_rows <= 0 = leave as is.  Capturable in a HIP graph
+ * to the serial order.  Measured not faster: OFF by default.  side_dw: 1 on, 0 off (default), negative = leave as is; max_rows <= 0 = leave as is.  Capturable in a HIP graph
  * (event fork / join from the capturing stream). */
 void pcl_set_stack_overlap(int side_dw, int max_rows);
 int pcl_get_stack_overlap(void);
@@ -461,7 +461,7 @@ int pcl_get_stack_overlap(void);
  * z = lrelu(prev_scale x + prev_shift) (or x when prev_scale is NULL) on the staged dW kernel reading dy as a plain operand (workspace:
  * pcl_linear_bwd_dw_plain_workspace_bytes); the input gradient of such a layer is pcl_frag_linear_bwd_dx_f32 on the same dy.
  * pcl_mlp_fewrow_layer: does layer (Cout <- Cin) of a plain stack on P rows take this path inside pcl_mlp_stack_bwd_f32 (the host's
- * per-kernel path asks the same question).  pcl_set_fewrow_backward: lab switch, 1 on (default) / 0 off / negative leave as is.
+ * per-kernel path asks the same question).  pcl_set_fewrow_backward: lab switch, 1 on / 0 off (default: measured a wash) / negative leave as is.
  * pcl_set_dw_tuning: lab knob, row-chunk workgroups per output tile of the plain-dy dW (0 = the library's choice). */
 int pcl_bn_bwd_dy_supported(int P, int C);
 int pcl_bn_bwd_dy_f32(const double* stats_ws, int stat_rows, const float* gamma, const float* mean, const float* invstd, int P_bn, int C,

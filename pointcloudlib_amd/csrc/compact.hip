@@ -556,13 +556,16 @@ __global__ __launch_bounds__(256) void group_linear_bwd_gather_kernel(const floa
     // points (the centre of a cloud is in every group: 100+ rows) are the kernel's tail, and this halves / quarters their dependent chain;
     // the row-lanes' sums meet by shuffles in a fixed order.  The next chunk's row indices are requested before this chunk's rows are used.
     const int stride = gridDim.x * 4;
+    // (a point in no group has o0 == o1, and for the trailing points of the last cloud that is in_off[P] = the number of rows: the
+    // prefetch index is clamped to the last row so that the -- unused -- value is never read past a full `in_rows`)
+    const int last = max(in_off[P] - 1, 0);
     for (int p = blockIdx.x * 4 + wave; p < P; p += stride) {
         const int o0 = in_off[p], o1 = in_off[p + 1];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int o = o0 + psub * U;
         int r[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) r[j] = in_rows[max(o0, min(o + j, o1 - 1))];
+        for (int j = 0; j < U; ++j) r[j] = in_rows[min(max(o0, min(o + j, o1 - 1)), last)];
         for (; o < o1; o += PPW * U) {
             float4 L[U], du[U], yv[U];
 #pragma unroll
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(256) void group_linear_bwd_gather_kernel(const floa
             }
             int rn[U];
 #pragma unroll
-            for (int j = 0; j < U; ++j) rn[j] = in_rows[max(o0, min(o + PPW * U + j, o1 - 1))];
+            for (int j = 0; j < U; ++j) rn[j] = in_rows[min(max(o0, min(o + PPW * U + j, o1 - 1)), last)];
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 if (o + j < o1) {

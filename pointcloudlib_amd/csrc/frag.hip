@@ -558,6 +558,15 @@ static void launch_gemm_t(const GemmArgs& g, int ksw, hipStream_t st) {
     const size_t cst = ACT ? (size_t)2 * (S + FG_D + 1) * 8 * 4 : 0;
     size_t red = (size_t)4 * TN * 16 * 64 * (FLUSH > 0 ? 8 : 4);                       // k-group reduction buffer (also the statistics exchange)
     const size_t lds = cst + red;
+    if (lds > 64 * 1024) {
+        // the folded input BatchNorm's constants (2 x 32 bytes per 8 k) beside the reduction buffer pass the 64 KB default from Cin ~ 4 000 on
+        // (the entry point admits Cin <= 8 192: 66 KB + 32 KB): raise the kernel's limit, once per instantiation
+        static size_t raised = 0;
+        if (lds > raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(frag_gemm_kernel<TN, FLUSH, ACT, BKN, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            raised = lds;
+        }
+    }
     FG_LAUNCH((frag_gemm_kernel<TN, FLUSH, ACT, BKN, EP>), dim3(g.nrt * g.nct), dim3(256 * ksw), lds, st, g);
 }
 

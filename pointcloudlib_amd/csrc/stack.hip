@@ -288,7 +288,13 @@ static void tagf(const char* fmt, int a, int b) {
 // backward), one copies the 96 real entries of the running statistics / the gradients back.  +33 % flops on two layers for kernels that
 // run 2-3 x faster.
 struct PadItem { const float* src; float* dst; int rows, cols, lds, ldd, rows_p, cols_p; };      // dst [rows_p][ldd] <- src [rows][lds], zero elsewhere (pad) or dst [rows][ldd] <- src (unpad: rows_p = cols_p = 0)
-struct PadTable { PadItem it[12]; int n; };
+// Capacity = the most a legal descriptor can ask for: per layer one padded weight + five parameter rows (forward), PCL_STACK_MAX_LAYERS layers
+// (1 928 bytes of kernel argument).  push() refuses instead of writing past the table (the check used to run after the writes).
+constexpr int PAD_ITEMS = PCL_STACK_MAX_LAYERS * 6;
+struct PadTable {
+    PadItem it[PAD_ITEMS]; int n;
+    bool push(const PadItem& q) { if (n >= PAD_ITEMS) return false; it[n++] = q; return true; }
+};
 __global__ __launch_bounds__(256) void pad_copy_kernel(const PadTable t) {
     const PadItem q = t.it[blockIdx.y];
     const bool unpad = q.rows_p == 0;
@@ -394,15 +400,16 @@ extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
     const int L = d.n_layers;
     for (int l = 0; l < L; ++l) {
         const pcl_stack_layer_t& y = d.layer[l];
-        if (p.wpad[l]) t.it[t.n++] = PadItem{y.W, sx + p.w_off[l], d.c[l + 1], d.c[l], d.c[l], p.cp[l], p.cp[l + 1], p.cp[l]};
+        bool ok = true;
+        if (p.wpad[l]) ok = t.push(PadItem{y.W, sx + p.w_off[l], d.c[l + 1], d.c[l], d.c[l], p.cp[l], p.cp[l + 1], p.cp[l]}) && ok;
         if (p.opad[l]) {
             float* v = sx + p.v_off[l];
             const int c = d.c[l + 1], cp = p.cp[l + 1];
             // gamma | beta | running mean | running var | bias: five rows of one [5][cp] block; absent ones are copied from gamma (never read)
             const float* srcs[5] = {y.gamma, y.beta, y.running_mean, y.running_var, y.bias};
-            for (int k = 0; k < 5; ++k) if (srcs[k]) t.it[t.n++] = PadItem{srcs[k], v + (size_t)k * cp, 1, c, c, cp, 1, cp};
+            for (int k = 0; k < 5; ++k) if (srcs[k]) ok = t.push(PadItem{srcs[k], v + (size_t)k * cp, 1, c, c, cp, 1, cp}) && ok;
         }
-        PCL_REQUIRE(t.n <= 12, "pcl_mlp_stack_fwd_f32: more padded layers than the pad table holds");
+        PCL_REQUIRE(ok, "pcl_mlp_stack_fwd_f32: more padded layers than the pad table holds");
     }
     PCL_TRY(launch_pad(t, d.stream));
     PCL_TRY(stack_fwd_impl(&q));
@@ -413,8 +420,10 @@ extern "C" int pcl_mlp_stack_fwd_f32(const pcl_mlp_stack_t* dp) {
         const pcl_stack_layer_t& y = d.layer[l];
         float* v = sx + p.v_off[l];
         const int c = d.c[l + 1], cp = p.cp[l + 1];
-        if (y.running_mean) u.it[u.n++] = PadItem{v + 2 * (size_t)cp, y.running_mean, 1, c, cp, c, 0, 0};
-        if (y.running_var) u.it[u.n++] = PadItem{v + 3 * (size_t)cp, y.running_var, 1, c, cp, c, 0, 0};
+        bool ok = true;
+        if (y.running_mean) ok = u.push(PadItem{v + 2 * (size_t)cp, y.running_mean, 1, c, cp, c, 0, 0}) && ok;
+        if (y.running_var) ok = u.push(PadItem{v + 3 * (size_t)cp, y.running_var, 1, c, cp, c, 0, 0}) && ok;
+        PCL_REQUIRE(ok, "pcl_mlp_stack_fwd_f32: more padded layers than the pad table holds");
     }
     return launch_pad(u, d.stream);
 }
@@ -443,15 +452,16 @@ extern "C" int pcl_mlp_stack_bwd_f32(const pcl_mlp_stack_t* dp) {
     PadTable u = {};
     for (int l = 0; l < L; ++l) {
         const pcl_stack_layer_t& y = d.layer[l];
-        if (p.wpad[l]) u.it[u.n++] = PadItem{bx + p.dw_off[l], y.dW, d.c[l + 1], d.c[l], p.cp[l], d.c[l], 0, 0};
+        bool ok = true;
+        if (p.wpad[l]) ok = u.push(PadItem{bx + p.dw_off[l], y.dW, d.c[l + 1], d.c[l], p.cp[l], d.c[l], 0, 0}) && ok;
         if (p.opad[l]) {
             float* g = bx + p.dv_off[l];
             const int c = d.c[l + 1], cp = p.cp[l + 1];
-            u.it[u.n++] = PadItem{g, y.dgamma, 1, c, cp, c, 0, 0};
-            u.it[u.n++] = PadItem{g + cp, y.dbeta, 1, c, cp, c, 0, 0};
-            if (y.bias) u.it[u.n++] = PadItem{g + 2 * (size_t)cp, y.dbias, 1, c, cp, c, 0, 0};
+            ok = u.push(PadItem{g, y.dgamma, 1, c, cp, c, 0, 0}) && ok;
+            ok = u.push(PadItem{g + cp, y.dbeta, 1, c, cp, c, 0, 0}) && ok;
+            if (y.bias) ok = u.push(PadItem{g + 2 * (size_t)cp, y.dbias, 1, c, cp, c, 0, 0}) && ok;
         }
-        PCL_REQUIRE(u.n <= 12, "pcl_mlp_stack_bwd_f32: more padded layers than the pad table holds");
+        PCL_REQUIRE(ok, "pcl_mlp_stack_bwd_f32: more padded layers than the pad table holds");
     }
     return launch_pad(u, d.stream);
 }

@@ -25,6 +25,10 @@ from .. import _lib
 from .layers import PointwiseMLP
 from .ops import _dev, _p, _stream, furthest_point_sample, index_points, knn_indices, three_interpolate, three_nn
 
+# Accumulation of the per-point Linear(16 C -> C) of every PointConv level (misc/pointconv_utils.py:395-397): 0 = one fp32 fma chain
+# per output over all 16 C terms (the staged MFMA GEMM), 8 | 32 = chains of that length summed in fp64 (csrc/frag.hip).
+POINTCONV_LINEAR_FLUSH = int(os.environ.get("PCL_POINTCONV_FLUSH", "0"))
+
 
 def farthest_point_sample(xyz, npoint, start_idx=None):
     """xyz [B,N,3] -> int32 [B,npoint] (:74-116).  ``start_idx`` [B] int32; default: random like :88."""
@@ -227,6 +231,8 @@ class PointConvDensitySetAbstraction(nn.Module):
         self.weightnet = WeightNet(3, 16)
         self.densitynet = DensityNet()
         self.linear = PointwiseMLP([16 * mlp[-1], mlp[-1]], bias=True)       # Linear + BatchNorm1d + ReLU  :395-397
+        # K = 16 C = 2 048 / 4 096 terms per output: fp32 chains of 32 summed in fp64 (csrc/frag.hip), see POINTCONV_LINEAR_FLUSH
+        self.linear.flush_k = POINTCONV_LINEAR_FLUSH
         self.group_all = group_all
         self.bandwidth = bandwidth
 

@@ -492,7 +492,7 @@ def test_stack_backward_reads_a_column_slice_of_a_wider_gradient_in_place(dev, g
         assert torch.equal(a[1][n], b[1][n]), n
 
 
-@pytest.mark.parametrize("grouped", [False, True])
+@pytest.mark.parametrize("grouped", [False, True, "deep"])
 def test_stack_with_a_96_wide_hidden_layer_runs_zero_padded(dev, grouped):
     """csrc/stack.hip runs a hidden width of 96 (the MSG part-seg encoder's [3, 64, 96, 128]) as 128 with zero weights / gamma / beta in
     the pad once the stack has >= 32768 rows: the 96 real channels see the same products, so outputs, input gradient, every parameter
@@ -501,6 +501,8 @@ def test_stack_with_a_96_wide_hidden_layer_runs_zero_padded(dev, grouped):
     from pointcloudlib_amd import synth
     from pointcloudlib_amd.misc import ops
     torch.manual_seed(11)
+    deep = grouped == "deep"         # three 96-wide hidden layers with bias: 19 items in the forward's pad table (it held 12)
+    grouped = grouped is True
     if grouped:
         B, N, m, ns = 8, 1024, 512, 32                 # 131072 grouped rows
         x = torch.from_numpy(synth.gauss_ball(B, N, 33)).to(dev)
@@ -511,7 +513,7 @@ def test_stack_with_a_96_wide_hidden_layer_runs_zero_padded(dev, grouped):
         mlp = PointwiseMLP([6, 64, 96, 128]).to(dev).train()
         gout = torch.randn(B, m, 128, device=dev)
     else:
-        mlp = PointwiseMLP([32, 64, 96, 128], bias=True).to(dev).train()
+        mlp = PointwiseMLP([32, 96, 96, 96, 128] if deep else [32, 64, 96, 128], bias=True).to(dev).train()
         xin = torch.randn(40000, 32, device=dev)
         gout = torch.randn(40000, 128, device=dev)
     with torch.no_grad():
