@@ -262,8 +262,6 @@ def main():
         summ = _lib.PROFILER.summary()
         _lib.PROFILER = None
         mlp_hip.USE_STACK = stack_default; _head.USE_STACK = head_default
-        for _ in range(max(2, args.rewarm)):      # back on the product path before anything is timed (the per-kernel pass leaves the
-            step(it); it += 1                     # caching allocator's pools in another shape: the first stack-path steps after it re-grow them)
         torch.cuda.synchronize()
         # dominant = the C-ABI entry point with the largest total time, then its most expensive launch shape
         # (FPS is excluded: it is a latency-bound chain that runs on the side stream beside the GEMMs)
@@ -297,7 +295,27 @@ def main():
     lab_idle_ms = float(os.environ.get("PCL_BENCH_IDLE_MS", "0"))         # host sleep (GPU idle) in front of window 2
     if not lab_no_gc:
         gc.collect()
-        gc.disable()             # no collector pauses inside the timed region (a gen-2 pass over the autograd objects is ~ms)
+        gc.disable()             # no collector pauses inside the timed region (a gen-2 pass over the autograd objects is ~5 ms: a window of 5.3 ms per step, measured)
+    # Round 6, root cause of round 5's driver line (2.135 ms where the same run's N = 4096 row took 2.187): the GPU IDLES through the
+    # profiling pre-pass's summary and the full gc.collect() above (tens of ms), and the first ~40 ms of work after an idle period run 4-5 %
+    # slow (14 of 14 runs: first window 1.93-1.97 ms, the four behind it 1.86-1.87; without the collect the first window is 1.863; a 100 / 400 ms
+    # host sleep in front of ANY window makes that window 1.93 / 1.95 -- gpurun_out/r06a, r06b, tools/first_window.sh).  So the untimed
+    # re-warm steps come AFTER the collect, and run until two consecutive 10-step windows agree within 1 % (at most 100 steps), like the
+    # settling pass in front of the pre-pass.
+    prev = None
+    for k in range(10):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10 if k or args.rewarm <= 10 else args.rewarm):
+            step(it); it += 1
+        torch.cuda.synchronize(); cur = time.perf_counter() - t0
+        stop = k >= 1 and prev is not None and abs(cur - prev) <= 0.01 * cur
+        if distributed:
+            flag = torch.tensor([1.0 if stop else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            stop = bool(flag.item() > 0.5)
+        if stop or not args.settle and k >= 1:
+            break
+        prev = cur
     # The timed region: `--windows` consecutive windows of EXACTLY `--steps` steps, each bracketed by barrier + synchronize on both
     # sides.  ms_per_step / value come from the MEDIAN window (MAX over ranks per window); every window is listed in the line.  One
     # window of 20 steps is 40 ms -- the size of one host hiccup or one clock ramp (round 5's driver line: 2.135 ms from a single window

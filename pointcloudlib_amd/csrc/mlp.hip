@@ -1790,9 +1790,13 @@ static int launch_fwd_res(const LinArgs& a, int stat_rows, hipStream_t st) {
 //      another's MFMAs, and every chunk boundary drained the matrix pipe).  The epilogue masks with
 //      relu'(BN(Yprev)) read from LDS, sums (du, du*Yprev) for the BatchNorm below and stores dU_prev in the C/D layout;
 //   3. dW += dy^T z, z = lrelu(BN(Yprev)) applied while reading the staged Yprev: K = the tile's rows, A = dy columns, B = z
-//      columns, single-dword LDS reads of the same tiles; the [Cout x Cin] accumulators stay in registers for the whole
-//      kernel (1-4 32x32 tiles per wave; 64 x 64 has only four, so there two wave groups take half of the rows each) and
-//      leave once, as this workgroup's partial tile(s).
+//      columns; the [Cout x Cin] accumulators stay in registers for the whole kernel and leave once, as this workgroup's
+//      partial tile.  Round 6: a wave owns TMW = min(Cout / 32, 4) output-channel tiles whose channels INTERLEAVE -- tile a holds
+//      channels TMW i + a of its 128- (64-) channel block -- so that the A operands of its TMW MFMAs are ONE 16- (8-) byte LDS read of
+//      the dy row as stored (lane i takes dy[row][TMW i .. TMW i + TMW - 1]); one input-channel block per wave, so the z
+//      transform runs once per TMW MFMAs; the waves that this leaves over split the tile's rows (KW row groups), and the KW
+//      partial sums meet in LDS once, at the kernel's end.  Per MFMA of this loop: 0.5 LDS reads + 0.75 vector instructions
+//      (128 x 64; before: 2 + 3) -- on gfx950 every one of them is matrix-pipe time.
 // The next tile's raw operands are requested into registers where nothing that is waited for soon queues behind them in the
 // wave's in-order memory counter: under the dX loop (resident weight), or under the FIRST HALF of the dW loop (weight from L2:
 // a weight operand waited for behind a row-tile prefetch waits for all of it, so the prefetch has landed before dX starts).
@@ -1800,7 +1804,15 @@ static int launch_fwd_res(const LinArgs& a, int stat_rows, hipStream_t st) {
 constexpr int FB_T = 512;
 __host__ __device__ constexpr int fb_rows(int Cin) { return Cin == 64 ? 128 : 64; }
 __host__ __device__ constexpr bool fb_resident(int Cout, int Cin) { return Cout * Cin * 4 <= 64 * 1024; }
-__host__ __device__ constexpr int fb_ksplit(int Cout, int Cin) { return (Cout / 32) * (Cin / 32) < 8 ? 8 / ((Cout / 32) * (Cin / 32)) : 1; }
+// partial dW tiles a workgroup writes (round 6: always one -- the row groups of a tile, fb_wsplit, are summed in LDS at the kernel's end)
+__host__ __device__ constexpr int fb_ksplit(int, int) { return 1; }
+#if PCL_EXP == 9                    // lab build (tools/lab.sh): 128 x 64 with two tiles per wave (32 accumulator registers instead of 64, 8-byte A reads)
+#define PCL_FB_TMW_128x64 2
+#else
+#define PCL_FB_TMW_128x64 4
+#endif
+__host__ __device__ constexpr int fb_tmw(int Cout, int Cin) { return Cout == 128 && Cin == 64 ? PCL_FB_TMW_128x64 : Cout / 32 < 4 ? Cout / 32 : 4; }      // dW tiles per wave = dwords per A read
+__host__ __device__ constexpr int fb_wsplit(int Cout, int Cin) { return 8 / ((Cout / 32 / fb_tmw(Cout, Cin)) * (Cin / 32)); }     // row groups of a tile in the dW phase
 
 struct FbArgs {
     const float* dU; const float* Y;                            // [P,Cout] (dU null in the sparse mode)
@@ -1837,8 +1849,11 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
     if (p.p_dev) p.P = __builtin_amdgcn_readfirstlane(*p.p_dev);
     constexpr int COUT = 64 * CO, CIN = 64 * CI, R = fb_rows(CIN);
     constexpr bool WRES = fb_resident(COUT, CIN);
-    constexpr int DLD = COUT + 4, YLD = CIN + 4, WLD = CIN + 4;          // LDS row strides (dwords)
-    constexpr int WROWS = WRES ? COUT : 0;                               // resident weight (else: B operand from L2, no LDS copy)
+    // LDS row strides (dwords).  The resident weight is kept TRANSPOSED, sW[n][k] with WLD = COUT + 4: the B operands of four
+    // consecutive dX MFMAs -- W[k .. k + 3][n] -- are then one 16-byte read like the A operands (round 6; as stored they were four
+    // single-dword reads a row apart)
+    constexpr int DLD = COUT + 4, YLD = CIN + 4, WLD = COUT + 4;
+    constexpr int WROWS = WRES ? CIN : 0;                                // resident weight (else: B operand from L2, no LDS copy)
     // staging maps: thread -> (16-byte column piece, rows row0 + RP*i)
     constexpr int CPR_O = COUT / 4, RP_O = FB_T / CPR_O, NI_O = R / RP_O;
     constexpr int CPR_I = CIN / 4, RP_I = FB_T / CPR_I, NI_I = R / RP_I;
@@ -1846,12 +1861,13 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
     // dX: (R/32) x (CIN/32) = 8 output tiles, wave -> (rbx, cbx)
     constexpr int CB = CIN / 32;
     static_assert((R / 32) * CB == 8, "one dX tile per wave");
-    // dW: NTI x NTJ accumulator tiles over KW row groups of WPG waves; wave (wa, wb) of a group owns TMW x TNW tiles
-    constexpr int NTI = COUT / 32, NTJ = CIN / 32, KW = fb_ksplit(COUT, CIN), WPG = 8 / KW;
-    // (the z transform costs 3 VALU per B element read: as few B tiles per wave as the shape allows)
-    constexpr int WB = NTJ < WPG ? NTJ : WPG, WA = WPG / WB, TMW = NTI / WA, TNW = NTJ / WB;
-    static_assert(WA * WB == WPG && TMW * WA == NTI && TNW * WB == NTJ, "dW tiling");
+    // dW: NTI x NTJ accumulator tiles over KW row groups of WPG waves; wave (wa, wb) of a group owns the TMW channel-interleaved
+    // tiles of output-channel block wa (32 TMW channels) x input-channel block wb (see the header, point 3)
+    constexpr int NTI = COUT / 32, NTJ = CIN / 32, TMW = fb_tmw(COUT, CIN), TNW = 1, WA = NTI / TMW, WB = NTJ;
+    constexpr int KW = fb_wsplit(COUT, CIN), WPG = 8 / KW;
+    static_assert(WA * WB == WPG && TMW * WA == NTI && WPG * KW == 8 && (TMW == 2 || TMW == 4), "dW tiling");
     constexpr int KR = R / KW;                                           // rows of a tile one wave group accumulates
+    static_assert(KW == 1 || (size_t)KW * COUT * CIN <= (size_t)R * DLD + R * YLD + WROWS * WLD, "the row groups' partial tiles meet in the tile image's LDS");
     __shared__ __attribute__((aligned(16))) float lds[R * DLD + R * YLD + WROWS * WLD + 2 * R * 2 + 2 * 128 + 4 * COUT];
     float* const sDY = lds;
     float* const sY = sDY + R * DLD;
@@ -1895,7 +1911,7 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
     float4 rY[NI_O], rU[SPARSE ? 1 : NI_O], rP[NI_I];
     // sparse mode: (arg, gz) of the first NFX * GP groups of the tile at this thread's channel (thread -> channel tid % COUT of
     // group tid / COUT of the round); further groups of a tile (rare: many groups of one or two rows) are read in the pass itself
-    constexpr int GP = FB_T / COUT, NFX = COUT >= 256 ? 2 : 4;        // (256 x 128 has no registers to spare: 4 groups per tile prefetched)
+    constexpr int GP = FB_T / COUT, NFX = COUT >= 128 ? 2 : 4;        // (the 128- and 256-wide shapes have no registers to spare: 8 | 4 groups per tile prefetched, the rest read in the pass)
     const int fxc = tid % COUT, fxg = tid / COUT;
     int fxA[SPARSE ? NFX : 1]; float fxG[SPARSE ? NFX : 1];
     const float fxa = SPARSE ? p.a[fxc] : 0.f;
@@ -2005,10 +2021,11 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
             rWt[i] = buf_ld4(rW, (unsigned)(tid / CPR_I) * irow + (unsigned)(tid % CPR_I) * 16u, (unsigned)(kc * 32 + (FB_T / CPR_I) * i) * irow);
         }
     };
-    auto w_deposit = [&](int buf) {
+    auto w_deposit = [&](int) {                      // piece (row k, columns n .. n + 3) of W[Cout][Cin] -> sW[n + j][k] (once per kernel)
 #pragma unroll
         for (int i = 0; i < NWB; ++i) {
-            *reinterpret_cast<float4*>(sWb + buf * 32 * WLD + (tid / CPR_I) * WLD + (tid % CPR_I) * 4 + (FB_T / CPR_I) * i * WLD) = rWt[i];
+            float* q = sWb + ((tid % CPR_I) * 4) * WLD + tid / CPR_I + (FB_T / CPR_I) * i;
+            q[0] = rWt[i].x; q[WLD] = rWt[i].y; q[2 * WLD] = rWt[i].z; q[3 * WLD] = rWt[i].w;
         }
     };
 
@@ -2075,26 +2092,27 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
         // (operands of step k+1 are read from LDS before the MFMAs of step k are issued -- pinned with sched_barrier: left to
         // itself hipcc sinks every load down to its first use and the LDS / L2 latency of each step is exposed)
         const float* sAx = sDY + (rbx * 32 + lr) * DLD + lh * 4;
-        struct XOp { float4 a; float b0, b1, b2, b3; };
+        struct XOp { float4 a, b; };
         auto x_load = [&](const float* pa, const float* pb) -> XOp {
             XOp o;
             o.a = *reinterpret_cast<const float4*>(pa);
-            o.b0 = pb[0]; o.b1 = pb[WLD]; o.b2 = pb[2 * WLD]; o.b3 = pb[3 * WLD];
+            o.b = *reinterpret_cast<const float4*>(pb);
             return o;
         };
         auto x_mfma = [&](const XOp& o) {
-            accx = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a.x, o.b0, accx, 0, 0, 0);
-            accx = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a.y, o.b1, accx, 0, 0, 0);
-            accx = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a.z, o.b2, accx, 0, 0, 0);
-            accx = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a.w, o.b3, accx, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a.x, o.b.x, accx, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a.y, o.b.y, accx, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a.z, o.b.z, accx, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a.w, o.b.w, accx, 0, 0, 0);
         };
         if constexpr (WRES) {
-            const float* sBx = sWb + (lh * 4) * WLD + xcol;
+            // lane (lr, lh) of MFMA j of step k8 contracts k = 8 k8 + 4 lh + j: A = dy[its row][k], B = W[k][its column] = sW[xcol][k]
+            const float* sBx = sWb + xcol * WLD + lh * 4;
             XOp cur = x_load(sAx, sBx);
 #pragma unroll
             for (int k8 = 0; k8 < COUT / 8; ++k8) {
                 XOp nxt = cur;
-                if (k8 + 1 < COUT / 8) nxt = x_load(sAx + (k8 + 1) * 8, sBx + (k8 + 1) * 8 * WLD);
+                if (k8 + 1 < COUT / 8) nxt = x_load(sAx + (k8 + 1) * 8, sBx + (k8 + 1) * 8);
                 req_slice(cn, k8, COUT / 8);
                 __builtin_amdgcn_sched_barrier(0);
                 x_mfma(cur);
@@ -2157,13 +2175,20 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
         // ---- dW += dy^T z over this wave group's rows of the tile (rows past P have dy = 0)
         auto phase_dw = [&]() {
         {
-            const float* sAw = sDY + (kq * KR + lh) * DLD + wa * TMW * 32 + lr;
+            // lane (lr, lh) of step ks contracts row kq KR + 2 ks + lh: A = dy[row][channels TMW lr .. + TMW - 1 of block wa] (one LDS
+            // read for the TMW tiles), B = z[row][column lr of block wb]
+            const float* sAw = sDY + (kq * KR + lh) * DLD + wa * TMW * 32 + TMW * lr;
             const float* sBw = sY + (kq * KR + lh) * YLD + wb * TNW * 32 + lr;
             struct WOp { float a[TMW], b[TNW]; };
             auto w_load = [&](int ks) -> WOp {
                 WOp o;
-#pragma unroll
-                for (int a = 0; a < TMW; ++a) o.a[a] = sAw[2 * ks * DLD + a * 32];
+                if constexpr (TMW == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(sAw + 2 * ks * DLD);
+                    o.a[0] = v.x; o.a[1] = v.y; o.a[2] = v.z; o.a[3] = v.w;
+                } else {
+                    const float2 v = *reinterpret_cast<const float2*>(sAw + 2 * ks * DLD);
+                    o.a[0] = v.x; o.a[1] = v.y;
+                }
 #pragma unroll
                 for (int b = 0; b < TNW; ++b) o.b[b] = sBw[2 * ks * YLD + b * 32];
                 return o;
@@ -2205,16 +2230,38 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
 #if PCL_EXP == 7
     tk[2] = __builtin_readcyclecounter();
 #endif
-    // ---- this workgroup's partial dW tile(s) and its row of the BatchNorm sums
-    float* out = p.part + ((size_t)bx * KW + kq) * COUT * CIN;
+    // ---- this workgroup's partial dW tile and its row of the BatchNorm sums
+    // accumulator r of tile a: output channel wa 32 TMW + TMW i + a with i = (r & 3) + 8 (r >> 2) + 4 lh (the MFMA's row), column wb 32 + lr
+    float* out = p.part + (size_t)bx * COUT * CIN;
+    if constexpr (KW == 1) {
 #pragma unroll
-    for (int a = 0; a < TMW; ++a)
+        for (int a = 0; a < TMW; ++a) {
+            const int col = wb * 32 + lr;
 #pragma unroll
-        for (int b = 0; b < TNW; ++b) {
-            const int col = (wb * TNW + b) * 32 + lr;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) out[(size_t)((wa * TMW + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CIN + col] = accw[a][b][r];
+            for (int r = 0; r < 16; ++r) out[(size_t)(wa * TMW * 32 + TMW * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a) * CIN + col] = accw[a][0][r];
         }
+    } else {
+        // the KW row groups' partial tiles meet in LDS (the tile image is dead: barrier B of the last tile was passed), summed in the order
+        // of the groups and written once, 16 bytes per thread and store
+        float* const sRed = lds;
+#pragma unroll
+        for (int a = 0; a < TMW; ++a) {
+            const int col = wb * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sRed[(size_t)kq * COUT * CIN + (size_t)(wa * TMW * 32 + TMW * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a) * CIN + col] = accw[a][0][r];
+        }
+        __syncthreads();
+        for (int e = tid; e < COUT * CIN / 4; e += FB_T) {
+            float4 v = reinterpret_cast<const float4*>(sRed)[e];
+#pragma unroll
+            for (int q = 1; q < KW; ++q) {
+                const float4 u = reinterpret_cast<const float4*>(sRed + (size_t)q * COUT * CIN)[e];
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            reinterpret_cast<float4*>(out)[e] = v;
+        }
+    }
     {
         double s = st_s, q = st_q;
         s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);

@@ -77,3 +77,54 @@ def test_dgcnn_cls_b32_n1024(oracle, dev):
     print("\n    fraction of points whose own-feature kNN SET differs between the HIP net and the fp32 restatement, per stage: "
           + ", ".join(f"{d:.4f}" for d in differ))
     report.finish()
+
+
+def _closer_count(oracle, dev, seed):
+    """On how many of the 23 parameter-gradient tensors is the HIP network closer to the fp64 restatement than the PyTorch-CPU fp32
+    restatement (relative L2), weights and input drawn from `seed` (tools/dbg/dgcnn_seeds.py's protocol: shared neighbour lists)."""
+    from oracle.cpu_dgcnn import DGCNNCPU
+    from pointcloudlib_amd.networks.cls.dgcnn import DGCNN
+    from pointcloudlib_amd.train_utils import soft_cross_entropy_loss
+    B, N, k = 32, 1024, 20
+    rel = lambda a, b: ((a.double().cpu() - b).norm() / b.norm()).item()
+    torch.manual_seed(seed)
+    pts, lab = synth.gauss_ball(B, N, 20243 + seed), synth.labels(B, 40, 21143 + seed)
+    net = _no_dropout(DGCNN().to(dev)).train()
+    state = net.state_dict()
+    r32, r64 = DGCNNCPU(state, k), DGCNNCPU(state, k, dtype=torch.float64)
+    xin = torch.from_numpy(pts).transpose(1, 2).contiguous()
+    l32, a32 = r32(xin, return_aux=True)
+    lists = a32["lists"]
+    l64, _ = r64(xin, lists=lists, return_aux=True)
+    y = torch.from_numpy(lab)
+    soft_cross_entropy_loss(l32, y).backward()
+    soft_cross_entropy_loss(l64, y).backward()
+    out = net(xin.to(dev), lists=[l.to(dev).int().contiguous() for l in lists])
+    soft_cross_entropy_loss(out, y.to(dev)).backward()
+    closer = n = 0
+    worst_h = worst_c = 0.0
+    for name, p in net.named_parameters():
+        g64 = r64.grad(name)
+        if g64.abs().max() < 1e-12:
+            continue
+        eh, ec = rel(p.grad, g64), rel(r32.grad(name), g64)
+        closer += eh < ec
+        n += 1
+        worst_h, worst_c = max(worst_h, eh), max(worst_c, ec)
+    return closer, n, worst_h, worst_c
+
+
+def test_dgcnn_gradients_closer_to_fp64_than_the_fp32_restatement_median_of_six_seeds(oracle, dev):
+    """VERDICT r5 item 5.  On ONE seed the count "HIP closer to fp64 than PyTorch-CPU fp32" is a lottery: ~10 of a stage's 8.4 M max-pool
+    winners flip under an input 3e-7 away from the fp64 one, and which ones decides a tensor's error (round 5: 10, 21, 9, 18,
+    15, 15 of 23 on seeds 0..5).  A real regression of the EdgeConv kernels' accuracy moves ALL seeds (round 4's fp32 chains: 4, 7, 13):
+    the MEDIAN over the six seeds must stay >= 12 of 23, and no seed's worst gradient tensor may be further from fp64 than 3e-2."""
+    import statistics
+    rows = [_closer_count(oracle, dev, s) for s in range(6)]
+    for s, (c, n, wh, wc) in enumerate(rows):
+        print(f"\n    seed {s}: HIP closer to fp64 than PyTorch-CPU fp32 on {c} of {n} gradient tensors; worst relL2 hip {wh:.2e} / fp32 restatement {wc:.2e}", end="")
+    med = statistics.median(r[0] for r in rows)
+    print(f"\n    median {med} of {rows[0][1]}")
+    assert all(r[1] == 23 for r in rows)
+    assert med >= 12, [r[0] for r in rows]
+    assert max(r[2] for r in rows) <= 3e-2

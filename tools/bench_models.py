@@ -134,6 +134,7 @@ def _selected(name):
 
 
 WINDOWS = []                                           # the windows of the last _timed() call, seconds per step
+N_WINDOWS = 3                                          # --windows: consecutive timed windows per config (the median is reported)
 
 
 def _timed(step, steps, windows=1):
@@ -149,7 +150,7 @@ def _timed(step, steps, windows=1):
     return statistics.median(WINDOWS)
 
 
-def run(name, make, inputs, loss_fn, steps, warmup=3, cpu_kind=None, windows=1):
+def run(name, make, inputs, loss_fn, steps, warmup=3, cpu_kind=None, windows=None):
     if not _selected(name):
         return None
     torch.manual_seed(0)
@@ -161,7 +162,7 @@ def run(name, make, inputs, loss_fn, steps, warmup=3, cpu_kind=None, windows=1):
         opt.step()
     for _ in range(warmup):
         step()
-    dt = _timed(step, steps, windows)
+    dt = _timed(step, steps, windows or N_WINDOWS)
     B = inputs[0].shape[0]
     r = {"config": name, "ms_per_step": round(dt * 1e3, 3), "clouds_per_s": round(B / dt, 1), "batch": B,
          "windows_ms_per_step": [round(w * 1e3, 3) for w in WINDOWS],
@@ -181,7 +182,7 @@ def run_prefetch(name, make, inputs, loss_fn, steps, warmup=3):
     return _run_prefetch(name, make, inputs, loss_fn, steps, warmup)
 
 
-def _run_prefetch(name, make, inputs, loss_fn, steps, warmup=120, windows=1):    # (two streams: the allocator pools settle over tens of steps)
+def _run_prefetch(name, make, inputs, loss_fn, steps, warmup=120, windows=None):    # (two streams: the allocator pools settle over tens of steps)
     """Same, with the encoder's FPS / ball query of the next batch issued on a side stream beside the backward pass
     (networks with ``precompute_sampling``; the input is the same tensor every step, the work is not)."""
     torch.manual_seed(0)
@@ -198,7 +199,7 @@ def _run_prefetch(name, make, inputs, loss_fn, steps, warmup=120, windows=1):   
         opt.step()
     for _ in range(warmup):
         step()
-    dt = _timed(step, steps, windows)
+    dt = _timed(step, steps, windows or N_WINDOWS)
     B = inputs[0].shape[0]
     r = {"config": name, "ms_per_step": round(dt * 1e3, 3), "clouds_per_s": round(B / dt, 1), "batch": B,
          "windows_ms_per_step": [round(w * 1e3, 3) for w in WINDOWS],
@@ -319,14 +320,15 @@ def other_configs(steps=20, keys=("cfg1", "cfg2_sphere_shell", "cfg2_n4096", "cf
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--windows", type=int, default=3, help="consecutive timed windows of --steps steps per config; the row reports the median and lists all")
     ap.add_argument("--out", default=None)
     ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU restatement of configs 2', 3, 4, 5 (tens of seconds each)")
     ap.add_argument("--table", type=int, default=0, help="print the N most expensive (entry point, launch shape) rows per config to stderr")
     ap.add_argument("--only", default=None, help="run only the configs whose name contains this (one config under rocprofv3)")
     ap.add_argument("--dump-launch-order", default=None, help="with --only: write the (entry point, shape, kernel) sequence of one step as JSON (tools/pmc_traffic.py)")
     a = ap.parse_args()
-    global ONLY, CPU_BASELINE, TABLE, ORDER_OUT
-    ONLY, CPU_BASELINE, TABLE, ORDER_OUT = a.only, a.cpu_baseline, a.table, a.dump_launch_order
+    global ONLY, CPU_BASELINE, TABLE, ORDER_OUT, N_WINDOWS
+    ONLY, CPU_BASELINE, TABLE, ORDER_OUT, N_WINDOWS = a.only, a.cpu_baseline, a.table, a.dump_launch_order, max(1, a.windows)
     from pointcloudlib_amd.networks.cls.pointnet import PointNet
     from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
     from pointcloudlib_amd.networks.cls.dgcnn import DGCNN
