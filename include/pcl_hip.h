@@ -277,6 +277,13 @@ int pcl_fc_head_bwd_f32(const pcl_fc_head_t* desc);
  * logits [R,C], target [R] int64 class ids; dlogits [R,C] (nullable) = d loss / d logits = (softmax - w)/R.  One launch
  * (one workgroup; R <= 65536) instead of the ~12 elementwise launches of the composite. */
 int pcl_soft_ce_f32(const float* logits, const int64_t* target, float eps, int R, int C, float* loss, float* dlogits, void* stream);
+/* The same loss over many rows -- the part-segmentation loss nn.cross_entropy_loss(pred [B*N, part_num], seg) of train_partseg.py:116 is
+ * eps = 0 on B * N = 32 768 rows: rows strided over pcl_soft_ce_rows_blocks(R) workgroups, partial [that many floats] = the workgroups'
+ * loss sums, folded in a fixed order by a second one-workgroup launch (deterministic); dlogits [R][C] (nullable) = the gradient of the
+ * MEAN loss.  R * C < 2^31. */
+int pcl_soft_ce_rows_blocks(int R);
+int pcl_soft_ce_rows_f32(const float* logits, const int64_t* target, float eps, int R, int C, float* partial, float* loss, float* dlogits,
+                         void* stream);
 
 /* DGCNN EdgeConv without the edge tensor (networks/cls/dgcnn.py:29-50,:72-83,:100-111).  With the 1x1 conv weight split
  * W = [Wa | Wb], y[i,j] = U[nbr(i,j)] + V[i] where UV [B*N, 2C] = x [Wa ; Wb-Wa]^T is ONE plain GEMM over the points.

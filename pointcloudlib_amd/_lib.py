@@ -97,6 +97,8 @@ _SIGS = {
     "pcl_head_layer_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "pcl_head_layer_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "pcl_soft_ce_f32": (c_int, [_P, _P, c_float, c_int, c_int, _P, _P, _P]),
+    "pcl_soft_ce_rows_blocks": (c_int, [c_int]),
+    "pcl_soft_ce_rows_f32": (c_int, [_P, _P, c_float, c_int, c_int, _P, _P, _P, _P]),
     "pcl_edgeconv_stat_rows": (c_int, [c_int, c_int]),
     "pcl_edgeconv_wcat_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "pcl_edgeconv_gather_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),

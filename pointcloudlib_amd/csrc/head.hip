@@ -682,6 +682,69 @@ __global__ __launch_bounds__(1024) void soft_ce_kernel(const float* __restrict__
 }
 }  // namespace pcl
 
+// ---- the same loss over tens of thousands of rows (round 6) --------------------------------------------------------------------------
+// Part segmentation takes the cross entropy over every point: nn.cross_entropy_loss(pred [B*N, 50], seg) (train_partseg.py:116) = B * N =
+// 32 768 rows.  PyTorch runs it as log-softmax forward / backward + three nll kernels + the layout copies around them (81 us and 7
+// launches per PointNet++ part-seg step, profiles/r05_cfg4_kernel_stats.csv).  Here: a wave per row as above, rows strided over the
+// grid's waves, the gradient of the MEAN loss written in the same pass; every workgroup leaves the sum of its rows' losses in
+// partial[block] (waves in order) and a one-workgroup launch folds the partials in a fixed tree -- no atomics, run-to-run identical.
+namespace pcl {
+__global__ __launch_bounds__(256) void soft_ce_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ target, float eps,
+                                                            int R, int C, float* __restrict__ partial, float* __restrict__ dx) {
+    __shared__ float part[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float lo = C > 1 ? eps / (float)(C - 1) : 0.f, hi = 1.f - eps, invR = 1.f / (float)R;
+    float acc = 0.f;
+    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+        const float* xr = x + (size_t)r * C;
+        const int t = (int)target[r];
+        float mx = -INFINITY;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, xr[c]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float se = 0.f;
+        for (int c = lane; c < C; c += 64) se += expf(xr[c] - mx);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+        const float lse = logf(se);
+        float l = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float lp = xr[c] - mx - lse, w = c == t ? hi : lo;
+            l -= w * lp;
+            if (dx) dx[(size_t)r * C + c] = (expf(lp) - w) * invR;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+        acc += l;
+    }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+__global__ __launch_bounds__(1024) void soft_ce_finish_kernel(const float* __restrict__ partial, int n, float invR, float* __restrict__ loss) {
+    __shared__ float s[1024];
+    s[threadIdx.x] = threadIdx.x < n ? partial[threadIdx.x] : 0.f;            // n <= 1024
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = s[0] * invR;
+}
+}  // namespace pcl
+
+extern "C" int pcl_soft_ce_rows_blocks(int R) { const int b = (R + 31) / 32; return b < 1 ? 1 : (b > 1024 ? 1024 : b); }
+
+extern "C" int pcl_soft_ce_rows_f32(const float* logits, const int64_t* target, float eps, int R, int C, float* partial, float* loss,
+                                    float* dlogits, void* stream) {
+    PCL_REQUIRE(logits && target && loss && partial, "pcl_soft_ce_rows_f32: null pointer");
+    PCL_REQUIRE(R >= 1 && C >= 1 && (size_t)R * C < 0x7fffffffull && eps >= 0.f && eps < 1.f, "pcl_soft_ce_rows_f32: bad sizes R=%d C=%d eps=%g", R, C, (double)eps);
+    const int nb = pcl_soft_ce_rows_blocks(R);
+    hipLaunchKernelGGL(pcl::soft_ce_rows_kernel, dim3(nb), dim3(256), 0, as_stream(stream), logits, target, eps, R, C, partial, dlogits);
+    hipLaunchKernelGGL(pcl::soft_ce_finish_kernel, dim3(1), dim3(1024), 0, as_stream(stream), partial, nb, 1.f / (float)R, loss);
+    return check_launch("pcl_soft_ce_rows_f32");
+}
+
 extern "C" int pcl_soft_ce_f32(const float* logits, const int64_t* target, float eps, int R, int C, float* loss, float* dlogits,
                                void* stream) {
     PCL_REQUIRE(logits && target && loss, "pcl_soft_ce_f32: null pointer");

@@ -1806,10 +1806,13 @@ __host__ __device__ constexpr int fb_rows(int Cin) { return Cin == 64 ? 128 : 64
 __host__ __device__ constexpr bool fb_resident(int Cout, int Cin) { return Cout * Cin * 4 <= 64 * 1024; }
 // partial dW tiles a workgroup writes (round 6: always one -- the row groups of a tile, fb_wsplit, are summed in LDS at the kernel's end)
 __host__ __device__ constexpr int fb_ksplit(int, int) { return 1; }
-#if PCL_EXP == 9                    // lab build (tools/lab.sh): 128 x 64 with two tiles per wave (32 accumulator registers instead of 64, 8-byte A reads)
-#define PCL_FB_TMW_128x64 2
-#else
+// 128 x 64 runs 128-row tiles (48 prefetch registers): with four tiles per wave (64 accumulator registers) hipcc spills 24-34 registers into
+// the tile loop; two tiles per wave (8-byte A reads, 32 accumulators) spill nothing and measure faster -- 177 against 183 us, 186 before the
+// interleaved tiles (gpurun_out/r06c, one box).  `make EXP=9` builds the four-tile form for A/B.
+#if PCL_EXP == 9
 #define PCL_FB_TMW_128x64 4
+#else
+#define PCL_FB_TMW_128x64 2
 #endif
 __host__ __device__ constexpr int fb_tmw(int Cout, int Cin) { return Cout == 128 && Cin == 64 ? PCL_FB_TMW_128x64 : Cout / 32 < 4 ? Cout / 32 : 4; }      // dW tiles per wave = dwords per A read
 __host__ __device__ constexpr int fb_wsplit(int Cout, int Cin) { return 8 / ((Cout / 32 / fb_tmw(Cout, Cin)) * (Cin / 32)); }     // row groups of a tile in the dW phase

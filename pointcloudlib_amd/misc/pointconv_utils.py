@@ -25,9 +25,26 @@ from .. import _lib
 from .layers import PointwiseMLP
 from .ops import _dev, _p, _stream, furthest_point_sample, index_points, knn_indices, three_interpolate, three_nn
 
-# Accumulation of the per-point Linear(16 C -> C) of every PointConv level (misc/pointconv_utils.py:395-397): 0 = one fp32 fma chain
-# per output over all 16 C terms (the staged MFMA GEMM), 8 | 32 = chains of that length summed in fp64 (csrc/frag.hip).
-POINTCONV_LINEAR_FLUSH = int(os.environ.get("PCL_POINTCONV_FLUSH", "0"))
+# Accumulation of the per-point Linear(16 C -> C) of a PointConv level (misc/pointconv_utils.py:395-397).  Its dot products are 16 C =
+# 2 048 .. 16 384 terms long; as ONE fp32 fma chain (the staged MFMA GEMM) the 4 096-term layer of PointConv cls' second level was the
+# row of the network furthest from the fp64 evaluation (sa2 output 6.72 x the 1e-5 bound against an fp32-storage floor of 3.72; round 6:
+# 3.61 with chains of 32 terms summed in fp64, csrc/frag.hip).  "auto" (default): chains of 32 where the layer is in the fragment GEMM's
+# regime -- K >= 4 096 on <= 8 192 rows (cls sa2: +0.04 ms per step); the 2 048-term layer on 16 384 rows keeps the staged kernel (its
+# row moved 5.97 -> 5.75 for +0.05 ms).  PCL_POINTCONV_FLUSH = 0 | 8 | 32 forces one setting on every level (A/B runs).
+POINTCONV_LINEAR_FLUSH = os.environ.get("PCL_POINTCONV_FLUSH", "auto")
+
+
+def _linear_flush(K, rows):
+    if POINTCONV_LINEAR_FLUSH != "auto":
+        return int(POINTCONV_LINEAR_FLUSH)
+    return 32 if 4096 <= K <= 8192 and rows <= 8192 else 0        # (K = 16 384 on the GroupAll level's 32 rows: the wide head kernels, csrc/head.hip)
+
+
+def _pointconv_linear(linear, out):
+    """``self.linear(out)`` with the accumulation chosen for this call's shape (``_linear_flush``)."""
+    K = out.shape[-1]
+    linear.flush_k = _linear_flush(K, out.numel() // K)
+    return linear(out)
 
 
 def farthest_point_sample(xyz, npoint, start_idx=None):
@@ -231,8 +248,6 @@ class PointConvDensitySetAbstraction(nn.Module):
         self.weightnet = WeightNet(3, 16)
         self.densitynet = DensityNet()
         self.linear = PointwiseMLP([16 * mlp[-1], mlp[-1]], bias=True)       # Linear + BatchNorm1d + ReLU  :395-397
-        # K = 16 C = 2 048 / 4 096 terms per output: fp32 chains of 32 summed in fp64 (csrc/frag.hip), see POINTCONV_LINEAR_FLUSH
-        self.linear.flush_k = POINTCONV_LINEAR_FLUSH
         self.group_all = group_all
         self.bandwidth = bandwidth
 
@@ -266,7 +281,7 @@ class PointConvDensitySetAbstraction(nn.Module):
             if out is None:
                 new_points = torch.cat([grouped_xyz_norm, index_points(points, idx)], dim=-1)
                 out = feature_mlp_contract(self.mlp, new_points, grouped_density, weights)
-            new_points = self.linear(out)                                                 # :395-397
+            new_points = _pointconv_linear(self.linear, out)                              # :395-397
             return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
         if self.group_all:
             new_xyz, new_points, grouped_xyz_norm, grouped_density = sample_and_group_all(xyz, points, density_scale)
@@ -276,7 +291,7 @@ class PointConvDensitySetAbstraction(nn.Module):
         weights = self.weightnet(grouped_xyz_norm.contiguous())                          # [B,S,ns,16]  :391-392
         # feature MLP :384-389 + density multiply and per-point matmul :393-394 (the MLP's last BatchNorm + ReLU ride in the contraction)
         new_points = feature_mlp_contract(self.mlp, new_points, grouped_density, weights)     # [B,S,C*16]
-        new_points = self.linear(new_points)                                              # :395-397
+        new_points = _pointconv_linear(self.linear, new_points)                           # :395-397
         return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
 
     def execute(self, *a, **k):
@@ -323,12 +338,12 @@ class PointConvDensitySetInterpolation(nn.Module):
             if out is None:
                 new_points = torch.cat([grouped_xyz_norm, index_points(interpolated, idx)], dim=-1)
                 out = feature_mlp_contract(self.mlp, new_points, grouped_density, weights)
-            return self.linear(out).permute(0, 2, 1)                                      # :321-323
+            return _pointconv_linear(self.linear, out).permute(0, 2, 1)                   # :321-323
         _, new_points, grouped_xyz_norm, _, grouped_density = sample_and_group(
             N, self.nsample, xyz1, interpolated, density_scale, start_idx)                # :307
         weights = self.weightnet(grouped_xyz_norm.contiguous())                           # :317-318
         new_points = feature_mlp_contract(self.mlp, new_points, grouped_density, weights)     # :311-315 + :319-320
-        return self.linear(new_points).permute(0, 2, 1)                                   # :321-323
+        return _pointconv_linear(self.linear, new_points).permute(0, 2, 1)                # :321-323
 
     def execute(self, *a, **k):
         return self(*a, **k)

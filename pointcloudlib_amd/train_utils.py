@@ -37,6 +37,49 @@ class _SoftCE(torch.autograd.Function):
         return dx * g, None, None
 
 
+class _CERows(torch.autograd.Function):
+    """pcl_soft_ce_rows_f32: mean cross entropy over the rows of a contiguous [R, C] matrix and its gradient, two launches."""
+
+    @staticmethod
+    def forward(ctx, rows, target, eps):
+        from . import _lib
+        R, C = rows.shape
+        loss = torch.empty((), dtype=torch.float32, device=rows.device)
+        partial = torch.empty(_lib.size_query("pcl_soft_ce_rows_blocks", R), dtype=torch.float32, device=rows.device)
+        dx = torch.empty_like(rows) if ctx.needs_input_grad[0] else None
+        _lib.call("pcl_soft_ce_rows_f32", rows.data_ptr(), target.data_ptr(), float(eps), R, C, partial.data_ptr(), loss.data_ptr(),
+                  None if dx is None else dx.data_ptr(), torch._C._cuda_getCurrentRawStream(rows.device.index))
+        ctx.save_for_backward(dx)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dx, = ctx.saved_tensors
+        return dx * g, None, None
+
+
+def seg_cross_entropy_loss(scores, seg):
+    """The part-segmentation loss of train_partseg.py:116, ``nn.cross_entropy_loss(pred, seg)``: mean cross entropy over every point.
+    ``scores`` [B, part_num, N] as the networks return it (a transposed VIEW of the head's [B, N, part_num] rows) or [R, part_num];
+    ``seg`` [B, N] / [R] integer part ids.  On the GPU the loss and its gradient are one library kernel + a fixed-order fold over the
+    rows as the head wrote them -- PyTorch's composite is log-softmax forward / backward, three nll kernels and two layout copies of the
+    [B, 50, N] tensor (81 us per PointNet++ part-seg step).  CPU tensors take ``F.cross_entropy`` (what the kernel is tested against)."""
+    if scores.dim() == 3:
+        rows = scores.permute(0, 2, 1)                     # [B, N, C]: the head's own layout when the network produced `scores`
+        target = seg.reshape(-1)
+    else:
+        rows, target = scores, seg.reshape(-1)
+    if not (scores.is_cuda and scores.dtype == torch.float32 and rows.numel() < 2 ** 31):
+        return F.cross_entropy(scores, seg.long() if scores.dim() == 3 else target.long())
+    rows = rows.reshape(-1, rows.shape[-1])                # a view when `rows` is contiguous; one copy otherwise
+    if not rows.is_contiguous():
+        rows = rows.contiguous()
+    target = target.long()
+    if target.device != rows.device:
+        target = target.to(rows.device)
+    return _CERows.apply(rows, target.contiguous(), 0.0)
+
+
 def soft_cross_entropy_loss(output, target, smoothing=True):
     """train_cls.py:31-51 (eps = 0.2).  On the GPU the smoothed loss is one HIP kernel (forward + gradient); CPU tensors
     take the composite below, which is also what the kernel is tested against."""

@@ -348,6 +348,29 @@ def test_soft_ce_kernel_matches_composite(R, C):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,N,C", [(16, 2048, 50), (1, 1, 50), (3, 777, 7), (2, 40000, 130)])
+def test_seg_cross_entropy_kernel_matches_torch(B, N, C):
+    """pcl_soft_ce_rows_f32 (train_partseg.py:116: mean cross entropy over every point; loss + gradient from one kernel and a
+    fixed-order fold) on the [B, C, N] VIEW the part-seg networks return, against F.cross_entropy in fp64; run-to-run identical."""
+    import torch.nn.functional as F
+    from pointcloudlib_amd.train_utils import seg_cross_entropy_loss
+    torch.manual_seed(B * 7 + C)
+    rows = (torch.randn(B, N, C, device="cuda") * 3).requires_grad_(True)        # the head's layout
+    seg = torch.randint(0, C, (B, N), device="cuda")
+    loss = seg_cross_entropy_loss(rows.permute(0, 2, 1), seg)
+    (loss * 0.6).backward()
+    xd = rows.detach().double().cpu().requires_grad_(True)
+    ref = F.cross_entropy(xd.permute(0, 2, 1), seg.cpu())
+    (ref * 0.6).backward()
+    assert abs(loss.item() - ref.item()) <= 3e-6 * max(1.0, abs(ref.item()))
+    assert torch.allclose(rows.grad.cpu().double(), xd.grad, rtol=1e-5, atol=1e-9)
+    again = seg_cross_entropy_loss(rows.detach().permute(0, 2, 1), seg)
+    assert again.item() == loss.item()
+    flat = seg_cross_entropy_loss(rows.detach().reshape(-1, C), seg.reshape(-1))             # the [R, C] form train_partseg.py passes
+    assert flat.item() == loss.item()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("R,K,N,bias", [(32, 16384, 1024, True), (7, 2048, 20, False), (32, 4096, 130, True)])
 def test_wide_single_layer_takes_head_kernels(dev, R, K, N, bias):
     """PointwiseMLP([K, N]) on <= 32 rows with K >= 2048 (PointConv's per-point Linear on the GroupAll level) runs on the

@@ -4,7 +4,7 @@ import argparse, json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointcloudlib_amd import synth
-from pointcloudlib_amd.train_utils import make_sgd, soft_cross_entropy_loss
+from pointcloudlib_amd.train_utils import make_sgd, seg_cross_entropy_loss, soft_cross_entropy_loss
 from pointcloudlib_amd.affinity import pin_to_gpu_node
 pin_to_gpu_node(0)
 
@@ -261,7 +261,7 @@ def other_configs(steps=20, keys=("cfg1", "cfg2_sphere_shell", "cfg2_n4096", "cf
             xs = cloud(16, 2048, 20244)
             oh = torch.zeros(16, 16, device=dev); oh[torch.arange(16), torch.arange(16) % 16] = 1
             seg = torch.randint(0, 50, (16, 2048), device=dev)
-            lossf = lambda o: torch.nn.functional.cross_entropy(o, seg)
+            lossf = lambda o: seg_cross_entropy_loss(o, seg)
             r = run("PointNet++ MSG part-seg B=16 N=2048 (BASELINE configs[3])", PointNetMSG, (xs, xs, oh), lossf, steps, warmup=10, windows=windows, cpu_kind="cfg4_msg")
             pre = (PointNetMSG, (xs, xs, oh), lossf)
         elif key == "cfg5":
@@ -351,14 +351,14 @@ def main():
     oh = torch.zeros(16, 16, device=dev); oh[torch.arange(16), torch.arange(16) % 16] = 1
     seg = torch.randint(0, 50, (16, 2048), device=dev)
     res.append(run("cfg4-ssg PointNet++ SSG part-seg B=16 N=2048 (the variant train_partseg.py wires)", PointNet2_partseg, (xs, xs, oh),
-                   lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps, cpu_kind="cfg4"))
+                   lambda o: seg_cross_entropy_loss(o, seg), a.steps, cpu_kind="cfg4"))
     res.append(run_prefetch("cfg4-ssg PointNet++ SSG part-seg B=16 N=2048, sampling of batch t+1 on a side stream", PointNet2_partseg, (xs, xs, oh),
-                            lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps))
+                            lambda o: seg_cross_entropy_loss(o, seg), a.steps))
     from pointcloudlib_amd.networks.seg.pointnet2_partseg import PointNetMSG
     res.append(run("cfg4 PointNet++ MSG part-seg B=16 N=2048 (BASELINE configs[3]; FP widths corrected, see DESIGN 7)", PointNetMSG, (xs, xs, oh),
-                   lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps, cpu_kind="cfg4_msg"))
+                   lambda o: seg_cross_entropy_loss(o, seg), a.steps, cpu_kind="cfg4_msg"))
     res.append(run_prefetch("cfg4 PointNet++ MSG part-seg B=16 N=2048, sampling of batch t+1 on a side stream", PointNetMSG, (xs, xs, oh),
-                            lambda o: torch.nn.functional.cross_entropy(o, seg), a.steps))
+                            lambda o: seg_cross_entropy_loss(o, seg), a.steps))
     res.append(run("cfg5 PointConv cls B=32 N=1024", PointConvDensityClsSsg, (x.transpose(1, 2).contiguous(),), lambda o: soft_cross_entropy_loss(o, y32), a.steps, cpu_kind="cfg5"))
     res.append(run_prefetch("cfg5 PointConv cls B=32 N=1024, densities / FPS / k-NN groups of batch t+1 on a side stream", PointConvDensityClsSsg,
                             (x.transpose(1, 2).contiguous(),), lambda o: soft_cross_entropy_loss(o, y32), a.steps))
@@ -367,7 +367,7 @@ def main():
     from pointcloudlib_amd.networks.seg.pointnet_partseg import PointNet_partseg
     from pointcloudlib_amd.networks.seg.dgcnn_partseg import DGCNN_partseg
     from pointcloudlib_amd.networks.seg.pointconv_partseg import PointConvDensity_partseg
-    ce = torch.nn.functional.cross_entropy
+    ce = seg_cross_entropy_loss
     xst = xs.transpose(1, 2).contiguous()
     res.append(run("PointCNN cls B=32 N=1024", PointCNNcls, (x,), lambda o: soft_cross_entropy_loss(o, y32), a.steps))
     res.append(run("PointNet part-seg B=16 N=2048", PointNet_partseg, (xst, oh), lambda o: ce(o, seg), a.steps))

@@ -149,25 +149,7 @@ def main():
         for _ in range(n):
             eager_step(it[0], delay); it[0] += 1
 
-    run_eager(60, 0)
-    torch.cuda.synchronize()
-    pending.clear()
-    gs = GraphedStep(net, loss_fn, opt, dp, batches[0])
-    err = None
-    try:
-        gs.capture()
-    except Exception as e:                                   # noqa: BLE001 -- the result of the measurement is then "not capturable"
-        err = f"{type(e).__name__}: {e}"[:500]
-    jt = [0]
-    def run_graph(n, delay, eager=False):
-        for _ in range(n):
-            if delay:
-                t_end = time.perf_counter() + delay * 1e-6
-                while time.perf_counter() < t_end:
-                    pass
-            gs.step(batches[jt[0] % 4], batches[(jt[0] + 1) % 4], eager=eager); jt[0] += 1
-
-    res = {"device": torch.cuda.get_device_name(0), "cpu_affinity": AFF, "steps": a.steps, "windows": a.windows, "capture_error": err}
+    res = {"device": torch.cuda.get_device_name(0), "cpu_affinity": AFF, "steps": a.steps, "windows": a.windows}
     def timed(fn, delay, **kw):
         w = []
         for _ in range(a.windows):
@@ -179,20 +161,36 @@ def main():
                 "host_ms": [round(x[1], 4) for x in w]}
     import gc
     gc.collect(); gc.disable()
-    run_eager(40, 0)
+    run_eager(100, 0)
+    # ---- 1. the eager step BEFORE anything is captured: the process has two streams, like bench.py's
+    for d in (0.0, a.host_delay_us, 1500.0):
+        res[f"eager_before_capture_delay{int(d)}"] = timed(run_eager, d)
+    torch.cuda.synchronize()
+    pending.clear()
+    gs = GraphedStep(net, loss_fn, opt, dp, batches[0])
+    err = None
+    try:
+        gs.capture()
+    except Exception as e:                                   # noqa: BLE001 -- the result of the measurement is then "not capturable"
+        err = f"{type(e).__name__}: {e}"[:500]
+    res["capture_error"] = err
+    jt = [0]
+    def run_graph(n, delay, eager=False):
+        for _ in range(n):
+            if delay:
+                t_end = time.perf_counter() + delay * 1e-6
+                while time.perf_counter() < t_end:
+                    pass
+            gs.step(batches[jt[0] % 4], batches[(jt[0] + 1) % 4], eager=eager); jt[0] += 1
+    # ---- 2. the replay (capture added a warm-up stream and torch's capture stream to the process), then the eager step AGAIN: HIP maps
+    # streams onto a few hardware queues, and with four streams the sampling stream may land on the main stream's queue
     if err is None:
-        run_graph(40, 0)
-    for rep in range(2):                                    # interleaved: eager, graph, eager + delay, graph + delay, twice
-        res[f"eager_{rep}"] = timed(run_eager, 0)
-        if err is None:
-            res[f"graph_{rep}"] = timed(run_graph, 0)
-            res[f"static_buffers_eager_{rep}"] = timed(run_graph, 0, eager=True)
-        res[f"eager_delay{int(a.host_delay_us)}_{rep}"] = timed(run_eager, a.host_delay_us)
-        if err is None:
-            res[f"graph_delay{int(a.host_delay_us)}_{rep}"] = timed(run_graph, a.host_delay_us)
-        res[f"eager_delay1500_{rep}"] = timed(run_eager, 1500.0)
-        if err is None:
-            res[f"graph_delay1500_{rep}"] = timed(run_graph, 1500.0)
+        run_graph(60, 0)
+        for rep in range(2):
+            for d in (0.0, a.host_delay_us, 1500.0):
+                res[f"graph_delay{int(d)}_{rep}"] = timed(run_graph, d)
+            res[f"eager_after_capture_{rep}"] = timed(run_eager, 0)
+        res["static_buffers_eager_after_capture"] = timed(run_graph, 0, eager=True)
     print(json.dumps(res, indent=1))
     if a.out:
         json.dump(res, open(a.out, "w"), indent=1)
