@@ -66,11 +66,13 @@ FEATURE_WAIVERS = [
       "eight PointConv levels in sequence (four set abstractions, four interpolations), each with the three-factor product of W-F2 and "
       "two BatchNorms: the fp64-arithmetic / fp32-storage pipeline itself is 43 x the bound at the logits, the HIP path 40 x, the "
       "PyTorch-CPU fp32 restatement 82 x")),
-    ("PointConv*", "sa1 output*", ("W-F2 density product", 7.9, _WF2)),             # 6.26 (floor 6.23)
-    ("PointConv*", "sa2 output*", ("W-F2 density product", 6.9, _WF2)),             # 5.49 / 3.70 with matmul-form groups (floor 3.72)
-    ("PointConv*", "sa3 output*", ("W-F2 density product", 3.5, _WF2)),             # 2.42 - 2.77 (floor 1.78)
+    # round 6: the per-point Linear(16 C -> C) of the second level (4 096-term dot products) sums fp32 chains of 32 terms in fp64
+    # (misc/pointconv_utils.py: _linear_flush): sa2 6.72 -> 3.89, beside its fp32-storage floor of 3.72.  Caps = measured + 25 %.
+    ("PointConv*", "sa1 output*", ("W-F2 density product", 7.5, _WF2)),             # 5.97 (floor 6.23); round 4: 6.26
+    ("PointConv*", "sa2 output*", ("W-F2 density product", 4.9, _WF2)),             # 3.89 / 3.82 with matmul-form groups (floor 3.72); round 5: 6.72, round 4: 5.49
+    ("PointConv*", "sa3 output*", ("W-F2 density product", 3.0, _WF2)),             # 2.25 (floor 1.78); round 5: 2.71
     ("PointConv*", "logits*",
-     ("W-F2 density product", 1.4,            # 0.93 - 1.11 depending on summation order
+     ("W-F2 density product", 1.25,           # 0.82 (0.97 with matmul-form groups); round 5: 0.93 - 1.11 depending on summation order
       "downstream of the three waived levels; the head's BatchNorms bring the error back to the edge of the bound: HIP 0.9-1.1 x "
       "(either side of 1 depending on summation order), PyTorch-CPU 2.5 x")),
     ("PointNet part-seg*", "logits*",
@@ -89,13 +91,24 @@ GRAD_WAIVERS = [
      ("W-G1 density-branch gradient", 5.3e-3,       # measured 3.3e-3 of the model's largest entry (weights.0) with round 4's contraction kernels, 4.2e-3 with
       "the mechanism of W-G1 below on the part-seg network, whose gradients are 17 x smaller overall (largest entry 7e-2): the same "   # round 5's; cap = the larger + 25 %
       "absolute noise (2.4e-4 .. 3.0e-4) is a larger fraction")),
-    ("PointConv part-seg*", "*.densitynet.mlp.*",
-     ("W-G1 density-branch gradient", 1.4e-2,       # measured 1.1e-2 (sa2 weights.2: max|err| 7.8e-4 on a tensor whose largest entry is 1.7e-2); PyTorch-CPU fp32 1.4e-2
-      "the DensityNets of the other seven levels of the part-seg network: the same residual-of-two-cancellations gradients, which TWO valid "
-      "fp32 summation orders of the contraction kernels put on either side of the 3e-2 relative cap -- round 4's kernels (LDS-staged "
-      "16x16x4 MFMA forward, vector feature-gradient) 2.8e-2 worst, round 5's (fragment-direct 32x32x2 MFMA) 5.4e-2 -- while the PyTorch-CPU "
-      "fp32 restatement sits at 4.5e-2 .. 8.7e-2 on the same rows (profiles/r05_parity_reports.txt: the HIP path is closer to fp64 than the "
-      "restatement on 13 of the 14 rows this waiver catches)")),
+    # The DensityNets of the other levels of the part-seg network (round 6: per level with its own cap instead of one wildcard -- ADVICE r5).
+    # Same mechanism: weight gradients that are residuals of two cancellations behind 8-wide ReLU layers, where ONE mask that two fp32
+    # evaluations of a pre-activation within 1e-7 of zero set differently moves a tensor by a row's whole term.  BOTH fp32 pipelines sit
+    # at 3-9e-2 relative L2 on these rows; measured (gpurun_out/r06c_pcseg_flush*.txt, relL2 vs fp64, HIP / PyTorch-CPU fp32, then
+    # max|err| relative to the model's largest gradient entry = what the cap is on):
+    #   sa2.weights.0  4.8e-2 / 8.7e-2  1.6e-3 | sa2.weights.1  3.9e-2 / 5.9e-2  5.5e-3 | sa2.weights.2  5.5e-2 / 7.2e-2  1.14e-2
+    #   sa2.gammas.0   3.2e-2 / 4.6e-2  2.0e-3 | sa2.gammas.1   4.0e-2 / 4.8e-2  2.8e-3 | sa2.betas.1    5.2e-2 / 7.2e-2  2.6e-3
+    #   sa3.weights.0  3.4e-2 / 4.5e-2  6.4e-3 | sa3.weights.1  3.6e-2 / 5.3e-2  1.5e-3 | sa3.weights.2  5.7e-2 / 4.8e-2  3.9e-4
+    #   sa3.gammas.0   4.0e-2 / 7.1e-2  8.1e-4 | sa3.gammas.1   6.4e-2 / 5.0e-2  9.4e-5 | sa3.betas.0    4.0e-2 / 6.3e-2  1.2e-3
+    #   sa3.betas.1    4.6e-2 / 4.3e-2  2.0e-4 | sa3.betas.2    4.9e-2 / 4.7e-2  4.1e-4 | in2.betas.2    6.2e-2 / 2.0e-1  1.0e-4
+    # (HIP closer to fp64 than PyTorch-CPU on 11 of the 15.)  Round 4's contraction kernels (LDS-staged 16x16x4 MFMA) put the worst of these
+    # at 2.8e-2, round 5's (fragment-direct 32x32x2) at 5.4e-2: two valid fp32 summation orders either side of the generic 3e-2 cap.
+    ("PointConv part-seg*", "sa2.densitynet.mlp.*",
+     ("W-G1 density-branch gradient", 1.43e-2, "second level of the part-seg network: see the table above (worst: weights.2, 1.14e-2 of the model's largest entry)")),
+    ("PointConv part-seg*", "sa3.densitynet.mlp.*",
+     ("W-G1 density-branch gradient", 8.0e-3, "third level of the part-seg network: see the table above (worst: weights.0, 6.4e-3)")),
+    ("PointConv part-seg*", "in2.densitynet.mlp.betas.2",
+     ("W-G1 density-branch gradient", 1.3e-4, "interpolation level 2: relL2 6.2e-2 against PyTorch-CPU's 2.0e-1, absolute error 1.0e-4 of the model's largest entry")),
     ("PointConv*", "sa1.densitynet.mlp.*",
      ("W-G1 density-branch gradient", 3e-4,       # measured 2.3e-4 of the model's largest gradient entry
       "DensityNet of the first level (1 -> 8 -> 8 -> 1 on 32 768 points): its weight gradients are residuals of two nested "

@@ -64,6 +64,20 @@ __device__ __forceinline__ unsigned long long wave_key_max(double v) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
+#ifndef PCL_EXP
+#define PCL_EXP 0
+#endif
+#if PCL_EXP == 6
+// lab build (`make EXP=6`, tools/fps_budget.py): shader cycles (s_memtime) per phase of the dependent step, summed over the chain by
+// thread 0 of cloud 0 -- [0] centre broadcast (LDS), [1] distances + lane-local key max, [2] wave reduction (DPP + readlane),
+// [3] cross-wave exchange (LDS slot, barrier, slot reads, maxima), [4] rank decode, [5] steps, [6] whole chain
+__device__ long long g_fps_ph[8];
+#define FPS_STAMP(i, dep) { asm volatile("" : "+v"(dep)); __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_readcyclecounter(); \
+                            __builtin_amdgcn_sched_barrier(0); ph[i] += t_ - tl; tl = t_; }
+#else
+#define FPS_STAMP(i, dep)
+#endif
+
 template <int T, int PPT>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int N, int m, int log2S,
                                                 double skip_thr, const int32_t* __restrict__ start_idx,
@@ -120,8 +134,13 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     if (tid == 0) s_out[0] = old;
     const int lane = tid & 63, wid = tid >> 6;
 
+#if PCL_EXP == 6
+    long long ph[5] = {0, 0, 0, 0, 0}, tl = __builtin_readcyclecounter();
+    const long long t_chain = tl;
+#endif
     for (int step = 1; step < m; ++step) {
-        const float4 c = s_xyz[old];
+        float4 c = s_xyz[old];
+        FPS_STAMP(0, c.x)
         double best = 0.0;
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
@@ -130,7 +149,11 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
             md[j] = d2;
             best = key_max(best, __longlong_as_double(((unsigned long long)__float_as_uint(d2) << 32) | lo[j]));
         }
+        FPS_STAMP(1, best)
         unsigned long long w = wave_key_max(best);               // wave-uniform
+#if PCL_EXP == 6
+        { unsigned wl_ = (unsigned)w; FPS_STAMP(2, wl_) w = (w & 0xffffffff00000000ull) | wl_; }
+#endif
         if (NW > 1) {
             unsigned long long* sl = slots + (step & 1) * NW;
             if (lane == 0) sl[wid] = w;
@@ -140,6 +163,9 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
             for (int i = 1; i < NW; ++i) wd = key_max(wd, __longlong_as_double(sl[i]));
             w = __double_as_longlong(wd);
         }
+#if PCL_EXP == 6
+        { unsigned wl_ = (unsigned)w; FPS_STAMP(3, wl_) w = (w & 0xffffffff00000000ull) | wl_; }
+#endif
         // invert the rank: low word 0 can only win when no point is live -> index 0
         const unsigned r = ~(unsigned)w;
         const unsigned kdiv = r & ((1u << sh) - 1u);
@@ -147,7 +173,14 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
         const unsigned kk = (kdiv << log2S) | (log2S ? (__brev(br) >> (32 - log2S)) : 0u);
         old = (unsigned)w ? (int)kk : 0;
         if (tid == 0) s_out[step] = old;
+        FPS_STAMP(4, old)
     }
+#if PCL_EXP == 6
+    if (b == 0 && tid == 0) {
+        for (int i = 0; i < 5; ++i) g_fps_ph[i] = ph[i];
+        g_fps_ph[5] = m - 1; g_fps_ph[6] = __builtin_readcyclecounter() - t_chain; g_fps_ph[7] = T * 1000 + PPT;
+    }
+#endif
     __syncthreads();
     for (int j = tid; j < m; j += T) out[j] = s_out[j];
     if (oxyz)
@@ -241,6 +274,14 @@ static int launch_fps(const float* xyz, int B, int N, int m, int log2S, double t
 }  // namespace pcl
 
 using namespace pcl;
+
+#if PCL_EXP == 6
+// lab build only (not declared in include/pcl_hip.h): the phase cycles of the last launch, after a device synchronisation
+extern "C" int pcl_lab_fps_read(long long* dst) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fps_ph), sizeof(g_fps_ph), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" void pcl_set_fps_tuning(int threads_per_cloud, int issue_priority) {
     g_fps_threads = threads_per_cloud > 0 ? threads_per_cloud : 0;

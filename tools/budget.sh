@@ -22,7 +22,7 @@ for r in csv.DictReader(open(cc)):
 PY
 python tools/fb_budget.py run $O/fbk.bin > $O/exp7.log 2>&1
 python tools/fb_budget.py show $O/fbk.bin > $O/${R}_fb_budget_raw.txt 2>&1
-S="python bench.py --steps 3 --warmup 2 --no-settle --no-cpu-baseline --no-other-configs --roofline-kernel none"
+S="python bench.py --steps 3 --warmup 2 --no-settle --no-cpu-baseline --no-other-configs --roofline-kernel none --windows 1"
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES \
     --output-format csv -d $O/sq -o b -- $S > $O/sq.log 2>&1
 python tools/pmc_sq.py $(find $O/sq -name '*counter_collection.csv' | head -1) $O/${R}_pmc_sq_wave_states.csv > $O/sq_tool.log 2>&1
@@ -43,7 +43,7 @@ print("# product build under rocprofv3 --pmc (same box): GRBM_GUI_ACTIVE / 8 XCD
 for k, v in acc.items():
     print(f"{k}: GUI_ACTIVE/8 median {st.median(x[0] for x in v):.0f}, duration median {st.median(x[1] for x in v):.1f} us, ratio {st.median(x[0]/x[1]/1e3 for x in v):.3f} 'GHz'")
 PY
-B="python bench.py --steps 20 --warmup 3 --no-settle --no-cpu-baseline --no-other-configs"
+B="python bench.py --steps 20 --warmup 3 --no-settle --no-cpu-baseline --no-other-configs --windows 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o b -- $B > $O/kt.log 2>&1
 T=$(find $O/kt -name '*kernel_trace.csv' | head -1)
 python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<true, true, 4, 2>' 1 0=fb256x128 > $O/${R}_dominant_kernel_by_shape.csv 2>&1

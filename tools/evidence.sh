@@ -25,6 +25,9 @@ rm -rf $O/kt/*/*.db $O/fetch $O/write $O/sq/*/*.db 2>/dev/null
 # every C-ABI entry point event-timed (GEMM kernels: their own begin/end timestamps), algorithmic GB/s and TF per launch shape
 python bench.py --steps 20 --warmup 3 --profile-all --no-cpu-baseline --no-other-configs --roofline-kernel none 2>&1 >/dev/null | grep -E "n/step|entry" > $O/${R}_entry_point_roofline.txt
 python -m pytest tests/test_parity_pointnet_gpu.py tests/test_parity_pointnet2_gpu.py tests/test_parity_dgcnn_gpu.py tests/test_parity_partseg_gpu.py tests/test_parity_pointconv_gpu.py tests/test_pointcnn_gpu.py tests/test_parity_partseg_zoo_gpu.py -k "not xconv and not stage and not partseg_network and not cls_network" -m gpu -s -q 2>&1 | grep -v Warning > $O/${R}_parity_reports.txt
+# any parity row that moved by more than 10 % against the previous round's committed report
+PREV=$(ls profiles/r0*_parity_reports.txt 2>/dev/null | grep -v "${R}_" | sort | tail -1)
+[ -n "$PREV" ] && python tools/parity_diff.py $PREV $O/${R}_parity_reports.txt > $O/${R}_parity_rows_moved.txt 2>&1
 # per-phase cycles of the fused backward's tile loop (lab build EXP=7: built beforehand with `make -C pointcloudlib_amd/csrc EXP=7`)
 if [ -f pointcloudlib_amd/libpcl_hip_exp7.so ]; then
   PCL_HIP_SO=$PWD/pointcloudlib_amd/libpcl_hip_exp7.so python bench.py --steps 3 --warmup 2 --no-settle --no-cpu-baseline --no-other-configs --roofline-kernel none 2>&1 | grep "^fb<" | sort | uniq -c | sort -rn | awk '{$1=""; print}' | sort | awk 'NR%5==1' > $O/${R}_fused_backward_phase_cycles.txt
@@ -36,5 +39,5 @@ bash tools/traffic_cfg.sh $R cfg3 "cfg3" > $O/tc_cfg3.log 2>&1
 bash tools/traffic_cfg.sh $R cfg4 "cfg4 PointNet++ MSG part-seg B=16 N=2048 (BASELINE" > $O/tc_cfg4.log 2>&1
 bash tools/traffic_cfg.sh $R cfg5 "cfg5 PointConv cls B=32 N=1024$" > $O/tc_cfg5.log 2>&1
 cp $O/${R}_traffic.json $O/${R}_traffic_cfg*.json profiles/ 2>/dev/null
-python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/${R}_bench_line.json 2> $O/bench.err      # the driver's exact command
 tail -3 $O/kt.log; cat $O/traffic.txt | head -40; cat $O/${R}_dominant_kernel_by_shape.csv; tail -1 $O/${R}_bench_line.json

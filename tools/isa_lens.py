@@ -27,7 +27,7 @@ LDS = re.compile(r"^\s*ds_")
 
 def demangle(names):
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"] + names, capture_output=True, text=True).stdout.split("\n")
+        out = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
         return dict(zip(names, out))
     except Exception:
         return {n: n for n in names}
