@@ -47,17 +47,33 @@ __device__ __forceinline__ double dpp_f64(double v) {
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
+// the same for the stages in which EVERY lane receives a valid value (full row mask, a permutation inside the row): no `old` operand, so
+// hipcc does not copy the value first (two v_mov_b32 + an s_nop per stage on the dependent chain; round 6)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_perm(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
 // wave-wide max of a key: 4 DPP butterfly steps inside each row of 16 lanes, row_bcast:15 / row_bcast:31 fold
 // the four rows, the total is read from lane 63 (wave-uniform).  Measured on MI355X: 382 ns/step at N=1024
 // with 4 waves; a two-pass 32-bit variant with the DPP modifier fused into v_max_u32 (fewer instructions, two
 // VALU->SGPR hops) measured 401 ns/step, the original compare/select/ballot form 582 ns/step.
+__device__ __forceinline__ double wave_key_max_lane63(double v) {            // the wave maximum, valid in lane 63 (only)
+    v = key_max(v, dpp_f64_perm<0xB1>(v));      // quad_perm [1,0,3,2]
+    v = key_max(v, dpp_f64_perm<0x4E>(v));      // quad_perm [2,3,0,1]
+    v = key_max(v, dpp_f64_perm<0x141>(v));     // row_half_mirror
+    v = key_max(v, dpp_f64_perm<0x140>(v));     // row_mirror  -> every lane holds its row's max
+    // the two row folds with FULL row masks: rows that receive nothing read 0 (bound_ctrl) -- the identity of a max over keys >= +0.0 -- and
+    // the rows that receive more than they need only see more of the same maximum; row 3 ends with all four rows either way
+    v = key_max(v, dpp_f64_perm<0x142>(v));     // row_bcast:15: lane 15 of a row into the next row
+    v = key_max(v, dpp_f64_perm<0x143>(v));     // row_bcast:31: lane 31 into rows 2,3 -> lane 63 has the wave max
+    return v;
+}
 __device__ __forceinline__ unsigned long long wave_key_max(double v) {
-    v = key_max(v, dpp_f64<0xB1, 0xf>(v));      // quad_perm [1,0,3,2]
-    v = key_max(v, dpp_f64<0x4E, 0xf>(v));      // quad_perm [2,3,0,1]
-    v = key_max(v, dpp_f64<0x141, 0xf>(v));     // row_half_mirror
-    v = key_max(v, dpp_f64<0x140, 0xf>(v));     // row_mirror  -> every lane holds its row's max
-    v = key_max(v, dpp_f64<0x142, 0xa>(v));     // row_bcast:15 into rows 1,3
-    v = key_max(v, dpp_f64<0x143, 0xc>(v));     // row_bcast:31 into rows 2,3 -> lane 63 has the wave max
+    v = wave_key_max_lane63(v);
     const unsigned long long u = __double_as_longlong(v);
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 63);
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
@@ -78,6 +94,12 @@ __device__ long long g_fps_ph[8];
 #define FPS_STAMP(i, dep)
 #endif
 
+// Round 6 -- the step chain, shortened where the cycle budget (tools/fps_budget.py, `make EXP=6`) showed instructions that carry no
+// information: (1) the cloud sits in LDS indexed by the tie RANK rank'(k), not by k, so the winner's key IS the address of the next
+// centre -- `~low word` clamped -- and the ten-instruction rank -> index decode left the chain (the m indices are decoded together,
+// in parallel, after it); (2) the next centre's LDS read is issued before the step's index store; (3) the four in-row DPP stages move
+// the key without first copying it (dpp_f64_perm); (4) with several waves, lane 63 stores the wave's maximum itself instead of going
+// through two v_readlane + a move back into a vector register.  Same arithmetic, same keys, same winners.
 template <int T, int PPT>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int N, int m, int log2S,
                                                 double skip_thr, const int32_t* __restrict__ start_idx,
@@ -85,8 +107,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = T / 64;
     unsigned long long* slots = reinterpret_cast<unsigned long long*>(smem);      // [2][NW] (NW > 1)
-    float4* s_xyz = reinterpret_cast<float4*>(smem + 256);
-    int* s_out = reinterpret_cast<int*>(smem + 256 + sizeof(float4) * (size_t)N);  // [m] sampled indices
+    float4* s_xyz = reinterpret_cast<float4*>(smem + 256);                        // [RT + 1], indexed by rank'(k); entry RT = point 0
 
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* p = xyz + (size_t)b * N * 3;
@@ -99,17 +120,30 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     else if (prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1) __builtin_amdgcn_s_setprio(1);
 
-    // stage the cloud: coalesced dword reads of the AoS xyz, scattered into float4 slots
-    float* s_flat = reinterpret_cast<float*>(s_xyz);
-    for (int i = tid; i < 3 * N; i += T) {
-        const int k = i / 3, c = i - 3 * k;
-        s_flat[4 * k + c] = p[i];
-    }
-    __syncthreads();
-
     const unsigned S = 1u << log2S;
     int sh = 0;
     while ((((unsigned)N - 1) >> log2S) >> sh) ++sh;                    // bits of (N-1) div S
+    const unsigned RT = S << sh;                                         // ranks are < RT (a power of two, N <= RT < 2 N)
+    unsigned* s_out = reinterpret_cast<unsigned*>(smem + 256 + sizeof(float4) * ((size_t)RT + 1));  // [m] sampled RANKS
+    auto rank_of = [&](unsigned k) -> unsigned {
+        const unsigned br = log2S ? (__brev(k & (S - 1)) >> (32 - log2S)) : 0u;
+        return (br << sh) | (k >> log2S);
+    };
+    auto index_of = [&](unsigned r) -> unsigned {                       // inverse of rank_of; the clamp value RT (no live point) -> 0
+        if (r >= RT) return 0u;
+        const unsigned kdiv = r & ((1u << sh) - 1u), br = r >> sh;
+        return (kdiv << log2S) | (log2S ? (__brev(br) >> (32 - log2S)) : 0u);
+    };
+
+    // stage the cloud: coalesced dword reads of the AoS xyz, scattered into the float4 slot of the point's rank
+    float* s_flat = reinterpret_cast<float*>(s_xyz);
+    for (int i = tid; i < 3 * N; i += T) {
+        const int k = i / 3, c = i - 3 * k;
+        s_flat[4 * rank_of((unsigned)k) + c] = p[i];
+    }
+    if (tid < 3) s_flat[4 * RT + tid] = p[tid];                          // entry RT: point 0 (misc/ops.py:152-153: a cloud without live points samples index 0)
+    __syncthreads();
+
     float px[PPT], py[PPT], pz[PPT], md[PPT];
     unsigned lo[PPT];                                                    // ~rank'(k), 0 = never a candidate
 #pragma unroll
@@ -117,12 +151,12 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
         const unsigned k = (unsigned)(tid + j * T);
         px[j] = py[j] = pz[j] = 0.f; md[j] = 0.f; lo[j] = 0u;
         if (k < (unsigned)N) {
-            const float4 v = s_xyz[k];
+            const unsigned rk = rank_of(k);
+            const float4 v = s_xyz[rk];
             px[j] = v.x; py[j] = v.y; pz[j] = v.z;
             const float mag = __fadd_rn(__fadd_rn(__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y)), __fmul_rn(v.z, v.z));
             if (!((double)mag <= skip_thr)) {                            // skip_thr < 0 disables the rule
-                const unsigned br = log2S ? (__brev(k & (S - 1)) >> (32 - log2S)) : 0u;
-                lo[j] = ~((br << sh) | (k >> log2S));
+                lo[j] = ~rk;
                 md[j] = 1e10f;
             }
         }
@@ -130,16 +164,17 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
 
     // NOTE: nothing is stored to global memory inside the chain: a global store per step would be drained
     // (vmcnt(0)) by every __syncthreads(), adding an HBM round trip to each of the m-1 dependent steps.
-    int old = start_idx ? min(max(start_idx[b], 0), N - 1) : 0;      // a caller's start index is clamped into the cloud, never trusted
-    if (tid == 0) s_out[0] = old;
+    const int old0 = start_idx ? min(max(start_idx[b], 0), N - 1) : 0;   // a caller's start index is clamped into the cloud, never trusted
+    unsigned r = rank_of((unsigned)old0);
+    if (tid == 0) s_out[0] = r;
     const int lane = tid & 63, wid = tid >> 6;
+    float4 c = s_xyz[r];
 
 #if PCL_EXP == 6
     long long ph[5] = {0, 0, 0, 0, 0}, tl = __builtin_readcyclecounter();
     const long long t_chain = tl;
 #endif
     for (int step = 1; step < m; ++step) {
-        float4 c = s_xyz[old];
         FPS_STAMP(0, c.x)
         double best = 0.0;
 #pragma unroll
@@ -150,30 +185,27 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
             best = key_max(best, __longlong_as_double(((unsigned long long)__float_as_uint(d2) << 32) | lo[j]));
         }
         FPS_STAMP(1, best)
-        unsigned long long w = wave_key_max(best);               // wave-uniform
-#if PCL_EXP == 6
-        { unsigned wl_ = (unsigned)w; FPS_STAMP(2, wl_) w = (w & 0xffffffff00000000ull) | wl_; }
-#endif
+        double v = wave_key_max_lane63(best);                     // lane 63: the wave's maximum
+        unsigned wlo;
         if (NW > 1) {
+            FPS_STAMP(2, v)
             unsigned long long* sl = slots + (step & 1) * NW;
-            if (lane == 0) sl[wid] = w;
+            if (lane == 63) sl[wid] = __double_as_longlong(v);
             __syncthreads();
             double wd = __longlong_as_double(sl[0]);
 #pragma unroll
             for (int i = 1; i < NW; ++i) wd = key_max(wd, __longlong_as_double(sl[i]));
-            w = __double_as_longlong(wd);
+            wlo = (unsigned)__double_as_longlong(wd);
+        } else {
+            wlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)__double_as_longlong(v), 63);
+            FPS_STAMP(2, wlo)
         }
-#if PCL_EXP == 6
-        { unsigned wl_ = (unsigned)w; FPS_STAMP(3, wl_) w = (w & 0xffffffff00000000ull) | wl_; }
-#endif
-        // invert the rank: low word 0 can only win when no point is live -> index 0
-        const unsigned r = ~(unsigned)w;
-        const unsigned kdiv = r & ((1u << sh) - 1u);
-        const unsigned br = r >> sh;
-        const unsigned kk = (kdiv << log2S) | (log2S ? (__brev(br) >> (32 - log2S)) : 0u);
-        old = (unsigned)w ? (int)kk : 0;
-        if (tid == 0) s_out[step] = old;
-        FPS_STAMP(4, old)
+        FPS_STAMP(3, wlo)
+        // the winner's rank IS the next centre's slot: low word 0 can only win when no point is live -> ~0 clamps to RT = point 0
+        r = min(~wlo, RT);
+        c = s_xyz[r];
+        if (tid == 0) s_out[step] = r;
+        FPS_STAMP(4, r)
     }
 #if PCL_EXP == 6
     if (b == 0 && tid == 0) {
@@ -182,7 +214,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     }
 #endif
     __syncthreads();
-    for (int j = tid; j < m; j += T) out[j] = s_out[j];
+    for (int j = tid; j < m; j += T) out[j] = (int32_t)index_of(s_out[j]);
     if (oxyz)
         for (int i = tid; i < 3 * m; i += T) {
             const int j = i / 3, cc = i - 3 * j;
@@ -258,10 +290,18 @@ __global__ __launch_bounds__(T) void fps_kernel_lds(const float* __restrict__ xy
 
 static int g_fps_threads = 0, g_fps_prio = 3;       // pcl_set_fps_tuning (process-wide, set between calls)
 
+// LDS of the register kernel: 256 B of slots + (RT + 1) float4 (RT = the power of two the tie ranks live under, N <= RT < 2 N) + m ranks
+static size_t fps_lds_bytes(int N, int m, int log2S) {
+    int sh = 0;
+    while ((((unsigned)N - 1) >> log2S) >> sh) ++sh;
+    const size_t RT = (size_t)1 << (log2S + sh);
+    return 256 + sizeof(float4) * (RT + 1) + sizeof(int) * (size_t)m;
+}
+
 template <int T, int PPT>
 static int launch_fps(const float* xyz, int B, int N, int m, int log2S, double thr, const int32_t* start,
                       int32_t* idx, float* nx, hipStream_t st) {
-    const size_t lds = 256 + sizeof(float4) * (size_t)N + sizeof(int) * (size_t)m;   // slots + xyz + indices
+    const size_t lds = fps_lds_bytes(N, m, log2S);                                    // slots + rank-indexed xyz + sampled ranks
     auto kern = fps_kernel<T, PPT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -307,7 +347,7 @@ extern "C" int pcl_fps_f32(const float* xyz, int B, int N, int m, int tie_stride
     const int ppt = (N + T - 1) / T;
 #define PCL_FPS_CASE(TT, PP) \
     if (T == TT && ppt <= PP) return launch_fps<TT, PP>(xyz, B, N, m, log2S, skip_sqnorm_le, start_idx, idx_out, new_xyz_out, st);
-    if ((size_t)N * 16 + (size_t)m * 4 + 256 <= 158 * 1024) {
+    if (fps_lds_bytes(N, m, log2S) <= 158 * 1024) {
         PCL_FPS_CASE(64, 1) PCL_FPS_CASE(64, 2) PCL_FPS_CASE(64, 4) PCL_FPS_CASE(64, 8) PCL_FPS_CASE(64, 16) PCL_FPS_CASE(64, 32)
         PCL_FPS_CASE(128, 1) PCL_FPS_CASE(128, 2) PCL_FPS_CASE(128, 4) PCL_FPS_CASE(128, 8) PCL_FPS_CASE(128, 16)
         PCL_FPS_CASE(256, 1) PCL_FPS_CASE(256, 2) PCL_FPS_CASE(256, 4) PCL_FPS_CASE(256, 8) PCL_FPS_CASE(256, 16)

@@ -1212,11 +1212,13 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p_in) 
 #pragma unroll 4
         for (int ks = 0; ks < DW_BP / 2; ++ks) {
             const int pr = ks * 2 + lh;                 // lanes 0-31: row 2ks, lanes 32-63: row 2ks+1
+            // a wave's two tiles along i (j) INTERLEAVE: tile t holds channels 2 lr + t of the wave's 64 -- one 8-byte LDS read feeds both
+            // (round 6: one read per tile before; on gfx950 LDS instructions are matrix-pipe time)
             float av[TM], bv[TN];
-#pragma unroll
-            for (int t = 0; t < TM; ++t) av[t] = sA[pr * (WI + 4) + wr * 32 * TM + t * 32 + lr];
-#pragma unroll
-            for (int t = 0; t < TN; ++t) bv[t] = sB[pr * (WJ + 4) + wc * 32 * TN + t * 32 + lr];
+            if constexpr (TM == 2) { const float2 v = *reinterpret_cast<const float2*>(&sA[pr * (WI + 4) + wr * 64 + 2 * lr]); av[0] = v.x; av[1] = v.y; }
+            else av[0] = sA[pr * (WI + 4) + wr * 32 + lr];
+            if constexpr (TN == 2) { const float2 v = *reinterpret_cast<const float2*>(&sB[pr * (WJ + 4) + wc * 64 + 2 * lr]); bv[0] = v.x; bv[1] = v.y; }
+            else bv[0] = sB[pr * (WJ + 4) + wc * 32 + lr];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -1224,17 +1226,23 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p_in) 
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
         }
     }
+    // accumulator r of tile (tm, tn): row i0 + wr 32 TM + TM i + tm with i = (r & 3) + 8 (r >> 2) + 4 lh (the MFMA's row), column
+    // j0 + wc 32 TN + TN lr + tn -- with TN = 2 a lane's two tiles are neighbouring columns: one 8-byte store where the row stride allows
     float* out = p.part + (size_t)bx * p.I * p.J;
+    const bool pair = TN == 2 && (p.ldo & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int col = j0 + wc * 32 * TN + tn * 32 + lr;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wr * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < p.I && col < p.J) out[(size_t)row * p.ldo + col] = acc[tm][tn][r];
+        for (int r = 0; r < 16; ++r) {
+            const int row = i0 + wr * 32 * TM + TM * ((r & 3) + 8 * (r >> 2) + 4 * lh) + tm;
+            const int col = j0 + wc * 32 * TN + TN * lr;
+            if (row >= p.I) continue;
+            if constexpr (TN == 2) {
+                if (pair && col + 1 < p.J) { *reinterpret_cast<float2*>(out + (size_t)row * p.ldo + col) = make_float2(acc[tm][0][r], acc[tm][1][r]); continue; }
             }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                if (col + tn < p.J) out[(size_t)row * p.ldo + col + tn] = acc[tm][tn][r];
         }
 }
 
