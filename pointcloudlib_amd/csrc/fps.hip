@@ -176,14 +176,20 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
 #endif
     for (int step = 1; step < m; ++step) {
         FPS_STAMP(0, c.x)
-        double best = 0.0;
+        double kq[PPT];
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             const float d = sq_dist3(px[j], py[j], pz[j], c.x, c.y, c.z);
             const float d2 = fminf(d, md[j]);                     // never-candidates stay at 0 forever
             md[j] = d2;
-            best = key_max(best, __longlong_as_double(((unsigned long long)__float_as_uint(d2) << 32) | lo[j]));
+            kq[j] = __longlong_as_double(((unsigned long long)__float_as_uint(d2) << 32) | lo[j]);
         }
+        // the lane's maximum as a TREE over its PPT keys (depth log2 PPT; a running maximum is a dependent chain of PPT v_max_f64)
+#pragma unroll
+        for (int w = 1; w < PPT; w <<= 1)
+#pragma unroll
+            for (int j = 0; j + w < PPT; j += 2 * w) kq[j] = key_max(kq[j], kq[j + w]);
+        double best = kq[0];
         FPS_STAMP(1, best)
         double v = wave_key_max_lane63(best);                     // lane 63: the wave's maximum
         unsigned wlo;
