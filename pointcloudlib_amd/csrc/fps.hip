@@ -107,7 +107,11 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = T / 64;
     unsigned long long* slots = reinterpret_cast<unsigned long long*>(smem);      // [2][NW] (NW > 1)
-    float4* s_xyz = reinterpret_cast<float4*>(smem + 256);                        // [RT + 1], indexed by rank'(k); entry RT = point 0
+    // [RT + 1] entries indexed by rank'(k); entry RT = point 0.  16 bytes per entry (one ds_read_b96 for the next centre) up to 1 024 points;
+    // beyond, 12 bytes: at N = 4 096 the table is 48 KB instead of 64 and the chain still fits beside the 105 KB workgroups of the first
+    // level's forward GEMMs when it runs a batch ahead on the side stream (with 70 KB it did not: those kernels waited for the CUs it held)
+    constexpr int ES = T * PPT > 1024 ? 3 : 4;
+    float* s_flat = reinterpret_cast<float*>(smem + 256);
 
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* p = xyz + (size_t)b * N * 3;
@@ -124,7 +128,11 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     int sh = 0;
     while ((((unsigned)N - 1) >> log2S) >> sh) ++sh;                    // bits of (N-1) div S
     const unsigned RT = S << sh;                                         // ranks are < RT (a power of two, N <= RT < 2 N)
-    unsigned* s_out = reinterpret_cast<unsigned*>(smem + 256 + sizeof(float4) * ((size_t)RT + 1));  // [m] sampled RANKS
+    unsigned* s_out = reinterpret_cast<unsigned*>(smem + 256 + (((size_t)ES * 4 * ((size_t)RT + 1) + 15) & ~(size_t)15));  // [m] sampled RANKS
+    auto entry = [&](unsigned rk) -> float4 {
+        if constexpr (ES == 4) return *reinterpret_cast<const float4*>(s_flat + 4 * rk);
+        else { const float* q = s_flat + 3 * rk; return make_float4(q[0], q[1], q[2], 0.f); }
+    };
     auto rank_of = [&](unsigned k) -> unsigned {
         const unsigned br = log2S ? (__brev(k & (S - 1)) >> (32 - log2S)) : 0u;
         return (br << sh) | (k >> log2S);
@@ -136,12 +144,11 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     };
 
     // stage the cloud: coalesced dword reads of the AoS xyz, scattered into the float4 slot of the point's rank
-    float* s_flat = reinterpret_cast<float*>(s_xyz);
     for (int i = tid; i < 3 * N; i += T) {
         const int k = i / 3, c = i - 3 * k;
-        s_flat[4 * rank_of((unsigned)k) + c] = p[i];
+        s_flat[ES * rank_of((unsigned)k) + c] = p[i];
     }
-    if (tid < 3) s_flat[4 * RT + tid] = p[tid];                          // entry RT: point 0 (misc/ops.py:152-153: a cloud without live points samples index 0)
+    if (tid < 3) s_flat[ES * RT + tid] = p[tid];                          // entry RT: point 0 (misc/ops.py:152-153: a cloud without live points samples index 0)
     __syncthreads();
 
     float px[PPT], py[PPT], pz[PPT], md[PPT];
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
         px[j] = py[j] = pz[j] = 0.f; md[j] = 0.f; lo[j] = 0u;
         if (k < (unsigned)N) {
             const unsigned rk = rank_of(k);
-            const float4 v = s_xyz[rk];
+            const float4 v = entry(rk);
             px[j] = v.x; py[j] = v.y; pz[j] = v.z;
             const float mag = __fadd_rn(__fadd_rn(__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y)), __fmul_rn(v.z, v.z));
             if (!((double)mag <= skip_thr)) {                            // skip_thr < 0 disables the rule
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     unsigned r = rank_of((unsigned)old0);
     if (tid == 0) s_out[0] = r;
     const int lane = tid & 63, wid = tid >> 6;
-    float4 c = s_xyz[r];
+    float4 c = entry(r);
 
 #if PCL_EXP == 6
     long long ph[5] = {0, 0, 0, 0, 0}, tl = __builtin_readcyclecounter();
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
         FPS_STAMP(3, wlo)
         // the winner's rank IS the next centre's slot: low word 0 can only win when no point is live -> ~0 clamps to RT = point 0
         r = min(~wlo, RT);
-        c = s_xyz[r];
+        c = entry(r);
         if (tid == 0) s_out[step] = r;
         FPS_STAMP(4, r)
     }
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     if (oxyz)
         for (int i = tid; i < 3 * m; i += T) {
             const int j = i / 3, cc = i - 3 * j;
-            oxyz[i] = s_flat[4 * s_out[j] + cc];
+            oxyz[i] = s_flat[ES * s_out[j] + cc];
         }
 }
 
@@ -296,18 +303,18 @@ __global__ __launch_bounds__(T) void fps_kernel_lds(const float* __restrict__ xy
 
 static int g_fps_threads = 0, g_fps_prio = 3;       // pcl_set_fps_tuning (process-wide, set between calls)
 
-// LDS of the register kernel: 256 B of slots + (RT + 1) float4 (RT = the power of two the tie ranks live under, N <= RT < 2 N) + m ranks
-static size_t fps_lds_bytes(int N, int m, int log2S) {
+// LDS of the register kernel: 256 B of slots + (RT + 1) entries of 16 | 12 bytes (RT = the power of two the tie ranks live under, N <= RT < 2 N) + m ranks
+static size_t fps_lds_bytes(int N, int m, int log2S, int entry_floats) {
     int sh = 0;
     while ((((unsigned)N - 1) >> log2S) >> sh) ++sh;
     const size_t RT = (size_t)1 << (log2S + sh);
-    return 256 + sizeof(float4) * (RT + 1) + sizeof(int) * (size_t)m;
+    return 256 + (((size_t)entry_floats * 4 * (RT + 1) + 15) & ~(size_t)15) + sizeof(int) * (size_t)m;
 }
 
 template <int T, int PPT>
 static int launch_fps(const float* xyz, int B, int N, int m, int log2S, double thr, const int32_t* start,
                       int32_t* idx, float* nx, hipStream_t st) {
-    const size_t lds = fps_lds_bytes(N, m, log2S);                                    // slots + rank-indexed xyz + sampled ranks
+    const size_t lds = fps_lds_bytes(N, m, log2S, T * PPT > 1024 ? 3 : 4);           // slots + rank-indexed xyz + sampled ranks
     auto kern = fps_kernel<T, PPT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -353,7 +360,7 @@ extern "C" int pcl_fps_f32(const float* xyz, int B, int N, int m, int tie_stride
     const int ppt = (N + T - 1) / T;
 #define PCL_FPS_CASE(TT, PP) \
     if (T == TT && ppt <= PP) return launch_fps<TT, PP>(xyz, B, N, m, log2S, skip_sqnorm_le, start_idx, idx_out, new_xyz_out, st);
-    if (fps_lds_bytes(N, m, log2S) <= 158 * 1024) {
+    if (fps_lds_bytes(N, m, log2S, N > 1024 ? 3 : 4) <= 158 * 1024) {
         PCL_FPS_CASE(64, 1) PCL_FPS_CASE(64, 2) PCL_FPS_CASE(64, 4) PCL_FPS_CASE(64, 8) PCL_FPS_CASE(64, 16) PCL_FPS_CASE(64, 32)
         PCL_FPS_CASE(128, 1) PCL_FPS_CASE(128, 2) PCL_FPS_CASE(128, 4) PCL_FPS_CASE(128, 8) PCL_FPS_CASE(128, 16)
         PCL_FPS_CASE(256, 1) PCL_FPS_CASE(256, 2) PCL_FPS_CASE(256, 4) PCL_FPS_CASE(256, 8) PCL_FPS_CASE(256, 16)
