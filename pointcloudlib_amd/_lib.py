@@ -246,7 +246,10 @@ class _HipEventPair:
     def elapsed_ms(self):
         ms = ctypes.c_float()
         rc = _hiprt().hipEventElapsedTime(ctypes.byref(ms), self.start, self.stop)
-        return None if rc else ms.value              # (error: this call launched no kernel of the timed families)
+        if rc:                                       # (this call launched no kernel of the timed families: the events were never recorded)
+            _hiprt().hipGetLastError()               # the runtime keeps the code as its "last error": torch's next check would raise it
+            return None
+        return ms.value
 
     def __del__(self):
         try:

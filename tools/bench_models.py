@@ -40,8 +40,11 @@ def roofline_of(step):
             tf = v["algo_flops"] / (v["avg_ms"] * 1e-3) / 1e12 if v["algo_flops"] else 0
             print(f"    {n:32s} {t:16s} n/step={v['launches'] / 2:4.1f} avg={v['avg_ms'] * 1e3:8.1f} us  {gbs:8.1f} GB/s {tf:7.2f} TF", file=sys.stderr)
     by_name = {}
+    # (entry points that state their algorithmic bytes / flops; the bookkeeping launches -- BatchNorm finalize, constants -- have no roofline
+    # to be priced against and, summed over a small network's many layers, would otherwise be named "dominant": config 1)
+    priced = any(v["algo_bytes"] or v["algo_flops"] for (n, t), v in summ.items() if n != "pcl_fps_f32")
     for (n, t), v in summ.items():
-        if n != "pcl_fps_f32":                        # latency-bound chain, runs beside the GEMMs where sampling is prefetched
+        if n != "pcl_fps_f32" and (not priced or v["algo_bytes"] or v["algo_flops"]):      # FPS: latency-bound chain, runs beside the GEMMs where sampling is prefetched
             by_name[n] = by_name.get(n, 0.0) + v["total_ms"]
     if not by_name:
         return None
@@ -294,7 +297,9 @@ def other_configs(steps=20, keys=("cfg1", "cfg2_sphere_shell", "cfg2_n4096", "cf
             try:
                 row = one(key)
             except Exception as e:                                  # noqa: BLE001 -- reported, not swallowed
-                row = {"key": key, "error": f"{type(e).__name__}: {e}"[:400]}
+                import traceback
+                where = "; ".join(f"{os.path.basename(f.filename)}:{f.lineno} {f.name}" for f in traceback.extract_tb(e.__traceback__)[-4:])
+                row = {"key": key, "error": f"{type(e).__name__}: {e}"[:300], "where": where}
             if row is not None:
                 out.append(row)
             try:
