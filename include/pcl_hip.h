@@ -439,6 +439,11 @@ int pcl_linear_bwd_dx_f32(const float* dU, const float* Y, const float* a, const
 /* reference: the autograd backward of nn.Conv 1x1 + nn.BatchNorm + nn.ReLU, networks/cls/pointnet2.py:25-29 */
 /* test / tuning hook: cap the persistent grid of the fused backward at n workgroups (0 = one per CU); process-wide, set between calls */
 void pcl_set_fb_max_blocks(int n);
+/* lab switch (A/B runs, tests): 1 (default) = the 128 x 64 fused backward walks 64-row tiles over TWO LDS images with the waves in two roles
+ * (dX | dW), the next tile deposited between the MFMAs of the current one; 0 = the one-image form of rounds 2-5 (128-row tiles).  Same
+ * arithmetic per element; dW / BatchNorm partial sums differ in summation order only.  Process-wide, set between calls. */
+void pcl_set_fb_two_images(int on);
+int pcl_get_fb_two_images(void);
 /* The optimiser step (reference: nn.SGD(net.parameters(), lr, momentum), train_cls.py:404; train_partseg.py: weight_decay 1e-4):
  *   g += weight_decay * p;  v = momentum * v + (1 - dampening) * g;  p -= lr * v        (no Nesterov, every tensor has its buffer v)
  * for n_tensors fp32 tensors in one launch per 96 tensors.  params / grads / bufs / numel are HOST arrays (device pointers, element

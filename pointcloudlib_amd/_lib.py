@@ -142,6 +142,8 @@ _SIGS = {
     "pcl_frag_dw_counter_words": (c_int, [c_int, c_int, c_int]),
     "pcl_frag_linear_bwd_dw_f32": (c_int, [_P, _P, c_int, _P, _P, c_float, c_int, c_int, c_int, _P, c_int, _P, c_size_t, c_int, _P]),
     "pcl_set_fb_max_blocks": (None, [c_int]),
+    "pcl_set_fb_two_images": (None, [c_int]),
+    "pcl_get_fb_two_images": (c_int, []),
     "pcl_set_kernel_paths": (None, [c_int, c_int, c_int]),
     "pcl_sgd_momentum_f32": (c_int, [_P, _P, _P, _P, c_int, c_double, c_double, c_double, c_double, _P]),
     "pcl_set_stack_overlap": (None, [c_int, c_int]),
@@ -195,6 +197,8 @@ def lib():
             L.pcl_set_pointconv_paths(int(os.environ["PCL_BWD_W_ROWS"] != "0"))
         if os.environ.get("PCL_SCATTER") is not None:
             L.pcl_set_scatter_form(int(os.environ["PCL_SCATTER"] != "0"))
+        if os.environ.get("PCL_FB_TWO") is not None:
+            L.pcl_set_fb_two_images(int(os.environ["PCL_FB_TWO"] != "0"))
         if os.environ.get("PCL_FEWROW") is not None:
             L.pcl_set_fewrow_backward(int(os.environ["PCL_FEWROW"] != "0"))
         if os.environ.get("PCL_DW_GX") is not None:

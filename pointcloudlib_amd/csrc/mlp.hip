@@ -1809,6 +1809,9 @@ static int launch_fwd_res(const LinArgs& a, int stat_rows, hipStream_t st) {
 // wave's in-order memory counter: under the dX loop (resident weight), or under the FIRST HALF of the dW loop (weight from L2:
 // a weight operand waited for behind a row-tile prefetch waits for all of it, so the prefetch has landed before dX starts).
 // Supported: (Cout, Cin) in {64,128} x {64,128} and 256 x 128, a masked (non-first) layer.
+#ifndef PCL_FB_TWO_PRIO
+#define PCL_FB_TWO_PRIO 3
+#endif
 constexpr int FB_T = 512;
 __host__ __device__ constexpr int fb_rows(int Cin) { return Cin == 64 ? 128 : 64; }
 __host__ __device__ constexpr bool fb_resident(int Cout, int Cin) { return Cout * Cin * 4 <= 64 * 1024; }
@@ -1850,7 +1853,7 @@ __host__ __device__ constexpr int fbk_shape(bool sparse, int co, int ci) {
     return sparse && co == 4 && ci == 2 ? 0 : sparse && co == 2 && ci == 1 ? 1 : !sparse && co == 2 && ci == 2 ? 2 : !sparse && co == 1 && ci == 1 ? 3 : -1;
 }
 #endif
-template <bool SPARSE, bool RAG, int CO, int CI>
+template <bool SPARSE, bool RAG, int CO, int CI, bool TWO = false>
 __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_in) {
     FbArgs p = p_in;
 #if PCL_EXP == 7
@@ -1858,8 +1861,15 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
     const long long cy_entry = __builtin_readcyclecounter();
 #endif
     if (p.p_dev) p.P = __builtin_amdgcn_readfirstlane(*p.p_dev);
-    constexpr int COUT = 64 * CO, CIN = 64 * CI, R = fb_rows(CIN);
+    // TWO (round 6, the 128 x 64 shape): TWO tile images of R = 64 rows beside the resident weight (2 x 51 + 34 KB) and the waves in two
+    // roles -- waves 0-3 (one per SIMD) own the four dX tiles of a row tile, waves 4-7 its dW tiles (two each, all 64 rows: no row groups)
+    // -- so that while tile t's MFMAs run on image t & 1, every wave deposits tile t + 1 into the other image and re-requests the freed
+    // registers for tile t + 2 BETWEEN its MFMAs.  The deposit, its wait for the loads and the barrier behind it -- the 4.6 k of 24.5 k
+    // cycles per 128 rows in which no wave of a SIMD had an MFMA to issue (profiles/r05_fused_backward_cycle_budget.txt) -- leave the
+    // critical path; what stays serial per tile is the winners' pass (sparse mode) between two barriers.
+    constexpr int COUT = 64 * CO, CIN = 64 * CI, R = TWO ? 64 : fb_rows(CIN);
     constexpr bool WRES = fb_resident(COUT, CIN);
+    static_assert(!TWO || (WRES && COUT == 128 && CIN == 64), "two tile images: the 128 x 64 shape");
     // LDS row strides (dwords).  The resident weight is kept TRANSPOSED, sW[n][k] with WLD = COUT + 4: the B operands of four
     // consecutive dX MFMAs -- W[k .. k + 3][n] -- are then one 16-byte read like the A operands (round 6; as stored they were four
     // single-dword reads a row apart)
@@ -1871,18 +1881,19 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
     constexpr int NWB = WRES ? COUT * CIN / 4 / FB_T : 1;                // 16-byte weight pieces per thread (resident weight)
     // dX: (R/32) x (CIN/32) = 8 output tiles, wave -> (rbx, cbx)
     constexpr int CB = CIN / 32;
-    static_assert((R / 32) * CB == 8, "one dX tile per wave");
+    static_assert((R / 32) * CB == (TWO ? 4 : 8), "one dX tile per wave (TWO: per wave of the dX role)");
     // dW: NTI x NTJ accumulator tiles over KW row groups of WPG waves; wave (wa, wb) of a group owns the TMW channel-interleaved
     // tiles of output-channel block wa (32 TMW channels) x input-channel block wb (see the header, point 3)
     constexpr int NTI = COUT / 32, NTJ = CIN / 32, TMW = fb_tmw(COUT, CIN), TNW = 1, WA = NTI / TMW, WB = NTJ;
-    constexpr int KW = fb_wsplit(COUT, CIN), WPG = 8 / KW;
-    static_assert(WA * WB == WPG && TMW * WA == NTI && WPG * KW == 8 && (TMW == 2 || TMW == 4), "dW tiling");
+    constexpr int KW = TWO ? 1 : fb_wsplit(COUT, CIN), WPG = TWO ? 4 : 8 / KW;
+    static_assert(WA * WB == WPG && TMW * WA == NTI && WPG * KW == (TWO ? 4 : 8) && (TMW == 2 || TMW == 4), "dW tiling");
     constexpr int KR = R / KW;                                           // rows of a tile one wave group accumulates
     static_assert(KW == 1 || (size_t)KW * COUT * CIN <= (size_t)R * DLD + R * YLD + WROWS * WLD, "the row groups' partial tiles meet in the tile image's LDS");
-    __shared__ __attribute__((aligned(16))) float lds[R * DLD + R * YLD + WROWS * WLD + 2 * R * 2 + 2 * 128 + 4 * COUT];
-    float* const sDY = lds;
-    float* const sY = sDY + R * DLD;
-    float* const sWb = sY + R * YLD;
+    constexpr int IMG = R * DLD + R * YLD, NIMG = TWO ? 2 : 1;          // one tile image: dy [R][DLD] | Yprev [R][YLD]
+    __shared__ __attribute__((aligned(16))) float lds[NIMG * IMG + WROWS * WLD + 2 * R * 2 + 2 * 128 + 4 * COUT];
+    float* sDY = lds;                                                    // (TWO: re-pointed at the image of the tile per iteration)
+    float* sY = sDY + R * DLD;
+    float* const sWb = lds + NIMG * IMG;
     int2* const sMeta = reinterpret_cast<int2*>(sWb + WROWS * WLD);      // [2][R] row records {group, row-in-group | mult << 16}
     // [2][128] sparse mode: (tile row) - (row-in-group) of the rows of group g, at slot g & 127 (a tile's <= R groups are consecutive)
     int* const sDelta = reinterpret_cast<int*>(sMeta + 2 * R);
@@ -1904,7 +1915,7 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
     const int rbx = wave / CB, cbx = wave % CB;
     const int xcol = cbx * 32 + lr;
     const float xsc = p.psc[xcol], xsh = p.psh[xcol];
-    const int kq = wave / WPG, wq = wave % WPG, wa = wq % WA, wb = wq / WA;
+    const int kq = TWO ? 0 : wave / WPG, wq = wave % WPG, wa = wq % WA, wb = wq / WA;
     float zsc[TNW], zsh[TNW];
 #pragma unroll
     for (int b = 0; b < TNW; ++b) { zsc[b] = p.psc[(wb * TNW + b) * 32 + lr]; zsh[b] = p.psh[(wb * TNW + b) * 32 + lr]; }
@@ -2050,6 +2061,194 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
 #define FB_MARK(i)
 #endif
     int tile = bx, it = 0;
+    if constexpr (TWO) {
+        static_assert(!TWO || TMW == 2, "two tile images: two dW tiles per wave of the dW role");
+        // ================= two tile images, waves in two roles (see the head of the kernel) =================
+        // Side work of a tile = NIT items (a 16-byte piece of Y [and dU] or of Yprev per thread and item): item n of tile t + 1 is
+        // deposited from its registers into the other image, then the registers are re-requested for tile t + 2; in sparse mode the
+        // (arg, gz) of tile t + 1's first groups follow.  One item per MFMA step (dX: 4 MFMAs, dW: every second step of 2 MFMAs).
+        constexpr int NIT = NI_O + NI_I, NSIDE = NIT + (SPARSE ? 2 * NFX : 0);
+        static_assert(NSIDE <= COUT / 8 && NSIDE <= R / 4, "side work fits the MFMA loops");
+        struct RowCtx { rsrc_t y, u, pr; };
+        auto rows_open = [&](int tile_, bool live) -> RowCtx {
+            const int r0 = tile_ * R;
+            RowCtx c;
+            c.y = buf_rsrc(p.Y, (size_t)r0 * orow, live ? (size_t)p.P * orow : 0);
+            c.u = buf_rsrc(p.dU, (size_t)r0 * orow, !SPARSE && live ? (size_t)p.P * orow : 0);
+            c.pr = buf_rsrc(p.Yprev, (size_t)r0 * irow, live ? (size_t)p.P * irow : 0);
+            return c;
+        };
+        const unsigned vo = (unsigned)orow0 * orow + (unsigned)oc4 * 4, vi = (unsigned)irow0 * irow + (unsigned)ic4 * 4;
+        auto item_req = [&](const RowCtx& c, int n) {                       // n: compile-time after unrolling
+            if (n < NI_O) {
+                rY[n] = buf_ld4(c.y, vo, (unsigned)(RP_O * n) * orow);
+                if constexpr (!SPARSE) rU[n] = buf_ld4(c.u, vo, (unsigned)(RP_O * n) * orow);
+            } else rP[n - NI_O] = buf_ld4(c.pr, vi, (unsigned)(RP_I * (n - NI_O)) * irow);
+        };
+        // the dy transform's constants of this thread's four channels: registers for the whole kernel (this shape has them)
+        const float4 ca = *reinterpret_cast<const float4*>(p.a + oc4), ck1 = *reinterpret_cast<const float4*>(p.k1 + oc4);
+        const float4 ck2 = *reinterpret_cast<const float4*>(p.k2 + oc4), cmu = *reinterpret_cast<const float4*>(p.mu + oc4);
+        (void)ca;
+        float wrow[NI_O];                                                   // multiplicities of this thread's rows of the tile being deposited
+        auto rows_w = [&](int mb_) {
+#pragma unroll
+            for (int n = 0; n < NI_O; ++n) wrow[n] = (float)(sMeta[mb_ * R + orow0 + RP_O * n].y >> 16);
+        };
+        auto item_dep = [&](int img, int n) {                               // registers of item n -> image `img`
+            float* const base = lds + img * IMG;
+            if (n < NI_O) {
+                const float w = wrow[n];
+                const float4 y = rY[n];
+                float4 d;            // rows past P: du = y = 0 (range-checked loads) and w = 0 -> dy = 0 exactly
+                if constexpr (SPARSE) {
+                    d.x = -w * fmaf(ck2.x, y.x - cmu.x, ck1.x); d.y = -w * fmaf(ck2.y, y.y - cmu.y, ck1.y);
+                    d.z = -w * fmaf(ck2.z, y.z - cmu.z, ck1.z); d.w = -w * fmaf(ck2.w, y.w - cmu.w, ck1.w);
+                } else {
+                    const float4 du = rU[n];
+                    d.x = fmaf(ca.x, du.x, -w * fmaf(ck2.x, y.x - cmu.x, ck1.x)); d.y = fmaf(ca.y, du.y, -w * fmaf(ck2.y, y.y - cmu.y, ck1.y));
+                    d.z = fmaf(ca.z, du.z, -w * fmaf(ck2.z, y.z - cmu.z, ck1.z)); d.w = fmaf(ca.w, du.w, -w * fmaf(ck2.w, y.w - cmu.w, ck1.w));
+                }
+                *reinterpret_cast<float4*>(base + (orow0 + RP_O * n) * DLD + oc4) = d;
+            } else *reinterpret_cast<float4*>(base + R * DLD + (irow0 + RP_I * (n - NI_O)) * YLD + ic4) = rP[n - NI_O];
+        };
+        auto fx_req = [&](int gf, int gl, int j2) {                         // (arg, gz) of groups gf + (j2 / 2) GP + fxg of the next tile
+            if constexpr (SPARSE) {
+                const int j = j2 / 2, g = gf + j * GP + fxg;
+                const unsigned go = g <= gl ? ((unsigned)g * COUT + (unsigned)fxc) * 4u : BUF_OOB;
+                if (j2 % 2 == 0) fxA[j] = __builtin_bit_cast(int, buf_ld1(rArg, go, 0));
+                else fxG[j] = buf_ld1(rGz, go, 0);
+            }
+        };
+        auto winners = [&](int tile_, int mb_, int img) {                   // dy[row of slot arg[g][c] of group g][c] += a[c] gz[g][c]
+            if constexpr (SPARSE) {
+                float* const dyb = lds + img * IMG;
+                int gf, gl;
+                tile_groups(tile_, mb_, gf, gl);
+                const int* dl = sDelta + mb_ * 128;
+                auto fix = [&](int g, int srow, float gzv) {
+                    const int r = srow + dl[g & 127];
+                    if (g <= gl && (unsigned)r < (unsigned)R) {
+                        float* q = dyb + r * DLD + fxc;
+                        *q = fmaf(fxa, gzv, *q);
+                    }
+                };
+#pragma unroll
+                for (int j = 0; j < NFX; ++j)
+                    if (gf + j * GP <= gl) fix(gf + j * GP + fxg, fxA[j], fxG[j]);
+                for (int g0 = gf + NFX * GP; g0 <= gl; g0 += GP) {          // (rare) groups beyond the prefetched rounds
+                    const int g = g0 + fxg;
+                    const unsigned go = g <= gl ? ((unsigned)g * COUT + (unsigned)fxc) * 4u : BUF_OOB;
+                    fix(g, __builtin_bit_cast(int, buf_ld1(rArg, go, 0)), buf_ld1(rGz, go, 0));
+                }
+            }
+        };
+        if (tile < tiles) {
+            // prologue: image 0 <- tile 0 (dense part), registers <- tile 1, (arg, gz) registers <- tile 0
+            meta_store(0, record_of(tile));
+            rM = record_of(tile + p.gx);
+            w_request(0); w_deposit(0);
+            __syncthreads();
+            const RowCtx c0 = rows_open(tile, true);
+#pragma unroll
+            for (int n = 0; n < NIT; ++n) item_req(c0, n);
+            if constexpr (SPARSE) {
+                int gf, gl;
+                tile_groups(tile, 0, gf, gl);
+#pragma unroll
+                for (int j2 = 0; j2 < 2 * NFX; ++j2) fx_req(gf, gl, j2);
+            }
+            const RowCtx c1 = rows_open(tile + p.gx, tile + p.gx < tiles);
+            rows_w(0);
+#pragma unroll
+            for (int n = 0; n < NIT; ++n) { item_dep(0, n); item_req(c1, n); }
+            __syncthreads();                                                // the dense part of tile 0 is complete
+        }
+#if PCL_EXP == 7
+        tk[1] = tlast = __builtin_readcyclecounter();
+#endif
+        for (; tile < tiles; tile += p.gx, ++it) {
+            const int m0 = tile * R, cur = it & 1, nxt = cur ^ 1;
+            sDY = lds + cur * IMG; sY = sDY + R * DLD;
+            FB_MARK(6)
+            meta_store(nxt, rM);                                            // records of tile t + 1 (the slot's last readers passed barrier B)
+            winners(tile, cur, cur);
+            rM = record_of(tile + 2 * p.gx);
+            FB_MARK(0)
+            __syncthreads();                                                // A: image `cur` and the records of tile t + 1 are complete
+            FB_MARK(1)
+            const RowCtx cq = rows_open(tile + 2 * p.gx, tile + 2 * p.gx < tiles);
+            int gf1 = 0, gl1 = -1;
+            if constexpr (SPARSE) { if (tile + p.gx < tiles) tile_groups(tile + p.gx, nxt, gf1, gl1); }
+            rows_w(nxt);
+            auto side = [&](int k) {                                        // slot k of the tile's side work (compile-time after unrolling)
+                if (k < NIT) { item_dep(nxt, k); item_req(cq, k); }
+                else if (k < NSIDE) fx_req(gf1, gl1, k - NIT);
+            };
+            if (wave < 4) {
+                // ---- dX = dy W on this wave's 32 x 32 tile (K = COUT), then its epilogue.  The dX wave of a SIMD issues ahead of its dW wave
+                // (s_setprio) so that its epilogue -- LDS reads, compares, 16 stores, no MFMA -- runs while the dW wave still has MFMAs to
+                // issue; at equal priority both loops end together and the matrix pipe idles through every epilogue.
+                __builtin_amdgcn_s_setprio(PCL_FB_TWO_PRIO);
+                f32x16 accx;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accx[r] = 0.f;
+                const float* sAx = sDY + (rbx * 32 + lr) * DLD + lh * 4;
+                const float* sBx = sWb + xcol * WLD + lh * 4;
+                float4 xa = *reinterpret_cast<const float4*>(sAx), xb = *reinterpret_cast<const float4*>(sBx);
+#pragma unroll
+                for (int k8 = 0; k8 < COUT / 8; ++k8) {
+                    float4 na = xa, nb = xb;
+                    if (k8 + 1 < COUT / 8) { na = *reinterpret_cast<const float4*>(sAx + (k8 + 1) * 8); nb = *reinterpret_cast<const float4*>(sBx + (k8 + 1) * 8); }
+                    side(k8);
+                    __builtin_amdgcn_sched_barrier(0);
+                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, xb.x, accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.y, xb.y, accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.z, xb.z, accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.w, xb.w, accx, 0, 0, 0);
+                    xa = na; xb = nb;
+                }
+                FB_MARK(2)
+                const rsrc_t rD = buf_rsrc(p.dUprev, (size_t)(m0 + rbx * 32) * irow, (size_t)p.P * irow);
+                float ts = 0.f, tq = 0.f;
+                const float* const yb = sY + (rbx * 32 + 4 * lh) * YLD + xcol;
+                const float piv = yb[0];
+                const unsigned v0 = (unsigned)(4 * lh) * irow + (unsigned)xcol * 4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = (r & 3) + 8 * (r >> 2);                  // + 4*lh + 32*rbx
+                    const float y = yb[rl * YLD];
+                    float c = accx[r];
+                    c = fmaf(xsc, y, xsh) > 0.f ? c : c * p.pslope;
+                    ts += c; tq = fmaf(c, y - piv, tq);
+                    buf_st1(rD, v0, (unsigned)rl * irow, c);
+                }
+                st_s += (double)ts; st_q += (double)tq + (double)piv * (double)ts;
+                __builtin_amdgcn_s_setprio(0);
+                FB_MARK(3)
+            } else {
+                // ---- dW += dy^T z over the tile's R rows: this wave's TMW channel-interleaved tiles
+                const float* sAw = sDY + lh * DLD + wa * TMW * 32 + TMW * lr;
+                const float* sBw = sY + lh * YLD + wb * 32 + lr;
+                float2 wa_ = *reinterpret_cast<const float2*>(sAw);
+                float wb_ = sBw[0];
+#pragma unroll
+                for (int ks = 0; ks < R / 2; ++ks) {
+                    float2 na = wa_; float nb = wb_;
+                    if (ks + 1 < R / 2) { na = *reinterpret_cast<const float2*>(sAw + 2 * (ks + 1) * DLD); nb = sBw[2 * (ks + 1) * YLD]; }
+                    if (ks % 2 == 0) side(ks / 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float t = fmaf(zsc[0], wb_, zsh[0]);
+                    const float bv = fmaxf(t, t * p.pslope);
+                    accw[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa_.x, bv, accw[0][0], 0, 0, 0);
+                    accw[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa_.y, bv, accw[1][0], 0, 0, 0);
+                    wa_ = na; wb_ = nb;
+                }
+                FB_MARK(4)
+            }
+            __syncthreads();                                                // B: image `cur` is free, image `nxt` holds tile t + 1's dense part
+            FB_MARK(5)
+        }
+    } else {
     if (tile < tiles) {
         meta_store(0, record_of(tile));
         rM = record_of(tile + p.gx);
@@ -2241,10 +2440,12 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
 #if PCL_EXP == 7
     tk[2] = __builtin_readcyclecounter();
 #endif
+    }
     // ---- this workgroup's partial dW tile and its row of the BatchNorm sums
     // accumulator r of tile a: output channel wa 32 TMW + TMW i + a with i = (r & 3) + 8 (r >> 2) + 4 lh (the MFMA's row), column wb 32 + lr
     float* out = p.part + (size_t)bx * COUT * CIN;
     if constexpr (KW == 1) {
+        if (!TWO || wave >= 4)                                  // (TWO: the waves of the dW role hold the accumulators)
 #pragma unroll
         for (int a = 0; a < TMW; ++a) {
             const int col = wb * 32 + lr;
@@ -2311,6 +2512,7 @@ __global__ __launch_bounds__(FB_T) void linear_bwd_fused_kernel(const FbArgs p_i
 // per workgroup at sizes small enough for an fp64 comparison free of ReLU-mask flips; tuning).  The cap is a process-wide
 // setting made BETWEEN calls: it sizes the statistics rows, the workspace and the finish reduction of every later call.
 static int g_fb_cap = 0;
+static int g_fb_two = 1;                 // the 128 x 64 shape on two tile images (pcl_set_fb_two_images)
 static int fb_cu_count() {
     static const int n = [] {
         int dev = 0, cu = 0;
@@ -3124,6 +3326,9 @@ extern "C" void pcl_set_fb_max_blocks(int n) { g_fb_cap = n; }
 extern "C" void pcl_set_matrix_form(int split) { g_split_mfma = split & 7; g_split_min_k = (split >> 8) > 0 ? (split >> 8) : 128; }
 extern "C" int pcl_get_matrix_form(void) { return g_split_mfma; }
 
+extern "C" void pcl_set_fb_two_images(int on) { g_fb_two = on != 0; }
+extern "C" int pcl_get_fb_two_images(void) { return g_fb_two; }
+
 extern "C" int pcl_linear_bwd_fused_supported(int Cout, int Cin) {
     return ((Cout == 64 || Cout == 128) && (Cin == 64 || Cin == 128)) || (Cout == 256 && Cin == 128);
 }
@@ -3148,7 +3353,11 @@ static int launch_fb(const FbArgs& a_in, int Cout, int Cin, hipStream_t st) {
 #define PCL_FB(CO, CI) PCL_LAUNCH_TIMED((linear_bwd_fused_kernel<SPARSE, RAG, CO, CI>), grid, blk, st, a)
     if (Cout == 64 && Cin == 64) PCL_FB(1, 1);
     else if (Cout == 64 && Cin == 128) PCL_FB(1, 2);
-    else if (Cout == 128 && Cin == 64) PCL_FB(2, 1);
+    else if (Cout == 128 && Cin == 64) {
+        // two tile images of 64 rows, waves in two roles (round 6); pcl_set_fb_two_images(0) keeps the one-image form for A/B runs
+        if (g_fb_two) PCL_LAUNCH_TIMED((linear_bwd_fused_kernel<SPARSE, RAG, 2, 1, true>), grid, blk, st, a);
+        else PCL_FB(2, 1);
+    }
     else if (Cout == 128 && Cin == 128) PCL_FB(2, 2);
     else PCL_FB(4, 2);
 #undef PCL_FB
