@@ -46,9 +46,9 @@ PY
 B="python bench.py --steps 20 --warmup 3 --no-settle --no-cpu-baseline --no-other-configs --windows 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o b -- $B > $O/kt.log 2>&1
 T=$(find $O/kt -name '*kernel_trace.csv' | head -1)
-python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<true, true, 4, 2>' 1 0=fb256x128 > $O/${R}_dominant_kernel_by_shape.csv 2>&1
-python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<true, true, 2, 1>' 1 0=fb128x64 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
-python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 2, 2>' 1 0=fb128x128 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
-python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 1, 1>' 1 0=fb64x64 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
+python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<true, true, 4, 2, false>' 1 0=fb256x128 > $O/${R}_dominant_kernel_by_shape.csv 2>&1
+python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<true, true, 2, 1, true>' 1 0=fb128x64 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
+python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 2, 2, false>' 1 0=fb128x128 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
+python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 1, 1, false>' 1 0=fb64x64 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
 rm -rf $O/kt/*/*.db $O/sq/*/*.db $O/clk/*/*.db 2>/dev/null
 cat $O/${R}_clock_ubench.txt; cat $O/${R}_fb_budget_raw.txt; cat $O/${R}_dominant_kernel_by_shape.csv; tail -2 $O/exp7.log

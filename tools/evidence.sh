@@ -16,10 +16,10 @@ python tools/pmc_sq.py $(find $O/sq -name '*counter_collection.csv' | head -1) $
 cp $(find $O/kt -name '*kernel_stats.csv' | head -1) $O/${R}_bench_kernel_stats.csv
 T=$(find $O/kt -name '*kernel_trace.csv' | head -1)
 python tools/timeline.py $T > $O/${R}_step_timeline.csv 2>&1
-python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<true, true, 4, 2>' 1 0=fb256x128 > $O/${R}_dominant_kernel_by_shape.csv 2>&1
-python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<true, true, 2, 1>' 1 0=fb128x64 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
-python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 2, 2>' 1 0=fb128x128 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
-python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 1, 1>' 1 0=fb64x64 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
+python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<true, true, 4, 2, false>' 1 0=fb256x128 > $O/${R}_dominant_kernel_by_shape.csv 2>&1
+python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<true, true, 2, 1, true>' 1 0=fb128x64 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
+python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 2, 2, false>' 1 0=fb128x128 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
+python tools/kernel_by_shape.py $T 'linear_bwd_fused_kernel<false, true, 1, 1, false>' 1 0=fb64x64 | tail -1 >> $O/${R}_dominant_kernel_by_shape.csv
 rm -rf $O/kt/*/*.db $O/fetch $O/write $O/sq/*/*.db 2>/dev/null
 # (the bench line is taken at the END of this script, after every traffic profile of THESE sources has been copied to profiles/ on this box)
 # every C-ABI entry point event-timed (GEMM kernels: their own begin/end timestamps), algorithmic GB/s and TF per launch shape
