@@ -486,6 +486,25 @@ int pcl_mlp_fewrow_layer(int P, int Cout, int Cin, int first_layer);
 void pcl_set_fewrow_backward(int on);
 int pcl_get_fewrow_backward(void);
 void pcl_set_dw_tuning(int gx);
+/* Both backward GEMMs of a few-row layer in ONE launch (round 6): dW partial tiles (the body of pcl_linear_bwd_dw_rows_f32) and
+ * dUprev = mask(dy W) + the BatchNorm-backward sums of the layer below (the body of pcl_linear_bwd_dx_rows_f32), plain rows.  Arguments as
+ * in those two; `masked` != 0: Xprev is the pre-BN output of the layer below (mask + sums), 0: Xprev is the stack's input (first_col as
+ * in pcl_linear_bwd_dx_rows_f32).  pcl_linear_bwd_pair_finish_f32 then sums the partial tiles into dW and, when stats_ws is given, turns
+ * the sums into the constants of the layer below in the same launch (the arguments of pcl_bn_bwd_consts_f32).  Results are bit-identical
+ * to the separate calls.  pcl_linear_bwd_pair_supported: 1 where the pair applies (Cout, Cin > 64, few enough rows for the 64-row dX
+ * tiles); workspace = pcl_linear_bwd_dw_workspace_bytes(P, Cout, Cin).  pcl_set_bwd_pair(0): lab switch, `supported` answers 0.
+ * reference: the autograd backward of nn.Conv 1x1 + nn.BatchNorm + nn.ReLU, networks/cls/pointnet2.py:25-29, at the GroupAll level :131-136 */
+int pcl_linear_bwd_pair_supported(int P, int Cout, int Cin, int first_col);
+int pcl_linear_bwd_pair_f32(const float* dU, const float* Y, const float* a, const float* k1, const float* k2, const float* mean,
+                            const int32_t* arg, const float* gz, int ns, const float* W, const float* Xprev,
+                            const float* prev_scale, const float* prev_shift, float prev_slope, int masked, int P, int Cout, int Cin,
+                            float* dUprev, double* stats_ws, int first_col, void* workspace, size_t workspace_bytes, void* stream);
+int pcl_linear_bwd_pair_finish_f32(const void* workspace, size_t workspace_bytes, int P, int Cout, int Cin, float* dW,
+                                   const double* stats_ws, int stat_rows, const float* gamma_prev, const float* mean_prev,
+                                   const float* invstd_prev, int P_bn, float* dgamma_prev, float* dbeta_prev,
+                                   float* a_prev, float* k1_prev, float* k2_prev, float* dbias_zero_prev, void* stream);
+void pcl_set_bwd_pair(int on);
+int pcl_get_bwd_pair(void);
 /* Matrix-pipe form of the GEMM family (no reference counterpart: the reference calls cuDNN / cuBLAS fp32 through jittor's nn.Conv /
  * nn.Linear, misc/layers.py:60-75).  Default 0: the fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere.  Opt-in, measured and not faster
  * as a whole: every fp32 operand split EXACTLY into three bf16 values, an fp32 product = nine exact bf16 products

@@ -156,6 +156,11 @@ _SIGS = {
     "pcl_set_fewrow_backward": (None, [c_int]),
     "pcl_get_fewrow_backward": (c_int, []),
     "pcl_set_dw_tuning": (None, [c_int]),
+    "pcl_linear_bwd_pair_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "pcl_linear_bwd_pair_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_float, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_size_t, _P]),
+    "pcl_linear_bwd_pair_finish_f32": (c_int, [_P, c_size_t, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "pcl_set_bwd_pair": (None, [c_int]),
+    "pcl_get_bwd_pair": (c_int, []),
     "pcl_set_matrix_form": (None, [c_int]),
     "pcl_get_matrix_form": (c_int, []),
     "pcl_set_fps_tuning": (None, [c_int, c_int]),
@@ -197,6 +202,8 @@ def lib():
             L.pcl_set_pointconv_paths(int(os.environ["PCL_BWD_W_ROWS"] != "0"))
         if os.environ.get("PCL_SCATTER") is not None:
             L.pcl_set_scatter_form(int(os.environ["PCL_SCATTER"] != "0"))
+        if os.environ.get("PCL_BWD_PAIR") is not None:
+            L.pcl_set_bwd_pair(int(os.environ["PCL_BWD_PAIR"] != "0"))
         if os.environ.get("PCL_FB_TWO") is not None:
             L.pcl_set_fb_two_images(int(os.environ["PCL_FB_TWO"] != "0"))
         if os.environ.get("PCL_FEWROW") is not None:

@@ -604,8 +604,10 @@ __device__ __forceinline__ void quad_transpose4(float& v0, float& v1, float& v2,
     y = quad_xchg2(b1 ? v1 : v3); v1 = b1 ? y : v1; v3 = b1 ? v3 : y;
 }
 
+// (`block`: the workgroup's id in the kernel's logical grid -- blockIdx.x for the plain launch; linear_bwd_pair_kernel hands the ids
+//  behind its dW workgroups to this body)
 template <int AM, int EM, bool VEC, int TN, int GM, bool RAG, int TM = 2, bool SP = false>
-__global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in) {
+__device__ __forceinline__ void linear_nt_body(const LinArgs& p_in, const int block) {
     static_assert(GM == 0 || TM == 2, "the fused group max works on 64-row wave slabs");
     static_assert(!SP || (VEC && GM == 0), "bf16-plane operands: vector path only");
     LinArgs p = p_in;
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     int bx, by;
-    tile_of_block(blockIdx.x, p.gx, p.nt, bx, by);
+    tile_of_block(block, p.gx, p.nt, bx, by);
     const int n0 = p.n_begin + by * TBN;
     const int m_tiles = (p.M + TBM - 1) / TBM;
     const int lr = lane & 31, lh = lane >> 5;
@@ -974,6 +976,10 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in)
         }
     }
 }
+template <int AM, int EM, bool VEC, int TN, int GM, bool RAG, int TM = 2, bool SP = false>
+__global__ __launch_bounds__(MLP_T, 2) void linear_nt_kernel(const LinArgs p_in) {
+    linear_nt_body<AM, EM, VEC, TN, GM, RAG, TM, SP>(p_in, (int)blockIdx.x);
+}
 
 // ---- weight gradient: dW[I,J] = sum_p A'[p,I] * B'[p,J]  (A' = dy of this layer, B' = activation below) ----
 struct DwArgs {
@@ -1148,7 +1154,7 @@ __device__ __forceinline__ void dw_store_b(const DwArgs& p, float* sX, int c0, i
 // dW tile (64*TM) x (64*TN) per workgroup (2 x 2 waves, wave tile (32*TM) x (32*TN)); persistent over
 // 32-row chunks of P with register prefetch of the next chunk; partial tiles go to `part`.
 template <int AM, bool VEC, int TM, int TN, bool RAG>
-__global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p_in) {
+__device__ __forceinline__ void linear_dw_body(const DwArgs& p_in, const int block) {
     DwArgs p = p_in;
     if (p.p_dev) p.P = *p.p_dev;
     constexpr int WI = 64 * TM, WJ = 64 * TN;
@@ -1159,7 +1165,7 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p_in) 
     // same XCD-aware decode as the forward / dX kernel: the ti*tj tiles fed by the same rows sit 8 ids apart (one XCD,
     // dispatched together), so the operand columns they share (all of X for tiles along i) are L2 hits
     int bx, bt;
-    tile_of_block(blockIdx.x, p.gx, p.ti * p.tj, bx, bt);
+    tile_of_block(block, p.gx, p.ti * p.tj, bx, bt);
     const int i0 = (bt % p.ti) * WI, j0 = (bt / p.ti) * WJ;
     const int chunks = (p.P + DW_BP - 1) / DW_BP;
     f32x16 acc[TM][TN];
@@ -1244,6 +1250,22 @@ __global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p_in) 
             for (int tn = 0; tn < TN; ++tn)
                 if (col + tn < p.J) out[(size_t)row * p.ldo + col + tn] = acc[tm][tn][r];
         }
+}
+template <int AM, bool VEC, int TM, int TN, bool RAG>
+__global__ __launch_bounds__(MLP_T, 2) void linear_dw_kernel(const DwArgs p_in) {
+    linear_dw_body<AM, VEC, TM, TN, RAG>(p_in, (int)blockIdx.x);
+}
+
+// Both backward GEMMs of a few-row layer (the GroupAll level's 4 096 rows, the part-seg decoders, heads) in ONE launch (round 6): the
+// first n_dw workgroups run the weight-gradient body on 128 x 128 tiles, the rest the input-gradient body on 64 x 64 tiles.  The two
+// read the same (dU | arg, gz ; Y ; constants) and write disjoint outputs, so nothing orders them; on separate streams they co-ran at the
+// SUM of their times, and that is what this launch takes as well -- what it saves is a dispatch + drain (~4.5 us on this
+// chip, six times per GroupAll level with the reduce folded into the finish launch) and the idle tail of the first kernel, which the
+// second one's workgroups fill.  Same bodies, same arithmetic: bit-identical to the two launches.
+template <int AM, int EM, bool VEC>
+__global__ __launch_bounds__(MLP_T, 2) void linear_bwd_pair_kernel(const DwArgs d, const LinArgs a, const int n_dw) {
+    if ((int)blockIdx.x < n_dw) linear_dw_body<AM, VEC, 2, 2, false>(d, (int)blockIdx.x);
+    else linear_nt_body<AM, EM, VEC, 1, 0, false, 1, false>(a, (int)blockIdx.x - n_dw);
 }
 
 static void dw_grid(int P, int I, int J, int& gx, int& ti, int& tj, int& tm, int& tn) {
@@ -3248,6 +3270,99 @@ extern "C" int pcl_linear_bwd_dw_rows_f32(const float* dU, const float* Y, const
     const int blocks = (int)((n + 31) / 32);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(blocks), dim3(256), 0, st, d.part, gx, n, Cin, dw_ld ? dw_ld : Cin, dW);
     return check_launch("pcl_linear_bwd_dw_f32(reduce)");
+}
+
+// ---- both backward GEMMs of a few-row layer in one launch, the partial-tile sum in the finish launch (round 6) --------------------------
+static int g_bwd_pair = 1;               // lab switch (pcl_set_bwd_pair): 0 = the two launches + reduce of rounds 1-5
+extern "C" void pcl_set_bwd_pair(int on) { g_bwd_pair = on != 0; }
+extern "C" int pcl_get_bwd_pair(void) { return g_bwd_pair; }
+
+extern "C" int pcl_linear_bwd_pair_supported(int P, int Cout, int Cin, int first_col) {
+    if (!g_bwd_pair || P < 1 || Cout <= 64 || Cin <= 64 || (g_split_mfma & 2)) return 0;
+    int gx, ti, tj, tm, tn;
+    dw_grid(P, Cout, Cin, gx, ti, tj, tm, tn);
+    if (gx == 1 || tm != 2 || tn != 2) return 0;                 // (gx == 1: the direct form, nothing to reduce)
+    int gxl, n_tiles; bool narrow, low;
+    linear_grid(P, Cin - first_col, true, false, gxl, n_tiles, narrow, low);
+    return low ? 1 : 0;
+}
+
+extern "C" int pcl_linear_bwd_pair_f32(const float* dU, const float* Y, const float* a_, const float* k1, const float* k2, const float* mu,
+                                       const int32_t* arg, const float* gz, int ns, const float* W, const float* Xprev,
+                                       const float* prev_scale, const float* prev_shift, float prev_slope, int masked, int P, int Cout, int Cin,
+                                       float* dUprev, double* stats_ws, int first_col, void* workspace, size_t workspace_bytes, void* stream) {
+    PCL_REQUIRE(Y && a_ && k1 && k2 && mu && W && Xprev && dUprev, "pcl_linear_bwd_pair_f32: null pointer");
+    PCL_REQUIRE((dU != nullptr) != (arg != nullptr && gz != nullptr), "pcl_linear_bwd_pair_f32: pass dU or (arg,gz)");
+    PCL_REQUIRE((prev_scale == nullptr) == (prev_shift == nullptr), "pcl_linear_bwd_pair_f32: scale/shift together");
+    PCL_REQUIRE(!masked || (prev_scale && stats_ws), "pcl_linear_bwd_pair_f32: masked mode needs scale/shift/stats");
+    PCL_REQUIRE(first_col >= 0 && first_col < Cin && (first_col == 0 || !masked), "pcl_linear_bwd_pair_f32: first_col=%d only for the input gradient", first_col);
+    PCL_REQUIRE(pcl_linear_bwd_pair_supported(P, Cout, Cin, first_col), "pcl_linear_bwd_pair_f32: shape P=%d Cout=%d Cin=%d not eligible", P, Cout, Cin);
+    const size_t need = pcl_linear_bwd_dw_workspace_bytes(P, Cout, Cin);
+    if (!workspace || workspace_bytes < need) return fail(PCL_EWS, "pcl_linear_bwd_pair_f32: workspace %zu < %zu", workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    int gx, ti, tj, tm, tn;
+    dw_grid(P, Cout, Cin, gx, ti, tj, tm, tn);
+    DwArgs d = {};
+    d.A = dU; d.A2 = Y; d.sc = a_; d.sh = k1; d.k2 = k2; d.mu = mu; d.arg = arg; d.gz = gz; d.ns = ns;
+    d.Bsrc = Xprev; d.bsc = prev_scale; d.bsh = prev_shift; d.bslope = prev_slope;
+    d.part = static_cast<float*>(workspace); d.P = P; d.I = Cout; d.J = Cin;
+    d.a_mode = dU ? A_DY : A_DY_SPARSE; d.b_mode = prev_scale ? A_BNACT : A_PLAIN;
+    d.gx = gx; d.ti = ti; d.tj = tj; d.ldo = Cin;
+    LinArgs a = {};
+    a.A = dU; a.A2 = Y; a.B = W; a.sc = a_; a.sh = k1; a.k2 = k2; a.mu = mu; a.arg = arg; a.gz = gz; a.ns = ns;
+    a.C = dUprev; a.stats = stats_ws; a.Yprev = masked ? Xprev : nullptr; a.esc = prev_scale; a.esh = prev_shift; a.eslope = prev_slope;
+    a.M = P; a.N = Cin; a.K = Cout; a.n_begin = first_col; a.ldc = a.ldb = Cin;
+    a.a_mode = d.a_mode; a.e_mode = masked ? E_MASK_STORE_STATS : E_STORE;
+    int gxl, n_tiles; bool narrow, low;
+    linear_grid(P, Cin - first_col, true, false, gxl, n_tiles, narrow, low);
+    a.gx = gxl; a.nt = n_tiles;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    // the two bodies' vector paths have different preconditions; the pair runs both on the same path (scalar when either needs it)
+    const bool vec_dw = (Cout % 4 == 0) && (Cin % 4 == 0) && al16(Y) && al16(Xprev) && (!dU || al16(dU)) && (!gz || (al16(gz) && al16(arg)));
+    const bool vec_nt = (a.K % 4 == 0) && al16(a.A) && al16(a.B) && al16(a.A2) && a.ldb % 4 == 0;
+    const int n_dw = gx * ti * tj;
+    if (vec_dw != vec_nt) {
+        // (an operand aligned for one body's vector path only: the two plain launches, each on its own path -- the finish launch still sums the tiles)
+        if (dU) { if (vec_dw) launch_dw_t<A_DY, true>(d, dim3(n_dw), tm, tn, st); else launch_dw_t<A_DY, false>(d, dim3(n_dw), tm, tn, st); }
+        else { if (vec_dw) launch_dw_t<A_DY_SPARSE, true>(d, dim3(n_dw), tm, tn, st); else launch_dw_t<A_DY_SPARSE, false>(d, dim3(n_dw), tm, tn, st); }
+        if (const int rc = check_launch("pcl_linear_bwd_pair_f32(dw)")) return rc;
+        return launch_linear(a, st);
+    }
+    const bool vec = vec_dw;
+    const dim3 grid(n_dw + gxl * n_tiles), blk(MLP_T);
+#define PCL_PAIR(AMv, EMv, VECv) PCL_LAUNCH_TIMED((linear_bwd_pair_kernel<AMv, EMv, VECv>), grid, blk, st, d, a, n_dw)
+    if (dU) {
+        if (masked) { if (vec) PCL_PAIR(A_DY, E_MASK_STORE_STATS, true); else PCL_PAIR(A_DY, E_MASK_STORE_STATS, false); }
+        else { if (vec) PCL_PAIR(A_DY, E_STORE, true); else PCL_PAIR(A_DY, E_STORE, false); }
+    } else {
+        if (masked) { if (vec) PCL_PAIR(A_DY_SPARSE, E_MASK_STORE_STATS, true); else PCL_PAIR(A_DY_SPARSE, E_MASK_STORE_STATS, false); }
+        else { if (vec) PCL_PAIR(A_DY_SPARSE, E_STORE, true); else PCL_PAIR(A_DY_SPARSE, E_STORE, false); }
+    }
+#undef PCL_PAIR
+    return check_launch("pcl_linear_bwd_pair_f32");
+}
+
+extern "C" int pcl_linear_bwd_pair_finish_f32(const void* workspace, size_t workspace_bytes, int P, int Cout, int Cin, float* dW,
+                                              const double* stats_ws, int stat_rows, const float* gamma_prev, const float* mean_prev,
+                                              const float* invstd_prev, int P_bn, float* dgamma_prev, float* dbeta_prev,
+                                              float* a_prev, float* k1_prev, float* k2_prev, float* dbias_zero_prev, void* stream) {
+    PCL_REQUIRE(workspace && dW && P >= 1 && Cout >= 1 && Cin >= 1, "pcl_linear_bwd_pair_finish_f32: bad arguments");
+    const size_t need = pcl_linear_bwd_dw_workspace_bytes(P, Cout, Cin);
+    if (workspace_bytes < need) return fail(PCL_EWS, "pcl_linear_bwd_pair_finish_f32: workspace %zu < %zu", workspace_bytes, need);
+    int gx, ti, tj, tm, tn;
+    dw_grid(P, Cout, Cin, gx, ti, tj, tm, tn);
+    BnConstsArgs q = {};
+    int extra = 0;
+    if (stats_ws) {
+        PCL_REQUIRE(mean_prev && invstd_prev && a_prev && k1_prev && k2_prev && P_bn >= 1 && stat_rows >= 1, "pcl_linear_bwd_pair_finish_f32: null pointer");
+        q = BnConstsArgs{stats_ws, stat_rows, gamma_prev, mean_prev, invstd_prev, P_bn, Cin, dgamma_prev, dbeta_prev, a_prev, k1_prev, k2_prev, dbias_zero_prev};
+        extra = (Cin + 3) / 4;
+    }
+    const size_t n = (size_t)Cout * Cin;
+    const int nred = (int)((n + 31) / 32);
+    // (the same sum, in the same order, as reduce_rows_kernel's: the weight gradient is bit-identical to the two-launch path's)
+    hipLaunchKernelGGL(fused_finish_kernel, dim3(nred + extra), dim3(256), 0, as_stream(stream), static_cast<const float*>(workspace), gx, n, Cin, dW, nred, q);
+    return check_launch("pcl_linear_bwd_pair_finish_f32");
 }
 
 // ---- few-row layers: constants + dy in one launch, weight gradient on the formed dy (round 5) ----------------------------------------

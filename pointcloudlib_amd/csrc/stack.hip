@@ -711,6 +711,31 @@ static int stack_bwd_impl(const pcl_mlp_stack_t* dp) {
             rows = pcl_linear_bwd_fused_stat_rows(P, cin);
             continue;
         }
+        if (!sd && !fr && !rmeta && (l > 0 || d.need_dx) && pcl_linear_bwd_pair_supported(P, cout, cin, l == 0 ? d.x_grad_from : 0)) {
+            // few-row layer on plain rows (the GroupAll level, decoders): dW's partial tiles and dX from ONE launch; the second launch sums
+            // the tiles and -- the layer below's sums being complete by then -- forms ITS constants as well (round 6: four launches per
+            // layer were consts, dW, reduce, dX).  Same kernels' arithmetic: bit-identical to the per-kernel path.
+            float* dUp = l > 0 ? t.dU[cur_du] : d.dx;
+            PCL_REQUIRE(dUp, "pcl_mlp_stack_bwd_f32: need_dx without dx");
+            double* stn = l > 0 ? t.stats[1 - cur_stats] : nullptr;
+            tagf("pair%dx%d", cout, cin);
+            PCL_TRY(pcl_linear_bwd_pair_f32(dU, Yl, a, k1, k2, mean, sparse ? s.arg : nullptr, sparse ? t.gz : nullptr, ns, ly.W, Xprev, psc, psh, d.slope,
+                                            l > 0 ? 1 : 0, P, cout, cin, dUp, stn, l == 0 ? d.x_grad_from : 0, t.ws, t.ws_bytes, st));
+            if (l > 0) {
+                const pcl_stack_layer_t& lp = d.layer[l - 1];
+                float* kp = t.consts[1 - cur_c];
+                const float* vp = s.vec[l - 1];
+                const int rows_below = pcl_mlp_stat_rows(P, cin, 1);
+                PCL_TRY(pcl_linear_bwd_pair_finish_f32(t.ws, t.ws_bytes, P, cout, cin, ly.dW, stn, rows_below, lp.gamma, vp + 2 * cin, vp + 3 * cin, P,
+                                                       lp.dgamma, lp.dbeta, kp, kp + cin, kp + 2 * cin, lp.dbias, st));
+                have_pre = true;
+                rows = rows_below;
+                dU = dUp; sparse = false; cur_du = 1 - cur_du; cur_stats = 1 - cur_stats; cur_c = 1 - cur_c;
+            } else
+                PCL_TRY(pcl_linear_bwd_pair_finish_f32(t.ws, t.ws_bytes, P, cout, cin, ly.dW, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                                                       nullptr, nullptr, nullptr, nullptr, st));
+            continue;
+        }
         void* dw_st = st;
         if (sd) {
             // fork: everything the dW launch reads is complete at this point of the caller's stream (consts(l) was the last to be written)
