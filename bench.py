@@ -148,7 +148,7 @@ def main():
     from pointcloudlib_amd import _lib
     from pointcloudlib_amd.dp import FlatBucketDP
     from pointcloudlib_amd.networks.cls.pointnet2 import PointNet2_cls
-    from pointcloudlib_amd.train_utils import make_sgd, soft_cross_entropy_loss
+    from pointcloudlib_amd.train_utils import loss_backward, make_sgd, soft_cross_entropy_loss
     _lib.lib()                                                # fail loudly when the extension is missing
     if os.environ.get("PCL_FPS_PRIO"):                        # lab switch (tools/ab.sh): issue priority of the FPS chain's waves
         _lib.lib().pcl_set_fps_tuning(0, int(os.environ["PCL_FPS_PRIO"]))
@@ -187,7 +187,7 @@ def main():
         loss = soft_cross_entropy_loss(out, y)
         if HOST_DELAY_US and HOST_DELAY_AT == "bwd":
             spin()
-        loss.backward()
+        loss_backward(loss)
         dp.all_reduce()
         opt.step()
         return loss

@@ -158,7 +158,7 @@ _SIGS = {
     "pcl_set_dw_tuning": (None, [c_int]),
     "pcl_linear_bwd_pair_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "pcl_linear_bwd_pair_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_float, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_size_t, _P]),
-    "pcl_linear_bwd_pair_finish_f32": (c_int, [_P, c_size_t, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "pcl_linear_bwd_pair_finish_f32": (c_int, [_P, c_size_t, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "pcl_set_bwd_pair": (None, [c_int]),
     "pcl_get_bwd_pair": (c_int, []),
     "pcl_set_matrix_form": (None, [c_int]),

@@ -2740,7 +2740,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dy_kernel(const BnDyArgs p) {
 // second (and last) launch of the fused backward of a layer: blocks [0, nred) sum the workgroups' partial dW tiles (as
 // reduce_rows_kernel), the blocks after them turn the BatchNorm sums the fused kernel left into the constants of the layer below.
 __global__ __launch_bounds__(256) void fused_finish_kernel(const float* __restrict__ part, int rows, size_t n, int ncols, float* __restrict__ out,
-                                                           int nred, const BnConstsArgs q) {
+                                                           int nred, const BnConstsArgs q, int ldo = 0) {
     __shared__ double red[2 * 64 * 4];
     if ((int)blockIdx.x >= nred) { bn_bwd_consts_block(q, blockIdx.x - nred, red); return; }
     float* redf = reinterpret_cast<float*>(red);            // [8][33]
@@ -2757,7 +2757,7 @@ __global__ __launch_bounds__(256) void fused_finish_kernel(const float* __restri
         float t = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) t += redf[j * 33 + el];
-        out[e] = t;
+        out[ldo == 0 || ldo == ncols ? e : (e / ncols) * ldo + e % ncols] = t;      // (ldo: the tile is a column block of a wider matrix)
     }
 }
 
@@ -3342,11 +3342,11 @@ extern "C" int pcl_linear_bwd_pair_f32(const float* dU, const float* Y, const fl
     return check_launch("pcl_linear_bwd_pair_f32");
 }
 
-extern "C" int pcl_linear_bwd_pair_finish_f32(const void* workspace, size_t workspace_bytes, int P, int Cout, int Cin, float* dW,
+extern "C" int pcl_linear_bwd_pair_finish_f32(const void* workspace, size_t workspace_bytes, int P, int Cout, int Cin, float* dW, int dw_ld,
                                               const double* stats_ws, int stat_rows, const float* gamma_prev, const float* mean_prev,
                                               const float* invstd_prev, int P_bn, float* dgamma_prev, float* dbeta_prev,
                                               float* a_prev, float* k1_prev, float* k2_prev, float* dbias_zero_prev, void* stream) {
-    PCL_REQUIRE(workspace && dW && P >= 1 && Cout >= 1 && Cin >= 1, "pcl_linear_bwd_pair_finish_f32: bad arguments");
+    PCL_REQUIRE(workspace && dW && P >= 1 && Cout >= 1 && Cin >= 1 && (dw_ld == 0 || dw_ld >= Cin), "pcl_linear_bwd_pair_finish_f32: bad arguments");
     const size_t need = pcl_linear_bwd_dw_workspace_bytes(P, Cout, Cin);
     if (workspace_bytes < need) return fail(PCL_EWS, "pcl_linear_bwd_pair_finish_f32: workspace %zu < %zu", workspace_bytes, need);
     int gx, ti, tj, tm, tn;
@@ -3361,7 +3361,7 @@ extern "C" int pcl_linear_bwd_pair_finish_f32(const void* workspace, size_t work
     const size_t n = (size_t)Cout * Cin;
     const int nred = (int)((n + 31) / 32);
     // (the same sum, in the same order, as reduce_rows_kernel's: the weight gradient is bit-identical to the two-launch path's)
-    hipLaunchKernelGGL(fused_finish_kernel, dim3(nred + extra), dim3(256), 0, as_stream(stream), static_cast<const float*>(workspace), gx, n, Cin, dW, nred, q);
+    hipLaunchKernelGGL(fused_finish_kernel, dim3(nred + extra), dim3(256), 0, as_stream(stream), static_cast<const float*>(workspace), gx, n, Cin, dW, nred, q, dw_ld);
     return check_launch("pcl_linear_bwd_pair_finish_f32");
 }
 

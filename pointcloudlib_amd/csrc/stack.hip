@@ -677,6 +677,16 @@ static int stack_bwd_impl(const pcl_mlp_stack_t* dp) {
                 float* one = t.unit;                 // written by the max-gradient kernel at the head of this call
                 float* zero = one + C1;
                 const int Pp = d.B * d.N;
+                if (d.need_dx && pcl_linear_bwd_pair_supported(Pp, C1, d.Cf, 0)) {
+                    // both point GEMMs from one launch, the tile sum in the next (see the few-row layers below)
+                    PCL_REQUIRE(d.dx, "pcl_mlp_stack_bwd_f32: need_dx without dx");
+                    tagf("ptpair%dx%d", C1, d.Cf);
+                    PCL_TRY(pcl_linear_bwd_pair_f32(t.dUf, t.dUf, one, zero, zero, zero, nullptr, nullptr, 1, d.Wf_dense, d.feature, nullptr, nullptr, 0.f, 0, Pp,
+                                                    C1, d.Cf, d.dx, nullptr, 0, t.ptws, t.ptws_bytes, st));
+                    PCL_TRY(pcl_linear_bwd_pair_finish_f32(t.ptws, t.ptws_bytes, Pp, C1, d.Cf, ly.dW + off, fan_in, nullptr, 0, nullptr, nullptr, nullptr, 0,
+                                                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st));
+                    break;
+                }
                 tagf("ptdw%dx%d", C1, d.Cf);
                 PCL_TRY(pcl_linear_bwd_dw_rows_f32(t.dUf, t.dUf, one, zero, zero, zero, nullptr, nullptr, 1, d.feature, nullptr, nullptr, 0.f, Pp,
                                                    C1, d.Cf, ly.dW + off, t.ptws, t.ptws_bytes, nullptr, nullptr, fan_in, st));
@@ -726,13 +736,13 @@ static int stack_bwd_impl(const pcl_mlp_stack_t* dp) {
                 float* kp = t.consts[1 - cur_c];
                 const float* vp = s.vec[l - 1];
                 const int rows_below = pcl_mlp_stat_rows(P, cin, 1);
-                PCL_TRY(pcl_linear_bwd_pair_finish_f32(t.ws, t.ws_bytes, P, cout, cin, ly.dW, stn, rows_below, lp.gamma, vp + 2 * cin, vp + 3 * cin, P,
+                PCL_TRY(pcl_linear_bwd_pair_finish_f32(t.ws, t.ws_bytes, P, cout, cin, ly.dW, 0, stn, rows_below, lp.gamma, vp + 2 * cin, vp + 3 * cin, P,
                                                        lp.dgamma, lp.dbeta, kp, kp + cin, kp + 2 * cin, lp.dbias, st));
                 have_pre = true;
                 rows = rows_below;
                 dU = dUp; sparse = false; cur_du = 1 - cur_du; cur_stats = 1 - cur_stats; cur_c = 1 - cur_c;
             } else
-                PCL_TRY(pcl_linear_bwd_pair_finish_f32(t.ws, t.ws_bytes, P, cout, cin, ly.dW, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                PCL_TRY(pcl_linear_bwd_pair_finish_f32(t.ws, t.ws_bytes, P, cout, cin, ly.dW, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                                                        nullptr, nullptr, nullptr, nullptr, st));
             continue;
         }

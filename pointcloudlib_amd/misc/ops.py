@@ -198,6 +198,9 @@ def group_points(xyz, new_xyz, feature, idx, use_xyz=True):
     return _GroupPoints.apply(xyz, new_xyz, feature, idx, bool(use_xyz))
 
 
+_GROUP_ALL_BWD_VIEW = __import__("os").environ.get("PCL_GROUP_ALL_BWD_VIEW", "1") != "0"      # lab switch (A/B on one box): 0 = the copy kernel
+
+
 class _GroupAll(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, feat, use_xyz):
@@ -216,6 +219,11 @@ class _GroupAll(torch.autograd.Function):
         B, N, C, use_xyz = ctx.dims
         gfeat = None
         if C > 0 and ctx.needs_input_grad[1]:
+            D = (3 if use_xyz else 0) + C
+            if _GROUP_ALL_BWD_VIEW and gout.is_contiguous() and gout.is_cuda and gout.dtype == torch.float32:
+                # the feature columns of the gradient AS A VIEW (row stride D): the stack below reads its gout in place through gout_ld
+                # (csrc/stack.hip), any other consumer makes it dense itself -- no copy launch here (round 6)
+                return None, gout.view(B, N, D)[:, :, D - C:], None
             gout = _dev(gout, "grad")
             gfeat = torch.empty((B, N, C), dtype=torch.float32, device=gout.device)
             _lib.call("pcl_group_all_bwd_f32", _p(gout), B, N, C, use_xyz, _p(gfeat), _stream())

@@ -16,6 +16,33 @@ seg_num = [4, 2, 2, 4, 4, 3, 3, 2, 4, 2, 6, 2, 3, 3, 3, 3]
 index_start = [0, 4, 6, 8, 12, 16, 19, 22, 24, 28, 30, 36, 38, 41, 44, 47]
 
 
+_ONES = {}
+
+
+def _one(device):
+    """The scalar 1.0 on ``device`` that ``loss_backward`` seeds autograd with (one tensor per device, created once)."""
+    t = _ONES.get(device)
+    if t is None:
+        t = _ONES[device] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
+def loss_backward(loss):
+    """``loss.backward()`` for a scalar loss without its two smallest launches: autograd is seeded with a cached device scalar 1.0
+    instead of a freshly filled ``ones_like(loss)``, and the loss kernels' backward, which already hold d loss / d logits, hand it on
+    as it is when the incoming gradient IS that cached 1.0 (recognised by its address: no read of a device value, no synchronisation)
+    instead of multiplying by it.  Same gradients bit for bit (x * 1.0 == x); any other gradient takes the product as before.
+    (The reference's ``optimizer.step(loss)``, train_cls.py:404, is backward + update of one scalar loss as well.)"""
+    torch.autograd.backward(loss, grad_tensors=(_one(loss.device),))
+
+
+def _scaled(dx, g):
+    one = _ONES.get(g.device)
+    if one is not None and g.data_ptr() == one.data_ptr():
+        return dx
+    return dx * g
+
+
 class _SoftCE(torch.autograd.Function):
     """pcl_soft_ce_f32: the loss and its gradient from one launch."""
 
@@ -34,7 +61,7 @@ class _SoftCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dx, = ctx.saved_tensors
-        return dx * g, None, None
+        return _scaled(dx, g), None, None
 
 
 class _CERows(torch.autograd.Function):
@@ -55,7 +82,7 @@ class _CERows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dx, = ctx.saved_tensors
-        return dx * g, None, None
+        return _scaled(dx, g), None, None
 
 
 def seg_cross_entropy_loss(scores, seg):

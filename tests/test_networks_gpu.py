@@ -505,3 +505,46 @@ def test_conv_max_mean_pool_equals_the_composition(dev, B, N, Cin, Cout):
             assert (got[2][n] - ref[2][n]).abs().max().item() <= 1e-4 * max(1e-6, ref[2][n].abs().max().item()), n
         for n in ref[3]:
             assert (got[3][n] - ref[3][n]).abs().max().item() <= 1e-5 * max(1.0, ref[3][n].abs().max().item()), n
+
+
+@pytest.mark.gpu
+def test_loss_backward_seeds_autograd_without_the_fill_and_the_product():
+    """``train_utils.loss_backward(loss)`` = ``loss.backward()`` bit for bit (the loss kernel's stored gradient goes on as it is when the
+    seed is the cached scalar 1.0, recognised by address); any other incoming gradient still takes the product."""
+    import torch
+    from pointcloudlib_amd.train_utils import loss_backward, seg_cross_entropy_loss, soft_cross_entropy_loss
+    torch.manual_seed(3)
+    x = torch.randn(32, 40, device="cuda")
+    y = torch.randint(0, 40, (32,), device="cuda")
+    s = torch.randn(4, 50, 333, device="cuda")
+    t = torch.randint(0, 50, (4, 333), device="cuda")
+    for fn, inp, tgt in ((soft_cross_entropy_loss, x, y), (seg_cross_entropy_loss, s, t)):
+        a = inp.clone().requires_grad_(True)
+        b = inp.clone().requires_grad_(True)
+        c = inp.clone().requires_grad_(True)
+        la = fn(a * 1.0, tgt); la.backward()
+        lb = fn(b * 1.0, tgt); loss_backward(lb)
+        assert torch.equal(la, lb) and torch.equal(a.grad, b.grad)
+        (fn(c * 1.0, tgt) * 3.0).backward()                      # a gradient that is not the seed: scaled as before
+        assert torch.allclose(c.grad, 3.0 * a.grad, rtol=1e-6, atol=0)
+
+
+@pytest.mark.gpu
+def test_group_all_backward_hands_the_feature_gradient_on_as_a_view():
+    """GroupAll's backward returns the feature columns of the gradient as a strided view (no copy launch); values as the copy kernel's."""
+    import torch
+    from pointcloudlib_amd.misc import ops
+    torch.manual_seed(4)
+    xyz = torch.randn(3, 50, 3, device="cuda")
+    f = torch.randn(3, 50, 7, device="cuda")
+    g = torch.randn(3, 1, 50, 10, device="cuda")
+    res = {}
+    for view in (True, False):
+        old, ops._GROUP_ALL_BWD_VIEW = ops._GROUP_ALL_BWD_VIEW, view
+        try:
+            ff = f.clone().requires_grad_(True)
+            ops.GroupAll(True)(None, xyz, ff).backward(g)
+            res[view] = ff.grad.clone()
+        finally:
+            ops._GROUP_ALL_BWD_VIEW = old
+    assert torch.equal(res[True], res[False]) and torch.equal(res[True], g[:, 0, :, 3:])

@@ -4,7 +4,7 @@ import argparse, json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointcloudlib_amd import synth
-from pointcloudlib_amd.train_utils import make_sgd, seg_cross_entropy_loss, soft_cross_entropy_loss
+from pointcloudlib_amd.train_utils import loss_backward, make_sgd, seg_cross_entropy_loss, soft_cross_entropy_loss
 from pointcloudlib_amd.affinity import pin_to_gpu_node
 pin_to_gpu_node(0)
 
@@ -161,7 +161,7 @@ def run(name, make, inputs, loss_fn, steps, warmup=3, cpu_kind=None, windows=Non
     opt = make_sgd(net.parameters(), lr=0.02, momentum=0.9)
     def step():
         opt.zero_grad(set_to_none=True)
-        loss_fn(net(*inputs)).backward()
+        loss_backward(loss_fn(net(*inputs)))
         opt.step()
     for _ in range(warmup):
         step()
@@ -198,7 +198,7 @@ def _run_prefetch(name, make, inputs, loss_fn, steps, warmup=120, windows=None):
         cur = pending[0]
         pending[0] = net.precompute_sampling(inputs[0], stream=side)      # enqueued ahead of the forward (bench.py: 1.900 vs 1.914 ms behind it)
         out = net(*inputs, sampling=cur)
-        loss_fn(out).backward()
+        loss_backward(loss_fn(out))
         opt.step()
     for _ in range(warmup):
         step()

@@ -22,7 +22,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from pointcloudlib_amd.data_utils.modelnet40_loader import ModelNet40, SyntheticModelNet40
-from pointcloudlib_amd.train_utils import make_sgd, soft_cross_entropy_loss
+from pointcloudlib_amd.train_utils import loss_backward, make_sgd, soft_cross_entropy_loss
 
 
 def build_model(name):
@@ -82,7 +82,7 @@ def run_epoch(net, name, loader, dev, optimizer=None, side=None):
             if train:
                 loss = soft_cross_entropy_loss(out, labels)
                 optimizer.zero_grad(set_to_none=True)
-                loss.backward()
+                loss_backward(loss)                            # optimizer.step(loss), train_cls.py:404: backward + update
                 optimizer.step()
                 loss_sum += loss.item() * len(labels)
         correct += int((out.argmax(1) == labels).sum())

@@ -21,7 +21,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from pointcloudlib_amd.data_utils.shapenet_loader import ShapeNetPart, SyntheticShapeNetPart  # noqa: E402
-from pointcloudlib_amd.train_utils import calculate_shape_IoU, make_sgd, seg_cross_entropy_loss  # noqa: E402
+from pointcloudlib_amd.train_utils import calculate_shape_IoU, loss_backward, make_sgd, seg_cross_entropy_loss  # noqa: E402
 
 
 def build_model(name, part_num=50):
@@ -95,7 +95,7 @@ def run_epoch(net, name, loader, dev, seg_num_all, optimizer=None, side=None):
             loss = seg_cross_entropy_loss(scores.reshape(-1, seg_num_all), seg.reshape(-1))        # nn.cross_entropy_loss(pred, seg), :116
             if train:
                 optimizer.zero_grad(set_to_none=True)
-                loss.backward()
+                loss_backward(loss)
                 optimizer.step()
         loss_sum += loss.item() * data.shape[0]
         count += data.shape[0]
