@@ -320,15 +320,19 @@ def main():
     # sides.  ms_per_step / value come from the MEDIAN window (MAX over ranks per window); every window is listed in the line.  One
     # window of 20 steps is 40 ms -- the size of one host hiccup or one clock ramp (round 5's driver line: 2.135 ms from a single window
     # whose neighbours ran 1.9) -- so a single window is not a measurement of the kernels; the same estimator serves `other_configs`.
-    # The dominant kernel's event pair is armed in every OTHER window (0, 2, 4, ...): `windows_timer_armed` in the line shows whether
+    # The dominant kernel's event pair is armed in every OTHER window (1, 3, ...): `windows_timer_armed` in the line shows whether
     # the in-stack timer moves a window (it is two events filled from the kernel's own dispatch packet, no marker packets).
     host_trace = [] if os.environ.get("PCL_HOST_TRACE") else None      # lab switch: when does the HOST leave each step?
     win_dt, win_host, win_armed = [], [], []
     if timer is not None:
         timer.max_records = None
     for w in range(max(1, args.windows)):
-        _lib.PROFILER = timer if w % 2 == 0 else None
-        win_armed.append(timer is not None and w % 2 == 0)
+        # (armed in windows 1, 3, ...: the event pair costs ~8 us per step -- 12 of 12 runs on one box: armed windows 1.809-1.815 ms, the
+        #  unarmed ones between them 1.800-1.807 -- and the product path does not carry it, so the MAJORITY of the windows, and with it the
+        #  median, is unarmed; a single window is armed, or the line would have no live kernel time)
+        armed = timer is not None and (w % 2 == 1 or max(1, args.windows) == 1)
+        _lib.PROFILER = timer if armed else None
+        win_armed.append(armed)
         if lab_idle_ms and w == 2:
             torch.cuda.synchronize(); time.sleep(lab_idle_ms * 1e-3)
         fence()
