@@ -1041,3 +1041,60 @@ def test_scatter_as_a_gather_over_the_points_row_lists(dev, B, N, m, ns, C1):
         assert (dW0.double() - refw).abs().max().item() <= 1e-4 * scw
     assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
     assert (outs[1][0][ref == 0] == 0).all()
+
+
+@pytest.mark.parametrize("spec,lead,ns,bias", [([259, 256, 512, 1024], (32, 1, 128), 128, False),     # the GroupAll level at full size (sparse max gradient, K = 259 scalar path)
+                                               ([1664, 256, 256], (16, 128), None, True),               # part-seg decoder fp3 (dense gradient, bias)
+                                               ([128, 128, 128, 128], (3, 700), None, False),           # 2 100 rows, every layer eligible
+                                               ([20, 96, 32], (2, 300), None, True)])                   # nothing eligible (widths <= 64 / padded): the old launches
+def test_backward_pair_launch_equals_the_separate_launches(dev, spec, lead, ns, bias):
+    """Round 6: both backward GEMMs of a few-row layer run in ONE launch and the split-K tile sum rides in the launch that forms the layer
+    below's constants (csrc/mlp.hip: linear_bwd_pair_kernel, pcl_linear_bwd_pair_finish_f32).  Same kernel bodies, same reduction order:
+    outputs and every gradient must be BIT-identical to the four-launch form (pcl_set_bwd_pair(0))."""
+    from pointcloudlib_amd import _lib
+    from pointcloudlib_amd.misc import mlp_hip
+    L = _lib.lib()
+    torch.manual_seed(12)
+    mlp = PointwiseMLP(spec, bias=bias, slope=0.0).to(dev).train()
+    x = torch.randn(*lead, spec[0], device=dev)
+    gshape = (lead[:-1] if ns else lead) + (spec[-1],)
+    gout = torch.randn(*gshape, device=dev)
+    prev = L.pcl_get_bwd_pair()
+    try:
+        L.pcl_set_bwd_pair(0); mlp_hip._PLANS.clear()
+        ref = run(copy.deepcopy(mlp), x, ns, gout, "auto")
+        L.pcl_set_bwd_pair(1); mlp_hip._PLANS.clear()
+        got = run(copy.deepcopy(mlp), x, ns, gout, "auto")
+        assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+        for n in ref[2]:
+            assert torch.equal(ref[2][n], got[2][n]), n
+    finally:
+        L.pcl_set_bwd_pair(prev); mlp_hip._PLANS.clear()
+
+
+@pytest.mark.parametrize("spec,lead,ns", [([16, 64, 128, 64], (3, 44444), None),            # dense 128 x 64 at size (2-9 tiles per workgroup)
+                                          ([5, 64, 64, 64, 128], (7, 900, 16), 16),         # sparse 128 x 64 under a max pool, 100 800 rows
+                                          ([4, 64, 128, 64], (1, 65), None)])               # 65 rows: one 64-row tile + 1 row
+def test_two_image_fused_backward_equals_the_one_image_form(dev, spec, lead, ns):
+    """Round 6: the 128 x 64 fused backward walks 64-row tiles over two LDS images with the waves in two roles (pcl_set_fb_two_images).
+    Same arithmetic per element; dW and the BatchNorm sums differ from the one-image form in summation order only."""
+    from pointcloudlib_amd import _lib
+    from pointcloudlib_amd.misc import mlp_hip
+    L = _lib.lib()
+    torch.manual_seed(13)
+    mlp = PointwiseMLP(spec, bias=False, slope=0.0).to(dev).train()
+    x = torch.randn(*lead, spec[0], device=dev)
+    gshape = (lead[:-1] if ns else lead) + (spec[-1],)
+    gout = torch.randn(*gshape, device=dev)
+    prev = L.pcl_get_fb_two_images()
+    try:
+        L.pcl_set_fb_two_images(0); mlp_hip._PLANS.clear()
+        ref = run(copy.deepcopy(mlp), x, ns, gout, "auto")
+        L.pcl_set_fb_two_images(1); mlp_hip._PLANS.clear()
+        got = run(copy.deepcopy(mlp), x, ns, gout, "auto")
+        assert torch.equal(ref[0], got[0])
+        for name, a, b in [("x", ref[1], got[1])] + [(n, ref[2][n], got[2][n]) for n in ref[2]]:
+            scale = a.abs().max().item()
+            assert (a - b).abs().max().item() <= 2e-5 * max(scale, 1e-6) + 1e-7, (name, (a - b).abs().max().item(), scale)
+    finally:
+        L.pcl_set_fb_two_images(prev); mlp_hip._PLANS.clear()
