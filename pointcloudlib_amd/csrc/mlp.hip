@@ -2739,9 +2739,22 @@ __global__ __launch_bounds__(256) void bn_bwd_dy_kernel(const BnDyArgs p) {
 
 // second (and last) launch of the fused backward of a layer: blocks [0, nred) sum the workgroups' partial dW tiles (as
 // reduce_rows_kernel), the blocks after them turn the BatchNorm sums the fused kernel left into the constants of the layer below.
+// a third kind of block (round 6): the coordinate columns of a folded first layer's weight gradient, dW0[c, 0..2] = sum_r px[r][c][0..2] -- the
+// reduce that followed the folded layer's backward as a launch of its own (csrc/compact.hip: group_linear_dw_kernel, same sum in the same order)
+struct FinishXJob { const float* px; int rows, C1, ld; float* dW0; int first; };
 __global__ __launch_bounds__(256) void fused_finish_kernel(const float* __restrict__ part, int rows, size_t n, int ncols, float* __restrict__ out,
-                                                           int nred, const BnConstsArgs q, int ldo = 0) {
+                                                           int nred, const BnConstsArgs q, int ldo = 0, const FinishXJob xj = FinishXJob{nullptr, 0, 0, 0, nullptr, 0}) {
     __shared__ double red[2 * 64 * 4];
+    if (xj.px && (int)blockIdx.x >= xj.first) {
+        const int nx = xj.C1 * 3, e = ((int)blockIdx.x - xj.first) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (e >= nx) return;
+        float s = 0.f;
+        for (int r = lane; r < xj.rows; r += 64) s += xj.px[(size_t)r * nx + e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) xj.dW0[(size_t)(e / 3) * xj.ld + e % 3] = s;
+        return;
+    }
     if ((int)blockIdx.x >= nred) { bn_bwd_consts_block(q, blockIdx.x - nred, red); return; }
     float* redf = reinterpret_cast<float*>(red);            // [8][33]
     const int el = threadIdx.x & 31, ry = threadIdx.x >> 5;
@@ -3342,10 +3355,26 @@ extern "C" int pcl_linear_bwd_pair_f32(const float* dU, const float* Y, const fl
     return check_launch("pcl_linear_bwd_pair_f32");
 }
 
+namespace pcl {
+int pair_finish_impl(const void* workspace, size_t workspace_bytes, int P, int Cout, int Cin, float* dW, int dw_ld,
+                     const double* stats_ws, int stat_rows, const float* gamma_prev, const float* mean_prev,
+                     const float* invstd_prev, int P_bn, float* dgamma_prev, float* dbeta_prev,
+                     float* a_prev, float* k1_prev, float* k2_prev, float* dbias_zero_prev, void* stream,
+                     const float* xpart, int xrows, int xC1, int xld, float* xdW0);
+}
 extern "C" int pcl_linear_bwd_pair_finish_f32(const void* workspace, size_t workspace_bytes, int P, int Cout, int Cin, float* dW, int dw_ld,
                                               const double* stats_ws, int stat_rows, const float* gamma_prev, const float* mean_prev,
                                               const float* invstd_prev, int P_bn, float* dgamma_prev, float* dbeta_prev,
                                               float* a_prev, float* k1_prev, float* k2_prev, float* dbias_zero_prev, void* stream) {
+    return pair_finish_impl(workspace, workspace_bytes, P, Cout, Cin, dW, dw_ld, stats_ws, stat_rows, gamma_prev, mean_prev, invstd_prev, P_bn, dgamma_prev,
+                            dbeta_prev, a_prev, k1_prev, k2_prev, dbias_zero_prev, stream, nullptr, 0, 0, 0, nullptr);
+}
+// (xpart ..: the coordinate-weight partials of a folded first layer [xrows][xC1][3] summed into xdW0[c * xld + 0..2] by extra blocks of this launch)
+int pcl::pair_finish_impl(const void* workspace, size_t workspace_bytes, int P, int Cout, int Cin, float* dW, int dw_ld,
+                          const double* stats_ws, int stat_rows, const float* gamma_prev, const float* mean_prev,
+                          const float* invstd_prev, int P_bn, float* dgamma_prev, float* dbeta_prev,
+                          float* a_prev, float* k1_prev, float* k2_prev, float* dbias_zero_prev, void* stream,
+                          const float* xpart, int xrows, int xC1, int xld, float* xdW0) {
     PCL_REQUIRE(workspace && dW && P >= 1 && Cout >= 1 && Cin >= 1 && (dw_ld == 0 || dw_ld >= Cin), "pcl_linear_bwd_pair_finish_f32: bad arguments");
     const size_t need = pcl_linear_bwd_dw_workspace_bytes(P, Cout, Cin);
     if (workspace_bytes < need) return fail(PCL_EWS, "pcl_linear_bwd_pair_finish_f32: workspace %zu < %zu", workspace_bytes, need);
@@ -3361,7 +3390,11 @@ extern "C" int pcl_linear_bwd_pair_finish_f32(const void* workspace, size_t work
     const size_t n = (size_t)Cout * Cin;
     const int nred = (int)((n + 31) / 32);
     // (the same sum, in the same order, as reduce_rows_kernel's: the weight gradient is bit-identical to the two-launch path's)
-    hipLaunchKernelGGL(fused_finish_kernel, dim3(nred + extra), dim3(256), 0, as_stream(stream), static_cast<const float*>(workspace), gx, n, Cin, dW, nred, q, dw_ld);
+    FinishXJob xj = {nullptr, 0, 0, 0, nullptr, 0};
+    int xblocks = 0;
+    if (xpart && xdW0) { xj = FinishXJob{xpart, xrows, xC1, xld, xdW0, nred + extra}; xblocks = (xC1 * 3 + 3) / 4; }
+    hipLaunchKernelGGL(fused_finish_kernel, dim3(nred + extra + xblocks), dim3(256), 0, as_stream(stream), static_cast<const float*>(workspace), gx, n, Cin, dW, nred, q,
+                       dw_ld, xj);
     return check_launch("pcl_linear_bwd_pair_finish_f32");
 }
 

@@ -227,6 +227,11 @@ int narrow_fwd(const pcl_mlp_stack_t& d);
 int narrow_bwd(const pcl_mlp_stack_t& d);
 int maxgrad_prep_impl(const float* gout, const float* out, const float* ymax, float slope, int G, int C, float* gz, double* stats_ws,
                       int* stat_rows_out, void* stream, float* zero, size_t n_zero, float* ones, int n_one, int n_one0, int ldg);
+int pair_finish_impl(const void* workspace, size_t workspace_bytes, int P, int Cout, int Cin, float* dW, int dw_ld,
+                     const double* stats_ws, int stat_rows, const float* gamma_prev, const float* mean_prev,
+                     const float* invstd_prev, int P_bn, float* dgamma_prev, float* dbeta_prev,
+                     float* a_prev, float* k1_prev, float* k2_prev, float* dbias_zero_prev, void* stream,
+                     const float* xpart, int xrows, int xC1, int xld, float* xdW0);
 int group_linear_fwd_impl(const float* xyz, const float* new_xyz, const float* Uf, const float* Wx, const float* feat_small,
                           const float* Wf_small, int CF, int ldw, const int32_t* idx, const int32_t* cnt, const int32_t* group_off, int B,
                           int N, int m, int ns, int C1, float* Y, int32_t* row_meta, int32_t* row_src, float* row_loc, float* row_feat,
@@ -665,10 +670,13 @@ static int stack_bwd_impl(const pcl_mlp_stack_t* dp) {
             // the folded first layer: dy = a*du - w*(k1 + k2*(y - mean)) per distinct row, scattered to the points / summed into dWx
             const int off = d.use_xyz ? 3 : 0, fan_in = d.c[0], C1 = cout;
             const bool inl = grouped_inline(d), wide = grouped_wide(d);
+            // (the point GEMMs as a pair + finish: the finish launch also sums the coordinate-weight partials -- one launch fewer)
+            const bool pt_pair = wide && d.need_dx && pcl_linear_bwd_pair_supported(d.B * d.N, C1, d.Cf, 0);
+            const bool x_in_finish = pt_pair && gather_scatter(d) && t.dWxp;
             tagf("glinbwd%d", C1, 0);
             if (gather_scatter(d))
                 PCL_TRY(pcl_group_linear_bwd_gather_f32(s.row_loc, dU, s.Y[0], a, k1, k2, mean, s.in_off, s.in_rows, d.B, d.N, C1, t.dUf, t.dWxp,
-                                                        t.dWxp ? ly.dW : nullptr, fan_in, st));
+                                                        (t.dWxp && !x_in_finish) ? ly.dW : nullptr, fan_in, st));
             else
             PCL_TRY(group_linear_bwd_impl(s.row_loc, s.row_feat, inl ? d.Cf : 0, dU, s.Y[0], a, k1, k2, mean, s.row_src, nrows, d.B, d.N, C1,
                                           t.dUf, t.dWxp, t.dWfp, (t.dWxp || t.dWfp) ? ly.dW : nullptr, fan_in, off, st, /*duf_is_zero=*/true));
@@ -677,14 +685,15 @@ static int stack_bwd_impl(const pcl_mlp_stack_t* dp) {
                 float* one = t.unit;                 // written by the max-gradient kernel at the head of this call
                 float* zero = one + C1;
                 const int Pp = d.B * d.N;
-                if (d.need_dx && pcl_linear_bwd_pair_supported(Pp, C1, d.Cf, 0)) {
+                if (pt_pair) {
                     // both point GEMMs from one launch, the tile sum in the next (see the few-row layers below)
                     PCL_REQUIRE(d.dx, "pcl_mlp_stack_bwd_f32: need_dx without dx");
                     tagf("ptpair%dx%d", C1, d.Cf);
                     PCL_TRY(pcl_linear_bwd_pair_f32(t.dUf, t.dUf, one, zero, zero, zero, nullptr, nullptr, 1, d.Wf_dense, d.feature, nullptr, nullptr, 0.f, 0, Pp,
                                                     C1, d.Cf, d.dx, nullptr, 0, t.ptws, t.ptws_bytes, st));
-                    PCL_TRY(pcl_linear_bwd_pair_finish_f32(t.ptws, t.ptws_bytes, Pp, C1, d.Cf, ly.dW + off, fan_in, nullptr, 0, nullptr, nullptr, nullptr, 0,
-                                                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st));
+                    PCL_TRY(pair_finish_impl(t.ptws, t.ptws_bytes, Pp, C1, d.Cf, ly.dW + off, fan_in, nullptr, 0, nullptr, nullptr, nullptr, 0,
+                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st,
+                                             x_in_finish ? t.dWxp : nullptr, pcl_group_linear_stat_rows(d.B, d.m), C1, fan_in, ly.dW));
                     break;
                 }
                 tagf("ptdw%dx%d", C1, d.Cf);
