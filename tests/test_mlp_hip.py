@@ -1098,3 +1098,60 @@ def test_two_image_fused_backward_equals_the_one_image_form(dev, spec, lead, ns)
             assert (a - b).abs().max().item() <= 2e-5 * max(scale, 1e-6) + 1e-7, (name, (a - b).abs().max().item(), scale)
     finally:
         L.pcl_set_fb_two_images(prev); mlp_hip._PLANS.clear()
+
+
+@pytest.mark.parametrize("P,Cout,Cin,sparse,masked,w_shift", [(4096, 512, 256, False, True, 0),      # a GroupAll-level layer, dense gradient
+                                                              (4096, 1024, 512, True, True, 0),      # its last layer: sparse max gradient (ns = 128)
+                                                              (700, 128, 128, False, False, 0),      # input gradient without a mask (a stack's first layer)
+                                                              (2048, 256, 128, False, True, 1)])     # W one float off a 16-byte boundary: the two bodies on different paths
+def test_pair_entry_point_against_the_two_entry_points(dev, P, Cout, Cin, sparse, masked, w_shift):
+    """pcl_linear_bwd_pair_f32 + pcl_linear_bwd_pair_finish_f32 through the C ABI against pcl_linear_bwd_dw_rows_f32 (+ its reduce) and
+    pcl_linear_bwd_dx_rows_f32: dW, dUprev and the BatchNorm-backward sums bit for bit -- also when only one of the two bodies can take
+    its vector path (a weight matrix that is not 16-byte aligned: the entry point then issues the two plain launches itself)."""
+    import ctypes
+    from pointcloudlib_amd import _lib
+    L = _lib.lib()
+    _p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.pcl_linear_bwd_pair_supported(P, Cout, Cin, 0) == 1
+    torch.manual_seed(21)
+    ns = 128
+    Y = torch.randn(P, Cout, device=dev)
+    a, k1, k2, mu = (torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev) * 0.1, torch.randn(Cout, device=dev) * 0.1, torch.randn(Cout, device=dev) * 0.1)
+    if sparse:
+        G = P // ns
+        arg = torch.randint(0, ns, (G, Cout), device=dev, dtype=torch.int32)
+        gz = torch.randn(G, Cout, device=dev)
+        dU = None
+    else:
+        arg = gz = None
+        dU = torch.randn(P, Cout, device=dev)
+    Wbuf = torch.randn(Cout * Cin + 4, device=dev)
+    W = Wbuf[w_shift:w_shift + Cout * Cin].view(Cout, Cin)
+    Xprev = torch.randn(P, Cin, device=dev)
+    psc, psh = (torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev) * 0.2) if masked else (None, None)
+    srows = L.pcl_mlp_stat_rows(P, Cin, 1)
+    wsb = L.pcl_linear_bwd_dw_workspace_bytes(P, Cout, Cin)
+
+    def fresh():
+        return (torch.full((P, Cin), float("nan"), device=dev), torch.zeros(srows, 2, Cin, dtype=torch.float64, device=dev),
+                torch.empty(wsb // 4, device=dev), torch.full((Cout, Cin), float("nan"), device=dev))
+
+    dXa, sta, wsa, dWa = fresh()
+    rc = L.pcl_linear_bwd_dw_rows_f32(_p(dU), _p(Y), _p(a), _p(k1), _p(k2), _p(mu), _p(arg), _p(gz), ns, _p(Xprev), _p(psc), _p(psh), ctypes.c_float(0.0), P, Cout, Cin,
+                                      _p(dWa), _p(wsa), wsb, None, None, 0, st)
+    assert rc == 0, L.pcl_last_error()
+    rc = L.pcl_linear_bwd_dx_rows_f32(_p(dU), _p(Y), _p(a), _p(k1), _p(k2), _p(mu), _p(arg), _p(gz), ns, _p(W), P, Cout, Cin, _p(Xprev) if masked else None, _p(psc), _p(psh),
+                                      ctypes.c_float(0.0), _p(dXa), _p(sta) if masked else None, None, None, 0, 0, st)
+    assert rc == 0, L.pcl_last_error()
+    dXb, stb, wsb_t, dWb = fresh()
+    rc = L.pcl_linear_bwd_pair_f32(_p(dU), _p(Y), _p(a), _p(k1), _p(k2), _p(mu), _p(arg), _p(gz), ns, _p(W), _p(Xprev), _p(psc), _p(psh), ctypes.c_float(0.0), int(masked),
+                                   P, Cout, Cin, _p(dXb), _p(stb) if masked else None, 0, _p(wsb_t), wsb, st)
+    assert rc == 0, L.pcl_last_error()
+    rc = L.pcl_linear_bwd_pair_finish_f32(_p(wsb_t), wsb, P, Cout, Cin, _p(dWb), 0, None, 0, None, None, None, 0, None, None, None, None, None, None, st)
+    assert rc == 0, L.pcl_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(dWa, dWb) and torch.equal(dXa, dXb)
+    if masked:
+        assert torch.equal(sta, stb)
+    assert not torch.isnan(dWb).any() and not torch.isnan(dXb).any()
