@@ -131,6 +131,10 @@ size_t pcl_knn_workspace_bytes(int B, int C, int Nr, int Nq, int k);
 /* reference: replaces compute_distances + modified_insertion_sort + the host glue, misc/ops.py:429-552, :562-663 */
 int pcl_knn_f32(const float* ref, const float* qry, int B, int C, int Nr, int Nq, int k,
                 int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream);
+/* pcl_knn_f32 with the lists written as [B, Nq, k] rows (the layout the EdgeConv gathers read; the reference permutes KNN's [B, k, Nq] right
+ * after the call, networks/cls/dgcnn.py:34-35): same search, same order within a list.  Fused kernel only: pcl_knn_nk_supported(Nr). */
+int pcl_knn_nk_supported(int Nr);
+int pcl_knn_nk_f32(const float* ref, const float* qry, int B, int C, int Nr, int Nq, int k, int32_t* idx_out, void* stream);
 /* The NAMED SECOND DEFINITION of the same search: distances accumulated as ssd = fma(tmp, tmp, ssd) -- what nvcc's default
  * -fmad=true makes of `ssd += tmp*tmp` (misc/ops.py:488-491) -- instead of a separately rounded product and sum.  2 VALU
  * operations per (query, reference, channel) instead of 3.  Bit-exact against the oracle's "fma" reading

@@ -156,6 +156,8 @@ _SIGS = {
     "pcl_set_fewrow_backward": (None, [c_int]),
     "pcl_get_fewrow_backward": (c_int, []),
     "pcl_set_dw_tuning": (None, [c_int]),
+    "pcl_knn_nk_supported": (c_int, [c_int]),
+    "pcl_knn_nk_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcl_linear_bwd_pair_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "pcl_linear_bwd_pair_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_float, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_size_t, _P]),
     "pcl_linear_bwd_pair_finish_f32": (c_int, [_P, c_size_t, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
@@ -230,7 +232,7 @@ PROFILER = None   # set to a KernelTimer by bench.py; None in normal operation (
 KERNEL_TIMED = {"pcl_linear_fwd_rows_f32", "pcl_linear_fwd_f32", "pcl_linear_bwd_dx_rows_f32", "pcl_linear_bwd_dx_f32",
                 "pcl_linear_bwd_dw_rows_f32", "pcl_linear_bwd_dw_f32", "pcl_linear_bwd_fused_rows_f32",
                 "pcl_linear_bwd_dw_plain_f32", "pcl_frag_linear_bwd_dx_f32", "pcl_frag_linear_fwd_f32",
-                "pcl_knn_f32", "pcl_knn_fma_f32"}      # (k-NN: the fused kernel; the two-pass form arms nothing and is not recorded)
+                "pcl_knn_f32", "pcl_knn_fma_f32", "pcl_knn_nk_f32"}      # (k-NN: the fused kernel; the two-pass form arms nothing and is not recorded)
 _hip = None
 
 

@@ -192,7 +192,7 @@ struct KnnCfg {
 
 template <int PPT, bool FMA = false>
 __global__ __launch_bounds__(256) void knn_fused_kernel(const float* __restrict__ ref, const float* __restrict__ qry, int C, int Nr,
-                                                        int Nq, int k, int32_t* __restrict__ idx_out) {
+                                                        int Nq, int k, int32_t* __restrict__ idx_out, int out_nk) {
     int b, qblk;
     knn_block(gridDim.x, gridDim.y, b, qblk);
     using Cfg = KnnCfg<PPT>;
@@ -327,7 +327,10 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(const float* __restrict_
             const int r = 256 * (j >> 2) + 4 * lane + (j & 3);
             key[j] = r < Nr ? __float_as_uint(acc[i][j >> 1][j & 1]) : 0xFFFFFFFFu;
         }
-        int32_t* out = idx_out + (size_t)b * k * Nq + q;
+        // out_nk: the lists as [B, Nq, k] rows (what the EdgeConv gathers read) instead of the reference's [B, k, Nq] (round 6: the permute
+        // copy after every search is gone)
+        int32_t* out = out_nk ? idx_out + ((size_t)b * Nq + q) * k : idx_out + (size_t)b * k * Nq + q;
+        const size_t ostr = out_nk ? 1 : (size_t)Nq;
         // Fast path (k <= 64): T = the k-th smallest of the 64 lane-local minima is an upper bound of the k-th smallest key
         // (those are 64 distinct elements), found by a bitwise search with one ballot per bit; the keys <= T (>= k of
         // them, typically ~1.5 k) are compacted into LDS and ranked by (key, r) -- ~400 issue slots instead of ~100 per
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(const float* __restrict_
                     for (int u = 0; u < 8; ++u)
                         rank += (c0 + u < n && (o[u].x < mine.x || (o[u].x == mine.x && o[u].y < mine.y))) ? 1 : 0;
                 }
-                if (lane < n && rank < k) out[(size_t)rank * Nq] = (int32_t)mine.y;
+                if (lane < n && rank < k) out[(size_t)rank * ostr] = (int32_t)mine.y;
                 __builtin_amdgcn_wave_barrier();                             // (the next query reuses the list)
                 done = true;
             }
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(const float* __restrict_
             } else {
                 r = wave_min_u32(bk == wmin ? br : 0xFFFFFFFFu);
             }
-            if (lane == 0) out[(size_t)t * Nq] = (int32_t)r;
+            if (lane == 0) out[(size_t)t * ostr] = (int32_t)r;
             const unsigned rj = 4u * (r >> 8) + (r & 3u), rl = (r & 255u) >> 2;
             const bool mine = (unsigned)lane == rl;
 #pragma unroll
@@ -531,7 +534,7 @@ extern "C" size_t pcl_knn_workspace_bytes(int B, int C, int Nr, int Nq, int k) {
 
 template <bool FMA>
 static int knn_impl(const float* ref, const float* qry, int B, int C, int Nr, int Nq, int k,
-                    int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream) {
+                    int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream, int out_nk = 0) {
     PCL_REQUIRE(ref && qry && idx_out, "pcl_knn_f32: null pointer");
     PCL_REQUIRE(B >= 0 && C >= 1 && Nr >= 1 && Nq >= 1, "pcl_knn_f32: bad sizes B=%d C=%d Nr=%d Nq=%d", B, C, Nr, Nq);
     PCL_REQUIRE(k >= 1 && k <= Nr, "pcl_knn_f32: need 1 <= k <= Nr (k=%d Nr=%d)", k, Nr);
@@ -540,10 +543,11 @@ static int knn_impl(const float* ref, const float* qry, int B, int C, int Nr, in
     if (Nr <= KNN_FUSED_MAX_NR) {
         hipStream_t st = as_stream(stream);
         const int ppt4 = (Nr + 255) / 256 * 4;                    // multiples of 4 registers per lane
-#define PCL_KF(P) if (ppt4 <= P) { PCL_LAUNCH_TIMED((knn_fused_kernel<P, FMA>), dim3((Nq + 4 * KnnCfg<P>::QW - 1) / (4 * KnnCfg<P>::QW), B), dim3(256), st, ref, qry, C, Nr, Nq, k, idx_out); return check_launch("pcl_knn_f32(fused)"); }
+#define PCL_KF(P) if (ppt4 <= P) { PCL_LAUNCH_TIMED((knn_fused_kernel<P, FMA>), dim3((Nq + 4 * KnnCfg<P>::QW - 1) / (4 * KnnCfg<P>::QW), B), dim3(256), st, ref, qry, C, Nr, Nq, k, idx_out, out_nk); return check_launch("pcl_knn_f32(fused)"); }
         PCL_KF(4) PCL_KF(8) PCL_KF(16) PCL_KF(32) PCL_KF(64)
 #undef PCL_KF
     }
+    PCL_REQUIRE(!out_nk, "pcl_knn_nk_f32: the [B, Nq, k] layout comes from the fused kernel only (Nr <= %d)", KNN_FUSED_MAX_NR);
     const size_t need = Nr <= KNN_FUSED_MAX_NR ? 0 : sizeof(float) * (size_t)B * Nr * Nq;
     if (need && (!workspace || workspace_bytes < need))
         return fail(PCL_EWS, "pcl_knn_f32: workspace %zu bytes < required %zu", workspace_bytes, need);
@@ -562,6 +566,10 @@ static int knn_impl(const float* ref, const float* qry, int B, int C, int Nr, in
     return check_launch("pcl_knn_f32(select-generic)");
 }
 
+extern "C" int pcl_knn_nk_supported(int Nr) { return Nr >= 1 && Nr <= KNN_FUSED_MAX_NR; }
+extern "C" int pcl_knn_nk_f32(const float* ref, const float* qry, int B, int C, int Nr, int Nq, int k, int32_t* idx_out, void* stream) {
+    return knn_impl<false>(ref, qry, B, C, Nr, Nq, k, idx_out, nullptr, 0, stream, 1);
+}
 extern "C" int pcl_knn_f32(const float* ref, const float* qry, int B, int C, int Nr, int Nq, int k,
                            int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream) {
     return knn_impl<false>(ref, qry, B, C, Nr, Nq, k, idx_out, workspace, workspace_bytes, stream);

@@ -146,6 +146,23 @@ def knn_indices(x_q, x_r, k, contract=None):
     return idx
 
 
+_KNN_NK = os.environ.get("PCL_KNN_NK", "1") != "0"          # lab switch (A/B on one box): 0 = the reference-layout search + a permute copy
+
+
+def knn_lists(x_q, x_r, k):
+    """``knn_indices(x_q, x_r, k).permute(0, 2, 1).contiguous()`` -- the neighbour lists as [B, Nq, k] rows (what ``get_graph_feature``
+    makes of KNN's result, networks/cls/dgcnn.py:34-35) -- written in that layout by the search itself where the fused kernel applies."""
+    if _KNN_NK and KNN_CONTRACT == "" and x_r.is_cuda and _lib.lib().pcl_knn_nk_supported(x_r.shape[2]):
+        x_q, x_r = _dev(x_q, "x_q"), _dev(x_r, "x_r")
+        B, C, Nq = x_q.shape
+        Nr = x_r.shape[2]
+        idx = torch.empty((B, Nq, k), dtype=torch.int32, device=x_q.device)
+        _lib.call("pcl_knn_nk_f32", _p(x_r), _p(x_q), B, C, Nr, Nq, int(k), _p(idx), _stream(),
+                  algo_bytes=4 * B * C * (Nr + Nq) + 4 * B * k * Nq, algo_flops=3 * B * Nr * Nq * C)
+        return idx
+    return knn_indices(x_q, x_r, k).permute(0, 2, 1).contiguous()
+
+
 def three_nn(xyz1, xyz2):
     """xyz1 [B,N,3] targets, xyz2 [B,S,3] sources -> (idx [B,N,3] int32, weight [B,N,3])."""
     xyz1 = _dev(xyz1, "xyz1")

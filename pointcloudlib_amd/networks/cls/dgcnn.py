@@ -18,12 +18,14 @@ from torch import nn
 from ...misc.layers import PointwiseMLP
 from ...misc.edgeconv import conv_max_mean_pool, edge_conv
 from ...misc.head import fc_head
-from ...misc.ops import KNN, edge_features
+from ...misc.ops import KNN, edge_features, knn_lists
 
 
 def knn_graph(x, knn):
     """x [B,N,C] channel-last -> neighbour lists int32 [B,N,k] in the CURRENT feature space (dgcnn.py:34-35)."""
     xt = x.transpose(1, 2).contiguous()               # [B,C,N] as KNN expects (misc/ops.py:651)
+    if xt.is_cuda:
+        return knn_lists(xt, xt, knn.k)               # the same lists, written as [B,N,k] rows by the search itself (no permute copy)
     return knn(xt, xt).permute(0, 2, 1).contiguous()
 
 

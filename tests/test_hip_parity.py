@@ -391,3 +391,17 @@ def test_ball_query_multi_equals_one_query_per_radius(oracle, dev, B, N, m, radi
         assert torch.equal(a, b)
     with pytest.raises(ValueError):
         ops.ball_query_multi(Q, X, [0.1] * 5, [4] * 5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,N,k", [(4, 3, 1024, 20), (2, 64, 1000, 20), (3, 128, 513, 40), (1, 7, 64, 64), (2, 16, 2048, 5)])
+def test_knn_lists_written_as_rows_equal_the_permuted_search(B, C, N, k):
+    """pcl_knn_nk_f32: the fused search writing [B, Nq, k] rows (round 6) is the reference-layout search permuted -- index for index."""
+    import torch
+    from pointcloudlib_amd.misc import ops
+    torch.manual_seed(31)
+    x = torch.randn(B, C, N, device="cuda")
+    x[:, :, 5] = x[:, :, 3]                                    # an exact tie per query
+    a = ops.knn_indices(x, x, k).permute(0, 2, 1).contiguous()
+    b = ops.knn_lists(x, x, k)
+    assert b.shape == (B, N, k) and b.dtype == torch.int32 and torch.equal(a, b)
