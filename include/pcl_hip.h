@@ -373,6 +373,11 @@ int pcl_linear_fwd_gmax_f32(const float* X, const float* W, const float* bias, c
 int pcl_group_minmax_finalize_f32(const float* gmax, const float* gmin, const int32_t* gamax, const int32_t* gamin,
                                   const float* scale, const float* shift, float slope, int G, int C, float* out,
                                   int32_t* arg, float* ymax, void* stream);
+/* ... and a second copy of `out` as a column slice of a wider matrix, out2[g * out2_ld + c] (round 6: DGCNN's concat(x1..x4),
+ * networks/cls/dgcnn.py:112, is written by its producers; out2 may be null) */
+int pcl_group_minmax_finalize2_f32(const float* gmax, const float* gmin, const int32_t* gamax, const int32_t* gamin,
+                                   const float* scale, const float* shift, float slope, int G, int C, float* out,
+                                   int32_t* arg, float* ymax, float* out2, int out2_ld, void* stream);
 /* mean/var (biased, max(E[y^2]-E[y]^2,0)) from the partials -> scale, shift, mean, invstd; running stats
  * r += (batch - r)*momentum with the biased variance (nullable). */
 /* reference: replaces nn.BatchNorm (training mode) statistics, networks/cls/pointnet2.py:28 (dgcnn.py:66-70) */

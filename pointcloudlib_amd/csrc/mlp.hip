@@ -2883,13 +2883,16 @@ __global__ __launch_bounds__(256) void group_minmax_finalize_kernel(const float*
                                                                     const int32_t* __restrict__ gamax, const int32_t* __restrict__ gamin,
                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                                     float slope, int C, size_t total, float* __restrict__ out,
-                                                                    int32_t* __restrict__ arg, float* __restrict__ ymax) {
+                                                                    int32_t* __restrict__ arg, float* __restrict__ ymax,
+                                                                    float* __restrict__ out2 = nullptr, int ld2 = 0) {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const int c = (int)(e % C);
         const float a = scale[c];
         const bool up = a >= 0.f;
         const float y = up ? gmax[e] : gmin[e];
-        out[e] = lrelu(fmaf(a, y, shift[c]), slope);
+        const float o = lrelu(fmaf(a, y, shift[c]), slope);
+        out[e] = o;
+        if (out2) out2[(e / C) * (size_t)ld2 + c] = o;        // a second copy as a column slice of a wider matrix (a concatenation written in place)
         arg[e] = up ? gamax[e] : gamin[e];
         ymax[e] = y;
     }
@@ -3178,16 +3181,24 @@ extern "C" int pcl_linear_fwd_gmax_f32(const float* X, const float* W, const flo
     return launch_linear(a, as_stream(stream));
 }
 
+extern "C" int pcl_group_minmax_finalize2_f32(const float* gmax, const float* gmin, const int32_t* gamax, const int32_t* gamin,
+                                              const float* scale, const float* shift, float slope, int G, int C, float* out,
+                                              int32_t* arg, float* ymax, float* out2, int out2_ld, void* stream);
 extern "C" int pcl_group_minmax_finalize_f32(const float* gmax, const float* gmin, const int32_t* gamax, const int32_t* gamin,
                                              const float* scale, const float* shift, float slope, int G, int C, float* out,
                                              int32_t* arg, float* ymax, void* stream) {
-    PCL_REQUIRE(gmax && gmin && gamax && gamin && scale && shift && out && arg && ymax && G >= 1 && C >= 1,
+    return pcl_group_minmax_finalize2_f32(gmax, gmin, gamax, gamin, scale, shift, slope, G, C, out, arg, ymax, nullptr, 0, stream);
+}
+extern "C" int pcl_group_minmax_finalize2_f32(const float* gmax, const float* gmin, const int32_t* gamax, const int32_t* gamin,
+                                              const float* scale, const float* shift, float slope, int G, int C, float* out,
+                                              int32_t* arg, float* ymax, float* out2, int out2_ld, void* stream) {
+    PCL_REQUIRE(gmax && gmin && gamax && gamin && scale && shift && out && arg && ymax && G >= 1 && C >= 1 && (!out2 || out2_ld >= C),
                 "pcl_group_minmax_finalize_f32: bad arguments");
     const size_t total = (size_t)G * C;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(group_minmax_finalize_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gmax, gmin, gamax, gamin, scale,
-                       shift, slope, C, total, out, arg, ymax);
+                       shift, slope, C, total, out, arg, ymax, out2, out2_ld);
     return check_launch("pcl_group_minmax_finalize_f32");
 }
 

@@ -19,7 +19,9 @@ class _EdgeConvPool(torch.autograd.Function):
     """UV [B,N,2C] (U | V), idx [B,N,k] -> max_j lrelu(BN(U[idx[.,j]] + V)) [B,N,C]."""
 
     @staticmethod
-    def forward(ctx, UV, idx, gamma, beta, rmean, rvar, cfg, UVlo=None):
+    def forward(ctx, UV, idx, gamma, beta, rmean, rvar, cfg, UVlo=None, cat_slice=None):
+        """``cat_slice``: a [B,N,C] column slice (unit stride along C) of a wider [B,N,Ctot] buffer that also receives the output -- the
+        concatenation of the stages' outputs is then written by the stages (``assemble``), not by a copy kernel."""
         slope, eps, momentum, training = cfg
         UV = _dev(UV, "UV")
         idx = _dev(idx, "idx", torch.int32)
@@ -59,8 +61,15 @@ class _EdgeConvPool(torch.autograd.Function):
         out = torch.empty((G, C), device=dev)
         arg = torch.empty((G, C), dtype=torch.int32, device=dev)
         ysel = torch.empty((G, C), device=dev)
-        _lib.call("pcl_group_minmax_finalize_f32", _p(ymax), _p(ymin), _p(jmax), _p(jmin), _p(scale), _p(shift), slope, G, C,
-                  _p(out), _p(arg), _p(ysel), st)
+        if cat_slice is not None:
+            if not (cat_slice.is_cuda and cat_slice.dtype == torch.float32 and tuple(cat_slice.shape) == (B, N, C) and cat_slice.stride(2) == 1
+                    and cat_slice.stride(0) == N * cat_slice.stride(1)):
+                raise ValueError("cat_slice: a [B,N,C] column slice of a contiguous [B,N,Ctot] float32 buffer")
+            _lib.call("pcl_group_minmax_finalize2_f32", _p(ymax), _p(ymin), _p(jmax), _p(jmin), _p(scale), _p(shift), slope, G, C,
+                      _p(out), _p(arg), _p(ysel), _p(cat_slice), cat_slice.stride(1), st)
+        else:
+            _lib.call("pcl_group_minmax_finalize_f32", _p(ymax), _p(ymin), _p(jmax), _p(jmin), _p(scale), _p(shift), slope, G, C,
+                      _p(out), _p(arg), _p(ysel), st)
         ctx.cfg = (slope, training, B, N, k, C)
         ctx.save_for_backward(UV, idx, out, arg, ysel, gamma, mean, invstd, scale, in_off, in_src, sumU)
         return out.view(B, N, C)
@@ -98,7 +107,31 @@ class _EdgeConvPool(torch.autograd.Function):
         lists = in_off is not None
         _lib.call("pcl_edgeconv_scatter_f32", _p(UV), _p(idx), _p(gz), _p(arg), _p(a), _p(k1), _p(k2), _p(mean), B, N, k, C,
                   _p(in_off), _p(in_src), _p(sumU) if lists else None, _p(dUV), st)
-        return dUV, None, dgamma, dbeta, None, None, None, None
+        return dUV, None, dgamma, dbeta, None, None, None, None, None
+
+
+class _Assembled(torch.autograd.Function):
+    """``torch.cat(parts, dim=-1)`` whose result already sits in ``buf``: every part's producer wrote its column slice (``cat_slice``).
+    Forward hands ``buf`` on, backward returns the column slices of the gradient -- what CatBackward returns."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        ctx.widths = [p.shape[-1] for p in parts]
+        return buf.view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, o = [], 0
+        for w in ctx.widths:
+            outs.append(g[..., o:o + w])
+            o += w
+        return (None, *outs)
+
+
+def assemble(buf, parts):
+    """The concatenation of ``parts`` along the last axis, given that each part's producer has also written it into its column slice of
+    ``buf`` (``edge_conv(..., cat_slice=buf[..., a:b])``)."""
+    return _Assembled.apply(buf, *parts)
 
 
 class _PointLinear(torch.autograd.Function):
@@ -164,7 +197,7 @@ class _PointLinear(torch.autograd.Function):
         return dx, dW, None, None
 
 
-def edge_conv(mlp, x, idx):
+def edge_conv(mlp, x, idx, cat_slice=None):
     """One EdgeConv stage on channel-last ``x`` [B,N,C] with neighbour lists ``idx`` [B,N,k] (int32) -> [B,N,Cout].
     ``mlp``: the stage's one-layer ``PointwiseMLP([2C, Cout], slope=0.2)``.  The HIP backend takes the factorised path;
     the plain-PyTorch backend (tests) and anything that is not a single bias-free conv+BN layer build the edge tensor."""
@@ -175,8 +208,11 @@ def edge_conv(mlp, x, idx):
         UV = _PointLinear.apply(x, mlp.weights[0], flush_k, hilo)             # one GEMM over the points
         UV, UVlo = UV if hilo else (UV, None)
         cfg = (mlp.slope, mlp.eps, mlp.momentum, mlp.training)
-        return _EdgeConvPool.apply(UV, idx, mlp.gammas[0], mlp.betas[0], mlp.running_mean_0, mlp.running_var_0, cfg, UVlo)
-    return mlp(edge_features(x, idx), group_max=k)
+        return _EdgeConvPool.apply(UV, idx, mlp.gammas[0], mlp.betas[0], mlp.running_mean_0, mlp.running_var_0, cfg, UVlo, cat_slice)
+    out = mlp(edge_features(x, idx), group_max=k)
+    if cat_slice is not None:
+        cat_slice.copy_(out.detach())
+    return out
 
 
 class _MaxMeanPoolBN(torch.autograd.Function):

@@ -16,7 +16,7 @@ import torch
 from torch import nn
 
 from ...misc.layers import PointwiseMLP
-from ...misc.edgeconv import conv_max_mean_pool, edge_conv
+from ...misc.edgeconv import assemble, conv_max_mean_pool, edge_conv
 from ...misc.head import fc_head
 from ...misc.ops import KNN, edge_features, knn_lists
 
@@ -37,6 +37,7 @@ def get_graph_feature(x, knn=None, k=None, idx=None):
     return edge_features(x, idx)
 
 
+_CAT_IN_PLACE = os.environ.get("PCL_DGCNN_CAT_IN_PLACE", "1") != "0"      # lab switch (A/B on one box): 0 = torch.cat
 _LRELU = nn.LeakyReLU(0.2)          # activation marker for fc_head (no parameters, not part of the state dict)
 
 
@@ -71,12 +72,15 @@ class DGCNN(nn.Module):
         two neighbours differently for inputs that agree to 1e-6."""
         x = x.transpose(1, 2).contiguous()                                 # channel-last
         g = (lambda i, t: knn_graph(t, self.knn)) if lists is None else (lambda i, t: lists[i])
-        x1 = edge_conv(self.conv1, x, g(0, x))                      # :100-102
-        x2 = edge_conv(self.conv2, x1, g(1, x1))                    # :103-105
-        x3 = edge_conv(self.conv3, x2, g(2, x2))                    # :106-108
-        x4 = edge_conv(self.conv4, x3, g(3, x3))                    # :109-111
+        # concat(x1..x4) [B,N,512] (:112) is written by the stages themselves (each output goes to its column slice as well): no copy kernel
+        cat = torch.empty((x.shape[0], x.shape[1], 512), dtype=x.dtype, device=x.device) if (x.is_cuda and _CAT_IN_PLACE) else None
+        sl = (lambda a, b: None) if cat is None else (lambda a, b: cat[:, :, a:b])
+        x1 = edge_conv(self.conv1, x, g(0, x), sl(0, 64))           # :100-102
+        x2 = edge_conv(self.conv2, x1, g(1, x1), sl(64, 128))       # :103-105
+        x3 = edge_conv(self.conv3, x2, g(2, x2), sl(128, 256))      # :106-108
+        x4 = edge_conv(self.conv4, x3, g(3, x3), sl(256, 512))      # :109-111
         stages = (x1, x2, x3, x4)
-        x = torch.cat((x1, x2, x3, x4), dim=2)                              # [B,N,512]   :112
+        x = torch.cat((x1, x2, x3, x4), dim=2) if cat is None else assemble(cat, stages)   # [B,N,512]   :112
         x = conv_max_mean_pool(self.conv5, x)                               # conv5 + max / mean over the points + concat  :113-116
         # :117-121 -- the whole head as one call per direction (misc/head.py: fc_head -> pcl_fc_head_*_f32)
         x = fc_head([self.linear1, self.bn6, _LRELU, self.dp1, self.linear2, self.bn7, _LRELU, self.dp2, self.linear3], x)

@@ -548,3 +548,36 @@ def test_group_all_backward_hands_the_feature_gradient_on_as_a_view():
         finally:
             ops._GROUP_ALL_BWD_VIEW = old
     assert torch.equal(res[True], res[False]) and torch.equal(res[True], g[:, 0, :, 3:])
+
+
+@pytest.mark.gpu
+def test_dgcnn_concat_written_by_the_stages_equals_torch_cat():
+    """DGCNN's concat(x1..x4) (networks/cls/dgcnn.py:112) is written by the EdgeConv stages themselves (each output also goes to its column
+    slice of the [B,N,512] buffer: pcl_group_minmax_finalize2_f32, misc/edgeconv.assemble): same logits bit for bit as torch.cat, same
+    gradients up to the head's atomic summation order."""
+    import torch
+    from pointcloudlib_amd import synth
+    from pointcloudlib_amd.networks.cls import dgcnn
+    from pointcloudlib_amd.train_utils import soft_cross_entropy_loss
+    torch.manual_seed(8)
+    net = dgcnn.DGCNN().cuda().train()
+    x = torch.from_numpy(synth.gauss_ball(4, 512, 5)).cuda().transpose(1, 2).contiguous()
+    y = torch.from_numpy(synth.labels(4, 40, 6)).cuda()
+    res = {}
+    for flag in (False, True):
+        old, dgcnn._CAT_IN_PLACE = dgcnn._CAT_IN_PLACE, flag
+        try:
+            torch.manual_seed(9)                              # dropout masks
+            net.zero_grad()
+            out, stages = net(x, return_stages=True)
+            soft_cross_entropy_loss(out, y).backward()
+            res[flag] = (out.detach().clone(), [s.detach().clone() for s in stages], {n: p.grad.clone() for n, p in net.named_parameters()})
+        finally:
+            dgcnn._CAT_IN_PLACE = old
+    a, b = res[False], res[True]
+    for u, v in zip(a[1], b[1]):
+        assert torch.equal(u, v)
+    assert torch.equal(a[0], b[0])
+    for n in a[2]:
+        scale = a[2][n].abs().max().item()
+        assert (a[2][n] - b[2][n]).abs().max().item() <= 1e-4 * scale + 1e-7, n      # (a bias in front of a BatchNorm: true gradient 0, rounding noise 1e-8)
