@@ -378,6 +378,12 @@ int pcl_group_minmax_finalize_f32(const float* gmax, const float* gmin, const in
 int pcl_group_minmax_finalize2_f32(const float* gmax, const float* gmin, const int32_t* gamax, const int32_t* gamin,
                                    const float* scale, const float* shift, float slope, int G, int C, float* out,
                                    int32_t* arg, float* ymax, float* out2, int out2_ld, void* stream);
+/* ... and a third copy transposed per cloud, out_t[b][c][n] for G = B * N groups (N % 32 == 0): the layout the next EdgeConv stage's KNN
+ * reads (networks/cls/dgcnn.py:34: the reference transposes nothing because its tensors are [B, C, N] throughout; here activations are
+ * channel-last and the stage hands both layouts on) */
+int pcl_group_minmax_finalize_t_f32(const float* gmax, const float* gmin, const int32_t* gamax, const int32_t* gamin,
+                                    const float* scale, const float* shift, float slope, int B, int N, int C, float* out,
+                                    int32_t* arg, float* ymax, float* out2, int out2_ld, float* out_t, void* stream);
 /* mean/var (biased, max(E[y^2]-E[y]^2,0)) from the partials -> scale, shift, mean, invstd; running stats
  * r += (batch - r)*momentum with the biased variance (nullable). */
 /* reference: replaces nn.BatchNorm (training mode) statistics, networks/cls/pointnet2.py:28 (dgcnn.py:66-70) */

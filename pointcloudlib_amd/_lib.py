@@ -112,6 +112,7 @@ _SIGS = {
     "pcl_linear_fwd_gmax_f32": (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "pcl_group_minmax_finalize_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P, _P]),
     "pcl_group_minmax_finalize2_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "pcl_group_minmax_finalize_t_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     "pcl_bn_finalize_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "pcl_bn_act_max_f32": (c_int, [_P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P]),
     "pcl_bn_act_f32": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P]),

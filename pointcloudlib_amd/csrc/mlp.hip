@@ -3181,9 +3181,63 @@ extern "C" int pcl_linear_fwd_gmax_f32(const float* X, const float* W, const flo
     return launch_linear(a, as_stream(stream));
 }
 
+// the same, on 32 x 32 (group, channel) tiles, with a THIRD copy of `out` in the transposed layout out_t[b][c][n] (groups = the N points of
+// B clouds, N % 32 == 0): the next EdgeConv stage's k-NN search reads [B, C, N] -- the transpose launch in front of it is gone (round 6)
+__global__ __launch_bounds__(256) void group_minmax_finalize_t_kernel(const float* __restrict__ gmax, const float* __restrict__ gmin,
+                                                                      const int32_t* __restrict__ gamax, const int32_t* __restrict__ gamin,
+                                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                      float slope, int C, int N, int tiles_c, size_t tiles, float* __restrict__ out,
+                                                                      int32_t* __restrict__ arg, float* __restrict__ ymax,
+                                                                      float* __restrict__ out2, int ld2, float* __restrict__ out_t) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const size_t g0 = (t / tiles_c) * 32;
+        const int c0 = (int)(t % tiles_c) * 32, c = c0 + tx;
+        float a = 0.f, sh = 0.f;
+        if (c < C) { a = scale[c]; sh = shift[c]; }
+        const bool up = a >= 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = ty + 8 * i;
+            float o = 0.f;
+            if (c < C) {
+                const size_t e = (g0 + r) * C + c;
+                const float y = up ? gmax[e] : gmin[e];
+                o = lrelu(fmaf(a, y, sh), slope);
+                out[e] = o;
+                arg[e] = up ? gamax[e] : gamin[e];
+                ymax[e] = y;
+                if (out2) out2[(g0 + r) * (size_t)ld2 + c] = o;
+            }
+            tile[r][tx] = o;
+        }
+        __syncthreads();
+        const size_t b = g0 / N, n0 = g0 % N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cl = ty + 8 * i;
+            if (c0 + cl < C) out_t[(b * C + c0 + cl) * (size_t)N + n0 + tx] = tile[tx][cl];
+        }
+        __syncthreads();
+    }
+}
+
 extern "C" int pcl_group_minmax_finalize2_f32(const float* gmax, const float* gmin, const int32_t* gamax, const int32_t* gamin,
                                               const float* scale, const float* shift, float slope, int G, int C, float* out,
                                               int32_t* arg, float* ymax, float* out2, int out2_ld, void* stream);
+extern "C" int pcl_group_minmax_finalize_t_f32(const float* gmax, const float* gmin, const int32_t* gamax, const int32_t* gamin,
+                                               const float* scale, const float* shift, float slope, int B, int N, int C, float* out,
+                                               int32_t* arg, float* ymax, float* out2, int out2_ld, float* out_t, void* stream) {
+    PCL_REQUIRE(gmax && gmin && gamax && gamin && scale && shift && out && arg && ymax && out_t && B >= 1 && N >= 32 && N % 32 == 0 && C >= 1 &&
+                (!out2 || out2_ld >= C), "pcl_group_minmax_finalize_t_f32: bad arguments (N a multiple of 32)");
+    const int tiles_c = (C + 31) / 32;
+    const size_t tiles = (size_t)B * N / 32 * tiles_c;
+    const int blocks = tiles < 8192 ? (int)tiles : 8192;
+    hipLaunchKernelGGL(group_minmax_finalize_t_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gmax, gmin, gamax, gamin, scale, shift, slope, C, N,
+                       tiles_c, tiles, out, arg, ymax, out2, out2_ld, out_t);
+    return check_launch("pcl_group_minmax_finalize_t_f32");
+}
 extern "C" int pcl_group_minmax_finalize_f32(const float* gmax, const float* gmin, const int32_t* gamax, const int32_t* gamin,
                                              const float* scale, const float* shift, float slope, int G, int C, float* out,
                                              int32_t* arg, float* ymax, void* stream) {

@@ -19,9 +19,10 @@ class _EdgeConvPool(torch.autograd.Function):
     """UV [B,N,2C] (U | V), idx [B,N,k] -> max_j lrelu(BN(U[idx[.,j]] + V)) [B,N,C]."""
 
     @staticmethod
-    def forward(ctx, UV, idx, gamma, beta, rmean, rvar, cfg, UVlo=None, cat_slice=None):
+    def forward(ctx, UV, idx, gamma, beta, rmean, rvar, cfg, UVlo=None, cat_slice=None, want_t=False):
         """``cat_slice``: a [B,N,C] column slice (unit stride along C) of a wider [B,N,Ctot] buffer that also receives the output -- the
         concatenation of the stages' outputs is then written by the stages (``assemble``), not by a copy kernel."""
+        # ``want_t``: also return the output transposed per cloud, [B,C,N] (non-differentiable; what the next stage's k-NN search reads)
         slope, eps, momentum, training = cfg
         UV = _dev(UV, "UV")
         idx = _dev(idx, "idx", torch.int32)
@@ -61,10 +62,16 @@ class _EdgeConvPool(torch.autograd.Function):
         out = torch.empty((G, C), device=dev)
         arg = torch.empty((G, C), dtype=torch.int32, device=dev)
         ysel = torch.empty((G, C), device=dev)
+        out_t = None
         if cat_slice is not None:
             if not (cat_slice.is_cuda and cat_slice.dtype == torch.float32 and tuple(cat_slice.shape) == (B, N, C) and cat_slice.stride(2) == 1
                     and cat_slice.stride(0) == N * cat_slice.stride(1)):
                 raise ValueError("cat_slice: a [B,N,C] column slice of a contiguous [B,N,Ctot] float32 buffer")
+        if want_t and N % 32 == 0:
+            out_t = torch.empty((B, C, N), device=dev)
+            _lib.call("pcl_group_minmax_finalize_t_f32", _p(ymax), _p(ymin), _p(jmax), _p(jmin), _p(scale), _p(shift), slope, B, N, C,
+                      _p(out), _p(arg), _p(ysel), _p(cat_slice), 0 if cat_slice is None else cat_slice.stride(1), _p(out_t), st)
+        elif cat_slice is not None:
             _lib.call("pcl_group_minmax_finalize2_f32", _p(ymax), _p(ymin), _p(jmax), _p(jmin), _p(scale), _p(shift), slope, G, C,
                       _p(out), _p(arg), _p(ysel), _p(cat_slice), cat_slice.stride(1), st)
         else:
@@ -72,10 +79,15 @@ class _EdgeConvPool(torch.autograd.Function):
                       _p(out), _p(arg), _p(ysel), st)
         ctx.cfg = (slope, training, B, N, k, C)
         ctx.save_for_backward(UV, idx, out, arg, ysel, gamma, mean, invstd, scale, in_off, in_src, sumU)
+        if want_t:
+            if out_t is None:
+                out_t = out.view(B, N, C).transpose(1, 2).contiguous()
+            ctx.mark_non_differentiable(out_t)
+            return out.view(B, N, C), out_t
         return out.view(B, N, C)
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, *unused):
         slope, training, B, N, k, C = ctx.cfg
         UV, idx, out, arg, ysel, gamma, mean, invstd, scale, in_off, in_src, sumU = ctx.saved_tensors
         dev = UV.device
@@ -107,7 +119,7 @@ class _EdgeConvPool(torch.autograd.Function):
         lists = in_off is not None
         _lib.call("pcl_edgeconv_scatter_f32", _p(UV), _p(idx), _p(gz), _p(arg), _p(a), _p(k1), _p(k2), _p(mean), B, N, k, C,
                   _p(in_off), _p(in_src), _p(sumU) if lists else None, _p(dUV), st)
-        return dUV, None, dgamma, dbeta, None, None, None, None, None
+        return dUV, None, dgamma, dbeta, None, None, None, None, None, None
 
 
 class _Assembled(torch.autograd.Function):
@@ -197,7 +209,7 @@ class _PointLinear(torch.autograd.Function):
         return dx, dW, None, None
 
 
-def edge_conv(mlp, x, idx, cat_slice=None):
+def edge_conv(mlp, x, idx, cat_slice=None, want_t=False):
     """One EdgeConv stage on channel-last ``x`` [B,N,C] with neighbour lists ``idx`` [B,N,k] (int32) -> [B,N,Cout].
     ``mlp``: the stage's one-layer ``PointwiseMLP([2C, Cout], slope=0.2)``.  The HIP backend takes the factorised path;
     the plain-PyTorch backend (tests) and anything that is not a single bias-free conv+BN layer build the edge tensor."""
@@ -208,11 +220,11 @@ def edge_conv(mlp, x, idx, cat_slice=None):
         UV = _PointLinear.apply(x, mlp.weights[0], flush_k, hilo)             # one GEMM over the points
         UV, UVlo = UV if hilo else (UV, None)
         cfg = (mlp.slope, mlp.eps, mlp.momentum, mlp.training)
-        return _EdgeConvPool.apply(UV, idx, mlp.gammas[0], mlp.betas[0], mlp.running_mean_0, mlp.running_var_0, cfg, UVlo, cat_slice)
+        return _EdgeConvPool.apply(UV, idx, mlp.gammas[0], mlp.betas[0], mlp.running_mean_0, mlp.running_var_0, cfg, UVlo, cat_slice, want_t)
     out = mlp(edge_features(x, idx), group_max=k)
     if cat_slice is not None:
         cat_slice.copy_(out.detach())
-    return out
+    return (out, out.detach().transpose(1, 2).contiguous()) if want_t else out
 
 
 class _MaxMeanPoolBN(torch.autograd.Function):

@@ -21,9 +21,11 @@ from ...misc.head import fc_head
 from ...misc.ops import KNN, edge_features, knn_lists
 
 
-def knn_graph(x, knn):
-    """x [B,N,C] channel-last -> neighbour lists int32 [B,N,k] in the CURRENT feature space (dgcnn.py:34-35)."""
-    xt = x.transpose(1, 2).contiguous()               # [B,C,N] as KNN expects (misc/ops.py:651)
+def knn_graph(x, knn, xt=None):
+    """x [B,N,C] channel-last -> neighbour lists int32 [B,N,k] in the CURRENT feature space (dgcnn.py:34-35).  ``xt``: x as [B,C,N] where
+    the producing stage handed that layout on as well (``edge_conv(..., want_t=True)``)."""
+    if xt is None:
+        xt = x.transpose(1, 2).contiguous()           # [B,C,N] as KNN expects (misc/ops.py:651)
     if xt.is_cuda:
         return knn_lists(xt, xt, knn.k)               # the same lists, written as [B,N,k] rows by the search itself (no permute copy)
     return knn(xt, xt).permute(0, 2, 1).contiguous()
@@ -37,6 +39,7 @@ def get_graph_feature(x, knn=None, k=None, idx=None):
     return edge_features(x, idx)
 
 
+_STAGE_T = os.environ.get("PCL_DGCNN_STAGE_T", "1") != "0"                # lab switch: 0 = a transpose launch in front of every search
 _CAT_IN_PLACE = os.environ.get("PCL_DGCNN_CAT_IN_PLACE", "1") != "0"      # lab switch (A/B on one box): 0 = torch.cat
 _LRELU = nn.LeakyReLU(0.2)          # activation marker for fc_head (no parameters, not part of the state dict)
 
@@ -70,15 +73,18 @@ class DGCNN(nn.Module):
         network's own kNN (the reference's ``get_graph_feature(..., idx=...)`` argument, dgcnn.py:29,33): whole-network
         comparisons between two fp32 pipelines share one set of lists, because a near-tie in a FEATURE-space kNN orders
         two neighbours differently for inputs that agree to 1e-6."""
+        x_in = x                                                           # [B,3,N]: the layout the first search reads
         x = x.transpose(1, 2).contiguous()                                 # channel-last
-        g = (lambda i, t: knn_graph(t, self.knn)) if lists is None else (lambda i, t: lists[i])
+        wt = lists is None and x.is_cuda and _STAGE_T                      # stages hand their output on in both layouts: no transpose launches
+        g = (lambda i, t, tt=None: knn_graph(t, self.knn, tt)) if lists is None else (lambda i, t, tt=None: lists[i])
         # concat(x1..x4) [B,N,512] (:112) is written by the stages themselves (each output goes to its column slice as well): no copy kernel
         cat = torch.empty((x.shape[0], x.shape[1], 512), dtype=x.dtype, device=x.device) if (x.is_cuda and _CAT_IN_PLACE) else None
         sl = (lambda a, b: None) if cat is None else (lambda a, b: cat[:, :, a:b])
-        x1 = edge_conv(self.conv1, x, g(0, x), sl(0, 64))           # :100-102
-        x2 = edge_conv(self.conv2, x1, g(1, x1), sl(64, 128))       # :103-105
-        x3 = edge_conv(self.conv3, x2, g(2, x2), sl(128, 256))      # :106-108
-        x4 = edge_conv(self.conv4, x3, g(3, x3), sl(256, 512))      # :109-111
+        pair = (lambda r: r) if wt else (lambda r: (r, None))
+        x1, t1 = pair(edge_conv(self.conv1, x, g(0, x, x_in if wt else None), sl(0, 64), wt))      # :100-102
+        x2, t2 = pair(edge_conv(self.conv2, x1, g(1, x1, t1), sl(64, 128), wt))                    # :103-105
+        x3, t3 = pair(edge_conv(self.conv3, x2, g(2, x2, t2), sl(128, 256), wt))                   # :106-108
+        x4 = edge_conv(self.conv4, x3, g(3, x3, t3), sl(256, 512))                                  # :109-111
         stages = (x1, x2, x3, x4)
         x = torch.cat((x1, x2, x3, x4), dim=2) if cat is None else assemble(cat, stages)   # [B,N,512]   :112
         x = conv_max_mean_pool(self.conv5, x)                               # conv5 + max / mean over the points + concat  :113-116

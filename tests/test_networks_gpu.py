@@ -566,6 +566,7 @@ def test_dgcnn_concat_written_by_the_stages_equals_torch_cat():
     res = {}
     for flag in (False, True):
         old, dgcnn._CAT_IN_PLACE = dgcnn._CAT_IN_PLACE, flag
+        old_t, dgcnn._STAGE_T = dgcnn._STAGE_T, flag          # (and: the stages hand their outputs on as [B,C,N] too -- no transpose launches)
         try:
             torch.manual_seed(9)                              # dropout masks
             net.zero_grad()
@@ -574,6 +575,7 @@ def test_dgcnn_concat_written_by_the_stages_equals_torch_cat():
             res[flag] = (out.detach().clone(), [s.detach().clone() for s in stages], {n: p.grad.clone() for n, p in net.named_parameters()})
         finally:
             dgcnn._CAT_IN_PLACE = old
+            dgcnn._STAGE_T = old_t
     a, b = res[False], res[True]
     for u, v in zip(a[1], b[1]):
         assert torch.equal(u, v)
