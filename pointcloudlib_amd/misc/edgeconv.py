@@ -83,6 +83,7 @@ class _EdgeConvPool(torch.autograd.Function):
             if out_t is None:
                 out_t = out.view(B, N, C).transpose(1, 2).contiguous()
             ctx.mark_non_differentiable(out_t)
+            ctx.set_materialize_grads(False)          # (else autograd fills a [B,C,N] zero tensor per stage for the transposed copy's gradient)
             return out.view(B, N, C), out_t
         return out.view(B, N, C)
 
@@ -90,6 +91,8 @@ class _EdgeConvPool(torch.autograd.Function):
     def backward(ctx, gout, *unused):
         slope, training, B, N, k, C = ctx.cfg
         UV, idx, out, arg, ysel, gamma, mean, invstd, scale, in_off, in_src, sumU = ctx.saved_tensors
+        if gout is None:                              # (gradients are not materialised: nothing flowed into this stage's output)
+            gout = torch.zeros((B, N, C), device=UV.device)
         dev = UV.device
         G = B * N
         st = _stream()
